@@ -1,0 +1,276 @@
+"""Constraint layer of the beam-SD path: `Trie`, `prefix_allowed_tokens_fn` and the mask
+functions the reference installs, plus their compilation to the device-side automaton.
+
+Drop-in surface (same names / semantics as the reference):
+  * `Trie(sequences=[])`, `.add/.get/.append/.load_from_dict/__iter__/__len__/__getitem__`
+        <- reference `code/generation_trie.py:7-88`
+  * `prefix_allowed_tokens_fn(trie)`            <- `code/generation_trie.py:92-98`
+        (also `code/utils.py:201-207`)
+  * `PositionSetConstraint`  (`fn(batch_id, sentence)`) <- `code/data.py:84-104`, the mask
+        `code/inference.py:131` really uses
+  * `SuffixTrieConstraint`                      <- `code/generate_teacher_data.py:174-188`
+
+New here: every constraint can `compile()` itself into a `ConstraintFSM` — a CSR
+automaton (node -> sorted child tokens -> next node) that the HIP scan kernels walk on the
+device, replacing the reference's per-beam host call + `.tolist()` round trip
+(`code/generation_trie.py:94`, `code/data.py:98`).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+class Trie:
+    """Prefix tree over token-id sequences, stored as nested dicts in `trie_dict`."""
+
+    def __init__(self, sequences: Optional[Iterable[Sequence[int]]] = None):
+        self.trie_dict: Dict[int, Dict] = {}
+        self.len = 0
+        self.append_trie: Optional["Trie"] = None
+        self.bos_token_id: Optional[int] = None
+        if sequences:
+            for seq in sequences:
+                self.add(seq)
+
+    # -- mutation ---------------------------------------------------------------
+    def add(self, sequence: Sequence[int]) -> None:
+        level = self.trie_dict
+        for token in sequence:
+            nxt = level.get(token)
+            if nxt is None:
+                nxt = level[token] = {}
+            level = nxt
+        self.len += 1
+
+    def append(self, trie: "Trie", bos_token_id: int) -> None:
+        """Chain a second trie that takes over where this one has no continuation."""
+        self.append_trie = trie
+        self.bos_token_id = bos_token_id
+
+    # -- lookup -----------------------------------------------------------------
+    def _descend(self, prefix: Sequence[int]) -> Tuple[Optional[Dict], int]:
+        level = self.trie_dict
+        for depth, token in enumerate(prefix):
+            nxt = level.get(token)
+            if nxt is None:
+                return None, depth
+            level = nxt
+        return level, len(prefix)
+
+    def get(self, prefix_sequence: Sequence[int]) -> List[int]:
+        prefix = [int(t) for t in prefix_sequence]
+        level, depth = self._descend(prefix)
+        if level is None:
+            if self.append_trie is not None:
+                return self.append_trie.get(prefix[depth:])
+            return []
+        children = list(level)
+        if self.append_trie is not None and self.bos_token_id in children:
+            children.remove(self.bos_token_id)
+            children.extend(self.append_trie.trie_dict)
+        return children
+
+    def __getitem__(self, prefix_sequence: Sequence[int]) -> List[int]:
+        return self.get(prefix_sequence)
+
+    def __len__(self) -> int:
+        return self.len
+
+    def __iter__(self) -> Iterator[List[int]]:
+        """Depth-first, insertion-ordered walk yielding every root-to-leaf sequence."""
+        path: List[int] = []
+        stack: List[Iterator] = [iter(self.trie_dict.items())]
+        if not self.trie_dict:
+            yield []
+            return
+        while stack:
+            try:
+                token, child = next(stack[-1])
+            except StopIteration:
+                stack.pop()
+                if path:
+                    path.pop()
+                continue
+            path.append(token)
+            if child:
+                stack.append(iter(child.items()))
+            else:
+                yield list(path)
+                path.pop()
+
+    @staticmethod
+    def load_from_dict(trie_dict: Dict) -> "Trie":
+        trie = Trie()
+        trie.trie_dict = trie_dict
+        trie.len = sum(1 for _ in trie)
+        return trie
+
+    # -- device form ------------------------------------------------------------
+    def flatten(self, root_prefix: Sequence[int] = ()) -> "ConstraintFSM":
+        """CSR automaton of the subtree below `root_prefix` (breadth-first node ids,
+        children sorted by token id).  Chained tries (`append`) are not flattened."""
+        if self.append_trie is not None:
+            raise NotImplementedError("flatten() of a chained Trie (append) is not supported")
+        root, _ = self._descend([int(t) for t in root_prefix])
+        if root is None:
+            root = {}
+        nodes = [root]
+        row_ptr = [0]
+        tok: List[int] = []
+        nxt: List[int] = []
+        i = 0
+        while i < len(nodes):
+            for t in sorted(nodes[i]):
+                tok.append(int(t))
+                nxt.append(len(nodes))
+                nodes.append(nodes[i][t])
+            row_ptr.append(len(tok))
+            i += 1
+        return ConstraintFSM(np.asarray(row_ptr, np.int32), np.asarray(tok, np.int32), np.asarray(nxt, np.int32), 0)
+
+
+@dataclass
+class ConstraintFSM:
+    """node n allows tokens tok[row_ptr[n]:row_ptr[n+1]] (ascending); taking tok[e] moves to nxt[e]."""
+    row_ptr: np.ndarray   # int32 [n_nodes + 1]
+    tok: np.ndarray       # int32 [n_edges]
+    nxt: np.ndarray       # int32 [n_edges]
+    start: int = 0
+
+    @property
+    def n_nodes(self) -> int:
+        return len(self.row_ptr) - 1
+
+    @property
+    def max_children(self) -> int:
+        return int(np.max(np.diff(self.row_ptr))) if self.n_nodes else 0
+
+    def allowed(self, node: int) -> np.ndarray:
+        return self.tok[self.row_ptr[node]: self.row_ptr[node + 1]]
+
+    def step(self, node: int, token: int) -> int:
+        lo, hi = int(self.row_ptr[node]), int(self.row_ptr[node + 1])
+        j = lo + int(np.searchsorted(self.tok[lo:hi], token))
+        if j >= hi or self.tok[j] != token:
+            raise KeyError((node, token))
+        return int(self.nxt[j])
+
+    def validate(self, vocab_size: int) -> None:
+        assert self.row_ptr[0] == 0 and np.all(np.diff(self.row_ptr) >= 0)
+        assert len(self.tok) == len(self.nxt) == self.row_ptr[-1]
+        if len(self.tok):
+            assert self.tok.min() >= 0 and self.tok.max() < vocab_size
+            assert self.nxt.min() >= 0 and self.nxt.max() < self.n_nodes
+        for n in range(self.n_nodes):
+            a = self.allowed(n)
+            assert np.all(a[1:] > a[:-1]), "children must be strictly ascending"
+
+
+def _tokens_after_last(sentence: List[int], sep: List[int]) -> Optional[int]:
+    """How many tokens follow the last occurrence of `sep` in `sentence`."""
+    m = len(sep)
+    for start in range(len(sentence) - m, -1, -1):
+        if sentence[start: start + m] == sep:
+            return len(sentence) - start - m
+    return None
+
+
+def _as_list(sentence) -> List[int]:
+    return [int(x) for x in (sentence.tolist() if hasattr(sentence, "tolist") else sentence)]
+
+
+class PositionSetConstraint:
+    """Allowed set = f(number of tokens generated after "Response:").
+
+    `allowed_tokens[i]` is the id set legal at generated position i and
+    `allowed_tokens[L] = {eos}` — the dict `BaseDataset.get_prefix_allowed_tokens_fn`
+    builds (reference `code/data.py:84-94`).  Calling the object reproduces
+    `code/data.py:96-102`: scan from the end for the separator, index by distance.
+    """
+
+    def __init__(self, allowed_tokens: Dict[int, Iterable[int]], sep: Sequence[int]):
+        self.allowed_tokens = {int(i): list(v) for i, v in allowed_tokens.items()}
+        self.sep = [int(s) for s in sep]
+
+    def __call__(self, batch_id, sentence) -> Optional[List[int]]:
+        i = _tokens_after_last(_as_list(sentence), self.sep)
+        if i is None:
+            return None          # same as the reference falling out of its loop
+        return list(self.allowed_tokens[i])
+
+    def compile(self, prompt: Sequence[int]) -> ConstraintFSM:
+        i0 = _tokens_after_last([int(t) for t in prompt], self.sep)
+        if i0 is None:
+            raise TypeError("separator not found in prompt: the reference's mask function returns None here "
+                            "(code/data.py:97-102) and the HF processor then fails with TypeError")
+        n_pos = max(self.allowed_tokens) + 1
+        row_ptr, tok, nxt = [0], [], []
+        for i in range(n_pos):
+            ids = sorted(set(self.allowed_tokens.get(i, [])))
+            tok += ids
+            nxt += [min(i + 1, n_pos)] * len(ids)
+            row_ptr.append(len(tok))
+        row_ptr.append(len(tok))   # terminal node: nothing allowed (reference: KeyError)
+        return ConstraintFSM(np.asarray(row_ptr, np.int32), np.asarray(tok, np.int32), np.asarray(nxt, np.int32), i0)
+
+
+class SuffixTrieConstraint:
+    """Strict item trie keyed on `[bos] + tokens generated after "Response:"`
+    (reference `code/generate_teacher_data.py:174-188`)."""
+
+    def __init__(self, trie: Trie, sep: Sequence[int], bos_token_id: int = 1):
+        self.trie = trie
+        self.sep = [int(s) for s in sep]
+        self.bos_token_id = int(bos_token_id)
+        self._fsm: Optional[ConstraintFSM] = None
+
+    def _suffix(self, s: List[int]) -> List[int]:
+        m = len(self.sep)
+        for end in range(m, len(s) + 1):        # first occurrence wins, as in the reference loop
+            if s[end - m: end] == self.sep:
+                return s[end:]
+        raise NameError("sentence_")            # the reference leaves `sentence_` unbound
+
+    def __call__(self, batch_id, sentence) -> List[int]:
+        return self.trie.get([self.bos_token_id] + self._suffix(_as_list(sentence)))
+
+    def compile(self, prompt: Sequence[int]) -> ConstraintFSM:
+        if self._fsm is None:
+            self._fsm = self.trie.flatten([self.bos_token_id])
+        fsm = self._fsm
+        node = 0
+        for t in self._suffix([int(x) for x in prompt]):
+            node = fsm.step(node, t)
+        return ConstraintFSM(fsm.row_ptr, fsm.tok, fsm.nxt, node)
+
+
+class WholeSentenceTrieConstraint:
+    """`prefix_allowed_tokens_fn(trie)` of the reference: the ENTIRE sentence, prompt
+    included, is looked up in the trie (`code/generation_trie.py:92-98`)."""
+
+    def __init__(self, trie: Trie):
+        self.trie = trie
+        self._fsm: Optional[ConstraintFSM] = None
+
+    def __call__(self, batch_id, sentence) -> List[int]:
+        return self.trie.get(_as_list(sentence))
+
+    def compile(self, prompt: Sequence[int]) -> ConstraintFSM:
+        if self._fsm is None:
+            self._fsm = self.trie.flatten()
+        fsm = self._fsm
+        node = 0
+        try:
+            for t in prompt:
+                node = fsm.step(node, int(t))
+        except KeyError:
+            raise ValueError("`prefix_allowed_tokens_fn` returned an empty list for batch ID 0.") from None
+        return ConstraintFSM(fsm.row_ptr, fsm.tok, fsm.nxt, node)
+
+
+def prefix_allowed_tokens_fn(candidate_trie: Trie) -> WholeSentenceTrieConstraint:
+    """Same call as the reference factory; the returned callable is also compilable."""
+    return WholeSentenceTrieConstraint(candidate_trie)

@@ -1,0 +1,100 @@
+"""Product-side constraint layer (atspeed_amd/generation_trie.py) vs the reference's golden
+vectors and vs the oracle restatement; FSM compilation checks.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from atspeed_amd import synth
+from atspeed_amd.generation_trie import (PositionSetConstraint, SuffixTrieConstraint, Trie,
+                                         WholeSentenceTrieConstraint, prefix_allowed_tokens_fn)
+from oracle.trie_ref import RefTrie, ref_position_set_fn, ref_suffix_trie_fn
+from tests.golden.cases import TRIE_CASES
+
+
+@pytest.mark.parametrize("tc", TRIE_CASES, ids=[t["name"] for t in TRIE_CASES])
+def test_trie_equals_reference_golden(tc, trie_golden):
+    gold = trie_golden[tc["name"]]
+    t = Trie(tc["sequences"])
+    assert len(t) == gold["len"]
+    assert [list(x) for x in t] == gold["iter"]
+    for q, exp in gold["gets"]:
+        assert t.get(q) == exp and t[q] == exp
+    fn = prefix_allowed_tokens_fn(Trie(tc["sequences"]))
+    for q, exp in gold["fn"]:
+        assert fn(0, torch.tensor(q, dtype=torch.long)) == exp
+    if tc.get("append"):
+        t.append(Trie(tc["append"]["sequences"]), tc["append"]["bos"])
+        for q, exp in gold["gets_appended"]:
+            assert t.get(q) == exp
+    assert len(Trie.load_from_dict(t.trie_dict)) == gold["loaded_len"]
+
+
+def test_trie_add_and_incremental_len():
+    t = Trie()
+    assert len(t) == 0 and t.get([]) == []
+    t.add([1, 2, 3]); t.add([1, 2, 4]); t.add([1, 2, 3])
+    assert len(t) == 3 and t.get([1, 2]) == [3, 4] and t.get([9]) == []
+
+
+def test_flatten_matches_nested_lookup():
+    items = synth.synthetic_items(synth.BEAUTY)
+    seqs = [[1] + [int(x) for x in r] + [2] for r in items]
+    t = Trie(seqs)
+    fsm = t.flatten([1])
+    fsm.validate(synth.BEAUTY.vocab_size)
+    rng = np.random.default_rng(0)
+    for r in rng.integers(0, len(seqs), 200):
+        node, pre = 0, [1]
+        for tok in seqs[r][1:]:
+            assert sorted(t.get(pre)) == fsm.allowed(node).tolist()
+            node = fsm.step(node, tok)
+            pre.append(tok)
+        assert fsm.allowed(node).tolist() == []
+    # breadth-first layout: node counts per depth match the number of distinct prefixes
+    assert fsm.n_nodes == 1 + sum(len({tuple(s[1:d]) for s in seqs}) for d in range(2, 7))
+    assert fsm.max_children <= 256
+
+
+def test_position_set_constraint_and_compile():
+    al = synth.BEAUTY.allowed_tokens()
+    c = PositionSetConstraint(al, synth.RESPONSE_SEP)
+    ref = ref_position_set_fn(al, synth.RESPONSE_SEP)
+    p = synth.synthetic_prompt(30, 1)
+    for extra in ([], [32000], [32000, 32100], [32000, 32100, 32400, 32700]):
+        s = torch.tensor(list(p) + extra)
+        assert c(0, s) == ref(0, s)
+    assert c(0, torch.tensor([1, 5, 6])) is None
+    fsm = c.compile(p)
+    fsm.validate(synth.BEAUTY.vocab_size)
+    assert fsm.start == 0 and fsm.n_nodes == 6
+    for i in range(4):
+        lo, hi = synth.BEAUTY.level_range(i)
+        assert fsm.allowed(i).tolist() == list(range(lo, hi))
+    assert fsm.allowed(4).tolist() == [2] and fsm.allowed(5).tolist() == []
+    assert c.compile(list(p) + [32000]).start == 1
+    with pytest.raises(TypeError):
+        c.compile([1, 5, 6])
+
+
+def test_suffix_trie_constraint_and_compile():
+    items = synth.synthetic_items(synth.TINY)
+    seqs = [[1] + [int(x) for x in r] + [2] for r in items]
+    c = SuffixTrieConstraint(Trie(seqs), synth.RESPONSE_SEP, 1)
+    ref = ref_suffix_trie_fn(RefTrie(seqs), synth.RESPONSE_SEP, 1)
+    p = list(synth.synthetic_prompt(20, 3))
+    it = [int(x) for x in items[17]]
+    for n in range(5):
+        s = torch.tensor(p + it[:n])
+        assert sorted(c(0, s)) == sorted(ref(0, s))
+        fsm = c.compile(p + it[:n])
+        assert fsm.allowed(fsm.start).tolist() == sorted(c(0, s))
+    with pytest.raises(KeyError):
+        c.compile(p + [32000 + 63, 32000])       # not a prefix of any item
+
+
+def test_whole_sentence_constraint_compile():
+    t = Trie([[1, 5, 7], [1, 5, 8], [1, 6, 9]])
+    c = WholeSentenceTrieConstraint(t)
+    assert c.compile([1, 5]).allowed(c.compile([1, 5]).start).tolist() == [7, 8]
+    with pytest.raises(ValueError):
+        c.compile([1, 4])
