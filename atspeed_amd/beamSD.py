@@ -1,0 +1,241 @@
+"""Drop-in surface of the reference's `code/beamSD.py` for the MI355X engine.
+
+  BSSD(target_model, draft_model, inputs, gamma, max_new_tokens, logits_processor=None,
+       prefix_allowed_tokens_fn=None) -> Dict            <- beamSD.py:458-542
+  target_generate(model, inputs, max_new_tokens, logits_processor=None,
+       prefix_allowed_tokens_fn=None) -> Dict            <- beamSD.py:544-595
+  Timer(func="", sync_cuda=True, syn_device=0)            <- beamSD.py:12-37
+  beam_sd_generate = BSSD (name used by BASELINE.json's north star)
+
+Same positional order and the same result keys (`beam_sequence, beam_scores, n_run,
+total_accept_steps, total_accept_tokens, ave_accept_tokens, draft_time_cost,
+target_time_cost, verify_time_cost, time_cost`; consumed at `code/inference.py:179-187`).
+The models are `HipLlama` objects; the whole loop runs in libatspeed_hip
+(`atspeed_bssd_generate`) with one host read-back per verification round instead of the
+reference's per-beam mask calls and `.tolist()` syncs (beamSD.py:62-64,371-372).
+
+Not on this path (raise): sampling (`do_sample`, beamSD.py:293-321,332-369 — SURVEY 8a V'),
+extra `logits_processor` entries (the reference always passes None, inference.py:175-176),
+and mask callables that cannot be compiled to the device automaton.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .generation_trie import ConstraintFSM
+from .model import HipLlama
+
+
+class Timer:
+    """Context manager / decorator; as a decorator it injects `result["time_cost"]`."""
+
+    def __init__(self, func="", sync_cuda=True, syn_device=0):
+        self.func = func
+        self.sync_cuda = sync_cuda
+        self.syn_device = syn_device
+
+    def _sync(self):
+        if self.sync_cuda and torch.cuda.is_available():
+            torch.cuda.synchronize(self.syn_device)
+
+    def __enter__(self):
+        self.start = time.time()
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        self._sync()
+        self.time_cost = time.time() - self.start
+
+    def __call__(self, func):
+        def wrapper(*args, syn_device=None, **kwargs):
+            if syn_device is not None:
+                self.syn_device = syn_device
+            self.start = time.time()
+            result = func(*args, **kwargs)
+            self._sync()
+            self.time_cost = time.time() - self.start
+            result["time_cost"] = self.time_cost
+            return result
+        wrapper.__name__ = getattr(func, "__name__", "wrapped")
+        wrapper.__doc__ = func.__doc__
+        return wrapper
+
+
+# ---------------------------------------------------------------- device handles (cached)
+class _DeviceFSM:
+    """Device copy of a ConstraintFSM's CSR arrays (shared by every prompt; only the start node differs)."""
+    _cache: Dict[int, "_DeviceFSM"] = {}
+
+    def __init__(self, fsm: ConstraintFSM, vocab_size: int):
+        lib = _lib.load()
+        self.arrays = (np.ascontiguousarray(fsm.row_ptr, np.int32), np.ascontiguousarray(fsm.tok, np.int32),
+                       np.ascontiguousarray(fsm.nxt, np.int32))
+        h = C.c_void_p()
+        _lib.check(lib.atspeed_fsm_create(self.arrays[0].ctypes.data, self.arrays[1].ctypes.data, self.arrays[2].ctypes.data,
+                                          fsm.n_nodes, len(self.arrays[1]), vocab_size, C.byref(h)))
+        self.handle = h
+        self.src = fsm.row_ptr       # keeps id() stable while cached
+
+    @classmethod
+    def get(cls, fsm: ConstraintFSM, vocab_size: int) -> "_DeviceFSM":
+        key = (id(fsm.row_ptr), id(fsm.tok), vocab_size)
+        d = cls._cache.get(key)
+        if d is None or d.src is not fsm.row_ptr:
+            d = cls(fsm, vocab_size)
+            cls._cache[key] = d
+        return d
+
+
+class _Decoder:
+    _cache: Dict[tuple, "_Decoder"] = {}
+
+    def __init__(self, target: HipLlama, draft: Optional[HipLlama], max_prompt: int):
+        lib = _lib.load()
+        h = C.c_void_p()
+        with torch.cuda.device(target.device):
+            _lib.check(lib.atspeed_decoder_create(target._handle, draft._handle if draft is not None else None,
+                                                  max_prompt, C.byref(h)))
+        self.handle, self.max_prompt = h, max_prompt
+        self.models = (target, draft)
+
+    @classmethod
+    def get(cls, target: HipLlama, draft: Optional[HipLlama], prompt_len: int) -> "_Decoder":
+        key = (id(target), id(draft))
+        d = cls._cache.get(key)
+        if d is None or d.max_prompt < prompt_len or d.models[0] is not target or d.models[1] is not draft:
+            d = cls(target, draft, max(prompt_len, min(target.max_tokens, 512)))
+            cls._cache[key] = d
+        return d
+
+
+def _compile_constraint(fn, prompt):
+    if fn is None:
+        raise NotImplementedError(
+            "unconstrained beam search is not on the MI355X hot path: the reference's harness always installs a "
+            "prefix_allowed_tokens_fn (code/inference.py:131,175)")
+    if not hasattr(fn, "compile"):
+        raise TypeError(
+            "prefix_allowed_tokens_fn must be compilable to the device automaton: use atspeed_amd.PositionSetConstraint "
+            "(code/data.py:84-104), SuffixTrieConstraint or prefix_allowed_tokens_fn(trie); arbitrary Python callables "
+            "would need the reference's per-beam host round trip")
+    return fn.compile(prompt)
+
+
+def _check_models(*models):
+    for m in models:
+        if not isinstance(m, HipLlama):
+            raise TypeError("models must be atspeed_amd.HipLlama (use HipLlama.from_hf(model) for an HF module)")
+        if m.generation_config.do_sample:
+            raise NotImplementedError("sampling-mode verification (beamSD.py:293-321,332-369) is out of scope of this path")
+
+
+def _prompt_row(inputs) -> torch.Tensor:
+    ids = inputs["input_ids"]
+    if ids.dim() == 2:
+        ids = ids[0]            # the reference reads batch row 0 only (beamSD.py:57,203,224)
+    return ids
+
+
+def _result(prompt: torch.Tensor, toks: torch.Tensor, scores: torch.Tensor, k: int) -> Dict:
+    seq = torch.cat((prompt.to(torch.int64)[None, :].repeat(k, 1), toks.to(torch.int64)), dim=1)
+    return {"beam_sequence": seq, "beam_scores": scores}
+
+
+@Timer()
+@torch.no_grad()
+def BSSD(target_model, draft_model, inputs: Dict, gamma: int, max_new_tokens: int,
+         logits_processor=None, prefix_allowed_tokens_fn=None) -> Dict:
+    _check_models(target_model, draft_model)
+    if logits_processor is not None and len(logits_processor) != 0:
+        raise NotImplementedError("extra logits processors are not on this path (reference passes None)")
+    lib = _lib.load()
+    dev = target_model.device
+    prompt = _prompt_row(inputs).to(dev)
+    P = int(prompt.numel())
+    k = int(target_model.generation_config.num_beams)                 # beamSD.py:482
+    dk = int(draft_model.generation_config.num_beams)                 # beamSD.py:483
+    fsm = _compile_constraint(prefix_allowed_tokens_fn, prompt.tolist())
+    dfsm = _DeviceFSM.get(fsm, target_model.dims.vocab_size)
+    dec = _Decoder.get(target_model, draft_model, P)
+    with torch.cuda.device(dev):
+        ids32 = prompt.to(torch.int32).contiguous()
+        toks = torch.empty(k, max_new_tokens, dtype=torch.int32, device=dev)
+        scores = torch.empty(k, dtype=torch.float32, device=dev)
+        stats = _lib.GenStats()
+        _lib.check(lib.atspeed_bssd_generate(dec.handle, ids32.data_ptr(), P, dfsm.handle, fsm.start, int(gamma),
+                                             int(max_new_tokens), k, dk, toks.data_ptr(), scores.data_ptr(),
+                                             C.byref(stats), _lib.stream_ptr(dev)))
+    out = _result(prompt, toks, scores, k)
+    n_run = int(stats.n_run)
+    total = int(stats.total_accept_steps)
+    out.update({
+        "n_run": n_run,                                              # beamSD.py:527-541
+        "total_accept_steps": total,
+        "total_accept_tokens": total * k,
+        "ave_accept_tokens": total * k / n_run if n_run else 0.0,
+        "draft_time_cost": stats.draft_ms * 1e-3,
+        "target_time_cost": stats.target_ms * 1e-3,
+        "verify_time_cost": stats.verify_ms * 1e-3,
+        "device_time_cost": stats.total_ms * 1e-3,
+        "accept_steps": [int(stats.accept_steps[i]) for i in range(min(n_run, _lib.MAX_NEW_TOKENS))],
+        "n_valid": int(stats.n_valid),
+        "n_target_forwards": int(stats.n_target_forwards),
+        "n_draft_forwards": int(stats.n_draft_forwards),
+    })
+    return out
+
+
+beam_sd_generate = BSSD
+
+
+@Timer()
+@torch.no_grad()
+def target_generate(model, inputs: Dict, max_new_tokens: int, logits_processor=None,
+                    prefix_allowed_tokens_fn=None) -> Dict:
+    _check_models(model)
+    if logits_processor is not None and len(logits_processor) != 0:
+        raise NotImplementedError("extra logits processors are not on this path (reference passes None)")
+    lib = _lib.load()
+    dev = model.device
+    prompt = _prompt_row(inputs).to(dev)
+    P = int(prompt.numel())
+    k = int(model.generation_config.num_beams)                        # beamSD.py:553
+    fsm = _compile_constraint(prefix_allowed_tokens_fn, prompt.tolist())
+    dfsm = _DeviceFSM.get(fsm, model.dims.vocab_size)
+    dec = _Decoder.get(model, None, P)
+    with torch.cuda.device(dev):
+        ids32 = prompt.to(torch.int32).contiguous()
+        toks = torch.empty(k, max_new_tokens, dtype=torch.int32, device=dev)
+        scores = torch.empty(k, dtype=torch.float32, device=dev)
+        stats = _lib.GenStats()
+        _lib.check(lib.atspeed_target_generate(dec.handle, ids32.data_ptr(), P, dfsm.handle, fsm.start,
+                                               int(max_new_tokens), k, toks.data_ptr(), scores.data_ptr(),
+                                               C.byref(stats), _lib.stream_ptr(dev)))
+    out = _result(prompt, toks, scores, k)
+    out.update({"n_valid": int(stats.n_valid), "device_time_cost": stats.total_ms * 1e-3})
+    return out
+
+
+def last_trace(target_model, draft_model):
+    """Per-round trace of the last BSSD call on this model pair (parity tests):
+    list of dict(draft_len, n_matches, n_beams, draft_ids=[draft_len][dk])."""
+    lib = _lib.load()
+    dec = _Decoder._cache[(id(target_model), id(draft_model))]
+    n = lib.atspeed_decoder_trace(dec.handle, None, 0)
+    buf = (C.c_int32 * max(n, 1))()
+    lib.atspeed_decoder_trace(dec.handle, buf, n)
+    dk = int(draft_model.generation_config.num_beams)
+    rounds, i = [], 0
+    while i < n:
+        dl, nm, nb = buf[i], buf[i + 1], buf[i + 2]
+        i += 3
+        ids = [[int(buf[i + s * dk + j]) for j in range(dk)] for s in range(dl)]
+        i += dl * dk
+        rounds.append(dict(draft_len=int(dl), n_matches=int(nm), n_beams=int(nb), draft_ids=ids))
+    return rounds

@@ -1,0 +1,96 @@
+// Shared device helpers and host-side error plumbing for libatspeed_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/atspeed_hip.h"
+
+typedef unsigned short bf16_t;   // raw bf16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ---------------------------------------------------------------- host error plumbing
+void atspeed_set_error(const char* fmt, ...);
+
+#define ATS_HIP(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      atspeed_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return ATSPEED_ERR_HIP;                                                                      \
+    }                                                                                              \
+  } while (0)
+
+#define ATS_REQUIRE(cond, code, ...)     \
+  do {                                   \
+    if (!(cond)) {                       \
+      atspeed_set_error(__VA_ARGS__);    \
+      return (code);                     \
+    }                                    \
+  } while (0)
+
+#define ATS_LAUNCH_CHECK() ATS_HIP(hipGetLastError())
+
+#define ATS_TRY(expr)            \
+  do {                           \
+    int _s = (expr);             \
+    if (_s != ATSPEED_OK) return _s; \
+  } while (0)
+
+// ---------------------------------------------------------------- device helpers
+#if defined(__HIPCC__)
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                               // round to nearest even
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elt;
+template <> struct Elt<float> {
+  static constexpr int kPerChunk = 4;   // elements per 16-byte chunk
+  __device__ static __forceinline__ float load(const float* p) { return *p; }
+  __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct Elt<bf16_t> {
+  static constexpr int kPerChunk = 8;
+  __device__ static __forceinline__ float load(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), o, 64);
+    unsigned hi = __shfl_xor((unsigned)(v >> 32), o, 64);
+    unsigned long long w = ((unsigned long long)hi << 32) | lo;
+    v = w > v ? w : v;
+  }
+  return v;
+}
+
+// monotone float <-> uint32 map: a > b  <=>  ford(a) > ford(b)   (-inf -> 0x007fffff)
+__device__ __forceinline__ uint32_t ford(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ford_inv(uint32_t o) {
+  uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+#endif

@@ -1,0 +1,148 @@
+// Streaming kernels of the Llama forward: synthetic fill, embedding gather, RMSNorm,
+// RoPE + KV scatter.  All HBM-bound: 16-byte coalesced accesses, wave64 reductions.
+#include "internal.h"
+
+// ---------------------------------------------------------------------------- fill
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ uint32_t hash_u32(uint32_t idx, uint32_t seed) { return fmix32(idx * 0x9E3779B1u + seed); }
+
+template <typename T>
+__global__ void fill_hash_normal_kernel(T* dst, size_t n, uint32_t seed, float scale, float add, uint64_t offset) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint32_t idx = (uint32_t)(i + offset);
+    uint32_t h1 = hash_u32(idx, seed), h2 = hash_u32(idx, seed ^ 0x5BD1E995u);
+    int s = (int)((h1 & 0xffffu) + (h1 >> 16) + (h2 & 0xffffu) + (h2 >> 16)) - 131070;
+    float v = (float)s * scale;          // exact int->float, one fp32 multiply: matches numpy bit for bit
+    if (add != 0.0f) v = add + v;
+    Elt<T>::store(dst + i, v);
+  }
+}
+
+extern "C" int atspeed_fill_hash_normal(void* dst, size_t n, uint32_t seed, float scale, float add, int dtype,
+                                        uint64_t offset, void* stream) {
+  ATS_REQUIRE(dst && (dtype == ATSPEED_F32 || dtype == ATSPEED_BF16), ATSPEED_ERR_INVALID, "fill: bad arguments");
+  if (n == 0) return ATSPEED_OK;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == ATSPEED_F32)
+    fill_hash_normal_kernel<float><<<(unsigned)blocks, 256, 0, st>>>((float*)dst, n, seed, scale, add, offset);
+  else
+    fill_hash_normal_kernel<bf16_t><<<(unsigned)blocks, 256, 0, st>>>((bf16_t*)dst, n, seed, scale, add, offset);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+// ---------------------------------------------------------------------------- embed
+// one 16-byte chunk per thread; a token row is hidden*sizeof(T) contiguous bytes
+__global__ void embed_kernel(const uint4* __restrict__ table, const int32_t* __restrict__ ids, uint4* __restrict__ out,
+                             int n_tokens, int chunks_per_row, int vocab) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int total = n_tokens * chunks_per_row;
+  if (i >= total) return;
+  int t = i / chunks_per_row, c = i - t * chunks_per_row;
+  int id = ids[t];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  out[i] = table[(size_t)id * chunks_per_row + c];
+}
+
+int ats_embed(const void* table, const int32_t* ids, void* out, int n_tokens, int hidden, int vocab, int dtype,
+              hipStream_t st) {
+  int esz = dtype == ATSPEED_F32 ? 4 : 2;
+  int cpr = hidden * esz / 16;
+  int total = n_tokens * cpr;
+  embed_kernel<<<(total + 255) / 256, 256, 0, st>>>((const uint4*)table, ids, (uint4*)out, n_tokens, cpr, vocab);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+// ---------------------------------------------------------------------------- rmsnorm
+// one workgroup per row; fp32 statistics (HF LlamaRMSNorm upcasts); y = w * (x * rsqrt(mean(x^2)+eps))
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y,
+                                                      int hidden, float eps) {
+  __shared__ float red[4];
+  const T* xr = x + (size_t)blockIdx.x * hidden;
+  T* yr = y + (size_t)blockIdx.x * hidden;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < hidden; i += 256) { float v = Elt<T>::load(xr + i); ss += v * v; }
+  ss = wave_sum_f32(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  float tot = red[0] + red[1] + red[2] + red[3];
+  float rs = rsqrtf(tot / (float)hidden + eps);
+  for (int i = threadIdx.x; i < hidden; i += 256) {
+    float v = Elt<T>::load(xr + i) * rs;
+    if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));    // HF casts the normalised value to the input dtype first
+    Elt<T>::store(yr + i, Elt<T>::load(w + i) * v);
+  }
+}
+
+int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, float eps, int dtype, hipStream_t st) {
+  if (rows <= 0) return ATSPEED_OK;
+  if (dtype == ATSPEED_F32)
+    rmsnorm_kernel<float><<<rows, 256, 0, st>>>((const float*)x, (const float*)w, (float*)y, hidden, eps);
+  else
+    rmsnorm_kernel<bf16_t><<<rows, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, hidden, eps);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+extern "C" int atspeed_rmsnorm(const void* x, const void* w, void* y, int32_t rows, int32_t hidden, float eps,
+                               int32_t dtype, void* stream) {
+  ATS_REQUIRE(x && w && y && hidden > 0, ATSPEED_ERR_INVALID, "rmsnorm: bad arguments");
+  return ats_rmsnorm(x, w, y, rows, hidden, eps, dtype, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------- rope + kv scatter
+// rotate-half convention of HF Llama: pairs (i, i + dh/2); cos/sin tables [max_pos][dh/2] fp32.
+// thread = (token, head, pair i): rotates q in place, writes rotated k and v to the cache slot.
+template <typename T>
+__global__ void rope_kv_kernel(T* __restrict__ qkv, const int32_t* __restrict__ pos, const int32_t* __restrict__ slots,
+                               const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+                               T* __restrict__ kcache, T* __restrict__ vcache, int n_tokens, int n_heads, int head_dim,
+                               int max_pos) {
+  int half = head_dim >> 1;
+  int hidden = n_heads * head_dim;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int total = n_tokens * n_heads * half;
+  if (i >= total) return;
+  int p = i % half;
+  int h = (i / half) % n_heads;
+  int t = i / (half * n_heads);
+  int ps = pos[t];
+  ps = ps < 0 ? 0 : (ps >= max_pos ? max_pos - 1 : ps);
+  float c = cos_tab[(size_t)ps * half + p], s = sin_tab[(size_t)ps * half + p];
+  T* row = qkv + (size_t)t * 3 * hidden;
+  int d0 = h * head_dim + p, d1 = d0 + half;
+  float q0 = Elt<T>::load(row + d0), q1 = Elt<T>::load(row + d1);
+  Elt<T>::store(row + d0, q0 * c - q1 * s);
+  Elt<T>::store(row + d1, q1 * c + q0 * s);
+  float k0 = Elt<T>::load(row + hidden + d0), k1 = Elt<T>::load(row + hidden + d1);
+  size_t co = (size_t)slots[t] * hidden;
+  Elt<T>::store(kcache + co + d0, k0 * c - k1 * s);
+  Elt<T>::store(kcache + co + d1, k1 * c + k0 * s);
+  vcache[co + d0] = row[2 * hidden + d0];
+  vcache[co + d1] = row[2 * hidden + d1];
+}
+
+int ats_rope_kv(void* qkv, const int32_t* pos, const int32_t* slots, const float* cos_tab, const float* sin_tab,
+                void* kcache, void* vcache, int n_tokens, int n_heads, int head_dim, int max_pos, int dtype,
+                hipStream_t st) {
+  int total = n_tokens * n_heads * (head_dim / 2);
+  if (total <= 0) return ATSPEED_OK;
+  if (dtype == ATSPEED_F32)
+    rope_kv_kernel<float><<<(total + 255) / 256, 256, 0, st>>>((float*)qkv, pos, slots, cos_tab, sin_tab, (float*)kcache,
+                                                                (float*)vcache, n_tokens, n_heads, head_dim, max_pos);
+  else
+    rope_kv_kernel<bf16_t><<<(total + 255) / 256, 256, 0, st>>>((bf16_t*)qkv, pos, slots, cos_tab, sin_tab,
+                                                                 (bf16_t*)kcache, (bf16_t*)vcache, n_tokens, n_heads,
+                                                                 head_dim, max_pos);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}

@@ -1,0 +1,345 @@
+// Projection GEMMs of the draft / target forward on the CDNA4 matrix cores.
+//
+//   C[M,N] (+)= A[M,K] * W[N,K]^T      A, W row-major with K contiguous (HF nn.Linear layout)
+//
+// M is the number of tokens in the forward (<= a few hundred: prompt + gamma*DK draft beams),
+// so every launch streams the weight matrix W exactly once from HBM and is bound by that
+// stream: algorithmic bytes = N*K*sizeof(T) (+ the small A and C).  Structure:
+//   * workgroup = 256 threads = 4 waves, tile BM x 128 x (128 bytes of K), LDS double buffered,
+//     register-staged 16-byte global loads issued one tile ahead of the MFMAs;
+//   * LDS rows are 128 B; 16-B chunk c of row r is stored at chunk c ^ (r & 7) so that the
+//     ds_read_b128 fragment reads of 16 consecutive rows spread over all banks;
+//   * bf16: v_mfma_f32_16x16x32_bf16 (A/B fragment = 8 consecutive k of one row = one chunk);
+//     f32 (parity mode): v_mfma_f32_16x16x4_f32 with the k order permuted so that a lane's
+//     four k-steps come from one 16-byte chunk (same permutation on A and W);
+//   * split-K over blockIdx.z into fp32 partial slabs when M*N tiles alone cannot fill the
+//     256 CUs; a second kernel reduces the slabs and applies the epilogue.
+// Epilogues: store (dtype), fp32 store (logits), residual add, SwiGLU over interleaved
+// gate/up 16-column groups.
+#include "internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRowBytes = 128;      // bytes of K per LDS row
+constexpr int kChunks = 8;          // 16-byte chunks per row
+
+template <typename T> struct GemmTraits;
+template <> struct GemmTraits<bf16_t> { static constexpr int BK = 64; static constexpr int EPC = 8; };
+template <> struct GemmTraits<float>  { static constexpr int BK = 32; static constexpr int EPC = 4; };
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row * kChunks + (chunk ^ (row & 7))) * 16; }
+
+template <typename T, int BM, int BN, int WM, int WN>
+struct TileCfg {
+  static constexpr int MI = BM / WM / 16;
+  static constexpr int NI = BN / WN / 16;
+  static constexpr int A_CHUNKS = BM * kChunks;
+  static constexpr int W_CHUNKS = BN * kChunks;
+  static constexpr int A_PER_THREAD = (A_CHUNKS + kThreads - 1) / kThreads;
+  static constexpr int W_PER_THREAD = (W_CHUNKS + kThreads - 1) / kThreads;
+  static constexpr int STAGE_BYTES = (BM + BN) * kRowBytes;
+};
+
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool SPLIT>
+__global__ __launch_bounds__(kThreads) void gemm_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                        void* __restrict__ Cv, int M, int N, int K, int lda, int ldc,
+                                                        int k_per_split, float* __restrict__ partial) {
+  using Cfg = TileCfg<T, BM, BN, WM, WN>;
+  constexpr int BK = GemmTraits<T>::BK;
+  constexpr int EPC = GemmTraits<T>::EPC;
+  constexpr int MI = Cfg::MI, NI = Cfg::NI;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kz0 = blockIdx.z * k_per_split;
+  const int kz1 = min(K, kz0 + k_per_split);
+  const int n_ktiles = (kz1 - kz0 + BK - 1) / BK;
+
+  uint4 ra[Cfg::A_PER_THREAD], rw[Cfg::W_PER_THREAD];
+
+  auto load_tile = [&](int kt) {
+    const int kbase = kz0 + kt * BK;
+#pragma unroll
+    for (int i = 0; i < Cfg::A_PER_THREAD; ++i) {
+      int q = tid + i * kThreads;
+      if (q < Cfg::A_CHUNKS) {
+        int r = q >> 3, c = q & 7;
+        int gm = min(m0 + r, M - 1);
+        int gk = kbase + c * EPC;
+        ra[i] = (gk < kz1) ? *reinterpret_cast<const uint4*>(A + (size_t)gm * lda + gk) : make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::W_PER_THREAD; ++i) {
+      int q = tid + i * kThreads;
+      if (q < Cfg::W_CHUNKS) {
+        int r = q >> 3, c = q & 7;
+        int gn = min(n0 + r, N - 1);
+        int gk = kbase + c * EPC;
+        rw[i] = (gk < kz1) ? *reinterpret_cast<const uint4*>(W + (size_t)gn * K + gk) : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* sa = smem + buf * Cfg::STAGE_BYTES;
+    unsigned char* sw = sa + BM * kRowBytes;
+#pragma unroll
+    for (int i = 0; i < Cfg::A_PER_THREAD; ++i) {
+      int q = tid + i * kThreads;
+      if (q < Cfg::A_CHUNKS) *reinterpret_cast<uint4*>(sa + swz(q >> 3, q & 7)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::W_PER_THREAD; ++i) {
+      int q = tid + i * kThreads;
+      if (q < Cfg::W_CHUNKS) *reinterpret_cast<uint4*>(sw + swz(q >> 3, q & 7)) = rw[i];
+    }
+  };
+
+  f32x4_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  if (n_ktiles > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  const int frow = lane & 15, fk = lane >> 4;
+  for (int kt = 0; kt < n_ktiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < n_ktiles) load_tile(kt + 1);        // global loads in flight under the MFMAs
+    const unsigned char* sa = smem + buf * Cfg::STAGE_BYTES + (wm * (BM / WM)) * kRowBytes;
+    const unsigned char* sw = smem + buf * Cfg::STAGE_BYTES + BM * kRowBytes + (wn * (BN / WN)) * kRowBytes;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {                // two k-steps of 32
+        s16x8_t af[MI], bfr[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const s16x8_t*>(sa + swz(i * 16 + frow, ks * 4 + fk));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const s16x8_t*>(sw + swz(j * 16 + frow, ks * 4 + fk));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
+                                                                __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {                // two groups of 16 k: lane group g owns chunk ks*4+g
+        f32x4_t af[MI], bfr[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const f32x4_t*>(sa + swz(i * 16 + frow, ks * 4 + fk));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const f32x4_t*>(sw + swz(j * 16 + frow, ks * 4 + fk));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < n_ktiles) store_tile(buf ^ 1);       // other buffer: nobody reads it this iteration
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
+  const int crow = (lane >> 4) * 4, ccol = lane & 15;
+  const int wrow0 = m0 + wm * (BM / WM), wcol0 = n0 + wn * (BN / WN);
+  if constexpr (SPLIT) {
+    float* P = partial + (size_t)blockIdx.z * M * N;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int gm = wrow0 + i * 16 + crow + r, gn = wcol0 + j * 16 + ccol;
+          if (gm < M && gn < N) P[(size_t)gm * N + gn] = acc[i][j][r];
+        }
+  } else if constexpr (EPI == EPI_SWIGLU) {
+    T* C = reinterpret_cast<T*>(Cv);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; j += 2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int gm = wrow0 + i * 16 + crow + r, gn = wcol0 + j * 16;      // gate group start (multiple of 32)
+          if (gm < M && gn < N) {
+            float g = acc[i][j][r], u = acc[i][j + 1][r];
+            if constexpr (sizeof(T) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
+            float s = g / (1.f + __expf(-g));
+            Elt<T>::store(C + (size_t)gm * ldc + (gn >> 1) + ccol, s * u);
+          }
+        }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int gm = wrow0 + i * 16 + crow + r, gn = wcol0 + j * 16 + ccol;
+          if (gm < M && gn < N) {
+            float v = acc[i][j][r];
+            if constexpr (EPI == EPI_F32) {
+              reinterpret_cast<float*>(Cv)[(size_t)gm * ldc + gn] = v;
+            } else if constexpr (EPI == EPI_RESID) {
+              T* C = reinterpret_cast<T*>(Cv);
+              if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));           // HF: o_proj output is bf16 before the add
+              Elt<T>::store(C + (size_t)gm * ldc + gn, Elt<T>::load(C + (size_t)gm * ldc + gn) + v);
+            } else {
+              Elt<T>::store(reinterpret_cast<T*>(Cv) + (size_t)gm * ldc + gn, v);
+            }
+          }
+        }
+  }
+}
+
+// sum the split-K slabs and apply the epilogue; one thread per output element (pair for SwiGLU)
+template <typename T, int EPI>
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, void* __restrict__ Cv, int M, int N, int ldc,
+                                     int splits) {
+  const size_t mn = (size_t)M * N;
+  if constexpr (EPI == EPI_SWIGLU) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over M * N/2 outputs
+    size_t tot = (size_t)M * (N / 2);
+    if (i >= tot) return;
+    int m = (int)(i / (N / 2)), o = (int)(i % (N / 2));
+    int grp = o >> 4, c = o & 15;
+    size_t gi = (size_t)m * N + grp * 32 + c, ui = gi + 16;
+    float g = 0.f, u = 0.f;
+    for (int z = 0; z < splits; ++z) { g += partial[z * mn + gi]; u += partial[z * mn + ui]; }
+    if constexpr (sizeof(T) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
+    float s = g / (1.f + __expf(-g));
+    Elt<T>::store(reinterpret_cast<T*>(Cv) + (size_t)m * ldc + o, s * u);
+  } else {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= mn) return;
+    int m = (int)(i / N), n = (int)(i % N);
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += partial[z * mn + i];
+    if constexpr (EPI == EPI_F32) {
+      reinterpret_cast<float*>(Cv)[(size_t)m * ldc + n] = v;
+    } else if constexpr (EPI == EPI_RESID) {
+      T* C = reinterpret_cast<T*>(Cv);
+      if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
+      Elt<T>::store(C + (size_t)m * ldc + n, Elt<T>::load(C + (size_t)m * ldc + n) + v);
+    } else {
+      Elt<T>::store(reinterpret_cast<T*>(Cv) + (size_t)m * ldc + n, v);
+    }
+  }
+}
+
+struct Plan { int bm; int splits; int k_per_split; };
+
+template <typename T>
+Plan make_plan(int m, int n, int k) {
+  constexpr int BK = GemmTraits<T>::BK;
+  Plan p;
+  p.bm = m <= 16 ? 16 : (m <= 32 ? 32 : (m <= 64 ? 64 : 128));
+  int tiles = ((m + p.bm - 1) / p.bm) * ((n + 127) / 128);
+  int ktiles = (k + BK - 1) / BK;
+  int splits = 1;
+  if (tiles < 192) {
+    splits = (384 + tiles - 1) / tiles;
+    int max_splits = ktiles / 4;              // keep >= 4 k-tiles per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 16) splits = 16;
+    if (splits < 1) splits = 1;
+  }
+  int kps = ((ktiles + splits - 1) / splits) * BK;
+  p.splits = (k + kps - 1) / kps;
+  p.k_per_split = kps;
+  return p;
+}
+
+template <typename T, int BM, int WM, int WN, int EPI>
+int launch_cfg(const T* a, const T* w, void* c, int m, int n, int k, int lda, int ldc, const Plan& p, float* partial,
+               hipStream_t st) {
+  constexpr int BN = 128;
+  using Cfg = TileCfg<T, BM, BN, WM, WN>;
+  dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM, p.splits);
+  size_t lds = 2 * Cfg::STAGE_BYTES;
+  if (p.splits > 1) {
+    auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI, true>;
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a, w, c, m, n, k, lda, ldc, p.k_per_split, partial);
+    ATS_LAUNCH_CHECK();
+    size_t outs = EPI == EPI_SWIGLU ? (size_t)m * (n / 2) : (size_t)m * n;
+    splitk_reduce_kernel<T, EPI><<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(partial, c, m, n, ldc, p.splits);
+    ATS_LAUNCH_CHECK();
+  } else {
+    auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI, false>;
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a, w, c, m, n, k, lda, ldc, p.k_per_split, partial);
+    ATS_LAUNCH_CHECK();
+  }
+  return ATSPEED_OK;
+}
+
+template <typename T, int EPI>
+int launch_epi(const T* a, const T* w, void* c, int m, int n, int k, int lda, int ldc, float* partial, size_t ws_bytes,
+               hipStream_t st) {
+  Plan p = make_plan<T>(m, n, k);
+  if (p.splits > 1 && (size_t)p.splits * m * n * sizeof(float) > ws_bytes) {   // not enough workspace: no split
+    p.splits = 1;
+    p.k_per_split = ((k + GemmTraits<T>::BK - 1) / GemmTraits<T>::BK) * GemmTraits<T>::BK;
+  }
+  switch (p.bm) {
+    case 16:  return launch_cfg<T, 16, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st);
+    case 32:  return launch_cfg<T, 32, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st);
+    case 64:  return launch_cfg<T, 64, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st);
+    default:  return launch_cfg<T, 128, 2, 2, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st);
+  }
+}
+
+template <typename T>
+int launch_typed(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int epi, void* ws,
+                 size_t ws_bytes, hipStream_t st) {
+  const T* A = (const T*)a; const T* Wt = (const T*)w; float* P = (float*)ws;
+  switch (epi) {
+    case EPI_STORE:  return launch_epi<T, EPI_STORE>(A, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
+    case EPI_F32:    return launch_epi<T, EPI_F32>(A, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
+    case EPI_RESID:  return launch_epi<T, EPI_RESID>(A, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
+    case EPI_SWIGLU: return launch_epi<T, EPI_SWIGLU>(A, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
+  }
+  atspeed_set_error("gemm: unknown epilogue %d", epi);
+  return ATSPEED_ERR_INVALID;
+}
+
+}  // namespace
+
+size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype) {
+  Plan p = dtype == ATSPEED_F32 ? make_plan<float>(m, n, k) : make_plan<bf16_t>(m, n, k);
+  return p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
+}
+
+int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int dtype, int epilogue,
+             void* workspace, size_t workspace_bytes, hipStream_t st) {
+  if (m <= 0 || n <= 0) return ATSPEED_OK;
+  int epc = dtype == ATSPEED_F32 ? 4 : 8;
+  ATS_REQUIRE(a && w && c && k > 0, ATSPEED_ERR_INVALID, "gemm: null operand");
+  ATS_REQUIRE(k % epc == 0 && lda % epc == 0, ATSPEED_ERR_INVALID, "gemm: K=%d / lda=%d must be multiples of %d", k, lda, epc);
+  ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "gemm: operands must be 16-byte aligned");
+  ATS_REQUIRE(epilogue != EPI_SWIGLU || n % 32 == 0, ATSPEED_ERR_INVALID, "gemm: SwiGLU needs N %% 32 == 0 (N=%d)", n);
+  if (dtype == ATSPEED_F32) return launch_typed<float>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st);
+  if (dtype == ATSPEED_BF16) return launch_typed<bf16_t>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st);
+  atspeed_set_error("gemm: unknown dtype %d", dtype);
+  return ATSPEED_ERR_INVALID;
+}
+
+extern "C" int atspeed_gemm(const void* a, const void* w, void* c, int32_t m, int32_t n, int32_t k, int32_t lda,
+                            int32_t ldc, int32_t dtype, int32_t epilogue, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+  return ats_gemm(a, w, c, m, n, k, lda, ldc, dtype, epilogue, workspace, workspace_bytes, (hipStream_t)stream);
+}

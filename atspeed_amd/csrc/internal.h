@@ -1,0 +1,93 @@
+// Internal host-side interfaces between the translation units of libatspeed_hip.
+#pragma once
+#include "common.h"
+
+// ---- fill.hip / elementwise.hip -------------------------------------------------------
+int ats_embed(const void* table, const int32_t* ids, void* out, int n_tokens, int hidden, int vocab, int dtype,
+              hipStream_t st);
+int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, float eps, int dtype, hipStream_t st);
+// rotate q and k in place inside the fused qkv buffer ([T][3*hidden]) and scatter k,v to the cache slots
+int ats_rope_kv(void* qkv, const int32_t* pos, const int32_t* slots, const float* cos_tab, const float* sin_tab,
+                void* kcache, void* vcache, int n_tokens, int n_heads, int head_dim, int max_pos, int dtype,
+                hipStream_t st);
+
+// ---- gemm.hip -------------------------------------------------------------------------
+enum { EPI_STORE = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_SWIGLU = 3 };
+size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype);
+int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int dtype, int epilogue,
+             void* workspace, size_t workspace_bytes, hipStream_t st);
+
+// ---- attn.hip -------------------------------------------------------------------------
+int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* vcache, const uint64_t* vis,
+                       int vis_words, void* out, int ldo, int n_tokens, int n_slots, int n_heads, int head_dim,
+                       int dtype, hipStream_t st);
+
+// ---- scan.hip -------------------------------------------------------------------------
+struct FsmDev {
+  const int32_t* row_ptr;
+  const int32_t* tok;
+  const int32_t* nxt;
+  int32_t n_nodes, n_edges, vocab;
+};
+struct atspeed_fsm {
+  FsmDev dev;
+  int32_t *d_row_ptr, *d_tok, *d_nxt;
+};
+
+struct TokBuf {       // inputs of a forward: one row per token
+  int32_t* ids;
+  int32_t* pos;
+  int32_t* slot;
+  uint64_t* vis;      // [rows][W]
+};
+struct BeamSet {      // a block of beams (round beams or one draft step's output)
+  float* score;       // [MAXB]
+  int32_t* node;      // [MAXB] FSM node after the beam's last token
+  int32_t* seq;       // [MAXB][ATSPEED_MAX_NEW_TOKENS] generated suffix
+  int32_t* parent;    // [MAXB] index into the previous block
+  int32_t* tok;       // [MAXB]
+  int32_t* flat;      // [MAXB] parent*V + tok, -1 = not a beam
+};
+struct Mailbox {      // device -> host, one per round
+  int32_t n_matches;
+  int32_t status;     // 0 ok, ATSPEED_ERR_*
+  int32_t n_valid;
+  int32_t pad;
+};
+
+int ats_lse_rows(const float* logits, int n_rows, int vocab, int ld, float* lse, hipStream_t st);
+
+struct BeamStepArgs {
+  BeamSet src;  int n_src;  int gen_len;     // beams being expanded; tokens generated so far
+  const float* logits;  int ld;  const float* lse;
+  FsmDev fsm;
+  int k;
+  BeamSet dst;
+  int emit;                                   // write next-step inputs?
+  TokBuf in;   int in_row0;                   // rows of the src beams (for parent vis/pos)
+  TokBuf out;  int out_row0;  int out_slot0;  int vis_words;
+  Mailbox* mail;                              // status only
+};
+int ats_beam_step(const BeamStepArgs& a, hipStream_t st);
+
+struct VerifyArgs {
+  BeamSet blk[ATSPEED_MAX_GAMMA + 1];         // blk[0] round beams, blk[i] draft step i
+  int nb, dl, k, dk, gen_len0;
+  const float* logits;  int ld;  const float* lse;   // rows: block 0 (nb), then dl blocks of dk
+  FsmDev fsm;
+  TokBuf cur;  int n0;                        // packed target inputs of this round
+  TokBuf next;                                // next round's target inputs (k rows)
+  TokBuf dnext;                               // draft re-ingest inputs (dk + k rows) when everything was accepted
+  int vis_words;
+  BeamSet res;                                // new round beams (k)
+  Mailbox* mail;
+};
+int ats_verify_walk(const VerifyArgs& a, hipStream_t st);
+
+int ats_init_prompt(TokBuf tb, const int32_t* prompt, int prompt_len, int vis_words, BeamSet beams, int start_node,
+                    int vocab, Mailbox* mail, hipStream_t st);
+// out_tokens[k][max_new] / out_scores[k] from a beam set
+int ats_export_beams(BeamSet b, int k, int max_new, int32_t* out_tokens, float* out_scores, hipStream_t st);
+
+int ats_accept(const int32_t* target_flat, const float* target_score, int k, const int32_t* draft_flat, int dk,
+               int32_t* hit, float* score_by_hit, int32_t* accept, hipStream_t st);

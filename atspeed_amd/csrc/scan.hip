@@ -1,0 +1,439 @@
+// Scan kernels of beam speculative decoding: full-vocabulary log-sum-exp, fused
+// constraint-mask + beam expand + top-K prune, the top-K-aligned acceptance test, and the
+// on-device bookkeeping (visibility bitsets, positions, KV slots, beam suffixes) that the
+// reference does with host round trips (beamSD.py:58-91, :278-380, :383-416).
+//
+// Candidate keys are 64-bit: (monotone(score) << 32) | ~flat_id, so an unsigned max gives
+// "highest score first, lowest flat id on ties" — the tie-break this build defines
+// (torch.topk leaves it unspecified).  Key 0 = no candidate.
+#include "internal.h"
+
+namespace {
+
+constexpr int kScanThreads = 1024;
+constexpr int kScanWaves = kScanThreads / 64;
+constexpr int kCPT = 16;                               // candidate slots per thread
+constexpr int kMaxCand = kScanThreads * kCPT;          // 16384 >= 64 beams * 256 children
+constexpr int MAXB = ATSPEED_MAX_BEAMS;
+constexpr int LMAX = ATSPEED_MAX_NEW_TOKENS;
+constexpr uint32_t kOrdNegInf = 0x007fffffu;           // ford(-inf)
+
+// ---------------------------------------------------------------------------- LSE
+// one workgroup per row, float4 streaming reads, online (max, sum) per lane
+__global__ __launch_bounds__(1024) void lse_rows_kernel(const float* __restrict__ logits, int vocab, int ld,
+                                                        float* __restrict__ lse) {
+  __shared__ float smax[16], ssum[16];
+  const float* row = logits + (size_t)blockIdx.x * ld;
+  float m = -INFINITY, s = 0.f;
+  const int nv4 = vocab >> 2;
+  const float4* row4 = reinterpret_cast<const float4*>(row);
+  for (int i = threadIdx.x; i < nv4; i += 1024) {
+    float4 v = row4[i];
+    float mm = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    if (mm > m) { s *= expf(m - mm); m = mm; }
+    s += expf(v.x - m) + expf(v.y - m) + expf(v.z - m) + expf(v.w - m);
+  }
+  for (int i = (nv4 << 2) + threadIdx.x; i < vocab; i += 1024) {
+    float v = row[i];
+    if (v > m) { s *= expf(m - v); m = v; }
+    s += expf(v - m);
+  }
+  float wm = wave_max_f32(m);
+  s = (m == -INFINITY) ? 0.f : s * expf(m - wm);
+  s = wave_sum_f32(s);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { smax[wave] = wm; ssum[wave] = s; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float gm = smax[0];
+    for (int w = 1; w < 16; ++w) gm = fmaxf(gm, smax[w]);
+    float gs = 0.f;
+    for (int w = 0; w < 16; ++w) gs += (smax[w] == -INFINITY) ? 0.f : ssum[w] * expf(smax[w] - gm);
+    lse[blockIdx.x] = gm + logf(gs);
+  }
+}
+
+// ---------------------------------------------------------------------------- block top-k
+struct TopkShared {
+  unsigned long long wtop[kScanWaves][MAXB];
+  unsigned long long sel[MAXB];
+};
+
+template <int NK>
+__device__ __forceinline__ unsigned long long wave_topk_rounds(unsigned long long (&keys)[NK], int k,
+                                                               unsigned long long* out, int lane) {
+  // k rounds of wave-argmax; the owner lane retires its key. returns nothing useful.
+  for (int j = 0; j < k; ++j) {
+    unsigned long long m = 0;
+#pragma unroll
+    for (int c = 0; c < NK; ++c) m = keys[c] > m ? keys[c] : m;
+    unsigned long long M = wave_max_u64(m);
+    if (M == 0) {                                   // wave-uniform: nothing left
+      for (int jj = j + lane; jj < k; jj += 64) out[jj] = 0;
+      break;
+    }
+    if (m == M) {
+#pragma unroll
+      for (int c = 0; c < NK; ++c) if (keys[c] == M) keys[c] = 0;
+    }
+    if (lane == 0) out[j] = M;
+  }
+  return 0;
+}
+
+// every thread passes its kCPT candidate keys; afterwards sh.sel[0..k) holds the k largest, descending
+__device__ void block_topk(unsigned long long (&keys)[kCPT], int k, TopkShared& sh) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  wave_topk_rounds<kCPT>(keys, k, sh.wtop[wave], lane);
+  __syncthreads();
+  if (wave == 0) {
+    unsigned long long k2[kScanWaves];
+#pragma unroll
+    for (int c = 0; c < kScanWaves; ++c) {
+      int e = lane + 64 * c;                         // < 16*64
+      k2[c] = (e < kScanWaves * k) ? sh.wtop[e / k][e % k] : 0ull;
+    }
+    wave_topk_rounds<kScanWaves>(k2, k, sh.sel, lane);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int find_edge(const FsmDev& f, int node, int tok) {
+  int lo = f.row_ptr[node], hi = f.row_ptr[node + 1];
+  while (lo < hi) {                                   // children strictly ascending
+    int mid = (lo + hi) >> 1;
+    int t = f.tok[mid];
+    if (t == tok) return mid;
+    if (t < tok) lo = mid + 1; else hi = mid;
+  }
+  return -1;
+}
+
+struct ExpandShared {
+  TopkShared topk;
+  int off[MAXB + 1];
+  int node[MAXB];
+  int brow[MAXB];       // row index inside the block (parent id space)
+  int lrow[MAXB];       // row index inside the logits buffer
+  float bscore[MAXB];
+  float lse[MAXB];
+  int status;
+};
+
+// Expand n_rows parent rows (sh.node/brow/lrow/bscore filled by the caller, first n_rows entries)
+// through the FSM and leave the k best candidates in sh.topk.sel.  beamSD.py:58-78.
+__device__ void expand_and_select(ExpandShared& sh, int n_rows, const float* __restrict__ logits, int ld,
+                                  const float* __restrict__ lse, const FsmDev& fsm, int k) {
+  const int tid = threadIdx.x;
+  if (tid < n_rows) sh.lse[tid] = lse[sh.lrow[tid]];
+  if (tid == 0) {
+    int tot = 0;
+    for (int r = 0; r < n_rows; ++r) {
+      sh.off[r] = tot;
+      int nd = sh.node[r];
+      int deg = fsm.row_ptr[nd + 1] - fsm.row_ptr[nd];
+      bool live = sh.bscore[r] > -INFINITY;
+      if (live && deg == 0) sh.status = ATSPEED_ERR_CONSTRAINT;   // HF: "returned an empty list" ValueError
+      tot += live ? deg : 0;
+    }
+    sh.off[n_rows] = tot;
+    if (tot > kMaxCand) sh.status = ATSPEED_ERR_CAPACITY;
+  }
+  __syncthreads();
+  const int total = min(sh.off[n_rows], kMaxCand);
+  unsigned long long keys[kCPT];
+#pragma unroll
+  for (int i = 0; i < kCPT; ++i) {
+    int c = tid + i * kScanThreads;
+    unsigned long long key = 0;
+    if (c < total) {
+      int lo = 0, hi = n_rows;                        // last r with off[r] <= c
+      while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (sh.off[mid] <= c) lo = mid; else hi = mid; }
+      int r = lo;
+      int e = fsm.row_ptr[sh.node[r]] + (c - sh.off[r]);
+      int tok = fsm.tok[e];
+      float sc = (logits[(size_t)sh.lrow[r] * ld + tok] - sh.lse[r]) + sh.bscore[r];
+      uint32_t o = ford(sc);
+      uint32_t flat = (uint32_t)sh.brow[r] * (uint32_t)fsm.vocab + (uint32_t)tok;
+      if (o > kOrdNegInf || sc != sc) key = ((unsigned long long)o << 32) | (unsigned long long)(~flat);
+    }
+    keys[i] = key;
+  }
+  block_topk(keys, k, sh.topk);
+}
+
+struct Pick { float score; int parent; int tok; int node; int flat; };
+
+__device__ __forceinline__ Pick decode_pick(unsigned long long key, const FsmDev& fsm, const int* rows_brow,
+                                            const int* rows_node, int n_rows) {
+  Pick p;
+  if (key == 0) { p.score = -INFINITY; p.parent = 0; p.tok = 0; p.node = 0; p.flat = -1; return p; }
+  uint32_t flat = ~(uint32_t)(key & 0xffffffffull);
+  p.flat = (int)flat;
+  p.parent = (int)(flat / (uint32_t)fsm.vocab);
+  p.tok = (int)(flat % (uint32_t)fsm.vocab);
+  p.score = ford_inv((uint32_t)(key >> 32));
+  int nd = 0;
+  for (int r = 0; r < n_rows; ++r) if (rows_brow[r] == p.parent) { nd = rows_node[r]; break; }
+  int e = find_edge(fsm, nd, p.tok);
+  p.node = e >= 0 ? fsm.nxt[e] : 0;
+  return p;
+}
+
+// write a block of k new beams + (optionally) the forward inputs that feed them next
+__device__ void emit_block(const Pick& pk, int j, int k, const BeamSet& src, int gen_len, const BeamSet& dst, bool emit,
+                           const TokBuf& in, int in_row0, const TokBuf& out, int out_row0, int out_slot0, int W) {
+  if (j < k) {
+    dst.score[j] = pk.score; dst.parent[j] = pk.parent; dst.tok[j] = pk.tok; dst.node[j] = pk.node; dst.flat[j] = pk.flat;
+    if (dst.seq) {
+      for (int g = 0; g < gen_len; ++g) dst.seq[j * LMAX + g] = src.seq ? src.seq[pk.parent * LMAX + g] : 0;
+      if (gen_len < LMAX) dst.seq[j * LMAX + gen_len] = pk.tok;
+    }
+    if (emit) {
+      out.ids[out_row0 + j] = pk.tok;
+      out.pos[out_row0 + j] = in.pos[in_row0 + pk.parent] + 1;
+      out.slot[out_row0 + j] = out_slot0 + j;
+    }
+  }
+}
+__device__ void emit_vis(const int* parents /*LDS*/, int k, const TokBuf& in, int in_row0, const TokBuf& out,
+                         int out_row0, int out_slot0, int W) {
+  for (int idx = threadIdx.x; idx < k * W; idx += blockDim.x) {
+    int j = idx / W, w = idx - j * W;
+    uint64_t bits = in.vis[(size_t)(in_row0 + parents[j]) * W + w];
+    int s = out_slot0 + j;
+    if ((s >> 6) == w) bits |= 1ull << (s & 63);
+    out.vis[(size_t)(out_row0 + j) * W + w] = bits;
+  }
+}
+
+// ---------------------------------------------------------------------------- beam step
+__global__ __launch_bounds__(kScanThreads) void beam_step_kernel(BeamStepArgs a) {
+  __shared__ ExpandShared sh;
+  __shared__ int parents[MAXB];
+  const int tid = threadIdx.x;
+  if (tid == 0) sh.status = 0;
+  if (tid < a.n_src) {
+    sh.node[tid] = a.src.node[tid];
+    sh.brow[tid] = tid;
+    sh.lrow[tid] = tid;
+    sh.bscore[tid] = a.src.score[tid];
+  }
+  __syncthreads();
+  expand_and_select(sh, a.n_src, a.logits, a.ld, a.lse, a.fsm, a.k);
+  Pick pk;
+  if (tid < a.k) {
+    pk = decode_pick(sh.topk.sel[tid], a.fsm, sh.brow, sh.node, a.n_src);
+    parents[tid] = pk.parent;
+  }
+  __syncthreads();
+  emit_block(pk, tid, a.k, a.src, a.gen_len, a.dst, a.emit != 0, a.in, a.in_row0, a.out, a.out_row0, a.out_slot0, a.vis_words);
+  if (a.emit) emit_vis(parents, a.k, a.in, a.in_row0, a.out, a.out_row0, a.out_slot0, a.vis_words);
+  if (a.mail) {
+    int valid = __syncthreads_count(tid < a.k && pk.flat >= 0);
+    if (tid == 0) {
+      if (sh.status != 0) a.mail->status = sh.status;
+      a.mail->n_valid = valid;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- verify
+__global__ __launch_bounds__(kScanThreads) void verify_walk_kernel(VerifyArgs a) {
+  __shared__ ExpandShared sh;
+  __shared__ int t_parent[MAXB], t_pos[MAXB], hit[MAXB];
+  __shared__ float sbh[MAXB];
+  __shared__ int reject;
+  const int tid = threadIdx.x;
+  const int k = a.k, dk = a.dk;
+  if (tid == 0) { sh.status = 0; reject = 0; }
+  int nm = 0;
+  Pick pk;
+  pk.flat = -1; pk.score = -INFINITY; pk.parent = 0; pk.tok = 0; pk.node = 0;
+  for (int i = 0; i <= a.dl; ++i) {
+    const int n_rows = i == 0 ? a.nb : k;
+    __syncthreads();
+    if (tid < n_rows) {                                                  // beamSD.py:279-296
+      int br = i == 0 ? tid : hit[tid];
+      sh.brow[tid] = br;
+      sh.node[tid] = a.blk[i].node[br];
+      sh.lrow[tid] = i == 0 ? tid : a.nb + (i - 1) * dk + br;
+      sh.bscore[tid] = i == 0 ? a.blk[0].score[tid] : sbh[tid];
+    }
+    __syncthreads();
+    expand_and_select(sh, n_rows, a.logits, a.ld, a.lse, a.fsm, k);     // :297-298,323-328
+    if (tid < k) {
+      pk = decode_pick(sh.topk.sel[tid], a.fsm, sh.brow, sh.node, n_rows);
+      t_parent[tid] = pk.parent;
+    }
+    if (i == a.dl) break;                                                // :329-330 (uniform)
+    // acceptance: every target id must be among the draft's ids of step i+1 (:371-380)
+    int pos = -1;
+    if (tid < k && pk.flat >= 0) {
+      const int* df = a.blk[i + 1].flat;
+      for (int d = 0; d < dk; ++d) if (df[d] == pk.flat) { pos = d; break; }
+    }
+    if (tid < k) { t_pos[tid] = pos; if (pos < 0) atomicOr(&reject, 1); }
+    __syncthreads();
+    if (reject) break;                                                   // uniform
+    if (tid < k) {                                                       // :373-376: order by draft position
+      int rank = 0;
+      for (int j = 0; j < k; ++j) rank += (t_pos[j] < pos) ? 1 : 0;
+      hit[rank] = pos;
+      sbh[rank] = pk.score;
+    }
+    nm += 1;
+  }
+  __syncthreads();
+  // ---- outputs: new round beams, next-round inputs (:383-416)
+  const int cnt = nm == 0 ? a.nb : dk;
+  const int rowbase = nm == 0 ? a.n0 - a.nb : a.n0 + (nm - 1) * dk;
+  const int base_next = a.cur.slot[rowbase] + cnt;
+  const int W = a.vis_words;
+  emit_block(pk, tid, k, a.blk[nm], a.gen_len0 + nm, a.res, true, a.cur, rowbase, a.next, 0, base_next, W);
+  emit_vis(t_parent, k, a.cur, rowbase, a.next, 0, base_next, W);
+  if (nm == a.dl && a.dl > 0) {
+    // the draft has not seen its own last block: next draft input = that block ++ the new beams (:402-416)
+    for (int j = tid; j < dk; j += blockDim.x) {
+      a.dnext.ids[j] = a.cur.ids[rowbase + j];
+      a.dnext.pos[j] = a.cur.pos[rowbase + j];
+      a.dnext.slot[j] = a.cur.slot[rowbase + j];
+    }
+    for (int idx = tid; idx < dk * W; idx += blockDim.x) a.dnext.vis[idx] = a.cur.vis[(size_t)rowbase * W + idx];
+    emit_block(pk, tid, k, a.blk[nm], a.gen_len0 + nm, a.res, true, a.cur, rowbase, a.dnext, dk, base_next, W);
+    emit_vis(t_parent, k, a.cur, rowbase, a.dnext, dk, base_next, W);
+  }
+  int valid = __syncthreads_count(tid < k && pk.flat >= 0);
+  if (tid == 0) {
+    a.mail->n_matches = nm;
+    a.mail->n_valid = valid;
+    if (sh.status != 0) a.mail->status = sh.status;
+  }
+}
+
+// ---------------------------------------------------------------------------- prompt init / export / accept
+__global__ void init_prompt_kernel(TokBuf tb, const int32_t* __restrict__ prompt, int P, int W, BeamSet beams,
+                                   int start_node, int vocab, Mailbox* mail) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < P) {
+    int id = prompt[t];
+    tb.ids[t] = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    tb.pos[t] = t;
+    tb.slot[t] = t;
+    for (int w = 0; w < W; ++w) {                       // causal prefix: bits [0, t]
+      int lo = w * 64;
+      uint64_t bits = (t >= lo + 63) ? ~0ull : (t < lo ? 0ull : ((~0ull) >> (63 - (t - lo))));
+      tb.vis[(size_t)t * W + w] = bits;
+    }
+  }
+  if (t == 0) {
+    beams.score[0] = 0.f; beams.node[0] = start_node; beams.parent[0] = 0; beams.tok[0] = 0; beams.flat[0] = 0;
+    mail->n_matches = 0; mail->status = 0; mail->n_valid = 1; mail->pad = 0;
+  }
+}
+
+__global__ void export_beams_kernel(BeamSet b, int k, int max_new, int32_t* out_tokens, float* out_scores) {
+  int j = threadIdx.x;
+  if (j < k) {
+    out_scores[j] = b.score[j];
+    for (int g = 0; g < max_new; ++g) out_tokens[j * max_new + g] = b.seq[j * LMAX + g];
+  }
+}
+
+__global__ void accept_kernel(const int32_t* __restrict__ tflat, const float* __restrict__ tscore, int k,
+                              const int32_t* __restrict__ dflat, int dk, int32_t* hit, float* sbh, int32_t* accept) {
+  __shared__ int t_pos[MAXB];
+  int j = threadIdx.x;
+  int pos = -1;
+  if (j < k && tflat[j] >= 0)
+    for (int d = 0; d < dk; ++d) if (dflat[d] == tflat[j]) { pos = d; break; }
+  if (j < k) t_pos[j] = pos;
+  int bad = __syncthreads_count(j < k && pos < 0);
+  if (j == 0) *accept = bad == 0;
+  if (j < k) { hit[j] = -1; sbh[j] = -INFINITY; }
+  __syncthreads();
+  if (bad == 0 && j < k) {
+    int rank = 0;
+    for (int i = 0; i < k; ++i) rank += t_pos[i] < pos ? 1 : 0;
+    hit[rank] = pos;
+    sbh[rank] = tscore[j];
+  }
+}
+
+}  // namespace
+
+int ats_lse_rows(const float* logits, int n_rows, int vocab, int ld, float* lse, hipStream_t st) {
+  if (n_rows <= 0) return ATSPEED_OK;
+  ATS_REQUIRE((ld & 3) == 0 && ((uintptr_t)logits & 15) == 0, ATSPEED_ERR_INVALID, "lse: rows must be 16-byte aligned (ld %d)", ld);
+  lse_rows_kernel<<<n_rows, 1024, 0, st>>>(logits, vocab, ld, lse);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+int ats_beam_step(const BeamStepArgs& a, hipStream_t st) {
+  ATS_REQUIRE(a.k >= 1 && a.k <= MAXB && a.n_src >= 1 && a.n_src <= MAXB, ATSPEED_ERR_CAPACITY,
+              "beam step: k=%d / rows=%d exceed %d", a.k, a.n_src, MAXB);
+  beam_step_kernel<<<1, kScanThreads, 0, st>>>(a);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+int ats_verify_walk(const VerifyArgs& a, hipStream_t st) {
+  ATS_REQUIRE(a.k >= 1 && a.k <= MAXB && a.dk >= a.k && a.dk <= MAXB && a.dl >= 1 && a.dl <= ATSPEED_MAX_GAMMA,
+              ATSPEED_ERR_CAPACITY, "verify: k=%d dk=%d dl=%d out of range", a.k, a.dk, a.dl);
+  verify_walk_kernel<<<1, kScanThreads, 0, st>>>(a);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+int ats_init_prompt(TokBuf tb, const int32_t* prompt, int prompt_len, int vis_words, BeamSet beams, int start_node,
+                    int vocab, Mailbox* mail, hipStream_t st) {
+  init_prompt_kernel<<<(prompt_len + 255) / 256, 256, 0, st>>>(tb, prompt, prompt_len, vis_words, beams, start_node, vocab, mail);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+int ats_export_beams(BeamSet b, int k, int max_new, int32_t* out_tokens, float* out_scores, hipStream_t st) {
+  export_beams_kernel<<<1, 64, 0, st>>>(b, k, max_new, out_tokens, out_scores);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+int ats_accept(const int32_t* target_flat, const float* target_score, int k, const int32_t* draft_flat, int dk,
+               int32_t* hit, float* score_by_hit, int32_t* accept, hipStream_t st) {
+  ATS_REQUIRE(k >= 1 && k <= MAXB && dk >= 1 && dk <= MAXB, ATSPEED_ERR_CAPACITY, "accept: k=%d dk=%d out of range", k, dk);
+  accept_kernel<<<1, 64, 0, st>>>(target_flat, target_score, k, draft_flat, dk, hit, score_by_hit, accept);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+extern "C" int atspeed_lse_rows(const float* logits, int32_t n_rows, int32_t vocab, int32_t ld, float* lse, void* stream) {
+  ATS_REQUIRE(logits && lse && vocab > 0 && ld >= vocab, ATSPEED_ERR_INVALID, "lse: bad arguments");
+  return ats_lse_rows(logits, n_rows, vocab, ld, lse, (hipStream_t)stream);
+}
+
+extern "C" int atspeed_accept(const int32_t* target_flat, const float* target_score, int32_t k, const int32_t* draft_flat,
+                              int32_t dk, int32_t* hit, float* score_by_hit, int32_t* accept, void* stream) {
+  ATS_REQUIRE(target_flat && target_score && draft_flat && hit && score_by_hit && accept, ATSPEED_ERR_INVALID, "accept: null argument");
+  return ats_accept(target_flat, target_score, k, draft_flat, dk, hit, score_by_hit, accept, (hipStream_t)stream);
+}
+
+extern "C" int atspeed_beam_expand_prune(const float* logits, int32_t ld, const float* lse, const float* beam_score,
+                                         const int32_t* beam_node, int32_t n_rows, const atspeed_fsm* fsm, int32_t k,
+                                         float* out_score, int32_t* out_parent, int32_t* out_token, int32_t* out_node,
+                                         int32_t* out_flat, void* stream) {
+  ATS_REQUIRE(logits && lse && beam_score && beam_node && fsm && out_score && out_parent && out_token && out_node && out_flat,
+              ATSPEED_ERR_INVALID, "beam_expand_prune: null argument");
+  BeamStepArgs a{};
+  a.src.score = const_cast<float*>(beam_score);
+  a.src.node = const_cast<int32_t*>(beam_node);
+  a.src.seq = nullptr;
+  a.n_src = n_rows; a.gen_len = 0;
+  a.logits = logits; a.ld = ld; a.lse = lse;
+  a.fsm = fsm->dev;
+  a.k = k;
+  a.dst.score = out_score; a.dst.parent = out_parent; a.dst.tok = out_token; a.dst.node = out_node; a.dst.flat = out_flat;
+  a.dst.seq = nullptr;
+  a.emit = 0; a.mail = nullptr; a.vis_words = 0;
+  return ats_beam_step(a, (hipStream_t)stream);
+}

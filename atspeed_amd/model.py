@@ -1,0 +1,178 @@
+"""`HipLlama`: the model object the beam-SD path drives, with weights resident in HBM and the
+forward executed by libatspeed_hip (MFMA GEMMs, tree attention, fused norms/RoPE/SwiGLU).
+
+It stands where the reference uses an HF `LlamaForCausalLM` (`code/inference.py:75-100`,
+called at `code/beamSD.py:52,221`) and exposes the attributes the path reads from it:
+`generation_config.{num_beams,do_sample}` (`beamSD.py:53,482-483`), `.dtype`, `.device`.
+PyTorch is plumbing here: it owns the device memory of the weights and provides the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, synth
+
+
+def _gen_config(num_beams: int = 1) -> SimpleNamespace:
+    return SimpleNamespace(num_beams=num_beams, num_return_sequences=num_beams, do_sample=False,
+                           temperature=1.0, max_new_tokens=4, return_dict_in_generate=True)
+
+
+def _interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """[2*ffn, hidden] with rows 32b..32b+15 = gate[16b..], 32b+16..32b+31 = up[16b..] (SwiGLU epilogue layout)."""
+    ffn, hidden = gate.shape
+    out = torch.empty(2 * ffn, hidden, dtype=gate.dtype, device=gate.device)
+    v = out.view(ffn // 16, 2, 16, hidden)
+    v[:, 0] = gate.view(ffn // 16, 16, hidden)
+    v[:, 1] = up.view(ffn // 16, 16, hidden)
+    return out
+
+
+class HipLlama:
+    def __init__(self, dims: synth.LlamaDims, packed: Dict, dtype: torch.dtype, device: torch.device,
+                 max_slots: int = 512, max_tokens: int = 512, max_logit_rows: int = 384, num_beams: int = 1):
+        if device.type != "cuda":
+            raise RuntimeError("HipLlama needs a HIP device; atspeed_amd has no CPU path")
+        self.dims = dims
+        self._packed = packed          # keeps the weight tensors alive
+        self._dtype = dtype
+        self._device = device
+        self.generation_config = _gen_config(num_beams)
+        self.config = SimpleNamespace(vocab_size=dims.vocab_size, hidden_size=dims.hidden, pad_token_id=0, bos_token_id=1,
+                                      eos_token_id=2, use_cache=True)
+        self.max_slots, self.max_tokens, self.max_logit_rows = max_slots, max_tokens, max_logit_rows
+        lib = _lib.load()
+        cfg = _lib.LlamaConfig(dims.vocab_size, dims.hidden, dims.n_layers, dims.n_heads, dims.ffn, dims.rope_theta,
+                               dims.rms_eps, _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16,
+                               max_slots, max_tokens, max_logit_rows)
+        layers = (_lib.LlamaLayerWeights * dims.n_layers)()
+        for l, lw in enumerate(packed["layers"]):
+            layers[l] = _lib.LlamaLayerWeights(lw["input_norm"].data_ptr(), lw["wqkv"].data_ptr(), lw["wo"].data_ptr(),
+                                               lw["post_norm"].data_ptr(), lw["wgu"].data_ptr(), lw["wd"].data_ptr())
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.atspeed_llama_create(C.byref(cfg), packed["embed"].data_ptr(), packed["final_norm"].data_ptr(),
+                                                packed["lm_head"].data_ptr(), layers, C.byref(h)))
+        self._handle = h
+        self.logits_ld = int(lib.atspeed_llama_logits_ld(h))
+
+    # ---- attributes the reference path reads ---------------------------------------
+    @property
+    def dtype(self) -> torch.dtype:
+        return self._dtype
+
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    def eval(self):
+        return self
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            try:
+                _lib.load().atspeed_llama_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    # ---- construction --------------------------------------------------------------
+    @staticmethod
+    def _pack(sd: Dict[str, torch.Tensor], dims: synth.LlamaDims) -> Dict:
+        def g(name):
+            return sd[name]
+        layers = []
+        for l in range(dims.n_layers):
+            p = f"model.layers.{l}."
+            layers.append(dict(
+                input_norm=g(p + "input_layernorm.weight").contiguous(),
+                wqkv=torch.cat((g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"),
+                                g(p + "self_attn.v_proj.weight")), 0).contiguous(),
+                wo=g(p + "self_attn.o_proj.weight").contiguous(),
+                post_norm=g(p + "post_attention_layernorm.weight").contiguous(),
+                wgu=_interleave_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")),
+                wd=g(p + "mlp.down_proj.weight").contiguous()))
+        return dict(embed=g("model.embed_tokens.weight").contiguous(), final_norm=g("model.norm.weight").contiguous(),
+                    lm_head=g("lm_head.weight").contiguous(), layers=layers)
+
+    @classmethod
+    def from_state_dict(cls, dims: synth.LlamaDims, state_dict: Dict, dtype: torch.dtype = torch.float32,
+                        device="cuda", **kw) -> "HipLlama":
+        """HF-named tensors (numpy or torch, any float dtype) -> packed device weights."""
+        device = torch.device(device)
+        sd = {}
+        for k, v in state_dict.items():
+            t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v.detach()
+            sd[k] = t.to(device=device, dtype=torch.float32).to(dtype)
+        return cls(dims, cls._pack(sd, dims), dtype, device, **kw)
+
+    @classmethod
+    def from_hf(cls, hf_model, dtype: Optional[torch.dtype] = None, device="cuda", **kw) -> "HipLlama":
+        """Adapter for an HF `LlamaForCausalLM` (the object the reference loads, inference.py:75-100)."""
+        c = hf_model.config
+        dims = synth.LlamaDims(c.vocab_size, c.hidden_size, c.num_hidden_layers, c.num_attention_heads,
+                               c.intermediate_size, float(getattr(c, "rope_theta", 10000.0)), float(c.rms_norm_eps))
+        if getattr(c, "num_key_value_heads", c.num_attention_heads) != c.num_attention_heads:
+            raise NotImplementedError("grouped-query attention is not on this path (Llama-68M / Llama-7B are MHA)")
+        sd = {k: v for k, v in hf_model.state_dict().items() if "rotary" not in k}
+        m = cls.from_state_dict(dims, sd, dtype or hf_model.dtype, device, **kw)
+        m.generation_config.num_beams = getattr(hf_model.generation_config, "num_beams", 1)
+        return m
+
+    @classmethod
+    def from_synthetic(cls, dims: synth.LlamaDims, seed: int, std: float = 0.02, head_std: Optional[float] = None,
+                       norm_jitter: float = 0.1, dtype: torch.dtype = torch.bfloat16, device="cuda", **kw) -> "HipLlama":
+        """Weights generated ON THE DEVICE by the same hash recipe as `synth.synthetic_state_dict`
+        (bit-identical values), so 7B-sized models need no host generation or PCIe transfer."""
+        device = torch.device(device)
+        lib = _lib.load()
+        head_std = std if head_std is None else head_std
+        code = _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16
+        sd: Dict[str, torch.Tensor] = {}
+        with torch.cuda.device(device):
+            st = _lib.stream_ptr(device)
+            for name, shape, kind in synth.weight_specs(dims):
+                t = torch.empty(shape, dtype=dtype, device=device)
+                s = synth.tensor_seed(seed, name)
+                if kind == "norm":
+                    scale, add = float(synth.normal_scale(norm_jitter)), 1.0
+                else:
+                    scale, add = float(synth.normal_scale(synth.weight_std(name, dims, std, head_std))), 0.0
+                _lib.check(lib.atspeed_fill_hash_normal(t.data_ptr(), t.numel(), s, scale, add, code, 0, st))
+                sd[name] = t
+            packed = cls._pack(sd, dims)
+            del sd
+        return cls(dims, packed, dtype, device, **kw)
+
+    # ---- forward (tests / tools; the decoder calls the C entry point directly) --------
+    def forward_raw(self, ids: torch.Tensor, pos: torch.Tensor, slots: torch.Tensor, vis_bits: torch.Tensor,
+                    n_slots: int, n_logit_rows: int) -> torch.Tensor:
+        """ids/pos/slots int32 [T]; vis_bits int64 [T, max_slots/64] (bit s of word s//64 = slot s visible).
+        Returns fp32 logits [n_logit_rows, vocab] of the last rows."""
+        lib = _lib.load()
+        T = ids.numel()
+        assert vis_bits.shape == (T, self.max_slots // 64) and vis_bits.dtype == torch.int64
+        with torch.cuda.device(self._device):
+            raw = torch.empty(n_logit_rows * self.logits_ld, dtype=torch.float32, device=self._device)
+            _lib.check(lib.atspeed_llama_forward(self._handle, ids.data_ptr(), pos.data_ptr(), slots.data_ptr(),
+                                                 vis_bits.data_ptr(), T, n_slots, n_logit_rows, raw.data_ptr(),
+                                                 _lib.stream_ptr(self._device)))
+        return raw.view(n_logit_rows, self.logits_ld)[:, : self.dims.vocab_size]
+
+
+def vis_bits_from_bool(vis: torch.Tensor, max_slots: int) -> torch.Tensor:
+    """bool [T, S] -> int64 [T, max_slots/64] bitset (host helper for tests)."""
+    T, S = vis.shape
+    v = torch.zeros(T, max_slots, dtype=torch.bool)
+    v[:, :S] = vis.cpu()
+    w = v.view(T, max_slots // 64, 64).to(torch.int64)
+    shifts = torch.arange(64, dtype=torch.int64)
+    lo = (w[..., :63] << shifts[:63]).sum(-1)
+    hi = w[..., 63] << 63            # wraps to the sign bit, which is what the bit pattern needs
+    return (lo + hi).contiguous()

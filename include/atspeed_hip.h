@@ -1,0 +1,200 @@
+/*
+ * atspeed_hip.h — C-ABI of libatspeed_hip.so, the MI355X (gfx950) engine behind the
+ * AtSpeed beam-speculative-decoding hot path.
+ *
+ * The reference (/root/reference, Linxyhaha/AtSpeed) has NO native layer and no FFI: its
+ * "plugin surface" for this path is four Python callables.  Each entry point below names
+ * the reference interface it replaces (file:line under /root/reference/code).  A
+ * maintainer binds these with ctypes; atspeed_amd/_lib.py is that
+ * binding.
+ *
+ * Conventions
+ *   - every pointer named *_dev is DEVICE memory owned by the caller (PyTorch-ROCm
+ *     tensors' data_ptr()); the library never allocates caller-visible memory.  Handles
+ *     own only their private workspace / KV arena (create/destroy pairs).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
+ *     stream-ordered and never synchronise the device unless documented.
+ *   - return value: 0 = ok, negative = atspeed_status; atspeed_last_error() gives the text
+ *     (thread-local).
+ *   - dtype: ATSPEED_F32 (fp32 weights/activations, exact-fp32 MFMA; parity mode) or
+ *     ATSPEED_BF16 (bf16 weights/activations/KV, fp32 accumulate, fp32 logits).
+ */
+#ifndef ATSPEED_HIP_H
+#define ATSPEED_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum atspeed_status {
+  ATSPEED_OK = 0,
+  ATSPEED_ERR_INVALID = -1,      /* bad argument / shape the kernels do not support   */
+  ATSPEED_ERR_HIP = -2,          /* a HIP runtime call failed                          */
+  ATSPEED_ERR_CAPACITY = -3,     /* prompt/beam/slot count exceeds the handle's limits */
+  ATSPEED_ERR_CONSTRAINT = -4,   /* a beam reached a node with no allowed token (HF raises ValueError there) */
+  ATSPEED_ERR_NO_DEVICE = -5
+} atspeed_status;
+
+typedef enum atspeed_dtype { ATSPEED_F32 = 0, ATSPEED_BF16 = 1 } atspeed_dtype;
+
+#define ATSPEED_MAX_BEAMS 64      /* K, DK <= 64 (one wavefront holds a beam list)       */
+#define ATSPEED_MAX_NEW_TOKENS 16 /* generated-suffix capacity per beam                  */
+#define ATSPEED_MAX_GAMMA 8
+
+const char* atspeed_version(void);
+const char* atspeed_last_error(void);
+/* number of HIP devices visible (0 on a CPU-only host; never initialises a context) */
+int atspeed_device_count(void);
+
+/* ------------------------------------------------------------------ synthetic fill
+ * value(i) = float(int(s_i) - 131070) * scale, s_i = sum of four 16-bit hash pieces of
+ * (i + offset, seed) — bit-identical to atspeed_amd.synth.hash_normal.  `add` is added
+ * after scaling (norm weights: 1 + jitter).  No reference counterpart (test/bench input). */
+int atspeed_fill_hash_normal(void* dst_dev, size_t n, uint32_t seed, float scale, float add,
+                             int dtype, uint64_t offset, void* stream);
+
+/* ------------------------------------------------------------------ constraint automaton
+ * Device form of the reference's mask functions — Trie.get() (generation_trie.py:27-70),
+ * prefix_allowed_tokens_fn (generation_trie.py:92-98), the position-set function
+ * (data.py:84-104) — which the reference calls once per beam per step on the host through
+ * HF's PrefixConstrainedLogitsProcessor (beamSD.py:62-64,288-291).
+ * CSR: node n allows tok[row_ptr[n]..row_ptr[n+1]) (strictly ascending), edge e leads to
+ * node nxt[e].  Arrays are HOST pointers, copied to the device. */
+typedef struct atspeed_fsm atspeed_fsm;
+int atspeed_fsm_create(const int32_t* row_ptr, const int32_t* tok, const int32_t* nxt,
+                       int32_t n_nodes, int32_t n_edges, int32_t vocab_size, atspeed_fsm** out);
+void atspeed_fsm_destroy(atspeed_fsm* fsm);
+/* host-side flattening of token sequences into the CSR above (breadth-first node ids,
+ * children ascending): native counterpart of Trie.__init__/_add_to_trie
+ * (generation_trie.py:8-14,40-44).  Two-call protocol: pass NULL outputs to get the sizes. */
+int atspeed_trie_flatten(const int32_t* seq_tokens, const int32_t* seq_offsets, int32_t n_seqs,
+                         int32_t* row_ptr_out, int32_t* tok_out, int32_t* nxt_out,
+                         int32_t* n_nodes_out, int32_t* n_edges_out);
+
+/* ------------------------------------------------------------------ model
+ * Replaces the model object the path calls as model(**inputs) (beamSD.py:52,221):
+ * a Llama decoder whose weights live in HBM.  Weight pointers are device pointers in the
+ * handle's dtype, row-major [out, in] like HF nn.Linear:
+ *   wqkv  [3*hidden, hidden]   rows = q_proj | k_proj | v_proj
+ *   wo    [hidden, hidden]
+ *   wgu   [2*ffn, hidden]      gate/up interleaved in 16-row groups: rows 32b..32b+15 =
+ *                              gate[16b..], rows 32b+16..32b+31 = up[16b..]
+ *   wd    [hidden, ffn]
+ *   norm weights [hidden]; embed [vocab, hidden]; lm_head [vocab, hidden]           */
+typedef struct atspeed_llama_layer_weights {
+  const void* input_norm;
+  const void* wqkv;
+  const void* wo;
+  const void* post_norm;
+  const void* wgu;
+  const void* wd;
+} atspeed_llama_layer_weights;
+
+typedef struct atspeed_llama_config {
+  int32_t vocab_size, hidden, n_layers, n_heads, ffn;
+  float rope_theta, rms_eps;
+  int32_t dtype;          /* atspeed_dtype */
+  int32_t max_slots;      /* KV capacity (multiple of 64) */
+  int32_t max_tokens;     /* max tokens per forward */
+  int32_t max_logit_rows; /* max rows the lm_head is applied to */
+} atspeed_llama_config;
+
+typedef struct atspeed_llama atspeed_llama;
+int atspeed_llama_create(const atspeed_llama_config* cfg, const void* embed_dev, const void* final_norm_dev,
+                         const void* lm_head_dev, const atspeed_llama_layer_weights* layers /* host array */,
+                         atspeed_llama** out);
+void atspeed_llama_destroy(atspeed_llama* m);
+
+/* One forward (beamSD.py:52 / :221): T tokens, written to KV slots `slots`, each row seeing
+ * the slots whose bit is set in vis_bits[t][0..max_slots/64).  The 4-D additive mask of the
+ * reference (beamSD.py:89,204-209) is never materialised.  Logits (fp32, row stride
+ * atspeed_llama_logits_ld()) of the LAST n_logit_rows tokens go to the handle's logits
+ * buffer (atspeed_llama_logits()) or to logits_out_dev when not NULL. */
+int atspeed_llama_forward(atspeed_llama* m, const int32_t* ids_dev, const int32_t* pos_dev,
+                          const int32_t* slots_dev, const uint64_t* vis_bits_dev, int32_t n_tokens,
+                          int32_t n_slots_visible, int32_t n_logit_rows, float* logits_out_dev, void* stream);
+float* atspeed_llama_logits(atspeed_llama* m);
+int32_t atspeed_llama_logits_ld(const atspeed_llama* m);
+
+/* ------------------------------------------------------------------ scan kernels
+ * log-softmax normaliser over the FULL vocabulary, before masking (beamSD.py:58,285):
+ * lse[r] = log(sum_v exp(logits[r][v])).  Rows are `ld` floats apart. */
+int atspeed_lse_rows(const float* logits_dev, int32_t n_rows, int32_t vocab, int32_t ld,
+                     float* lse_out_dev, void* stream);
+
+/* Fused constraint mask + beam expand + prune (beamSD.py:60-87):
+ *   cand(r, t) = logits[r][t] - lse[r] + beam_score[r]   for t allowed at node[r]
+ *   top-k by (score desc, flat id r*vocab+t asc)  ->  out_*[0..k)
+ * -inf / missing candidates are flagged out_flat = -1 (never a beam).
+ * Standalone form used by tests; the decoder uses the same device code inside its step
+ * kernels together with the mask/position bookkeeping (beamSD.py:88-91). */
+int atspeed_beam_expand_prune(const float* logits_dev, int32_t ld, const float* lse_dev,
+                              const float* beam_score_dev, const int32_t* beam_node_dev, int32_t n_rows,
+                              const atspeed_fsm* fsm, int32_t k,
+                              float* out_score_dev, int32_t* out_parent_dev, int32_t* out_token_dev,
+                              int32_t* out_node_dev, int32_t* out_flat_dev, void* stream);
+
+/* Top-K-aligned acceptance test (beamSD.py:371-380): accept iff every target id is among
+ * the draft ids.  hit[r] = r-th smallest draft position that was hit, score_by_hit[r] = the
+ * target score of that entry (beamSD.py:295-296,373-376).  out_accept = 1/0. */
+int atspeed_accept(const int32_t* target_flat_dev, const float* target_score_dev, int32_t k,
+                   const int32_t* draft_flat_dev, int32_t dk,
+                   int32_t* hit_out_dev, float* score_by_hit_out_dev, int32_t* accept_out_dev, void* stream);
+
+/* ------------------------------------------------------------------ decoder
+ * Replaces BSSD() (beamSD.py:458-542) and target_generate() (beamSD.py:544-595) for one
+ * user stream: draft steps, the packed target verification forward, verify(), and all
+ * bookkeeping (masks as bitsets, positions, KV slots, beam suffixes) stay on the device;
+ * the host reads back one small mailbox per round. */
+typedef struct atspeed_decoder atspeed_decoder;
+int atspeed_decoder_create(atspeed_llama* target, atspeed_llama* draft /* may be NULL */,
+                           int32_t max_prompt, atspeed_decoder** out);
+void atspeed_decoder_destroy(atspeed_decoder* d);
+
+typedef struct atspeed_gen_stats {
+  int32_t n_run;               /* verification rounds (beamSD.py:527)                 */
+  int32_t total_accept_steps;  /* sum of n_matches (beamSD.py:528)                    */
+  int32_t accept_steps[ATSPEED_MAX_NEW_TOKENS];
+  int32_t n_valid;             /* beams with a finite score                           */
+  int32_t n_target_forwards, n_draft_forwards;
+  float draft_ms, target_ms, verify_ms, total_ms;   /* hipEvent stage times (Timer, beamSD.py:12-37) */
+} atspeed_gen_stats;
+
+/* prompt_ids_dev: [prompt_len] int32.  out_tokens_dev: [k][max_new_tokens] int32 generated
+ * suffixes ordered by score desc; out_scores_dev: [k] fp32.  Synchronises `stream` once per
+ * round (to read n_matches) and at exit. */
+int atspeed_bssd_generate(atspeed_decoder* d, const int32_t* prompt_ids_dev, int32_t prompt_len,
+                          const atspeed_fsm* fsm, int32_t start_node, int32_t gamma, int32_t max_new_tokens,
+                          int32_t k, int32_t dk, int32_t* out_tokens_dev, float* out_scores_dev,
+                          atspeed_gen_stats* stats_host, void* stream);
+
+int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt_ids_dev, int32_t prompt_len,
+                            const atspeed_fsm* fsm, int32_t start_node, int32_t max_new_tokens, int32_t k,
+                            int32_t* out_tokens_dev, float* out_scores_dev, atspeed_gen_stats* stats_host,
+                            void* stream);
+
+/* per-round trace of the last atspeed_bssd_generate call (host memory, for parity tests):
+ * for round r, step i: the draft's flat ids (dk entries, -1 = not a beam).  Returns the
+ * number of ints written. */
+int atspeed_decoder_trace(atspeed_decoder* d, int32_t* rounds_out, int32_t cap);
+
+/* ------------------------------------------------------------------ low-level ops (tests, benches)
+ * C[M,N] = A[M,K] * W[N,K]^T on MFMA; epilogue: 0 store (dtype), 1 fp32 store, 2 residual add into
+ * C (dtype), 3 SwiGLU over interleaved gate/up column groups (C is [M, N/2]). */
+int atspeed_gemm(const void* a_dev, const void* w_dev, void* c_dev, int32_t m, int32_t n, int32_t k,
+                 int32_t lda, int32_t ldc, int32_t dtype, int32_t epilogue, void* workspace_dev,
+                 size_t workspace_bytes, void* stream);
+int atspeed_rmsnorm(const void* x_dev, const void* w_dev, void* y_dev, int32_t rows, int32_t hidden,
+                    float eps, int32_t dtype, void* stream);
+/* tree attention over a slot-addressed KV cache ([max_slots][hidden] per K and V) */
+int atspeed_tree_attention(const void* q_dev, int32_t ldq, const void* kcache_dev, const void* vcache_dev,
+                           const uint64_t* vis_bits_dev, int32_t vis_words, void* out_dev, int32_t n_tokens,
+                           int32_t n_slots, int32_t n_heads, int32_t head_dim, int32_t dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATSPEED_HIP_H */

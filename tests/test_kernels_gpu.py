@@ -1,0 +1,298 @@
+"""GPU parity of the individual HIP kernels, called through the C-ABI (ctypes), against the
+oracle / plain fp32 torch on the same seeded inputs.  Run with -m gpu on the MI355X box."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from atspeed_amd import _lib, synth
+from atspeed_amd.generation_trie import PositionSetConstraint, Trie
+from oracle import beamsd_ref as R
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    l = _lib.load()
+    assert l.atspeed_device_count() >= 1
+    return l
+
+
+def _st():
+    return _lib.stream_ptr()
+
+
+def _rand(shape, seed, std=1.0):
+    n = int(np.prod(shape))
+    return torch.from_numpy(synth.hash_normal(n, seed, std).reshape(shape))
+
+
+# ------------------------------------------------------------------ fill
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fill_hash_normal_bit_exact(lib, dtype):
+    n, seed, std = 100003, 12345, 0.02
+    t = torch.empty(n, dtype=dtype, device="cuda")
+    code = _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16
+    _lib.check(lib.atspeed_fill_hash_normal(t.data_ptr(), n, seed, float(synth.normal_scale(std)), 0.0, code, 0, _st()))
+    ref = synth.hash_normal(n, seed, std)
+    if dtype == torch.bfloat16:
+        ref = synth.bf16_round(ref)
+    assert np.array_equal(t.float().cpu().numpy(), ref)
+    # offset + add (norm weights)
+    _lib.check(lib.atspeed_fill_hash_normal(t.data_ptr(), 1000, seed, float(synth.normal_scale(0.1)), 1.0, code, 0, _st()))
+    ref = np.float32(1.0) + synth.hash_normal(1000, seed, 0.1)
+    if dtype == torch.bfloat16:
+        ref = synth.bf16_round(ref)
+    assert np.array_equal(t[:1000].float().cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------ gemm
+def _gemm(lib, a, w, epi, dtype, resid=None, n_out=None):
+    m, k = a.shape
+    n = w.shape[0]
+    code = _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    if epi == _lib.EPI_F32:
+        c = torch.zeros(m, n, dtype=torch.float32, device="cuda")
+    elif epi == _lib.EPI_SWIGLU:
+        c = torch.zeros(m, n // 2, dtype=dtype, device="cuda")
+    elif epi == _lib.EPI_RESID:
+        c = resid.clone()
+    else:
+        c = torch.zeros(m, n, dtype=dtype, device="cuda")
+    _lib.check(lib.atspeed_gemm(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, a.stride(0), c.stride(0), code, epi,
+                                ws.data_ptr(), ws.numel(), _st()))
+    torch.cuda.synchronize()
+    return c
+
+
+SHAPES = [(1, 128, 128), (5, 200, 96), (16, 384, 352), (20, 4096, 768), (40, 2304, 768), (61, 768, 3072),
+          (100, 512, 4096), (228, 1024, 1024), (228, 4096, 4096), (130, 32256, 128), (121, 32859, 768),
+          (257, 640, 1376)]
+
+
+@pytest.mark.parametrize("m,n,k", SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_store_and_f32(lib, m, n, k, dtype):
+    a = _rand((m, k), 1).to(dtype).cuda()
+    w = _rand((n, k), 2, 0.05).to(dtype).cuda()
+    ref = (a.double().cpu() @ w.double().cpu().T)
+    scale = float(ref.abs().max())
+    c32 = _gemm(lib, a, w, _lib.EPI_F32, dtype)
+    tol = 2e-5 * scale * max(1.0, np.sqrt(k) / 8) if dtype == torch.float32 else 2e-5 * scale * np.sqrt(k)
+    np.testing.assert_allclose(c32.double().cpu().numpy(), ref.numpy(), atol=tol, rtol=0)
+    c = _gemm(lib, a, w, _lib.EPI_STORE, dtype)
+    tol2 = tol if dtype == torch.float32 else 1e-2 * scale
+    np.testing.assert_allclose(c.double().cpu().numpy(), ref.numpy(), atol=tol2, rtol=0)
+
+
+@pytest.mark.parametrize("m,n,k", [(7, 256, 128), (40, 768, 768), (228, 4096, 11008), (228, 4096, 4096)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_residual(lib, m, n, k, dtype):
+    a = _rand((m, k), 3).to(dtype).cuda()
+    w = _rand((n, k), 4, 0.03).to(dtype).cuda()
+    r = _rand((m, n), 5).to(dtype).cuda()
+    ref = r.double().cpu() + a.double().cpu() @ w.double().cpu().T
+    c = _gemm(lib, a, w, _lib.EPI_RESID, dtype, resid=r)
+    tol = 1e-4 * float(ref.abs().max()) if dtype == torch.float32 else 2e-2 * float(ref.abs().max())
+    np.testing.assert_allclose(c.double().cpu().numpy(), ref.numpy(), atol=tol, rtol=0)
+
+
+@pytest.mark.parametrize("m,ffn,k", [(3, 32, 64), (40, 352, 128), (228, 11008, 4096), (20, 3072, 768)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_swiglu(lib, m, ffn, k, dtype):
+    from atspeed_amd.model import _interleave_gate_up
+    a = _rand((m, k), 6).to(dtype).cuda()
+    g = _rand((ffn, k), 7, 0.05).to(dtype).cuda()
+    u = _rand((ffn, k), 8, 0.05).to(dtype).cuda()
+    wgu = _interleave_gate_up(g, u)
+    ad = a.double().cpu()
+    ref = torch.nn.functional.silu(ad @ g.double().cpu().T) * (ad @ u.double().cpu().T)
+    c = _gemm(lib, a, wgu, _lib.EPI_SWIGLU, dtype)
+    tol = 1e-4 * float(ref.abs().max()) if dtype == torch.float32 else 3e-2 * float(ref.abs().max())
+    np.testing.assert_allclose(c.double().cpu().numpy(), ref.numpy(), atol=tol, rtol=0)
+
+
+# ------------------------------------------------------------------ rmsnorm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rmsnorm(lib, dtype):
+    x = _rand((37, 768), 9, 2.0).to(dtype).cuda()
+    w = (1 + _rand((768,), 10, 0.1)).to(dtype).cuda()
+    y = torch.empty_like(x)
+    code = _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16
+    _lib.check(lib.atspeed_rmsnorm(x.data_ptr(), w.data_ptr(), y.data_ptr(), 37, 768, 1e-6, code, _st()))
+    xf = x.float().cpu()
+    ref = w.float().cpu() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), atol=1e-5 if dtype == torch.float32 else 4e-2, rtol=0)
+
+
+# ------------------------------------------------------------------ lse
+@pytest.mark.parametrize("rows,V", [(1, 32859), (121, 32859), (40, 33014), (3, 1000), (2, 7)])
+def test_lse_rows(lib, rows, V):
+    ld = (V + 63) // 64 * 64
+    x = torch.full((rows, ld), 1e30)              # padding columns must be ignored
+    x[:, :V] = _rand((rows, V), 11, 3.0)
+    x[0, 5] = 40.0                                  # one dominant logit
+    xd = x.cuda()
+    out = torch.empty(rows, device="cuda")
+    _lib.check(lib.atspeed_lse_rows(xd.data_ptr(), rows, V, ld, out.data_ptr(), _st()))
+    ref = torch.logsumexp(x[:, :V].double(), -1)
+    np.testing.assert_allclose(out.double().cpu().numpy(), ref.numpy(), atol=2e-6 * float(ref.abs().max()) + 1e-6, rtol=0)
+
+
+# ------------------------------------------------------------------ expand + prune
+def _dev_fsm(lib, fsm, V):
+    rp, tk, nx = (np.ascontiguousarray(x, np.int32) for x in (fsm.row_ptr, fsm.tok, fsm.nxt))
+    h = C.c_void_p()
+    _lib.check(lib.atspeed_fsm_create(rp.ctypes.data, tk.ctypes.data, nx.ctypes.data, fsm.n_nodes, len(tk), V, C.byref(h)))
+    return h
+
+
+@pytest.mark.parametrize("vocab,rows,k,mode", [(synth.BEAUTY, 1, 20, "pos"), (synth.BEAUTY, 20, 20, "pos"),
+                                                (synth.BEAUTY, 40, 40, "pos"), (synth.GAMES, 40, 40, "pos"),
+                                                (synth.GAMES, 64, 64, "pos"), (synth.BEAUTY, 40, 40, "trie"),
+                                                (synth.BEAUTY, 20, 1, "pos")])
+def test_beam_expand_prune_equals_oracle(lib, vocab, rows, k, mode):
+    V = vocab.vocab_size
+    ld = (V + 63) // 64 * 64
+    logits = _rand((rows, V), 21 + rows, 2.5)
+    beam_scores = -torch.rand(rows, generator=torch.Generator().manual_seed(rows)) * 5
+    if rows > 3:
+        beam_scores[2] = float("-inf")             # a dead beam must never be expanded
+    prompt = list(synth.synthetic_prompt(16, 4))
+    items = synth.synthetic_items(vocab)
+    rng = np.random.default_rng(rows * 7 + k)
+    if mode == "pos":
+        depth = int(rng.integers(0, 4))
+        con = PositionSetConstraint(vocab.allowed_tokens(), synth.RESPONSE_SEP)
+        suffixes = [[int(items[rng.integers(len(items))][d]) for d in range(depth)] for _ in range(rows)]
+    else:
+        from atspeed_amd.generation_trie import SuffixTrieConstraint
+        con = SuffixTrieConstraint(Trie([[1] + [int(t) for t in it] + [2] for it in items]), synth.RESPONSE_SEP, 1)
+        suffixes = [[int(t) for t in items[rng.integers(len(items))][: int(rng.integers(0, 4))]] for _ in range(rows)]
+    fsm0 = con.compile(prompt)
+    nodes = []
+    for s in suffixes:
+        nd = fsm0.start
+        for t in s:
+            nd = fsm0.step(nd, t)
+        nodes.append(nd)
+    # oracle: sequences prompt + suffix, reference-style callable
+    L = max(len(s) for s in suffixes)
+    if mode == "pos":
+        seqs = torch.tensor([prompt + s for s in suffixes])
+        lp = torch.log_softmax(logits, -1)
+        masked = R.constrain(seqs, lp, con)
+    else:
+        lp = torch.log_softmax(logits, -1)
+        masked = torch.full_like(lp, float("-inf"))
+        for r, s in enumerate(suffixes):
+            al = con(0, torch.tensor(prompt + s))
+            masked[r, al] = lp[r, al]
+    flat = (masked + beam_scores[:, None]).reshape(-1)
+    vals, idx = R.topk_desc_stable(flat, k)
+    h = _dev_fsm(lib, fsm0, V)
+    lg = torch.zeros(rows, ld)
+    lg[:, :V] = logits
+    lg = lg.cuda()
+    lse = torch.empty(rows, device="cuda")
+    _lib.check(lib.atspeed_lse_rows(lg.data_ptr(), rows, V, ld, lse.data_ptr(), _st()))
+    bs, nd = beam_scores.cuda(), torch.tensor(nodes, dtype=torch.int32).cuda()
+    o_s = torch.empty(k, device="cuda")
+    o_p, o_t, o_n, o_f = (torch.empty(k, dtype=torch.int32, device="cuda") for _ in range(4))
+    _lib.check(lib.atspeed_beam_expand_prune(lg.data_ptr(), ld, lse.data_ptr(), bs.data_ptr(), nd.data_ptr(), rows, h, k,
+                                             o_s.data_ptr(), o_p.data_ptr(), o_t.data_ptr(), o_n.data_ptr(), o_f.data_ptr(), _st()))
+    torch.cuda.synchronize()
+    finite = torch.isfinite(vals)
+    nfin = int(finite.sum())
+    assert o_f.cpu()[:nfin].tolist() == idx[:nfin].tolist()              # bit-exact candidate ids, in order
+    assert (o_f.cpu()[nfin:] == -1).all()
+    np.testing.assert_allclose(o_s.cpu()[:nfin].numpy(), vals[:nfin].numpy(), atol=1e-4, rtol=0)
+    assert o_p.cpu()[:nfin].tolist() == (idx[:nfin] // V).tolist()
+    assert o_t.cpu()[:nfin].tolist() == (idx[:nfin] % V).tolist()
+    for j in range(nfin):
+        assert int(o_n[j]) == fsm0.step(nodes[int(o_p[j])], int(o_t[j]))
+    lib.atspeed_fsm_destroy(h)
+
+
+def test_constraint_dead_end_raises(lib):
+    V = synth.TINY.vocab_size
+    con = PositionSetConstraint(synth.TINY.allowed_tokens(), synth.RESPONSE_SEP)
+    fsm = con.compile(list(synth.synthetic_prompt(8, 1)))
+    h = _dev_fsm(lib, fsm, V)
+    # node 5 (after EOS) allows nothing: HF raises ValueError; here the standalone op just returns no candidates
+    ld = (V + 63) // 64 * 64
+    lg = torch.zeros(1, ld, device="cuda")
+    lse = torch.zeros(1, device="cuda")
+    bs = torch.zeros(1, device="cuda")
+    nd = torch.tensor([5], dtype=torch.int32, device="cuda")
+    o_s = torch.empty(4, device="cuda")
+    o = [torch.empty(4, dtype=torch.int32, device="cuda") for _ in range(4)]
+    _lib.check(lib.atspeed_beam_expand_prune(lg.data_ptr(), ld, lse.data_ptr(), bs.data_ptr(), nd.data_ptr(), 1, h, 4,
+                                             o_s.data_ptr(), *[x.data_ptr() for x in o], _st()))
+    torch.cuda.synchronize()
+    assert (o[3].cpu() == -1).all()
+    lib.atspeed_fsm_destroy(h)
+
+
+# ------------------------------------------------------------------ accept
+@pytest.mark.parametrize("k,dk,kind", [(20, 40, "all"), (20, 40, "miss"), (20, 20, "all"), (1, 1, "all"), (10, 64, "all"),
+                                        (20, 40, "invalid")])
+def test_accept_equals_reference_logic(lib, k, dk, kind):
+    rng = np.random.default_rng(k * 100 + dk)
+    draft = rng.choice(10 ** 6, size=dk, replace=False).astype(np.int32)
+    pos = rng.choice(dk, size=k, replace=False)
+    target = draft[pos].copy()
+    if kind == "miss":
+        target[k // 2] = 10 ** 6 + 5
+    if kind == "invalid":
+        target[0] = -1
+    tscore = -np.sort(rng.random(k)).astype(np.float32)
+    # beamSD.py:371-380 in plain Python
+    hit_ref = [i for i, d in enumerate(draft.tolist()) if d in set(target.tolist())]
+    found = [draft.tolist().index(y) for y in target.tolist() if y in draft.tolist()]
+    order = np.argsort(np.array(found), kind="stable")
+    accept_ref = len(hit_ref) == k
+    t, ts, d = torch.from_numpy(target).cuda(), torch.from_numpy(tscore).cuda(), torch.from_numpy(draft).cuda()
+    hit = torch.empty(k, dtype=torch.int32, device="cuda")
+    sbh = torch.empty(k, device="cuda")
+    acc = torch.empty(1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.atspeed_accept(t.data_ptr(), ts.data_ptr(), k, d.data_ptr(), dk, hit.data_ptr(), sbh.data_ptr(), acc.data_ptr(), _st()))
+    torch.cuda.synchronize()
+    assert bool(acc.item()) == accept_ref
+    if accept_ref:
+        assert hit.cpu().tolist() == hit_ref
+        assert np.array_equal(sbh.cpu().numpy(), tscore[order])
+
+
+# ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("heads,dh", [(4, 32), (12, 64), (32, 128)])
+def test_tree_attention(lib, dtype, heads, dh):
+    from atspeed_amd.model import vis_bits_from_bool
+    T, S, max_slots = 23, 150, 256
+    H = heads * dh
+    q = _rand((T, 3 * H), 31).to(dtype).cuda()
+    kc = _rand((max_slots, H), 32).to(dtype).cuda()
+    vc = _rand((max_slots, H), 33).to(dtype).cuda()
+    g = torch.Generator().manual_seed(5)
+    vis = torch.rand(T, S, generator=g) < 0.3
+    vis[:, 0] = True
+    vis[3] = False
+    vis[3, 149] = True           # a row with a single visible slot at the very end
+    bits = vis_bits_from_bool(vis, max_slots).cuda()
+    out = torch.zeros(T, H, dtype=dtype, device="cuda")
+    code = _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16
+    _lib.check(lib.atspeed_tree_attention(q.data_ptr(), 3 * H, kc.data_ptr(), vc.data_ptr(), bits.data_ptr(), max_slots // 64,
+                                          out.data_ptr(), T, S, heads, dh, code, _st()))
+    torch.cuda.synchronize()
+    qf = q.float().cpu()[:, :H].view(T, heads, dh)
+    kf = kc.float().cpu()[:S].view(S, heads, dh)
+    vf = vc.float().cpu()[:S].view(S, heads, dh)
+    sc = torch.einsum("thd,shd->hts", qf, kf) / np.sqrt(dh)
+    sc = sc.masked_fill(~vis[None], float("-inf"))
+    ref = torch.einsum("hts,shd->thd", torch.softmax(sc, -1), vf).reshape(T, H)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=2e-5 if dtype == torch.float32 else 3e-2, rtol=0)
