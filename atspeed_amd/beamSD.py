@@ -160,6 +160,8 @@ def BSSD(target_model, draft_model, inputs: Dict, gamma: int, max_new_tokens: in
     P = int(prompt.numel())
     k = int(target_model.generation_config.num_beams)                 # beamSD.py:482
     dk = int(draft_model.generation_config.num_beams)                 # beamSD.py:483
+    # the mask functions look at the prompt (position of "Response:", data.py:97-102): one D2H copy per
+    # user, where the reference does one per beam per step (generation_trie.py:94, data.py:98)
     fsm = _compile_constraint(prefix_allowed_tokens_fn, prompt.tolist())
     dfsm = _DeviceFSM.get(fsm, target_model.dims.vocab_size)
     dec = _Decoder.get(target_model, draft_model, P)

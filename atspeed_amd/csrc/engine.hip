@@ -117,6 +117,40 @@ struct atspeed_llama {
   float* logits;                   // [max_logit_rows][logits_ld]
   float *cos_tab, *sin_tab;        // [max_slots][head_dim/2]
   void* ws; size_t ws_bytes;       // split-K slabs
+  // optional per-GEMM hipEvent brackets (bench.py roofline): 0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head
+  bool prof_on = false, prof_pending = false;
+  std::vector<hipEvent_t> prof_ev;           // 2 events per bracket
+  std::vector<int> prof_kind;                // kind per bracket of the pending forward
+  double prof_ms[5] = {0, 0, 0, 0, 0};
+  long prof_cnt[5] = {0, 0, 0, 0, 0};
+  long prof_rows[5] = {0, 0, 0, 0, 0};       // sum of M over the bracketed launches
+  std::vector<int> prof_m;
+};
+
+static void prof_harvest(atspeed_llama* m) {
+  if (!m->prof_pending) return;
+  for (size_t b = 0; b < m->prof_kind.size(); ++b) {
+    float ms = 0.f;
+    if (hipEventSynchronize(m->prof_ev[2 * b + 1]) == hipSuccess &&
+        hipEventElapsedTime(&ms, m->prof_ev[2 * b], m->prof_ev[2 * b + 1]) == hipSuccess) {
+      int kd = m->prof_kind[b];
+      m->prof_ms[kd] += ms; m->prof_cnt[kd] += 1; m->prof_rows[kd] += m->prof_m[b];
+    }
+  }
+  m->prof_kind.clear(); m->prof_m.clear();
+  m->prof_pending = false;
+}
+
+struct ProfBracket {
+  atspeed_llama* m; hipStream_t st; bool on; size_t idx;
+  ProfBracket(atspeed_llama* m_, int kind, int rows, hipStream_t st_) : m(m_), st(st_), on(m_->prof_on), idx(0) {
+    if (!on) return;
+    idx = m->prof_kind.size();
+    while (m->prof_ev.size() < 2 * (idx + 1)) { hipEvent_t e; hipEventCreate(&e); m->prof_ev.push_back(e); }
+    m->prof_kind.push_back(kind); m->prof_m.push_back(rows);
+    hipEventRecord(m->prof_ev[2 * idx], st);
+  }
+  ~ProfBracket() { if (on) { hipEventRecord(m->prof_ev[2 * idx + 1], st); m->prof_pending = true; } }
 };
 
 static size_t gemm_ws_for(const atspeed_llama_config& c) {
@@ -191,7 +225,23 @@ extern "C" void atspeed_llama_destroy(atspeed_llama* m) {
   if (!m) return;
   hipFree(m->kcache); hipFree(m->vcache); hipFree(m->h); hipFree(m->xn); hipFree(m->qkv); hipFree(m->att);
   hipFree(m->act); hipFree(m->logits); hipFree(m->ws); hipFree(m->cos_tab); hipFree(m->sin_tab);
+  for (hipEvent_t e : m->prof_ev) hipEventDestroy(e);
   delete m;
+}
+
+extern "C" int atspeed_llama_profile(atspeed_llama* m, int32_t enable, double* ms_out, int64_t* count_out, int64_t* rows_out) {
+  ATS_REQUIRE(m, ATSPEED_ERR_INVALID, "profile: null model");
+  prof_harvest(m);
+  for (int i = 0; i < 5; ++i) {
+    if (ms_out) ms_out[i] = m->prof_ms[i];
+    if (count_out) count_out[i] = m->prof_cnt[i];
+    if (rows_out) rows_out[i] = m->prof_rows[i];
+  }
+  if (enable >= 0) {
+    m->prof_on = enable != 0;
+    for (int i = 0; i < 5; ++i) { m->prof_ms[i] = 0; m->prof_cnt[i] = 0; m->prof_rows[i] = 0; }
+  }
+  return ATSPEED_OK;
 }
 
 extern "C" float* atspeed_llama_logits(atspeed_llama* m) { return m ? m->logits : nullptr; }
@@ -206,6 +256,7 @@ static int llama_forward(atspeed_llama* m, const int32_t* ids, const int32_t* po
               "forward: %d logit rows exceed the limit %d", n_logit_rows, c.max_logit_rows);
   const int H = c.hidden, dt = c.dtype;
   const size_t e = m->esz;
+  if (m->prof_on) prof_harvest(m);
   const size_t layer_kv = (size_t)c.max_slots * H * e;
   ATS_TRY(ats_embed(m->embed, ids, m->h, T, H, c.vocab_size, dt, st));
   for (int l = 0; l < c.n_layers; ++l) {
@@ -213,18 +264,23 @@ static int llama_forward(atspeed_llama* m, const int32_t* ids, const int32_t* po
     char* kc = (char*)m->kcache + l * layer_kv;
     char* vc = (char*)m->vcache + l * layer_kv;
     ATS_TRY(ats_rmsnorm(m->h, w.input_norm, m->xn, T, H, c.rms_eps, dt, st));
-    ATS_TRY(ats_gemm(m->xn, w.wqkv, m->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, m->ws, m->ws_bytes, st));
+    { ProfBracket pb(m, 0, T, st);
+      ATS_TRY(ats_gemm(m->xn, w.wqkv, m->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, m->ws, m->ws_bytes, st)); }
     ATS_TRY(ats_rope_kv(m->qkv, pos, slots, m->cos_tab, m->sin_tab, kc, vc, T, c.n_heads, m->head_dim, c.max_slots, dt, st));
     ATS_TRY(ats_tree_attention(m->qkv, 3 * H, kc, vc, vis, m->vis_words, m->att, H, T, S, c.n_heads, m->head_dim, dt, st));
-    ATS_TRY(ats_gemm(m->att, w.wo, m->h, T, H, H, H, H, dt, EPI_RESID, m->ws, m->ws_bytes, st));
+    { ProfBracket pb(m, 1, T, st);
+      ATS_TRY(ats_gemm(m->att, w.wo, m->h, T, H, H, H, H, dt, EPI_RESID, m->ws, m->ws_bytes, st)); }
     ATS_TRY(ats_rmsnorm(m->h, w.post_norm, m->xn, T, H, c.rms_eps, dt, st));
-    ATS_TRY(ats_gemm(m->xn, w.wgu, m->act, T, 2 * c.ffn, H, H, c.ffn, dt, EPI_SWIGLU, m->ws, m->ws_bytes, st));
-    ATS_TRY(ats_gemm(m->act, w.wd, m->h, T, H, c.ffn, c.ffn, H, dt, EPI_RESID, m->ws, m->ws_bytes, st));
+    { ProfBracket pb(m, 2, T, st);
+      ATS_TRY(ats_gemm(m->xn, w.wgu, m->act, T, 2 * c.ffn, H, H, c.ffn, dt, EPI_SWIGLU, m->ws, m->ws_bytes, st)); }
+    { ProfBracket pb(m, 3, T, st);
+      ATS_TRY(ats_gemm(m->act, w.wd, m->h, T, H, c.ffn, c.ffn, H, dt, EPI_RESID, m->ws, m->ws_bytes, st)); }
   }
   if (n_logit_rows > 0) {
     char* hrows = (char*)m->h + (size_t)(T - n_logit_rows) * H * e;
     ATS_TRY(ats_rmsnorm(hrows, m->final_norm, m->xn, n_logit_rows, H, c.rms_eps, dt, st));
     float* lo = logits_out ? logits_out : m->logits;
+    ProfBracket pb(m, 4, n_logit_rows, st);
     ATS_TRY(ats_gemm(m->xn, m->lm_head, lo, n_logit_rows, c.vocab_size, H, H, m->logits_ld, dt, EPI_F32, m->ws, m->ws_bytes, st));
   }
   return ATSPEED_OK;

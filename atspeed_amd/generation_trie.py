@@ -194,6 +194,7 @@ class PositionSetConstraint:
     def __init__(self, allowed_tokens: Dict[int, Iterable[int]], sep: Sequence[int]):
         self.allowed_tokens = {int(i): list(v) for i, v in allowed_tokens.items()}
         self.sep = [int(s) for s in sep]
+        self._fsm: Optional[ConstraintFSM] = None     # CSR arrays are prompt-independent; only `start` varies
 
     def __call__(self, batch_id, sentence) -> Optional[List[int]]:
         i = _tokens_after_last(_as_list(sentence), self.sep)
@@ -206,15 +207,20 @@ class PositionSetConstraint:
         if i0 is None:
             raise TypeError("separator not found in prompt: the reference's mask function returns None here "
                             "(code/data.py:97-102) and the HF processor then fails with TypeError")
-        n_pos = max(self.allowed_tokens) + 1
-        row_ptr, tok, nxt = [0], [], []
-        for i in range(n_pos):
-            ids = sorted(set(self.allowed_tokens.get(i, [])))
-            tok += ids
-            nxt += [min(i + 1, n_pos)] * len(ids)
-            row_ptr.append(len(tok))
-        row_ptr.append(len(tok))   # terminal node: nothing allowed (reference: KeyError)
-        return ConstraintFSM(np.asarray(row_ptr, np.int32), np.asarray(tok, np.int32), np.asarray(nxt, np.int32), i0)
+        if self._fsm is None:
+            n_pos = max(self.allowed_tokens) + 1
+            row_ptr, tok, nxt = [0], [], []
+            for i in range(n_pos):
+                ids = sorted(set(self.allowed_tokens.get(i, [])))
+                tok += ids
+                nxt += [min(i + 1, n_pos)] * len(ids)
+                row_ptr.append(len(tok))
+            row_ptr.append(len(tok))   # terminal node: nothing allowed (reference: KeyError)
+            self._fsm = ConstraintFSM(np.asarray(row_ptr, np.int32), np.asarray(tok, np.int32), np.asarray(nxt, np.int32), 0)
+        f = self._fsm
+        if i0 >= f.n_nodes:
+            raise KeyError(i0)         # reference: allowed_tokens[i] KeyError past the last position
+        return ConstraintFSM(f.row_ptr, f.tok, f.nxt, i0)
 
 
 class SuffixTrieConstraint:

@@ -150,6 +150,43 @@ class HipLlama:
             del sd
         return cls(dims, packed, dtype, device, **kw)
 
+    # ---- measurement hooks --------------------------------------------------------------
+    GEMM_KINDS = ("qkv", "o_proj", "gate_up", "down", "lm_head")
+
+    def profile(self, enable: int = -1) -> Dict[str, Dict[str, float]]:
+        """hipEvent brackets around the forward's GEMMs (see atspeed_llama_profile)."""
+        ms = (C.c_double * 5)()
+        cnt = (C.c_int64 * 5)()
+        rows = (C.c_int64 * 5)()
+        _lib.check(_lib.load().atspeed_llama_profile(self._handle, enable, ms, cnt, rows))
+        return {k: dict(ms=ms[i], count=int(cnt[i]), rows=int(rows[i])) for i, k in enumerate(self.GEMM_KINDS)}
+
+    def gemm_shape(self, kind: str):
+        """(N, K) of a GEMM kind."""
+        d = self.dims
+        return {"qkv": (3 * d.hidden, d.hidden), "o_proj": (d.hidden, d.hidden), "gate_up": (2 * d.ffn, d.hidden),
+                "down": (d.hidden, d.ffn), "lm_head": (d.vocab_size, d.hidden)}[kind]
+
+    def export_state_dict(self) -> Dict[str, torch.Tensor]:
+        """HF-named fp32 CPU tensors (undoing the qkv / gate-up packing): lets bench.py's cpu_baseline run the
+        oracle on exactly the weights the device holds."""
+        d, pk = self.dims, self._packed
+        f = lambda t: t.detach().to("cpu", torch.float32)
+        sd = {"model.embed_tokens.weight": f(pk["embed"]), "model.norm.weight": f(pk["final_norm"]), "lm_head.weight": f(pk["lm_head"])}
+        for l, lw in enumerate(pk["layers"]):
+            p = f"model.layers.{l}."
+            qkv = f(lw["wqkv"])
+            sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"] = \
+                qkv[: d.hidden], qkv[d.hidden: 2 * d.hidden], qkv[2 * d.hidden:]
+            gu = f(lw["wgu"]).view(d.ffn // 16, 2, 16, d.hidden)
+            sd[p + "mlp.gate_proj.weight"] = gu[:, 0].reshape(d.ffn, d.hidden)
+            sd[p + "mlp.up_proj.weight"] = gu[:, 1].reshape(d.ffn, d.hidden)
+            sd[p + "self_attn.o_proj.weight"] = f(lw["wo"])
+            sd[p + "mlp.down_proj.weight"] = f(lw["wd"])
+            sd[p + "input_layernorm.weight"] = f(lw["input_norm"])
+            sd[p + "post_attention_layernorm.weight"] = f(lw["post_norm"])
+        return sd
+
     # ---- forward (tests / tools; the decoder calls the C entry point directly) --------
     def forward_raw(self, ids: torch.Tensor, pos: torch.Tensor, slots: torch.Tensor, vis_bits: torch.Tensor,
                     n_slots: int, n_logit_rows: int) -> torch.Tensor:

@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the beam-speculative-decoding hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Metric (BASELINE.json): recommended items/sec + mean accepted length, Llama-68M draft /
+Llama-7B target, K=20 beams, DK=40 draft beams, gamma=4, L=4 code tokens, Beauty vocabulary
+(V=32859), bf16, synthetic hash-PRNG weights and prompts (no tokenizer/checkpoints offline).
+A "step" is one user's complete BSSD() call (draft steps + packed target verification +
+verify rounds) with the prompt already resident in HBM; `value` = users * K / wall time.
+Users are independent, so N GPUs shard the user list (weak scaling: --steps users per GPU)
+and exchange only one all-gather of counters at the end.
+
+Extra objects on the JSON line:
+  roofline     — the dominant kernel family (target-forward projection GEMM with the largest total
+                 time), algorithmic bytes / launch over hipEvent-measured launch time vs 8 TB/s HBM.
+  cpu_baseline — the oracle (oracle/beamsd_ref.py, torch-CPU fp32) timed on the host cores on a
+                 bounded sample of the same workload with the same weights (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from atspeed_amd import synth                      # noqa: E402
+from atspeed_amd.beamSD import BSSD                # noqa: E402
+from atspeed_amd.generation_trie import PositionSetConstraint   # noqa: E402
+from atspeed_amd.model import HipLlama             # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24, help="users per GPU in the timed region")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--target-layers", type=int, default=32, help="32 = Llama-7B (the metric's config)")
+    ap.add_argument("--beam", type=int, default=20)
+    ap.add_argument("--draft-beam", type=int, default=40)
+    ap.add_argument("--gamma", type=int, default=4)
+    ap.add_argument("--new-tokens", type=int, default=4)
+    ap.add_argument("--seed", type=int, default=2025)
+    ap.add_argument("--cpu-baseline-users", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def traffic_from_profiles(kind: str):
+    """HBM bytes per launch from the committed PMC summary (profiles/pmc_traffic.json), if present."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        with open(p) as f:
+            return json.load(f).get(kind, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(target, draft, prompts, fn, args):
+    """Oracle (CPU restatement of the reference) on the same weights/prompts; bounded sample."""
+    from oracle import beamsd_ref as R
+    from oracle.llama_ref import RefLlama
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    rt = RefLlama(target.dims, target.export_state_dict(), max_slots=512)
+    rd = RefLlama(draft.dims, draft.export_state_dict(), max_slots=512)
+    setup = time.perf_counter() - t0
+    n = min(args.cpu_baseline_users, len(prompts))
+    t0 = time.perf_counter()
+    acc = runs = 0
+    outs = []
+    for u in range(n):
+        o = R.BSSD(rt, rd, prompts[u], args.gamma, args.new_tokens, args.beam, args.draft_beam, fn)
+        acc += o["total_accept_steps"]
+        runs += o["n_run"]
+        outs.append(o)
+    dt = time.perf_counter() - t0
+    return dict(value=n * args.beam / dt, unit="items/s", cores=cores, kind="port",
+                sample=f"{n} user(s) of the same workload (same weights, fp32 on CPU), {dt:.1f}s after {setup:.1f}s weight export",
+                mean_accept_len=(acc / runs if runs else 0.0)), outs
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")       # RCCL over xGMI
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    vocab = synth.BEAUTY
+    V = vocab.vocab_size
+    tdims = synth.llama_7b(V, args.target_layers)
+    ddims = synth.llama_68m(V)
+    kw = dict(max_slots=512, max_tokens=512, max_logit_rows=384, device=dev)
+    target = HipLlama.from_synthetic(tdims, args.seed, std=0.02, head_std=0.02, dtype=torch.bfloat16, num_beams=args.beam, **kw)
+    draft = HipLlama.from_synthetic(ddims, args.seed + 1, std=0.02, head_std=0.02, dtype=torch.bfloat16, num_beams=args.draft_beam, **kw)
+    fn = PositionSetConstraint(vocab.allowed_tokens(), synth.RESPONSE_SEP)
+
+    n_local = args.warmup + args.steps
+    first = rank * n_local                                   # contiguous user shard per rank
+    plens = synth.prompt_lengths(world * n_local, args.seed)
+    prompts = [synth.synthetic_prompt(int(plens[first + u]), synth.tensor_seed(args.seed, f"user{first + u}")) for u in range(n_local)]
+    dprompts = [{"input_ids": torch.from_numpy(p)[None].to(dev)} for p in prompts]   # resident in HBM before timing
+
+    for u in range(args.warmup):
+        BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
+    target.profile(1)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    n_run = acc = 0
+    stage = np.zeros(3)
+    n_tf = n_df = 0
+    outs = []
+    for u in range(args.warmup, n_local):
+        o = BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
+        n_run += o["n_run"]; acc += o["total_accept_steps"]
+        stage += (o["draft_time_cost"], o["target_time_cost"], o["verify_time_cost"])
+        n_tf += o["n_target_forwards"]; n_df += o["n_draft_forwards"]
+        outs.append(o)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = target.profile(0)
+
+    counters = torch.tensor([args.steps, n_run, acc, int(elapsed * 1e9)], dtype=torch.int64, device=dev)
+    if world > 1:
+        gathered = [torch.zeros_like(counters) for _ in range(world)]
+        dist.all_gather(gathered, counters)                  # the path's single collective
+        allc = torch.stack(gathered).cpu().numpy()
+    else:
+        allc = counters.cpu().numpy()[None]
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    users = int(allc[:, 0].sum())
+    t_max = float(allc[:, 3].max()) * 1e-9
+    value = users * args.beam / t_max
+    mean_accept = float(allc[:, 2].sum()) / max(1, int(allc[:, 1].sum()))
+
+    # ---- roofline of the dominant GEMM kind (weights streamed once per launch)
+    kind = max(prof, key=lambda k: prof[k]["ms"])
+    pk = prof[kind]
+    N, K = target.gemm_shape(kind)
+    avg_m = pk["rows"] / max(1, pk["count"])
+    n_out = N // 2 if kind == "gate_up" else N
+    out_b = 4 if kind == "lm_head" else 2
+    alg_bytes = N * K * 2 + avg_m * K * 2 + avg_m * n_out * out_b
+    avg_ms = pk["ms"] / max(1, pk["count"])
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    gemm_ms_total = sum(v["ms"] for v in prof.values())
+    roofline = dict(bound="hbm", kernel=f"gemm_kernel<bf16>[{kind}] N={N} K={K} avg_M={avg_m:.0f}",
+                    achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                    traffic=traffic_from_profiles(kind), avg_launch_us=avg_ms * 1e3, launches=pk["count"],
+                    algorithmic_bytes_per_launch=alg_bytes,
+                    target_forward=dict(avg_ms=1e3 * stage[1] / max(1, n_tf),
+                                        weight_bytes=tdims.n_params_streamed() * 2,
+                                        achieved_GBs=(tdims.n_params_streamed() * 2 / (stage[1] / max(1, n_tf))) / 1e9 if stage[1] > 0 else 0.0,
+                                        gemm_ms_share={k: v["ms"] / gemm_ms_total for k, v in prof.items()} if gemm_ms_total else {}))
+
+    line = {
+        "metric": "recommended items/sec (K=20 beams per user), mean accepted length alongside",
+        "value": value, "unit": "items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic (hash-PRNG weights, Beauty-shaped vocabulary and prompts)",
+        "config": {"workload": f"Beauty V={V}, Llama-68M draft / Llama-7B({args.target_layers}L) target, K={args.beam}, DK={args.draft_beam}, "
+                               f"gamma={args.gamma}, L={args.new_tokens}, batch=1 user stream per GPU, position-set mask",
+                   "users_per_gpu": args.steps, "mean_prompt_len": float(np.mean([len(p) for p in prompts[args.warmup:]])),
+                   "parallelism": f"user-shard x{world}"},
+        "mean_accept_len": mean_accept,
+        "accept_note": "unrelated random draft/target weights accept ~0 draft steps: worst-case bracket (4 target forwards per user)",
+        "per_user": {"n_run": float(allc[:, 1].sum()) / users, "target_forwards": n_tf / args.steps, "draft_forwards": n_df / args.steps,
+                     "draft_ms": 1e3 * stage[0] / args.steps, "target_ms": 1e3 * stage[1] / args.steps, "verify_ms": 1e3 * stage[2] / args.steps},
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        cb, ref_outs = cpu_baseline(target, draft, prompts[args.warmup:], fn, args)
+        line["cpu_baseline"] = cb
+        # parity note next to the timing: bf16 engine vs fp32 oracle on identical weights
+        P0 = len(prompts[args.warmup])
+        same = outs[0]["beam_sequence"][:, P0:].cpu().tolist() == ref_outs[0]["beam_sequence"][:, P0:].tolist()
+        line["cpu_baseline"]["items_equal_to_gpu_bf16"] = bool(same)
+        line["cpu_baseline"]["gpu_accept_len_same_users"] = float(sum(o["total_accept_steps"] for o in outs[:len(ref_outs)])) / max(
+            1, sum(o["n_run"] for o in outs[:len(ref_outs)]))
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -117,6 +117,11 @@ int atspeed_llama_forward(atspeed_llama* m, const int32_t* ids_dev, const int32_
                           const int32_t* slots_dev, const uint64_t* vis_bits_dev, int32_t n_tokens,
                           int32_t n_slots_visible, int32_t n_logit_rows, float* logits_out_dev, void* stream);
 float* atspeed_llama_logits(atspeed_llama* m);
+/* hipEvent brackets around the forward's five GEMM kinds (0 qkv, 1 o_proj, 2 gate_up+SwiGLU, 3 down,
+ * 4 lm_head), recorded on the launch stream.  Returns the sums since the last reset in ms_out[5] /
+ * count_out[5] / rows_out[5] (sum of M); enable = 1/0 switches the brackets on/off and resets,
+ * enable < 0 only reads.  Measurement hook for bench.py's roofline (no reference counterpart). */
+int atspeed_llama_profile(atspeed_llama* m, int32_t enable, double* ms_out, int64_t* count_out, int64_t* rows_out);
 int32_t atspeed_llama_logits_ld(const atspeed_llama* m);
 
 /* ------------------------------------------------------------------ scan kernels
