@@ -35,6 +35,7 @@ if ROOT not in sys.path:
 
 from atspeed_amd import synth                      # noqa: E402
 from atspeed_amd.beamSD import BSSD                # noqa: E402
+from atspeed_amd.dist import Counters, aggregate, all_gather_counters   # noqa: E402
 from atspeed_amd.generation_trie import PositionSetConstraint   # noqa: E402
 from atspeed_amd.model import HipLlama             # noqa: E402
 
@@ -144,21 +145,14 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = target.profile(0)
 
-    counters = torch.tensor([args.steps, n_run, acc, int(elapsed * 1e9)], dtype=torch.int64, device=dev)
-    if world > 1:
-        gathered = [torch.zeros_like(counters) for _ in range(world)]
-        dist.all_gather(gathered, counters)                  # the path's single collective
-        allc = torch.stack(gathered).cpu().numpy()
-    else:
-        allc = counters.cpu().numpy()[None]
+    per_rank = all_gather_counters(Counters(args.steps, n_run, acc, int(elapsed * 1e9)), dev)   # the path's single collective
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    users = int(allc[:, 0].sum())
-    t_max = float(allc[:, 3].max()) * 1e-9
-    value = users * args.beam / t_max
-    mean_accept = float(allc[:, 2].sum()) / max(1, int(allc[:, 1].sum()))
+    agg = aggregate(per_rank, args.beam)
+    users, t_max, value, mean_accept = agg["users"], agg["elapsed_s"], agg["items_per_s"], agg["mean_accept_len"]
+    total_runs = sum(c.n_run for c in per_rank)
 
     # ---- roofline of the dominant GEMM kind (weights streamed once per launch)
     kind = max(prof, key=lambda k: prof[k]["ms"])
@@ -191,7 +185,7 @@ def main():
                    "parallelism": f"user-shard x{world}"},
         "mean_accept_len": mean_accept,
         "accept_note": "unrelated random draft/target weights accept ~0 draft steps: worst-case bracket (4 target forwards per user)",
-        "per_user": {"n_run": float(allc[:, 1].sum()) / users, "target_forwards": n_tf / args.steps, "draft_forwards": n_df / args.steps,
+        "per_user": {"n_run": total_runs / users, "target_forwards": n_tf / args.steps, "draft_forwards": n_df / args.steps,
                      "draft_ms": 1e3 * stage[0] / args.steps, "target_ms": 1e3 * stage[1] / args.steps, "verify_ms": 1e3 * stage[2] / args.steps},
         "roofline": roofline,
     }
