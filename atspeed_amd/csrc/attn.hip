@@ -5,11 +5,14 @@
 // row carries a bitset over cache slots (prompt prefix + one ancestor per accepted/draft
 // block + itself); the kernel compacts the set bits and touches only visible slots.
 //
-// v1 kernel (round 1): one wave per (token, head).  Phase 1: lanes own visible slots and
-// compute q.k from global K rows; phase 2: wave softmax in fp32; phase 3: lanes own head
-// dims and accumulate p*V with coalesced V reads.  Attention is < 2 % of the forward's
-// bytes/FLOPs at these sizes (S <= ~250); an MFMA/LDS-tiled version is the next step once
-// the GEMMs stop dominating.
+// Two kernels:
+//  * tree_attn_mfma_kernel (bf16, head_dim 64/128): flash-style, one workgroup per (64 query
+//    rows, head), K tile and transposed V tile staged in LDS, both products on MFMA 16x16x32.
+//    Products are arranged so nothing moves between them: S^T = K.Q^T puts the key on the
+//    accumulator rows and the query on the lane (col = lane & 15), so the softmax statistics of a
+//    query live in the 4 lanes that share lane & 15, and the exponentiated S^T registers ARE the
+//    B operand of O^T = V^T.P^T (k-slots permuted identically on the V^T operand).
+//  * tree_attn_kernel (fp32 parity mode / odd head dims): one wave per (token, head), scalar.
 #include "internal.h"
 
 namespace {
@@ -92,6 +95,130 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q,
   }
 }
 
+// ---------------------------------------------------------------------------- MFMA kernel (bf16)
+template <int DH>
+__global__ __launch_bounds__(256) void tree_attn_mfma_kernel(const bf16_t* __restrict__ q, int ldq,
+                                                             const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+                                                             const uint64_t* __restrict__ vis, int vis_words,
+                                                             bf16_t* __restrict__ out, int ldo, int n_tokens, int n_slots,
+                                                             int n_heads, float scale) {
+  constexpr int KCH = DH / 8;                 // 16-byte chunks per K row
+  constexpr int VT_LD = 68;                   // padded row (elements) of the transposed V tile
+  constexpr int DT = DH / 16;                 // output d-tiles
+  constexpr int KS = DH / 32;                 // k-steps of the QK product
+  __shared__ __attribute__((aligned(16))) unsigned char ks_lds[64 * DH * 2];
+  __shared__ __attribute__((aligned(16))) bf16_t vt_lds[DH * VT_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, lq = lane & 15;
+  const int h = blockIdx.y;
+  const int hidden = n_heads * DH;
+  const int qrow = blockIdx.x * 64 + wave * 16 + lq;
+  const bool qok = qrow < n_tokens;
+
+  s16x8_t qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (qok) qf[ks] = *reinterpret_cast<const s16x8_t*>(q + (size_t)qrow * ldq + h * DH + ks * 32 + g * 8);
+    else qf[ks] = s16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  f32x4_t o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) o[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int n_tiles = (n_slots + 63) >> 6;
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    __syncthreads();                                   // previous tile fully consumed
+    // ---- stage K (swizzled rows) and V^T
+#pragma unroll
+    for (int i = 0; i < (64 * KCH) / 256; ++i) {
+      int qi = tid + i * 256;
+      int r = qi / KCH, c = qi % KCH;
+      int key = kt * 64 + r;
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+      if (key < n_slots) {
+        size_t off = (size_t)key * hidden + h * DH + c * 8;
+        kv = *reinterpret_cast<const uint4*>(kc + off);
+        vv = *reinterpret_cast<const uint4*>(vc + off);
+      }
+      *reinterpret_cast<uint4*>(ks_lds + (r * KCH + (c ^ (r & 7))) * 16) = kv;
+      const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vt_lds[(c * 8 + e) * VT_LD + r] = ve[e];
+    }
+    __syncthreads();
+    uint64_t word = qok ? vis[(size_t)qrow * vis_words + kt] : 0ull;
+    if (kt == n_tiles - 1 && (n_slots & 63)) word &= (~0ull) >> (64 - (n_slots & 63));
+    if (__ballot(word != 0ull) == 0ull) continue;      // this wave's 16 rows see nothing here (wave-uniform)
+
+    // ---- S^T = K_tile . Q^T : s[c][r] = score(key = kt*64 + c*16 + g*4 + r, query = lq)
+    f32x4_t s[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      s[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        int r = c * 16 + lq, ch = ks * 4 + g;
+        s16x8_t kf = *reinterpret_cast<const s16x8_t*>(ks_lds + (r * KCH + (ch ^ (r & 7))) * 16);
+        s[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ks]), s[c], 0, 0, 0);
+      }
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bool v = (word >> (c * 16 + g * 4 + r)) & 1ull;
+        float x = v ? s[c][r] * scale : -INFINITY;
+        s[c][r] = x;
+        mt = fmaxf(mt, x);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+    float psum = 0.f;
+    s16x8_t pf[2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = (s[c][r] == -INFINITY) ? 0.f : __expf(s[c][r] - m_new);
+        psum += p;
+        pf[c >> 1][(c & 1) * 4 + r] = (short)f2bf(p);
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha;
+    }
+    // ---- O^T += V^T . P^T  (k-slot j<4 -> key tile 2kk, j>=4 -> key tile 2kk+1, both 4g + (j&3))
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const bf16_t* vrow = vt_lds + (d * 16 + lq) * VT_LD + g * 4;
+        uint2 va = *reinterpret_cast<const uint2*>(vrow + (2 * kk) * 16);
+        uint2 vb = *reinterpret_cast<const uint2*>(vrow + (2 * kk + 1) * 16);
+        uint4 vv = make_uint4(va.x, va.y, vb.x, vb.y);
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), __builtin_bit_cast(bf16x8_t, pf[kk]), o[d], 0, 0, 0);
+      }
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (qok) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    bf16_t* orow = out + (size_t)qrow * ldo + h * DH;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      ushort4 pk;
+      pk.x = f2bf(o[d][0] * inv); pk.y = f2bf(o[d][1] * inv); pk.z = f2bf(o[d][2] * inv); pk.w = f2bf(o[d][3] * inv);
+      *reinterpret_cast<ushort4*>(orow + d * 16 + g * 4) = pk;
+    }
+  }
+}
+
 }  // namespace
 
 int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* vcache, const uint64_t* vis,
@@ -101,9 +228,20 @@ int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* v
   ATS_REQUIRE(head_dim % 8 == 0 && head_dim <= 256, ATSPEED_ERR_INVALID, "attention: head_dim %d unsupported", head_dim);
   ATS_REQUIRE(n_slots <= vis_words * 64 && vis_words * 64 <= kMaxSlots, ATSPEED_ERR_CAPACITY,
               "attention: %d slots exceed the visibility bitset (%d words)", n_slots, vis_words);
+  float scale = 1.0f / sqrtf((float)head_dim);
+  if (dtype == ATSPEED_BF16 && (head_dim == 64 || head_dim == 128) && (ldq % 8) == 0 && (ldo % 4) == 0) {
+    dim3 mgrid((n_tokens + 63) / 64, n_heads);
+    if (head_dim == 128)
+      tree_attn_mfma_kernel<128><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)kcache, (const bf16_t*)vcache, vis,
+                                                        vis_words, (bf16_t*)out, ldo, n_tokens, n_slots, n_heads, scale);
+    else
+      tree_attn_mfma_kernel<64><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)kcache, (const bf16_t*)vcache, vis,
+                                                       vis_words, (bf16_t*)out, ldo, n_tokens, n_slots, n_heads, scale);
+    ATS_LAUNCH_CHECK();
+    return ATSPEED_OK;
+  }
   dim3 grid(n_tokens, (n_heads + 3) / 4);
   size_t lds = (size_t)4 * (head_dim + 2 * vis_words * 64) * sizeof(float);
-  float scale = 1.0f / sqrtf((float)head_dim);
   if (dtype == ATSPEED_F32)
     tree_attn_kernel<float><<<grid, 256, lds, st>>>((const float*)q, ldq, (const float*)kcache, (const float*)vcache, vis,
                                                     vis_words, (float*)out, ldo, n_slots, n_heads, head_dim, scale);

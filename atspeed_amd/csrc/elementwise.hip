@@ -11,13 +11,14 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t idx, uint32_t seed) { retu
 
 template <typename T>
 __global__ void fill_hash_normal_kernel(T* dst, size_t n, uint32_t seed, float scale, float add, uint64_t offset) {
+#pragma clang fp contract(off)   // the multiply and the add must round separately (numpy does)
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     uint32_t idx = (uint32_t)(i + offset);
     uint32_t h1 = hash_u32(idx, seed), h2 = hash_u32(idx, seed ^ 0x5BD1E995u);
     int s = (int)((h1 & 0xffffu) + (h1 >> 16) + (h2 & 0xffffu) + (h2 >> 16)) - 131070;
-    float v = (float)s * scale;          // exact int->float, one fp32 multiply: matches numpy bit for bit
+    float v = (float)s * scale;          // exact int->float, ONE fp32 multiply: matches numpy bit for bit
     if (add != 0.0f) v = add + v;
     Elt<T>::store(dst + i, v);
   }

@@ -16,6 +16,8 @@
 //     256 CUs; a second kernel reduces the slabs and applies the epilogue.
 // Epilogues: store (dtype), fp32 store (logits), residual add, SwiGLU over interleaved
 // gate/up 16-column groups.
+#include <algorithm>
+
 #include "internal.h"
 
 namespace {
@@ -242,6 +244,275 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, void* __
   }
 }
 
+
+// =====================================================================================
+// Weight-streaming GEMM (bf16), the production path for the forward's projections.
+//
+//   C^T[N, M] = W[N, K] * X^T[K, M]          (same math as above, operands swapped)
+//
+// M (tokens) is small, so every launch is a single pass over W.  Each wave OWNS 16*RT rows of W
+// and streams them global -> VGPR with a D-step-deep register ring (no LDS round trip: a weight
+// element is used by exactly one wave), while the token block X[M, K] — shared by all waves and
+// L2-resident — is staged through LDS (two buffers, XOR-swizzled 128-byte rows).  W is the MFMA
+// A operand, X^T the B operand; the accumulator tile has the W row on the register index and
+// the token on the lane, so the epilogue writes 4 consecutive output columns per lane (8-byte
+// stores) and the SwiGLU pair (gate tile, up tile) sits in the same lane.
+// Bytes in flight per CU: 4 waves * 16*RT rows * D*128 B (= 64 KB at RT=2, D=4), which is what
+// an HBM stream at ~25-35 GB/s per CU needs against ~2 us of loaded latency.
+template <int MT, int RT, int EPI, bool SPLIT>
+__global__ __launch_bounds__(256, 1) void gemm_ws_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                         void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
+                                                         int k_per_split, float* __restrict__ partial) {
+  constexpr int D = 4;                          // ring depth in BK steps
+  constexpr int BK = 64;
+  constexpr int MP = MT * 16;                   // padded token rows per workgroup
+  constexpr int XCH = MP * 8 / 256;             // 16-byte chunks of the X tile per thread
+  constexpr int BN = 4 * 16 * RT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, g = lane >> 4;
+  const int n_wave = blockIdx.x * BN + wave * 16 * RT;
+  const int m0 = blockIdx.y * MP;
+  const int kz0 = blockIdx.z * k_per_split;
+  const int kz1 = min(K, kz0 + k_per_split);
+  const int nsteps = (kz1 - kz0 + BK - 1) / BK;
+
+  // per-lane W row pointers (rows beyond N are clamped; their results are never stored)
+  const bf16_t* wrow[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) wrow[rt] = W + (size_t)min(n_wave + rt * 16 + lq, N - 1) * K + g * 8;
+
+  uint4 wr[D][2][RT];                            // [ring slot][k-step][row tile]
+  uint4 xr[XCH];
+  f32x4_t acc[RT][MT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[rt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // Every load is unconditional and in bounds (K % 64 == 0 is required by the launcher): steps past the
+  // end re-read the last tile, token rows past M re-read row M-1 — their products are never stored.  A
+  // "load or zero" select would make hipcc branch around each load and drain vmcnt (guide: trap (c)).
+  const bf16_t* xrow[XCH];
+#pragma unroll
+  for (int i = 0; i < XCH; ++i) {
+    int qi = tid + i * 256;
+    xrow[i] = X + (size_t)min(m0 + (qi >> 3), M - 1) * ldx + (qi & 7) * 8;
+  }
+  auto load_w = [&](uint4 (&dst)[2][RT], int step) {
+    const int kb = kz0 + min(step, nsteps - 1) * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) dst[ks][rt] = *reinterpret_cast<const uint4*>(wrow[rt] + kb + ks * 32);
+  };
+  auto load_x = [&](int step) {
+    const int kb = kz0 + min(step, nsteps - 1) * BK;
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) xr[i] = *reinterpret_cast<const uint4*>(xrow[i] + kb);
+  };
+  auto store_x = [&](int buf) {
+    unsigned char* sx = smem + buf * (MP * kRowBytes);
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      int qi = tid + i * 256;
+      *reinterpret_cast<uint4*>(sx + swz(qi >> 3, qi & 7)) = xr[i];
+    }
+  };
+  auto compute = [&](const uint4 (&wf)[2][RT], int buf) {
+    const unsigned char* sx = smem + buf * (MP * kRowBytes);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        s16x8_t xf = *reinterpret_cast<const s16x8_t*>(sx + swz(mt * 16 + lq, ks * 4 + g));
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          acc[rt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[ks][rt]),
+                                                                __builtin_bit_cast(bf16x8_t, xf), acc[rt][mt], 0, 0, 0);
+      }
+  };
+
+  // prologue: ring slots 0..D-1, X step 0 in LDS, X step 1 in registers
+#pragma unroll
+  for (int d = 0; d < D; ++d) load_w(wr[d], d);
+  load_x(0);
+  store_x(0);
+  load_x(1);
+  __syncthreads();
+
+#define WS_STEP(SLOT)                                                                     \
+  {                                                                                       \
+    const int s = s0 + SLOT;                                                              \
+    if (s < nsteps) {                                                                     \
+      store_x((s + 1) & 1);               /* X of step s+1 (loaded one step ago) */       \
+      load_x(s + 2);                                                                      \
+      compute(wr[SLOT], s & 1);                                                           \
+      load_w(wr[SLOT], s + D);            /* refill the slot just consumed */             \
+      __syncthreads();                                                                    \
+    }                                                                                     \
+  }
+  for (int s0 = 0; s0 < nsteps; s0 += D) {
+    WS_STEP(0) WS_STEP(1) WS_STEP(2) WS_STEP(3)
+  }
+#undef WS_STEP
+
+  // ------------------------------------------------------------------ epilogue
+  // acc[rt][mt][r] = C[m = m0 + mt*16 + lq][n = n_wave + rt*16 + g*4 + r]
+  if constexpr (SPLIT) {
+    float* P = partial + (size_t)blockIdx.z * M * N;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        int gm = m0 + mt * 16 + lq, gn = n_wave + rt * 16 + g * 4;
+        if (gm < M) {
+          if (gn + 3 < N && (N & 3) == 0) {
+            *reinterpret_cast<float4*>(P + (size_t)gm * N + gn) = make_float4(acc[rt][mt][0], acc[rt][mt][1], acc[rt][mt][2], acc[rt][mt][3]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (gn + r < N) P[(size_t)gm * N + gn + r] = acc[rt][mt][r];
+          }
+        }
+      }
+  } else if constexpr (EPI == EPI_SWIGLU) {
+    static_assert(RT == 2 || EPI != EPI_SWIGLU, "SwiGLU needs the gate and up tiles in one wave");
+    bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      int gm = m0 + mt * 16 + lq, gn = n_wave;                      // 32-row group start
+      if (gm < M && gn < N) {
+        ushort4 o;
+        bf16_t* op = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float gt = bf2f(f2bf(acc[0][mt][r])), up = bf2f(f2bf(acc[RT - 1][mt][r]));
+          op[r] = f2bf(gt / (1.f + __expf(-gt)) * up);
+        }
+        *reinterpret_cast<ushort4*>(C + (size_t)gm * ldc + (gn >> 1) + g * 4) = o;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        int gm = m0 + mt * 16 + lq, gn = n_wave + rt * 16 + g * 4;
+        if (gm >= M || gn >= N) continue;
+        if constexpr (EPI == EPI_F32) {
+          float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
+          if (gn + 3 < N && (ldc & 3) == 0) *reinterpret_cast<float4*>(C) = make_float4(acc[rt][mt][0], acc[rt][mt][1], acc[rt][mt][2], acc[rt][mt][3]);
+          else
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[rt][mt][r];
+        } else {
+          bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
+          if (gn + 3 < N && (ldc & 3) == 0) {
+            ushort4 o;
+            bf16_t* op = reinterpret_cast<bf16_t*>(&o);
+            if constexpr (EPI == EPI_RESID) {
+              ushort4 rs = *reinterpret_cast<const ushort4*>(C);
+              const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) op[r] = f2bf(bf2f(rp[r]) + bf2f(f2bf(acc[rt][mt][r])));
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) op[r] = f2bf(acc[rt][mt][r]);
+            }
+            *reinterpret_cast<ushort4*>(C) = o;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (gn + r < N) {
+                float v = acc[rt][mt][r];
+                if constexpr (EPI == EPI_RESID) v = bf2f(C[r]) + bf2f(f2bf(v));
+                C[r] = f2bf(v);
+              }
+          }
+        }
+      }
+  }
+}
+
+struct WsPlan { int mt; int rt; int splits; int k_per_split; };
+
+WsPlan make_ws_plan(int m, int n, int k, int epi) {
+  WsPlan p;
+  const int mts[] = {2, 4, 8, 12, 16, 20};
+  p.mt = 20;
+  for (int c : mts) if (c * 16 >= m) { p.mt = c; break; }
+  p.rt = (epi == EPI_SWIGLU || p.mt >= 8) ? 2 : 1;
+  int bn = 64 * p.rt;
+  int wgs = ((n + bn - 1) / bn) * ((m + p.mt * 16 - 1) / (p.mt * 16));
+  int ksteps = (k + 63) / 64;
+  int splits = 1;
+  if (wgs < 160) {
+    splits = (256 + wgs - 1) / wgs;
+    int max_splits = ksteps / 8;                 // >= 8 BK steps per split keeps the ring busy
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 16) splits = 16;
+    if (splits < 1) splits = 1;
+  }
+  int kps = ((ksteps + splits - 1) / splits) * 64;
+  p.splits = (k + kps - 1) / kps;
+  p.k_per_split = kps;
+  return p;
+}
+
+template <int MT, int RT, int EPI>
+int launch_ws_cfg(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, const WsPlan& p,
+                  float* partial, hipStream_t st) {
+  constexpr int BN = 64 * RT;
+  dim3 grid((n + BN - 1) / BN, (m + MT * 16 - 1) / (MT * 16), p.splits);
+  size_t lds = 2 * (size_t)MT * 16 * kRowBytes;
+  if (p.splits > 1) {
+    auto kern = gemm_ws_kernel<MT, RT, EPI, true>;
+    if (lds > 48 * 1024) ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, w, c, m, n, k, ldx, ldc, p.k_per_split, partial);
+    ATS_LAUNCH_CHECK();
+    size_t outs = EPI == EPI_SWIGLU ? (size_t)m * (n / 2) : (size_t)m * n;
+    splitk_reduce_kernel<bf16_t, EPI><<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(partial, c, m, n, ldc, p.splits);
+    ATS_LAUNCH_CHECK();
+  } else {
+    auto kern = gemm_ws_kernel<MT, RT, EPI, false>;
+    if (lds > 48 * 1024) ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, w, c, m, n, k, ldx, ldc, p.k_per_split, partial);
+    ATS_LAUNCH_CHECK();
+  }
+  return ATSPEED_OK;
+}
+
+template <int EPI>
+int launch_ws_epi(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, float* partial,
+                  size_t ws_bytes, hipStream_t st) {
+  WsPlan p = make_ws_plan(m, n, k, EPI);
+  if (p.splits > 1 && (size_t)p.splits * m * n * sizeof(float) > ws_bytes) { p.splits = 1; p.k_per_split = ((k + 63) / 64) * 64; }
+#define WS_CASE(MTV)                                                                                          \
+  case MTV:                                                                                                   \
+    if (p.rt == 2) return launch_ws_cfg<MTV, 2, EPI>(x, w, c, m, n, k, ldx, ldc, p, partial, st);            \
+    if constexpr (EPI != EPI_SWIGLU) return launch_ws_cfg<MTV, 1, EPI>(x, w, c, m, n, k, ldx, ldc, p, partial, st); \
+    break;
+  switch (p.mt) {
+    WS_CASE(2) WS_CASE(4) WS_CASE(8) WS_CASE(12) WS_CASE(16) WS_CASE(20)
+  }
+#undef WS_CASE
+  atspeed_set_error("gemm: no weight-streaming configuration for M=%d", m);
+  return ATSPEED_ERR_INVALID;
+}
+
+int launch_ws(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int epi, void* ws,
+              size_t ws_bytes, hipStream_t st) {
+  const bf16_t* X = (const bf16_t*)a; const bf16_t* Wt = (const bf16_t*)w; float* P = (float*)ws;
+  switch (epi) {
+    case EPI_STORE:  return launch_ws_epi<EPI_STORE>(X, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
+    case EPI_F32:    return launch_ws_epi<EPI_F32>(X, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
+    case EPI_RESID:  return launch_ws_epi<EPI_RESID>(X, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
+    case EPI_SWIGLU: return launch_ws_epi<EPI_SWIGLU>(X, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
+  }
+  atspeed_set_error("gemm: unknown epilogue %d", epi);
+  return ATSPEED_ERR_INVALID;
+}
+
 struct Plan { int bm; int splits; int k_per_split; };
 
 template <typename T>
@@ -320,7 +591,16 @@ int launch_typed(const void* a, const void* w, void* c, int m, int n, int k, int
 }  // namespace
 
 size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype) {
-  Plan p = dtype == ATSPEED_F32 ? make_plan<float>(m, n, k) : make_plan<bf16_t>(m, n, k);
+  if (dtype == ATSPEED_BF16) {
+    Plan po = make_plan<bf16_t>(m, n, k);
+    size_t best = po.splits > 1 ? (size_t)po.splits * m * n * sizeof(float) : 0;
+    for (int epi = 0; epi < 4; ++epi) {
+      WsPlan p = make_ws_plan(m, n, k, epi);
+      if (p.splits > 1) best = std::max(best, (size_t)p.splits * m * n * sizeof(float));
+    }
+    return best;
+  }
+  Plan p = make_plan<float>(m, n, k);
   return p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
 }
 
@@ -333,7 +613,13 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
   ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "gemm: operands must be 16-byte aligned");
   ATS_REQUIRE(epilogue != EPI_SWIGLU || n % 32 == 0, ATSPEED_ERR_INVALID, "gemm: SwiGLU needs N %% 32 == 0 (N=%d)", n);
   if (dtype == ATSPEED_F32) return launch_typed<float>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st);
-  if (dtype == ATSPEED_BF16) return launch_typed<bf16_t>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st);
+  if (dtype == ATSPEED_BF16) {
+    // weight-streaming kernel needs whole 64-wide k steps and 8-byte aligned SwiGLU rows; odd shapes
+    // (only the tiny test models have them) take the LDS-tiled kernel
+    if (k % 64 == 0 && (epilogue != EPI_SWIGLU || (ldc & 3) == 0))
+      return launch_ws(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st);
+    return launch_typed<bf16_t>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st);
+  }
   atspeed_set_error("gemm: unknown dtype %d", dtype);
   return ATSPEED_ERR_INVALID;
 }
