@@ -16,7 +16,10 @@
 //     256 CUs; a second kernel reduces the slabs and applies the epilogue.
 // Epilogues: store (dtype), fp32 store (logits), residual add, SwiGLU over interleaved
 // gate/up 16-column groups.
+#include <stdlib.h>
+
 #include <algorithm>
+#include <set>
 
 #include "internal.h"
 
@@ -246,118 +249,32 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, void* __
 
 
 // =====================================================================================
-// Weight-streaming GEMM (bf16), the production path for the forward's projections.
+// Weight-streaming GEMMs (bf16), the production path for the forward's projections.
 //
 //   C^T[N, M] = W[N, K] * X^T[K, M]          (same math as above, operands swapped)
 //
 // M (tokens) is small, so every launch is a single pass over W.  Each wave OWNS 16*RT rows of W
-// and streams them global -> VGPR with a D-step-deep register ring (no LDS round trip: a weight
-// element is used by exactly one wave), while the token block X[M, K] — shared by all waves and
-// L2-resident — is staged through LDS (two buffers, XOR-swizzled 128-byte rows).  W is the MFMA
-// A operand, X^T the B operand; the accumulator tile has the W row on the register index and
-// the token on the lane, so the epilogue writes 4 consecutive output columns per lane (8-byte
-// stores) and the SwiGLU pair (gate tile, up tile) sits in the same lane.
-// Bytes in flight per CU: 4 waves * 16*RT rows * D*128 B (= 64 KB at RT=2, D=4), which is what
-// an HBM stream at ~25-35 GB/s per CU needs against ~2 us of loaded latency.
+// and streams them global -> VGPR through a 4-step register ring (no LDS round trip: a weight
+// element is used by exactly one wave), while the token block X — shared by all waves and
+// L2-resident — goes through LDS.  W is the MFMA A operand, X^T the B operand; the accumulator
+// has the W row on the register index and the token on the lane, so the epilogue writes 4
+// consecutive output columns per lane (8-byte stores) and the SwiGLU pair (gate tile, up
+// tile) sits in one lane.  Two variants, by how X reaches LDS:
+//   * gemm_wsr_kernel ("resident X", M <= 64): the workgroup's whole K-slice of X is staged
+//     once; the main loop has NO barrier — pure weight streaming with 16 KB per wave in flight.
+//   * gemm_ws_kernel ("ring X", M <= 320): X tiles of 64 k are prefetched FOUR steps ahead in
+//     registers and handed through a double-buffered LDS tile, one barrier per step.
+// All loads are unconditional and in bounds (steps past the end re-read the last tile, rows past
+// M or N re-read the last row: those products are never stored) — a "load or zero" select makes
+// hipcc branch around the load and drain vmcnt.
+
+__device__ __forceinline__ int swz16(int row, int chunk, int chunks_per_row) {   // 16-row conflict-free image
+  return (row * chunks_per_row + (chunk ^ (row & 15))) * 16;
+}
+
 template <int MT, int RT, int EPI, bool SPLIT>
-__global__ __launch_bounds__(256, 1) void gemm_ws_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
-                                                         void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
-                                                         int k_per_split, float* __restrict__ partial) {
-  constexpr int D = 4;                          // ring depth in BK steps
-  constexpr int BK = 64;
-  constexpr int MP = MT * 16;                   // padded token rows per workgroup
-  constexpr int XCH = MP * 8 / 256;             // 16-byte chunks of the X tile per thread
-  constexpr int BN = 4 * 16 * RT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 15, g = lane >> 4;
-  const int n_wave = blockIdx.x * BN + wave * 16 * RT;
-  const int m0 = blockIdx.y * MP;
-  const int kz0 = blockIdx.z * k_per_split;
-  const int kz1 = min(K, kz0 + k_per_split);
-  const int nsteps = (kz1 - kz0 + BK - 1) / BK;
-
-  // per-lane W row pointers (rows beyond N are clamped; their results are never stored)
-  const bf16_t* wrow[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) wrow[rt] = W + (size_t)min(n_wave + rt * 16 + lq, N - 1) * K + g * 8;
-
-  uint4 wr[D][2][RT];                            // [ring slot][k-step][row tile]
-  uint4 xr[XCH];
-  f32x4_t acc[RT][MT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[rt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  // Every load is unconditional and in bounds (K % 64 == 0 is required by the launcher): steps past the
-  // end re-read the last tile, token rows past M re-read row M-1 — their products are never stored.  A
-  // "load or zero" select would make hipcc branch around each load and drain vmcnt (guide: trap (c)).
-  const bf16_t* xrow[XCH];
-#pragma unroll
-  for (int i = 0; i < XCH; ++i) {
-    int qi = tid + i * 256;
-    xrow[i] = X + (size_t)min(m0 + (qi >> 3), M - 1) * ldx + (qi & 7) * 8;
-  }
-  auto load_w = [&](uint4 (&dst)[2][RT], int step) {
-    const int kb = kz0 + min(step, nsteps - 1) * BK;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) dst[ks][rt] = *reinterpret_cast<const uint4*>(wrow[rt] + kb + ks * 32);
-  };
-  auto load_x = [&](int step) {
-    const int kb = kz0 + min(step, nsteps - 1) * BK;
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) xr[i] = *reinterpret_cast<const uint4*>(xrow[i] + kb);
-  };
-  auto store_x = [&](int buf) {
-    unsigned char* sx = smem + buf * (MP * kRowBytes);
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) {
-      int qi = tid + i * 256;
-      *reinterpret_cast<uint4*>(sx + swz(qi >> 3, qi & 7)) = xr[i];
-    }
-  };
-  auto compute = [&](const uint4 (&wf)[2][RT], int buf) {
-    const unsigned char* sx = smem + buf * (MP * kRowBytes);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        s16x8_t xf = *reinterpret_cast<const s16x8_t*>(sx + swz(mt * 16 + lq, ks * 4 + g));
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-          acc[rt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[ks][rt]),
-                                                                __builtin_bit_cast(bf16x8_t, xf), acc[rt][mt], 0, 0, 0);
-      }
-  };
-
-  // prologue: ring slots 0..D-1, X step 0 in LDS, X step 1 in registers
-#pragma unroll
-  for (int d = 0; d < D; ++d) load_w(wr[d], d);
-  load_x(0);
-  store_x(0);
-  load_x(1);
-  __syncthreads();
-
-#define WS_STEP(SLOT)                                                                     \
-  {                                                                                       \
-    const int s = s0 + SLOT;                                                              \
-    if (s < nsteps) {                                                                     \
-      store_x((s + 1) & 1);               /* X of step s+1 (loaded one step ago) */       \
-      load_x(s + 2);                                                                      \
-      compute(wr[SLOT], s & 1);                                                           \
-      load_w(wr[SLOT], s + D);            /* refill the slot just consumed */             \
-      __syncthreads();                                                                    \
-    }                                                                                     \
-  }
-  for (int s0 = 0; s0 < nsteps; s0 += D) {
-    WS_STEP(0) WS_STEP(1) WS_STEP(2) WS_STEP(3)
-  }
-#undef WS_STEP
-
-  // ------------------------------------------------------------------ epilogue
+__device__ __forceinline__ void ws_epilogue(const f32x4_t (&acc)[RT][MT], void* __restrict__ Cv, float* __restrict__ partial,
+                                            int M, int N, int ldc, int m0, int n_wave, int lq, int g) {
   // acc[rt][mt][r] = C[m = m0 + mt*16 + lq][n = n_wave + rt*16 + g*4 + r]
   if constexpr (SPLIT) {
     float* P = partial + (size_t)blockIdx.z * M * N;
@@ -434,21 +351,217 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(const bf16_t* __restric
   }
 }
 
-struct WsPlan { int mt; int rt; int splits; int k_per_split; };
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));   // SSA vector (HIP's uint4 struct copies kept the ring in scratch)
+
+// ---- ring-X variant -------------------------------------------------------------------
+// (free functions + one named array per ring slot: lambdas over a [D][..] array kept the ring in scratch)
+template <int RT>
+__device__ __forceinline__ void ws_load_w(u32x4_t (&dst)[2][RT], const bf16_t* const (&wrow)[RT], int step, int nsteps) {
+  const int kb = min(step, nsteps - 1) * 64;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) dst[ks][rt] = *reinterpret_cast<const u32x4_t*>(wrow[rt] + kb + ks * 32);
+}
+template <int XCH>
+__device__ __forceinline__ void ws_load_x(u32x4_t (&dst)[XCH], const bf16_t* const (&xrow)[XCH], int step, int nsteps) {
+  const int kb = min(step, nsteps - 1) * 64;
+#pragma unroll
+  for (int i = 0; i < XCH; ++i) dst[i] = *reinterpret_cast<const u32x4_t*>(xrow[i] + kb);
+}
+template <int XCH>
+__device__ __forceinline__ void ws_store_x(const u32x4_t (&src)[XCH], unsigned char* sx, int tid) {
+#pragma unroll
+  for (int i = 0; i < XCH; ++i) {
+    int qi = tid + i * 256;
+    *reinterpret_cast<u32x4_t*>(sx + swz(qi >> 3, qi & 7)) = src[i];
+  }
+}
+template <int MT, int RT>
+__device__ __forceinline__ void ws_compute(f32x4_t (&acc)[RT][MT], const u32x4_t (&wf)[2][RT], const unsigned char* sx, int lq, int g) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      s16x8_t xf = *reinterpret_cast<const s16x8_t*>(sx + swz(mt * 16 + lq, ks * 4 + g));
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        acc[rt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[ks][rt]),
+                                                              __builtin_bit_cast(bf16x8_t, xf), acc[rt][mt], 0, 0, 0);
+    }
+}
+
+template <int MT, int RT, int EPI, bool SPLIT>
+__global__ __launch_bounds__(256, 1) void gemm_ws_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                         void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
+                                                         int k_per_split, float* __restrict__ partial) {
+  constexpr int D = 4;                          // ring depth (BK steps) of both register rings
+  constexpr int BK = 64;
+  constexpr int MP = MT * 16;                   // padded token rows per workgroup
+  constexpr int XCH = MP * 8 / 256;             // 16-byte chunks of one X tile per thread
+  constexpr int BN = 4 * 16 * RT;
+  constexpr int XBUF = MP * kRowBytes;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, g = lane >> 4;
+  const int n_wave = blockIdx.x * BN + wave * 16 * RT;
+  const int m0 = blockIdx.y * MP;
+  const int kz0 = blockIdx.z * k_per_split;
+  const int kz1 = min(K, kz0 + k_per_split);
+  const int nsteps = (kz1 - kz0) / BK;
+
+  const bf16_t* wrow[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) wrow[rt] = W + (size_t)min(n_wave + rt * 16 + lq, N - 1) * K + kz0 + g * 8;
+  const bf16_t* xrow[XCH];
+#pragma unroll
+  for (int i = 0; i < XCH; ++i) {
+    int qi = tid + i * 256;
+    xrow[i] = X + (size_t)min(m0 + (qi >> 3), M - 1) * ldx + kz0 + (qi & 7) * 8;
+  }
+
+  u32x4_t wr0[2][RT], wr1[2][RT], wr2[2][RT], wr3[2][RT];     // W ring: [k-step][row tile] per slot
+  u32x4_t xr0[XCH], xr1[XCH], xr2[XCH], xr3[XCH];             // X ring
+  f32x4_t acc[RT][MT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[rt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: X steps 0..3 and W steps 0..3 in flight; X(0) handed to LDS, its slot refilled with X(4)
+  ws_load_x<XCH>(xr0, xrow, 0, nsteps); ws_load_x<XCH>(xr1, xrow, 1, nsteps);
+  ws_load_x<XCH>(xr2, xrow, 2, nsteps); ws_load_x<XCH>(xr3, xrow, 3, nsteps);
+  ws_load_w<RT>(wr0, wrow, 0, nsteps); ws_load_w<RT>(wr1, wrow, 1, nsteps);
+  ws_load_w<RT>(wr2, wrow, 2, nsteps); ws_load_w<RT>(wr3, wrow, 3, nsteps);
+  ws_store_x<XCH>(xr0, smem, tid);
+  ws_load_x<XCH>(xr0, xrow, D, nsteps);
+  __syncthreads();
+
+#define WS_STEP(SLOT, NEXT)                                                                        \
+  {                                                                                                \
+    const int s = s0 + SLOT;                                                                       \
+    if (s < nsteps) {                                                                              \
+      ws_store_x<XCH>(xr##NEXT, smem + ((s + 1) & 1) * XBUF, tid);  /* X(s+1), loaded >= 3 steps ago */ \
+      ws_load_x<XCH>(xr##NEXT, xrow, s + 1 + D, nsteps);                                           \
+      ws_compute<MT, RT>(acc, wr##SLOT, smem + (s & 1) * XBUF, lq, g);                             \
+      ws_load_w<RT>(wr##SLOT, wrow, s + D, nsteps);                 /* refill the slot just consumed */ \
+      __syncthreads();                                                                             \
+    }                                                                                              \
+  }
+  for (int s0 = 0; s0 < nsteps; s0 += D) {
+    WS_STEP(0, 1) WS_STEP(1, 2) WS_STEP(2, 3) WS_STEP(3, 0)
+  }
+#undef WS_STEP
+  ws_epilogue<MT, RT, EPI, SPLIT>(acc, Cv, partial, M, N, ldc, m0, n_wave, lq, g);
+}
+
+// ---- resident-X variant -----------------------------------------------------------------
+// LDS image: [MP rows][k_per_split] bf16, 16-byte chunk c of row r at chunk c ^ (r & 15).
+template <int MT, int RT, int EPI, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_wsr_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                          void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
+                                                          int k_per_split, float* __restrict__ partial) {
+  constexpr int D = 4;
+  constexpr int BK = 64;
+  constexpr int MP = MT * 16;
+  constexpr int BN = 4 * 16 * RT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, g = lane >> 4;
+  const int n_wave = blockIdx.x * BN + wave * 16 * RT;
+  const int kz0 = blockIdx.z * k_per_split;
+  const int kz1 = min(K, kz0 + k_per_split);
+  const int klen = kz1 - kz0;                   // multiple of 64
+  const int nsteps = klen / BK;
+  const int cpr = k_per_split / 8;              // chunks per LDS row (>= 16)
+
+  const bf16_t* wrow[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) wrow[rt] = W + (size_t)min(n_wave + rt * 16 + lq, N - 1) * K + kz0 + g * 8;
+  u32x4_t wr0[2][RT], wr1[2][RT], wr2[2][RT], wr3[2][RT];
+  ws_load_w<RT>(wr0, wrow, 0, nsteps); ws_load_w<RT>(wr1, wrow, 1, nsteps);   // weights start flowing before X is staged
+  ws_load_w<RT>(wr2, wrow, 2, nsteps); ws_load_w<RT>(wr3, wrow, 3, nsteps);
+
+  // stage the whole X slice: rows past M re-read row M-1 (never stored)
+  {
+    const int cprl = klen / 8;                           // chunks actually present per row
+    const int total = MP * cprl;
+    for (int q0 = 0; q0 < total; q0 += 256 * 4) {
+      u32x4_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int qi = min(q0 + u * 256 + tid, total - 1);
+        int r = qi / cprl, c = qi - r * cprl;
+        v[u] = *reinterpret_cast<const u32x4_t*>(X + (size_t)min(r, M - 1) * ldx + kz0 + c * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int qi = min(q0 + u * 256 + tid, total - 1);
+        int r = qi / cprl, c = qi - r * cprl;
+        *reinterpret_cast<u32x4_t*>(smem + swz16(r, c, cpr)) = v[u];
+      }
+    }
+  }
+  f32x4_t acc[RT][MT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[rt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+#define WSR_STEP(SLOT)                                                                         \
+  {                                                                                            \
+    const int s = s0 + SLOT;                                                                   \
+    if (s < nsteps) {                                                                          \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                         \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                    \
+          s16x8_t xf = *reinterpret_cast<const s16x8_t*>(smem + swz16(mt * 16 + lq, s * 8 + ks * 4 + g, cpr)); \
+          _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                    \
+            acc[rt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wr##SLOT[ks][rt]), \
+                                                                  __builtin_bit_cast(bf16x8_t, xf), acc[rt][mt], 0, 0, 0); \
+        }                                                                                      \
+      ws_load_w<RT>(wr##SLOT, wrow, s + D, nsteps);                                            \
+    }                                                                                          \
+  }
+  for (int s0 = 0; s0 < nsteps; s0 += D) {
+    WSR_STEP(0) WSR_STEP(1) WSR_STEP(2) WSR_STEP(3)
+  }
+#undef WSR_STEP
+  ws_epilogue<MT, RT, EPI, SPLIT>(acc, Cv, partial, M, N, ldc, 0, n_wave, lq, g);
+}
+
+struct WsPlan { int mt; int rt; int splits; int k_per_split; bool resident; };
 
 WsPlan make_ws_plan(int m, int n, int k, int epi) {
   WsPlan p;
   const int mts[] = {2, 4, 8, 12, 16, 20};
   p.mt = 20;
   for (int c : mts) if (c * 16 >= m) { p.mt = c; break; }
-  p.rt = (epi == EPI_SWIGLU || p.mt >= 8) ? 2 : 1;
-  int bn = 64 * p.rt;
-  int wgs = ((n + bn - 1) / bn) * ((m + p.mt * 16 - 1) / (p.mt * 16));
-  int ksteps = (k + 63) / 64;
+  const int ksteps = k / 64;
+  p.resident = p.mt <= 4;
+  if (p.resident) {
+    // whole K-slice of X in LDS (<= 64 KB so two workgroups share a CU); aim at >= 512 workgroups
+    p.rt = 2;
+    const int wgs = (n + 127) / 128;
+    const int max_slice_steps = (64 * 1024) / (p.mt * 16 * 128);          // steps whose X fits in 64 KB
+    int splits = (512 + wgs - 1) / wgs;
+    int min_splits = (ksteps + max_slice_steps - 1) / max_slice_steps;
+    int max_splits = std::max(1, ksteps / 8);
+    splits = std::max(min_splits, std::min(splits, max_splits));
+    if (splits > 32) splits = std::max(min_splits, 32);
+    int sps = (ksteps + splits - 1) / splits;
+    sps = (std::max(sps, 2) + 1) & ~1;                                    // even: LDS rows are multiples of 16 chunks (swz16)
+    if (sps > max_slice_steps) sps = max_slice_steps & ~1;
+    p.k_per_split = sps * 64;
+    p.splits = (k + p.k_per_split - 1) / p.k_per_split;
+    return p;
+  }
+  p.rt = 2;
+  int wgs = ((n + 127) / 128) * ((m + p.mt * 16 - 1) / (p.mt * 16));
   int splits = 1;
   if (wgs < 160) {
     splits = (256 + wgs - 1) / wgs;
-    int max_splits = ksteps / 8;                 // >= 8 BK steps per split keeps the ring busy
+    int max_splits = ksteps / 8;
     if (splits > max_splits) splits = max_splits;
     if (splits > 16) splits = 16;
     if (splits < 1) splits = 1;
@@ -459,25 +572,31 @@ WsPlan make_ws_plan(int m, int n, int k, int epi) {
   return p;
 }
 
-template <int MT, int RT, int EPI>
+template <int MT, int RT, int EPI, bool RESIDENT>
 int launch_ws_cfg(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, const WsPlan& p,
                   float* partial, hipStream_t st) {
   constexpr int BN = 64 * RT;
-  dim3 grid((n + BN - 1) / BN, (m + MT * 16 - 1) / (MT * 16), p.splits);
-  size_t lds = 2 * (size_t)MT * 16 * kRowBytes;
-  if (p.splits > 1) {
-    auto kern = gemm_ws_kernel<MT, RT, EPI, true>;
-    if (lds > 48 * 1024) ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid((n + BN - 1) / BN, RESIDENT ? 1 : (m + MT * 16 - 1) / (MT * 16), p.splits);
+  size_t lds = RESIDENT ? (size_t)MT * 16 * p.k_per_split * 2 : 2 * (size_t)MT * 16 * kRowBytes;
+  auto launch = [&](auto kern) -> int {
+    static thread_local std::set<const void*> big_lds_done;           // one attribute call per kernel, not per launch
+    if (lds > 48 * 1024 && !big_lds_done.count((const void*)kern)) {
+      ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      big_lds_done.insert((const void*)kern);
+    }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, w, c, m, n, k, ldx, ldc, p.k_per_split, partial);
     ATS_LAUNCH_CHECK();
+    return ATSPEED_OK;
+  };
+  if (p.splits > 1) {
+    if constexpr (RESIDENT) { ATS_TRY(launch(gemm_wsr_kernel<MT, RT, EPI, true>)); }
+    else { ATS_TRY(launch(gemm_ws_kernel<MT, RT, EPI, true>)); }
     size_t outs = EPI == EPI_SWIGLU ? (size_t)m * (n / 2) : (size_t)m * n;
     splitk_reduce_kernel<bf16_t, EPI><<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(partial, c, m, n, ldc, p.splits);
     ATS_LAUNCH_CHECK();
   } else {
-    auto kern = gemm_ws_kernel<MT, RT, EPI, false>;
-    if (lds > 48 * 1024) ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, w, c, m, n, k, ldx, ldc, p.k_per_split, partial);
-    ATS_LAUNCH_CHECK();
+    if constexpr (RESIDENT) { ATS_TRY(launch(gemm_wsr_kernel<MT, RT, EPI, false>)); }
+    else { ATS_TRY(launch(gemm_ws_kernel<MT, RT, EPI, false>)); }
   }
   return ATSPEED_OK;
 }
@@ -486,16 +605,16 @@ template <int EPI>
 int launch_ws_epi(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, float* partial,
                   size_t ws_bytes, hipStream_t st) {
   WsPlan p = make_ws_plan(m, n, k, EPI);
-  if (p.splits > 1 && (size_t)p.splits * m * n * sizeof(float) > ws_bytes) { p.splits = 1; p.k_per_split = ((k + 63) / 64) * 64; }
-#define WS_CASE(MTV)                                                                                          \
-  case MTV:                                                                                                   \
-    if (p.rt == 2) return launch_ws_cfg<MTV, 2, EPI>(x, w, c, m, n, k, ldx, ldc, p, partial, st);            \
-    if constexpr (EPI != EPI_SWIGLU) return launch_ws_cfg<MTV, 1, EPI>(x, w, c, m, n, k, ldx, ldc, p, partial, st); \
-    break;
+  ATS_REQUIRE(p.splits == 1 || (size_t)p.splits * m * n * sizeof(float) <= ws_bytes, ATSPEED_ERR_CAPACITY,
+              "gemm: split-K workspace too small (%zu bytes needed)", (size_t)p.splits * m * n * sizeof(float));
   switch (p.mt) {
-    WS_CASE(2) WS_CASE(4) WS_CASE(8) WS_CASE(12) WS_CASE(16) WS_CASE(20)
+    case 2:  return launch_ws_cfg<2, 2, EPI, true>(x, w, c, m, n, k, ldx, ldc, p, partial, st);
+    case 4:  return launch_ws_cfg<4, 2, EPI, true>(x, w, c, m, n, k, ldx, ldc, p, partial, st);
+    case 8:  return launch_ws_cfg<8, 2, EPI, false>(x, w, c, m, n, k, ldx, ldc, p, partial, st);
+    case 12: return launch_ws_cfg<12, 2, EPI, false>(x, w, c, m, n, k, ldx, ldc, p, partial, st);
+    case 16: return launch_ws_cfg<16, 2, EPI, false>(x, w, c, m, n, k, ldx, ldc, p, partial, st);
+    case 20: return launch_ws_cfg<20, 2, EPI, false>(x, w, c, m, n, k, ldx, ldc, p, partial, st);
   }
-#undef WS_CASE
   atspeed_set_error("gemm: no weight-streaming configuration for M=%d", m);
   return ATSPEED_ERR_INVALID;
 }
@@ -616,7 +735,8 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
   if (dtype == ATSPEED_BF16) {
     // weight-streaming kernel needs whole 64-wide k steps and 8-byte aligned SwiGLU rows; odd shapes
     // (only the tiny test models have them) take the LDS-tiled kernel
-    if (k % 64 == 0 && (epilogue != EPI_SWIGLU || (ldc & 3) == 0))
+    static const bool use_ws = getenv("ATSPEED_GEMM_WS") != nullptr;     // experimental weight-streaming kernels (tools/gemm_bench.py)
+    if (use_ws && k % 64 == 0 && (epilogue != EPI_SWIGLU || (ldc & 3) == 0))
       return launch_ws(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st);
     return launch_typed<bf16_t>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st);
   }
