@@ -155,9 +155,7 @@ struct ProfBracket {
 
 static size_t gemm_ws_for(const atspeed_llama_config& c) {
   size_t best = 0;
-  int ms[] = {1, 16, 32, 64, 128, c.max_tokens};
-  for (int m : ms) {
-    if (m > c.max_tokens) m = c.max_tokens;
+  for (int m = 1; m <= c.max_tokens; ++m) {      // the split-K plan depends on the exact M: take the true maximum
     best = std::max(best, ats_gemm_workspace_bytes(m, 3 * c.hidden, c.hidden, c.dtype));
     best = std::max(best, ats_gemm_workspace_bytes(m, c.hidden, c.hidden, c.dtype));
     best = std::max(best, ats_gemm_workspace_bytes(m, 2 * c.ffn, c.hidden, c.dtype));
@@ -165,7 +163,7 @@ static size_t gemm_ws_for(const atspeed_llama_config& c) {
     int lm = std::min(m, c.max_logit_rows);
     best = std::max(best, ats_gemm_workspace_bytes(lm, c.vocab_size, c.hidden, c.dtype));
   }
-  return best + (best >> 1) + (1 << 20);   // head-room: plans depend on the exact M
+  return best + (1 << 20);
 }
 
 extern "C" int atspeed_llama_create(const atspeed_llama_config* cfg, const void* embed, const void* final_norm,
@@ -259,22 +257,27 @@ static int llama_forward(atspeed_llama* m, const int32_t* ids, const int32_t* po
   if (m->prof_on) prof_harvest(m);
   const size_t layer_kv = (size_t)c.max_slots * H * e;
   ATS_TRY(ats_embed(m->embed, ids, m->h, T, H, c.vocab_size, dt, st));
+  ATS_TRY(ats_rmsnorm(m->h, m->layers[0].input_norm, m->xn, T, H, c.rms_eps, dt, st));
   for (int l = 0; l < c.n_layers; ++l) {
     const atspeed_llama_layer_weights& w = m->layers[l];
     char* kc = (char*)m->kcache + l * layer_kv;
     char* vc = (char*)m->vcache + l * layer_kv;
-    ATS_TRY(ats_rmsnorm(m->h, w.input_norm, m->xn, T, H, c.rms_eps, dt, st));
+    // m->xn holds rmsnorm(h) * input_norm here (from the embed above or the previous layer's fused down_proj epilogue)
     { ProfBracket pb(m, 0, T, st);
       ATS_TRY(ats_gemm(m->xn, w.wqkv, m->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, m->ws, m->ws_bytes, st)); }
     ATS_TRY(ats_rope_kv(m->qkv, pos, slots, m->cos_tab, m->sin_tab, kc, vc, T, c.n_heads, m->head_dim, c.max_slots, dt, st));
     ATS_TRY(ats_tree_attention(m->qkv, 3 * H, kc, vc, vis, m->vis_words, m->att, H, T, S, c.n_heads, m->head_dim, dt, st));
-    { ProfBracket pb(m, 1, T, st);
-      ATS_TRY(ats_gemm(m->att, w.wo, m->h, T, H, H, H, H, dt, EPI_RESID, m->ws, m->ws_bytes, st)); }
-    ATS_TRY(ats_rmsnorm(m->h, w.post_norm, m->xn, T, H, c.rms_eps, dt, st));
+    { ProfBracket pb(m, 1, T, st);     // h += att Wo^T ; xn = rmsnorm(h) * post_norm
+      ATS_TRY(ats_gemm_resid_norm(m->att, w.wo, m->h, T, H, H, H, H, dt, w.post_norm, m->xn, c.rms_eps, m->ws, m->ws_bytes, st)); }
     { ProfBracket pb(m, 2, T, st);
       ATS_TRY(ats_gemm(m->xn, w.wgu, m->act, T, 2 * c.ffn, H, H, c.ffn, dt, EPI_SWIGLU, m->ws, m->ws_bytes, st)); }
-    { ProfBracket pb(m, 3, T, st);
-      ATS_TRY(ats_gemm(m->act, w.wd, m->h, T, H, c.ffn, c.ffn, H, dt, EPI_RESID, m->ws, m->ws_bytes, st)); }
+    { ProfBracket pb(m, 3, T, st);     // h += act Wd^T ; xn = rmsnorm(h) * next layer's input_norm
+      if (l + 1 < c.n_layers) {
+        ATS_TRY(ats_gemm_resid_norm(m->act, w.wd, m->h, T, H, c.ffn, c.ffn, H, dt, m->layers[l + 1].input_norm, m->xn, c.rms_eps,
+                                    m->ws, m->ws_bytes, st));
+      } else {
+        ATS_TRY(ats_gemm(m->act, w.wd, m->h, T, H, c.ffn, c.ffn, H, dt, EPI_RESID, m->ws, m->ws_bytes, st));
+      } }
   }
   if (n_logit_rows > 0) {
     char* hrows = (char*)m->h + (size_t)(T - n_logit_rows) * H * e;

@@ -632,19 +632,88 @@ int launch_ws(const void* a, const void* w, void* c, int m, int n, int k, int ld
   return ATSPEED_ERR_INVALID;
 }
 
-struct Plan { int bm; int splits; int k_per_split; };
+// split-K reduce + residual add + RMSNorm of the updated row, one workgroup per token row:
+//   h[m][:] += sum_z partial[z][m][:]        (the o_proj / down_proj epilogue)
+//   xn[m][:] = w * (h[m][:] * rsqrt(mean(h^2) + eps))   (the NEXT op's input norm)
+// Saves one launch and one read of h per projection; numerics identical to the unfused pair
+// (statistics are taken from the stored, dtype-rounded h).
+template <typename T, int NPT>
+__global__ __launch_bounds__(1024) void splitk_resid_rmsnorm_kernel(const float* __restrict__ partial, T* __restrict__ h,
+                                                                    const T* __restrict__ norm_w, T* __restrict__ xn, int M, int N,
+                                                                    int ldh, int splits, float eps) {
+  __shared__ float red[16];
+  const int m = blockIdx.x;
+  const size_t mn = (size_t)M * N;
+  float vals[NPT];
+  float ss = 0.f;
+  const float* prow = partial + (size_t)m * N;
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) vals[i] = 0.f;
+  for (int z = 0; z < splits; ++z) {              // NPT independent loads in flight per slab
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      int n = threadIdx.x + i * 1024;
+      if (n < N) vals[i] += prow[z * mn + n];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    int n = threadIdx.x + i * 1024;
+    if (n < N) {
+      float v = vals[i];
+      if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
+      v = Elt<T>::load(h + (size_t)m * ldh + n) + v;
+      Elt<T>::store(h + (size_t)m * ldh + n, v);
+      if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
+      ss += v * v;
+      vals[i] = v;
+    }
+  }
+  ss = wave_sum_f32(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) tot += red[w];
+  const float rs = rsqrtf(tot / (float)N + eps);
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    int n = threadIdx.x + i * 1024;
+    if (n < N) {
+      float v = vals[i] * rs;
+      if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
+      Elt<T>::store(xn + (size_t)m * N + n, Elt<T>::load(norm_w + n) * v);
+    }
+  }
+}
 
+struct Plan { int bm; int bn; int splits; int k_per_split; };
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+// Occupancy first: tools/stream_bench.hip shows streamed bandwidth ~ resident streaming waves (up to ~770), and a
+// workgroup keeps only one k-tile of loads in flight, so the plan aims at >= ~2 workgroups per CU (split-K when the
+// M x N tiling alone is too coarse) before anything else.
 template <typename T>
 Plan make_plan(int m, int n, int k) {
   constexpr int BK = GemmTraits<T>::BK;
+  static const int target_env = env_int("ATSPEED_GEMM_TARGET_WGS", 0);
+  static const int force_bn = env_int("ATSPEED_GEMM_BN", 0);
   Plan p;
   p.bm = m <= 16 ? 16 : (m <= 32 ? 32 : (m <= 64 ? 64 : 128));
-  int tiles = ((m + p.bm - 1) / p.bm) * ((n + 127) / 128);
+  // measured on MI355X (tools/sweep_gemm.sh): ~3 workgroups per CU for the pure streaming shapes (M <= 64),
+  // ~2 per CU above; the widest GEMM (gate_up) prefers 64-column tiles over split-K slabs at M > 128
+  const int target_wgs = target_env ? target_env : (m <= 64 ? 768 : 512);
+  p.bn = force_bn ? force_bn : ((sizeof(T) == 2 && p.bm == 128 && m > 128 && n >= 16384 && n < 32000) ? 64 : 128);
+  int tiles = ((m + p.bm - 1) / p.bm) * ((n + p.bn - 1) / p.bn);
   int ktiles = (k + BK - 1) / BK;
   int splits = 1;
-  if (tiles < 192) {
-    splits = (384 + tiles - 1) / tiles;
-    int max_splits = ktiles / 4;              // keep >= 4 k-tiles per split
+  if (tiles * 4 < target_wgs * 3) {              // below 75 % of the target: split K
+    splits = (target_wgs + tiles - 1) / tiles;
+    int max_splits = ktiles / 4;                 // keep >= 4 k-tiles per split
     if (splits > max_splits) splits = max_splits;
     if (splits > 16) splits = 16;
     if (splits < 1) splits = 1;
@@ -655,10 +724,11 @@ Plan make_plan(int m, int n, int k) {
   return p;
 }
 
-template <typename T, int BM, int WM, int WN, int EPI>
+struct FusedNorm { const void* w; void* xn; float eps; bool done; };
+
+template <typename T, int BM, int BN, int WM, int WN, int EPI>
 int launch_cfg(const T* a, const T* w, void* c, int m, int n, int k, int lda, int ldc, const Plan& p, float* partial,
-               hipStream_t st) {
-  constexpr int BN = 128;
+               hipStream_t st, FusedNorm* fn = nullptr) {
   using Cfg = TileCfg<T, BM, BN, WM, WN>;
   dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM, p.splits);
   size_t lds = 2 * Cfg::STAGE_BYTES;
@@ -666,6 +736,17 @@ int launch_cfg(const T* a, const T* w, void* c, int m, int n, int k, int lda, in
     auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI, true>;
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a, w, c, m, n, k, lda, ldc, p.k_per_split, partial);
     ATS_LAUNCH_CHECK();
+    if constexpr (EPI == EPI_RESID) {
+      if (fn && n <= 8192) {
+        if (n <= 4096)
+          splitk_resid_rmsnorm_kernel<T, 4><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, p.splits, fn->eps);
+        else
+          splitk_resid_rmsnorm_kernel<T, 8><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, p.splits, fn->eps);
+        ATS_LAUNCH_CHECK();
+        fn->done = true;
+        return ATSPEED_OK;
+      }
+    }
     size_t outs = EPI == EPI_SWIGLU ? (size_t)m * (n / 2) : (size_t)m * n;
     splitk_reduce_kernel<T, EPI><<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(partial, c, m, n, ldc, p.splits);
     ATS_LAUNCH_CHECK();
@@ -679,17 +760,19 @@ int launch_cfg(const T* a, const T* w, void* c, int m, int n, int k, int lda, in
 
 template <typename T, int EPI>
 int launch_epi(const T* a, const T* w, void* c, int m, int n, int k, int lda, int ldc, float* partial, size_t ws_bytes,
-               hipStream_t st) {
+               hipStream_t st, FusedNorm* fn = nullptr) {
   Plan p = make_plan<T>(m, n, k);
+  if (p.bn == 64 && p.bm != 128) p.bn = 128;
   if (p.splits > 1 && (size_t)p.splits * m * n * sizeof(float) > ws_bytes) {   // not enough workspace: no split
     p.splits = 1;
     p.k_per_split = ((k + GemmTraits<T>::BK - 1) / GemmTraits<T>::BK) * GemmTraits<T>::BK;
   }
+  if (p.bn == 64 && p.bm == 128) return launch_cfg<T, 128, 64, 2, 2, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn);
   switch (p.bm) {
-    case 16:  return launch_cfg<T, 16, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st);
-    case 32:  return launch_cfg<T, 32, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st);
-    case 64:  return launch_cfg<T, 64, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st);
-    default:  return launch_cfg<T, 128, 2, 2, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st);
+    case 16:  return launch_cfg<T, 16, 128, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn);
+    case 32:  return launch_cfg<T, 32, 128, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn);
+    case 64:  return launch_cfg<T, 64, 128, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn);
+    default:  return launch_cfg<T, 128, 128, 2, 2, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn);
   }
 }
 
@@ -742,6 +825,27 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
   }
   atspeed_set_error("gemm: unknown dtype %d", dtype);
   return ATSPEED_ERR_INVALID;
+}
+
+// h += a * w^T, then xn = rmsnorm(h) * norm_w  (split-K path fuses the reduce, the residual and the norm)
+int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int k, int lda, int ldh, int dtype,
+                        const void* norm_w, void* xn, float eps, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  if (m <= 0) return ATSPEED_OK;
+  FusedNorm fn{norm_w, xn, eps, false};
+  static const bool use_ws = getenv("ATSPEED_GEMM_WS") != nullptr;
+  int epc = dtype == ATSPEED_F32 ? 4 : 8;
+  if (!use_ws && k % epc == 0 && lda % epc == 0) {
+    int rc;
+    if (dtype == ATSPEED_F32)
+      rc = launch_epi<float, EPI_RESID>((const float*)a, (const float*)w, h, m, n, k, lda, ldh, (float*)workspace, workspace_bytes, st, &fn);
+    else
+      rc = launch_epi<bf16_t, EPI_RESID>((const bf16_t*)a, (const bf16_t*)w, h, m, n, k, lda, ldh, (float*)workspace, workspace_bytes, st, &fn);
+    if (rc != ATSPEED_OK) return rc;
+  } else {
+    ATS_TRY(ats_gemm(a, w, h, m, n, k, lda, ldh, dtype, EPI_RESID, workspace, workspace_bytes, st));
+  }
+  if (!fn.done) return ats_rmsnorm(h, norm_w, xn, m, n, eps, dtype, st);
+  return ATSPEED_OK;
 }
 
 extern "C" int atspeed_gemm(const void* a, const void* w, void* c, int32_t m, int32_t n, int32_t k, int32_t lda,

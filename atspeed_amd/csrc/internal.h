@@ -17,6 +17,9 @@ size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype);
 int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int dtype, int epilogue,
              void* workspace, size_t workspace_bytes, hipStream_t st);
 
+int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int k, int lda, int ldh, int dtype,
+                        const void* norm_w, void* xn, float eps, void* workspace, size_t workspace_bytes, hipStream_t st);
+
 // ---- attn.hip -------------------------------------------------------------------------
 int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* vcache, const uint64_t* vis,
                        int vis_words, void* out, int ldo, int n_tokens, int n_slots, int n_heads, int head_dim,
