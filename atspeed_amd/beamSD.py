@@ -105,8 +105,9 @@ class _Decoder:
         self.models = (target, draft)
 
     @classmethod
-    def get(cls, target: HipLlama, draft: Optional[HipLlama], prompt_len: int) -> "_Decoder":
-        key = (id(target), id(draft))
+    def get(cls, target: HipLlama, draft: Optional[HipLlama], prompt_len: int, lane: int = 0) -> "_Decoder":
+        """One decoder (= one user stream: private KV + activations) per (model pair, lane)."""
+        key = (id(target), id(draft), lane)
         d = cls._cache.get(key)
         if d is None or d.max_prompt < prompt_len or d.models[0] is not target or d.models[1] is not draft:
             d = cls(target, draft, max(prompt_len, min(target.max_tokens, 512)))
@@ -196,6 +197,57 @@ def BSSD(target_model, draft_model, inputs: Dict, gamma: int, max_new_tokens: in
 beam_sd_generate = BSSD
 
 
+@torch.no_grad()
+def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_tokens: int,
+               prefix_allowed_tokens_fn=None):
+    """BSSD for several independent users at once (one result dict per user, same keys as BSSD).
+
+    The reference decodes users strictly one after another (inference.py:162-176).  Here each user gets its own
+    decoder lane (private KV cache + activations, own HIP stream) and the lanes are interleaved by
+    `atspeed_bssd_generate_batch`, so the per-round host read-back of one user overlaps the kernels of the
+    others.  Results are identical to calling BSSD() per user."""
+    _check_models(target_model, draft_model)
+    lib = _lib.load()
+    dev = target_model.device
+    n = len(inputs_list)
+    k = int(target_model.generation_config.num_beams)
+    dk = int(draft_model.generation_config.num_beams)
+    t0 = time.time()
+    prompts = [_prompt_row(inp).to(dev) for inp in inputs_list]
+    fsms = [_compile_constraint(prefix_allowed_tokens_fn, p.tolist()) for p in prompts]
+    dfsm = _DeviceFSM.get(fsms[0], target_model.dims.vocab_size)
+    for f in fsms[1:]:
+        if f.row_ptr is not fsms[0].row_ptr:
+            raise ValueError("BSSD_batch needs one shared constraint automaton (only the start node may differ per user)")
+    decs = [_Decoder.get(target_model, draft_model, int(p.numel()), lane=i) for i, p in enumerate(prompts)]
+    with torch.cuda.device(dev):
+        ids32 = [p.to(torch.int32).contiguous() for p in prompts]
+        toks = [torch.empty(k, max_new_tokens, dtype=torch.int32, device=dev) for _ in range(n)]
+        scores = [torch.empty(k, dtype=torch.float32, device=dev) for _ in range(n)]
+        stats = (_lib.GenStats * n)()
+        arr_p = (C.c_void_p * n)
+        _lib.check(lib.atspeed_bssd_generate_batch(
+            arr_p(*[d.handle for d in decs]), n, arr_p(*[t.data_ptr() for t in ids32]),
+            (C.c_int32 * n)(*[int(p.numel()) for p in prompts]), dfsm.handle, (C.c_int32 * n)(*[f.start for f in fsms]),
+            int(gamma), int(max_new_tokens), k, dk, arr_p(*[t.data_ptr() for t in toks]),
+            arr_p(*[t.data_ptr() for t in scores]), stats, _lib.stream_ptr(dev)))
+    wall = time.time() - t0
+    outs = []
+    for i in range(n):
+        st = stats[i]
+        out = _result(prompts[i], toks[i], scores[i], k)
+        n_run, total = int(st.n_run), int(st.total_accept_steps)
+        out.update({"n_run": n_run, "total_accept_steps": total, "total_accept_tokens": total * k,
+                    "ave_accept_tokens": total * k / n_run if n_run else 0.0,
+                    "draft_time_cost": st.draft_ms * 1e-3, "target_time_cost": st.target_ms * 1e-3,
+                    "verify_time_cost": st.verify_ms * 1e-3, "device_time_cost": st.total_ms * 1e-3,
+                    "time_cost": wall / n, "n_valid": int(st.n_valid),
+                    "accept_steps": [int(st.accept_steps[j]) for j in range(min(n_run, _lib.MAX_NEW_TOKENS))],
+                    "n_target_forwards": int(st.n_target_forwards), "n_draft_forwards": int(st.n_draft_forwards)})
+        outs.append(out)
+    return outs
+
+
 @Timer()
 @torch.no_grad()
 def target_generate(model, inputs: Dict, max_new_tokens: int, logits_processor=None,
@@ -228,7 +280,7 @@ def last_trace(target_model, draft_model):
     """Per-round trace of the last BSSD call on this model pair (parity tests):
     list of dict(draft_len, n_matches, n_beams, draft_ids=[draft_len][dk])."""
     lib = _lib.load()
-    dec = _Decoder._cache[(id(target_model), id(draft_model))]
+    dec = _Decoder._cache[(id(target_model), id(draft_model), 0)]
     n = lib.atspeed_decoder_trace(dec.handle, None, 0)
     buf = (C.c_int32 * max(n, 1))()
     lib.atspeed_decoder_trace(dec.handle, buf, n)

@@ -106,51 +106,57 @@ extern "C" int atspeed_trie_flatten(const int32_t* seq_tokens, const int32_t* se
 }
 
 // ---------------------------------------------------------------------------- model
+// Weights/config/RoPE tables are shared and read-only; everything a forward WRITES lives in a LlamaCtx, so several
+// user streams can run the same model concurrently (one context per decoder).
+struct LlamaCtx {
+  void *kcache = nullptr, *vcache = nullptr;     // [n_layers][max_slots][hidden]
+  void *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *act = nullptr;   // activations
+  float* logits = nullptr;                       // [max_logit_rows][logits_ld]
+  void* ws = nullptr; size_t ws_bytes = 0;       // split-K slabs
+  // optional per-GEMM hipEvent brackets (bench.py roofline): 0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head
+  bool prof_pending = false;
+  std::vector<hipEvent_t> prof_ev;               // 2 events per bracket
+  std::vector<int> prof_kind, prof_m;            // kind / M per bracket of the pending forward
+};
+
 struct atspeed_llama {
   atspeed_llama_config cfg;
   const void *embed, *final_norm, *lm_head;
   std::vector<atspeed_llama_layer_weights> layers;
   int esz, head_dim, vis_words, logits_ld;
-  // arena (owned)
-  void *kcache, *vcache;           // [n_layers][max_slots][hidden]
-  void *h, *xn, *qkv, *att, *act;  // activations
-  float* logits;                   // [max_logit_rows][logits_ld]
-  float *cos_tab, *sin_tab;        // [max_slots][head_dim/2]
-  void* ws; size_t ws_bytes;       // split-K slabs
-  // optional per-GEMM hipEvent brackets (bench.py roofline): 0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head
-  bool prof_on = false, prof_pending = false;
-  std::vector<hipEvent_t> prof_ev;           // 2 events per bracket
-  std::vector<int> prof_kind;                // kind per bracket of the pending forward
+  float *cos_tab, *sin_tab;                      // [max_slots][head_dim/2]
+  LlamaCtx* ctx0;                                // context of the plain atspeed_llama_forward API
+  std::vector<LlamaCtx*> ctxs;                   // every live context (profiling harvest)
+  bool prof_on = false;
   double prof_ms[5] = {0, 0, 0, 0, 0};
   long prof_cnt[5] = {0, 0, 0, 0, 0};
-  long prof_rows[5] = {0, 0, 0, 0, 0};       // sum of M over the bracketed launches
-  std::vector<int> prof_m;
+  long prof_rows[5] = {0, 0, 0, 0, 0};           // sum of M over the bracketed launches
 };
 
-static void prof_harvest(atspeed_llama* m) {
-  if (!m->prof_pending) return;
-  for (size_t b = 0; b < m->prof_kind.size(); ++b) {
+static void prof_harvest(atspeed_llama* m, LlamaCtx* cx) {
+  if (!cx->prof_pending) return;
+  for (size_t b = 0; b < cx->prof_kind.size(); ++b) {
     float ms = 0.f;
-    if (hipEventSynchronize(m->prof_ev[2 * b + 1]) == hipSuccess &&
-        hipEventElapsedTime(&ms, m->prof_ev[2 * b], m->prof_ev[2 * b + 1]) == hipSuccess) {
-      int kd = m->prof_kind[b];
-      m->prof_ms[kd] += ms; m->prof_cnt[kd] += 1; m->prof_rows[kd] += m->prof_m[b];
+    if (hipEventSynchronize(cx->prof_ev[2 * b + 1]) == hipSuccess &&
+        hipEventElapsedTime(&ms, cx->prof_ev[2 * b], cx->prof_ev[2 * b + 1]) == hipSuccess) {
+      int kd = cx->prof_kind[b];
+      m->prof_ms[kd] += ms; m->prof_cnt[kd] += 1; m->prof_rows[kd] += cx->prof_m[b];
     }
   }
-  m->prof_kind.clear(); m->prof_m.clear();
-  m->prof_pending = false;
+  cx->prof_kind.clear(); cx->prof_m.clear();
+  cx->prof_pending = false;
 }
 
 struct ProfBracket {
-  atspeed_llama* m; hipStream_t st; bool on; size_t idx;
-  ProfBracket(atspeed_llama* m_, int kind, int rows, hipStream_t st_) : m(m_), st(st_), on(m_->prof_on), idx(0) {
+  LlamaCtx* cx; hipStream_t st; bool on; size_t idx;
+  ProfBracket(atspeed_llama* m, LlamaCtx* cx_, int kind, int rows, hipStream_t st_) : cx(cx_), st(st_), on(m->prof_on), idx(0) {
     if (!on) return;
-    idx = m->prof_kind.size();
-    while (m->prof_ev.size() < 2 * (idx + 1)) { hipEvent_t e; hipEventCreate(&e); m->prof_ev.push_back(e); }
-    m->prof_kind.push_back(kind); m->prof_m.push_back(rows);
-    hipEventRecord(m->prof_ev[2 * idx], st);
+    idx = cx->prof_kind.size();
+    while (cx->prof_ev.size() < 2 * (idx + 1)) { hipEvent_t e; hipEventCreate(&e); cx->prof_ev.push_back(e); }
+    cx->prof_kind.push_back(kind); cx->prof_m.push_back(rows);
+    hipEventRecord(cx->prof_ev[2 * idx], st);
   }
-  ~ProfBracket() { if (on) { hipEventRecord(m->prof_ev[2 * idx + 1], st); m->prof_pending = true; } }
+  ~ProfBracket() { if (on) { hipEventRecord(cx->prof_ev[2 * idx + 1], st); cx->prof_pending = true; } }
 };
 
 static size_t gemm_ws_for(const atspeed_llama_config& c) {
@@ -164,6 +170,37 @@ static size_t gemm_ws_for(const atspeed_llama_config& c) {
     best = std::max(best, ats_gemm_workspace_bytes(lm, c.vocab_size, c.hidden, c.dtype));
   }
   return best + (1 << 20);
+}
+
+static int ctx_create(atspeed_llama* m, LlamaCtx** out) {
+  const atspeed_llama_config& c = m->cfg;
+  LlamaCtx* cx = new LlamaCtx();
+  size_t T = c.max_tokens, H = c.hidden, e = m->esz;
+  size_t kv = (size_t)c.n_layers * c.max_slots * H * e;
+  ATS_HIP(hipMalloc(&cx->kcache, kv));
+  ATS_HIP(hipMalloc(&cx->vcache, kv));
+  ATS_HIP(hipMemset(cx->kcache, 0, kv));
+  ATS_HIP(hipMemset(cx->vcache, 0, kv));
+  ATS_HIP(hipMalloc(&cx->h, T * H * e));
+  ATS_HIP(hipMalloc(&cx->xn, T * H * e));
+  ATS_HIP(hipMalloc(&cx->qkv, T * 3 * H * e));
+  ATS_HIP(hipMalloc(&cx->att, T * H * e));
+  ATS_HIP(hipMalloc(&cx->act, T * (size_t)c.ffn * e));
+  ATS_HIP(hipMalloc((void**)&cx->logits, (size_t)c.max_logit_rows * m->logits_ld * sizeof(float)));
+  cx->ws_bytes = gemm_ws_for(c);
+  ATS_HIP(hipMalloc(&cx->ws, cx->ws_bytes));
+  m->ctxs.push_back(cx);
+  *out = cx;
+  return ATSPEED_OK;
+}
+
+static void ctx_destroy(atspeed_llama* m, LlamaCtx* cx) {
+  if (!cx) return;
+  hipFree(cx->kcache); hipFree(cx->vcache); hipFree(cx->h); hipFree(cx->xn); hipFree(cx->qkv); hipFree(cx->att);
+  hipFree(cx->act); hipFree(cx->logits); hipFree(cx->ws);
+  for (hipEvent_t e : cx->prof_ev) hipEventDestroy(e);
+  if (m) m->ctxs.erase(std::remove(m->ctxs.begin(), m->ctxs.end(), cx), m->ctxs.end());
+  delete cx;
 }
 
 extern "C" int atspeed_llama_create(const atspeed_llama_config* cfg, const void* embed, const void* final_norm,
@@ -186,26 +223,12 @@ extern "C" int atspeed_llama_create(const atspeed_llama_config* cfg, const void*
   m->head_dim = hd;
   m->vis_words = cfg->max_slots / 64;
   m->logits_ld = (cfg->vocab_size + 63) / 64 * 64;
-  size_t T = cfg->max_tokens, H = cfg->hidden, e = m->esz;
-  size_t kv = (size_t)cfg->n_layers * cfg->max_slots * H * e;
-  ATS_HIP(hipMalloc(&m->kcache, kv));
-  ATS_HIP(hipMalloc(&m->vcache, kv));
-  ATS_HIP(hipMemset(m->kcache, 0, kv));
-  ATS_HIP(hipMemset(m->vcache, 0, kv));
-  ATS_HIP(hipMalloc(&m->h, T * H * e));
-  ATS_HIP(hipMalloc(&m->xn, T * H * e));
-  ATS_HIP(hipMalloc(&m->qkv, T * 3 * H * e));
-  ATS_HIP(hipMalloc(&m->att, T * H * e));
-  ATS_HIP(hipMalloc(&m->act, T * (size_t)cfg->ffn * e));
-  ATS_HIP(hipMalloc((void**)&m->logits, (size_t)cfg->max_logit_rows * m->logits_ld * sizeof(float)));
-  m->ws_bytes = gemm_ws_for(*cfg);
-  ATS_HIP(hipMalloc(&m->ws, m->ws_bytes));
-  // RoPE tables in double precision on the host, rounded once to fp32
+  ATS_TRY(ctx_create(m, &m->ctx0));
+  // RoPE tables: HF computes inv_freq and the angle in fp32; cos/sin of that angle in double, rounded once
   int half = hd / 2;
   std::vector<float> ct((size_t)cfg->max_slots * half), stv((size_t)cfg->max_slots * half);
   for (int p = 0; p < cfg->max_slots; ++p)
     for (int i = 0; i < half; ++i) {
-      // HF: inv_freq (fp32) = 1 / theta^(2i/dh); angle = pos * inv_freq in fp32
       float inv = 1.0f / powf(cfg->rope_theta, (float)(2 * i) / (float)hd);
       float ang = (float)p * inv;
       ct[(size_t)p * half + i] = (float)cos((double)ang);
@@ -221,15 +244,14 @@ extern "C" int atspeed_llama_create(const atspeed_llama_config* cfg, const void*
 
 extern "C" void atspeed_llama_destroy(atspeed_llama* m) {
   if (!m) return;
-  hipFree(m->kcache); hipFree(m->vcache); hipFree(m->h); hipFree(m->xn); hipFree(m->qkv); hipFree(m->att);
-  hipFree(m->act); hipFree(m->logits); hipFree(m->ws); hipFree(m->cos_tab); hipFree(m->sin_tab);
-  for (hipEvent_t e : m->prof_ev) hipEventDestroy(e);
+  while (!m->ctxs.empty()) ctx_destroy(m, m->ctxs.back());
+  hipFree(m->cos_tab); hipFree(m->sin_tab);
   delete m;
 }
 
 extern "C" int atspeed_llama_profile(atspeed_llama* m, int32_t enable, double* ms_out, int64_t* count_out, int64_t* rows_out) {
   ATS_REQUIRE(m, ATSPEED_ERR_INVALID, "profile: null model");
-  prof_harvest(m);
+  for (LlamaCtx* cx : m->ctxs) prof_harvest(m, cx);
   for (int i = 0; i < 5; ++i) {
     if (ms_out) ms_out[i] = m->prof_ms[i];
     if (count_out) count_out[i] = m->prof_cnt[i];
@@ -242,10 +264,10 @@ extern "C" int atspeed_llama_profile(atspeed_llama* m, int32_t enable, double* m
   return ATSPEED_OK;
 }
 
-extern "C" float* atspeed_llama_logits(atspeed_llama* m) { return m ? m->logits : nullptr; }
+extern "C" float* atspeed_llama_logits(atspeed_llama* m) { return m ? m->ctx0->logits : nullptr; }
 extern "C" int32_t atspeed_llama_logits_ld(const atspeed_llama* m) { return m ? m->logits_ld : 0; }
 
-static int llama_forward(atspeed_llama* m, const int32_t* ids, const int32_t* pos, const int32_t* slots,
+static int llama_forward(atspeed_llama* m, LlamaCtx* cx, const int32_t* ids, const int32_t* pos, const int32_t* slots,
                          const uint64_t* vis, int T, int S, int n_logit_rows, float* logits_out, hipStream_t st) {
   const atspeed_llama_config& c = m->cfg;
   ATS_REQUIRE(T >= 1 && T <= c.max_tokens, ATSPEED_ERR_CAPACITY, "forward: %d tokens exceed max_tokens %d", T, c.max_tokens);
@@ -254,37 +276,37 @@ static int llama_forward(atspeed_llama* m, const int32_t* ids, const int32_t* po
               "forward: %d logit rows exceed the limit %d", n_logit_rows, c.max_logit_rows);
   const int H = c.hidden, dt = c.dtype;
   const size_t e = m->esz;
-  if (m->prof_on) prof_harvest(m);
+  if (m->prof_on) prof_harvest(m, cx);
   const size_t layer_kv = (size_t)c.max_slots * H * e;
-  ATS_TRY(ats_embed(m->embed, ids, m->h, T, H, c.vocab_size, dt, st));
-  ATS_TRY(ats_rmsnorm(m->h, m->layers[0].input_norm, m->xn, T, H, c.rms_eps, dt, st));
+  ATS_TRY(ats_embed(m->embed, ids, cx->h, T, H, c.vocab_size, dt, st));
+  ATS_TRY(ats_rmsnorm(cx->h, m->layers[0].input_norm, cx->xn, T, H, c.rms_eps, dt, st));
   for (int l = 0; l < c.n_layers; ++l) {
     const atspeed_llama_layer_weights& w = m->layers[l];
-    char* kc = (char*)m->kcache + l * layer_kv;
-    char* vc = (char*)m->vcache + l * layer_kv;
-    // m->xn holds rmsnorm(h) * input_norm here (from the embed above or the previous layer's fused down_proj epilogue)
-    { ProfBracket pb(m, 0, T, st);
-      ATS_TRY(ats_gemm(m->xn, w.wqkv, m->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, m->ws, m->ws_bytes, st)); }
-    ATS_TRY(ats_rope_kv(m->qkv, pos, slots, m->cos_tab, m->sin_tab, kc, vc, T, c.n_heads, m->head_dim, c.max_slots, dt, st));
-    ATS_TRY(ats_tree_attention(m->qkv, 3 * H, kc, vc, vis, m->vis_words, m->att, H, T, S, c.n_heads, m->head_dim, dt, st));
-    { ProfBracket pb(m, 1, T, st);     // h += att Wo^T ; xn = rmsnorm(h) * post_norm
-      ATS_TRY(ats_gemm_resid_norm(m->att, w.wo, m->h, T, H, H, H, H, dt, w.post_norm, m->xn, c.rms_eps, m->ws, m->ws_bytes, st)); }
-    { ProfBracket pb(m, 2, T, st);
-      ATS_TRY(ats_gemm(m->xn, w.wgu, m->act, T, 2 * c.ffn, H, H, c.ffn, dt, EPI_SWIGLU, m->ws, m->ws_bytes, st)); }
-    { ProfBracket pb(m, 3, T, st);     // h += act Wd^T ; xn = rmsnorm(h) * next layer's input_norm
+    char* kc = (char*)cx->kcache + l * layer_kv;
+    char* vc = (char*)cx->vcache + l * layer_kv;
+    // cx->xn holds rmsnorm(h) * input_norm here (from the embed above or the previous layer's fused down_proj epilogue)
+    { ProfBracket pb(m, cx, 0, T, st);
+      ATS_TRY(ats_gemm(cx->xn, w.wqkv, cx->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, cx->ws, cx->ws_bytes, st)); }
+    ATS_TRY(ats_rope_kv(cx->qkv, pos, slots, m->cos_tab, m->sin_tab, kc, vc, T, c.n_heads, m->head_dim, c.max_slots, dt, st));
+    ATS_TRY(ats_tree_attention(cx->qkv, 3 * H, kc, vc, vis, m->vis_words, cx->att, H, T, S, c.n_heads, m->head_dim, dt, st));
+    { ProfBracket pb(m, cx, 1, T, st);     // h += att Wo^T ; xn = rmsnorm(h) * post_norm
+      ATS_TRY(ats_gemm_resid_norm(cx->att, w.wo, cx->h, T, H, H, H, H, dt, w.post_norm, cx->xn, c.rms_eps, cx->ws, cx->ws_bytes, st)); }
+    { ProfBracket pb(m, cx, 2, T, st);
+      ATS_TRY(ats_gemm(cx->xn, w.wgu, cx->act, T, 2 * c.ffn, H, H, c.ffn, dt, EPI_SWIGLU, cx->ws, cx->ws_bytes, st)); }
+    { ProfBracket pb(m, cx, 3, T, st);     // h += act Wd^T ; xn = rmsnorm(h) * next layer's input_norm
       if (l + 1 < c.n_layers) {
-        ATS_TRY(ats_gemm_resid_norm(m->act, w.wd, m->h, T, H, c.ffn, c.ffn, H, dt, m->layers[l + 1].input_norm, m->xn, c.rms_eps,
-                                    m->ws, m->ws_bytes, st));
+        ATS_TRY(ats_gemm_resid_norm(cx->act, w.wd, cx->h, T, H, c.ffn, c.ffn, H, dt, m->layers[l + 1].input_norm, cx->xn, c.rms_eps,
+                                    cx->ws, cx->ws_bytes, st));
       } else {
-        ATS_TRY(ats_gemm(m->act, w.wd, m->h, T, H, c.ffn, c.ffn, H, dt, EPI_RESID, m->ws, m->ws_bytes, st));
+        ATS_TRY(ats_gemm(cx->act, w.wd, cx->h, T, H, c.ffn, c.ffn, H, dt, EPI_RESID, cx->ws, cx->ws_bytes, st));
       } }
   }
   if (n_logit_rows > 0) {
-    char* hrows = (char*)m->h + (size_t)(T - n_logit_rows) * H * e;
-    ATS_TRY(ats_rmsnorm(hrows, m->final_norm, m->xn, n_logit_rows, H, c.rms_eps, dt, st));
-    float* lo = logits_out ? logits_out : m->logits;
-    ProfBracket pb(m, 4, n_logit_rows, st);
-    ATS_TRY(ats_gemm(m->xn, m->lm_head, lo, n_logit_rows, c.vocab_size, H, H, m->logits_ld, dt, EPI_F32, m->ws, m->ws_bytes, st));
+    char* hrows = (char*)cx->h + (size_t)(T - n_logit_rows) * H * e;
+    ATS_TRY(ats_rmsnorm(hrows, m->final_norm, cx->xn, n_logit_rows, H, c.rms_eps, dt, st));
+    float* lo = logits_out ? logits_out : cx->logits;
+    ProfBracket pb(m, cx, 4, n_logit_rows, st);
+    ATS_TRY(ats_gemm(cx->xn, m->lm_head, lo, n_logit_rows, c.vocab_size, H, H, m->logits_ld, dt, EPI_F32, cx->ws, cx->ws_bytes, st));
   }
   return ATSPEED_OK;
 }
@@ -293,7 +315,7 @@ extern "C" int atspeed_llama_forward(atspeed_llama* m, const int32_t* ids, const
                                      const uint64_t* vis, int32_t n_tokens, int32_t n_slots_visible, int32_t n_logit_rows,
                                      float* logits_out, void* stream) {
   ATS_REQUIRE(m && ids && pos && slots && vis, ATSPEED_ERR_INVALID, "forward: null argument");
-  return llama_forward(m, ids, pos, slots, vis, n_tokens, n_slots_visible, n_logit_rows, logits_out, (hipStream_t)stream);
+  return llama_forward(m, m->ctx0, ids, pos, slots, vis, n_tokens, n_slots_visible, n_logit_rows, logits_out, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------- decoder
@@ -304,8 +326,12 @@ constexpr int NBLK = ATSPEED_MAX_GAMMA + 1;
 constexpr int kMaxEvents = 4 * (ATSPEED_MAX_NEW_TOKENS + 2);
 }  // namespace
 
+// One user stream: private forward contexts (KV + activations) for target and draft, device-side beam state, a
+// pinned mailbox, and the bookkeeping of the call in flight (so several decoders can be interleaved, see
+// atspeed_bssd_generate_batch).
 struct atspeed_decoder {
   atspeed_llama *target, *draft;
+  LlamaCtx *tctx, *dctx;
   int max_prompt, tok_cap, W;
   char* arena;
   TokBuf tin[2], dround;
@@ -314,8 +340,19 @@ struct atspeed_decoder {
   Mailbox* mail_dev;
   Mailbox* mail_host;       // pinned
   int32_t* trace_host;      // pinned: per round [dl][MAXB] draft flat ids
-  std::vector<int32_t> trace;   // rounds: {dl, n_matches, flat ids...}
+  std::vector<int32_t> trace;   // rounds: {dl, n_matches, nb, flat ids...}
   hipEvent_t ev[kMaxEvents];
+  hipStream_t own_stream;   // used by the batch API
+  // ---- state of the generate call in flight
+  struct Run {
+    const atspeed_fsm* fsm; int gamma, max_new, k, dk;
+    int32_t* out_tokens; float* out_scores; atspeed_gen_stats* stats_out;
+    hipStream_t st;
+    atspeed_gen_stats s;
+    int cur, gen, base, n0, nb, dl, nev, e_begin, e_end;
+    bool reingest, final_step, exported, done;
+    std::vector<int> ev_marks;
+  } run;
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -343,6 +380,9 @@ extern "C" int atspeed_decoder_create(atspeed_llama* target, atspeed_llama* draf
   }
   atspeed_decoder* d = new atspeed_decoder();
   d->target = target; d->draft = draft;
+  d->tctx = nullptr; d->dctx = nullptr;
+  ATS_TRY(ctx_create(target, &d->tctx));
+  if (draft) ATS_TRY(ctx_create(draft, &d->dctx));
   d->max_prompt = max_prompt;
   d->W = target->vis_words;
   d->tok_cap = max_prompt + ATSPEED_MAX_GAMMA * MAXB + MAXB;
@@ -363,12 +403,18 @@ extern "C" int atspeed_decoder_create(atspeed_llama* target, atspeed_llama* draf
   ATS_HIP(hipHostMalloc((void**)&d->mail_host, sizeof(Mailbox)));
   ATS_HIP(hipHostMalloc((void**)&d->trace_host, sizeof(int32_t) * ATSPEED_MAX_GAMMA * MAXB));
   for (int i = 0; i < kMaxEvents; ++i) ATS_HIP(hipEventCreate(&d->ev[i]));
+  ATS_HIP(hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking));
+  d->run.done = true;
   *out = d;
   return ATSPEED_OK;
 }
 
 extern "C" void atspeed_decoder_destroy(atspeed_decoder* d) {
   if (!d) return;
+  hipStreamSynchronize(d->own_stream);
+  hipStreamDestroy(d->own_stream);
+  ctx_destroy(d->target, d->tctx);
+  if (d->draft) ctx_destroy(d->draft, d->dctx);
   hipFree(d->arena);
   hipHostFree(d->mail_host);
   hipHostFree(d->trace_host);
@@ -395,7 +441,6 @@ static int check_common(atspeed_decoder* d, const int32_t* prompt, int P, const 
 }
 
 static int read_mailbox(atspeed_decoder* d, hipStream_t st) {
-  ATS_HIP(hipMemcpyAsync(d->mail_host, d->mail_dev, sizeof(Mailbox), hipMemcpyDeviceToHost, st));
   ATS_HIP(hipStreamSynchronize(st));
   if (d->mail_host->status == ATSPEED_ERR_CONSTRAINT) {
     atspeed_set_error("`prefix_allowed_tokens_fn` returned an empty list for batch ID 0. This means that the constraint is unsatisfiable.");
@@ -408,124 +453,201 @@ static int read_mailbox(atspeed_decoder* d, hipStream_t st) {
   return ATSPEED_OK;
 }
 
-extern "C" int atspeed_bssd_generate(atspeed_decoder* d, const int32_t* prompt, int32_t P, const atspeed_fsm* fsm,
-                                     int32_t start_node, int32_t gamma, int32_t max_new, int32_t k, int32_t dk,
-                                     int32_t* out_tokens, float* out_scores, atspeed_gen_stats* stats, void* stream) {
+static int run_mark(atspeed_decoder* d) {
+  atspeed_decoder::Run& r = d->run;
+  if (r.nev < kMaxEvents) hipEventRecord(d->ev[r.nev], r.st);
+  return r.nev++;
+}
+
+// -- BSSD as a resumable state machine: begin -> (enqueue_round -> finish_round)* ------------------------------
+static int bssd_begin(atspeed_decoder* d, const int32_t* prompt, int P, const atspeed_fsm* fsm, int start_node, int gamma,
+                      int max_new, int k, int dk, int32_t* out_tokens, float* out_scores, atspeed_gen_stats* stats,
+                      hipStream_t st) {
   ATS_TRY(check_common(d, prompt, P, fsm, start_node, max_new, k, out_tokens, out_scores));
   ATS_REQUIRE(d->draft, ATSPEED_ERR_INVALID, "bssd: decoder was created without a draft model");
   ATS_REQUIRE(dk >= k && dk <= MAXB, ATSPEED_ERR_CAPACITY, "bssd: draft beam size %d must be in [k=%d, %d]", dk, k, MAXB);
   ATS_REQUIRE(gamma >= 1 && gamma <= ATSPEED_MAX_GAMMA, ATSPEED_ERR_CAPACITY, "bssd: gamma %d out of [1,%d]", gamma, ATSPEED_MAX_GAMMA);
-  hipStream_t st = (hipStream_t)stream;
-  atspeed_llama *T = d->target, *D = d->draft;
-  const int W = d->W, V = T->cfg.vocab_size;
-  atspeed_gen_stats s;
-  memset(&s, 0, sizeof(s));
+  atspeed_decoder::Run& r = d->run;
+  r.fsm = fsm; r.gamma = gamma; r.max_new = max_new; r.k = k; r.dk = dk;
+  r.out_tokens = out_tokens; r.out_scores = out_scores; r.stats_out = stats; r.st = st;
+  memset(&r.s, 0, sizeof(r.s));
+  r.cur = 0; r.gen = 0; r.base = 0; r.n0 = P; r.nb = 1; r.dl = 0; r.nev = 0;
+  r.reingest = false; r.final_step = false; r.exported = false; r.done = false;
+  r.ev_marks.clear();
   d->trace.clear();
-  int nev = 0;
-  auto mark = [&](void) -> int { if (nev < kMaxEvents) { hipEventRecord(d->ev[nev], st); } return nev++; };
-  std::vector<int> ev_marks;   // per round: start, after draft, after target, after verify
-
-  int cur = 0;                 // ping-pong index of tin / round_beams
-  ATS_TRY(ats_init_prompt(d->tin[0], prompt, P, W, d->round_beams[0], start_node, V, d->mail_dev, st));
-  int gen = 0, base = 0, n0 = P, nb = 1;
-  bool draft_reingest = false;   // draft round inputs come from d->dround (dk + k rows)
-  int e_begin = mark();
-  while (gen < max_new) {
-    int dl = std::min(gamma, max_new - gen - 1);                                     // beamSD.py:504
-    TokBuf& tin = d->tin[cur];
-    BeamSet& beams = d->round_beams[cur];
-    if (dl == 0) {                                                                   // :505-509
-      ATS_TRY(llama_forward(T, tin.ids, tin.pos, tin.slot, tin.vis, n0, base + n0, nb, nullptr, st));
-      s.n_target_forwards++;
-      ATS_TRY(ats_lse_rows(T->logits, nb, V, T->logits_ld, d->lse, st));
-      BeamStepArgs a{};
-      a.src = beams; a.n_src = nb; a.gen_len = gen;
-      a.logits = T->logits; a.ld = T->logits_ld; a.lse = d->lse; a.fsm = fsm->dev; a.k = k;
-      a.dst = d->round_beams[cur ^ 1]; a.emit = 0; a.mail = d->mail_dev; a.vis_words = W;
-      ATS_TRY(ats_beam_step(a, st));
-      cur ^= 1;
-      gen += 1;
-      break;
-    }
-    ATS_REQUIRE(n0 + dl * dk <= d->tok_cap && n0 + dl * dk <= T->cfg.max_tokens, ATSPEED_ERR_CAPACITY, "bssd: packed target input too long");
-    ATS_REQUIRE(base + n0 + dl * dk <= T->cfg.max_slots, ATSPEED_ERR_CAPACITY, "bssd: KV slots exhausted (%d needed, %d available)",
-                base + n0 + dl * dk, T->cfg.max_slots);
-    ATS_REQUIRE(nb + dl * dk <= T->cfg.max_logit_rows, ATSPEED_ERR_CAPACITY, "bssd: %d logit rows exceed max_logit_rows", nb + dl * dk);
-    ev_marks.push_back(mark());
-    // ---- 1. draft: dl steps of one_step_beam_search (:108-179)
-    for (int i = 0; i < dl; ++i) {
-      int n_src;
-      if (i == 0) {
-        n_src = nb;
-        if (draft_reingest) {
-          ATS_TRY(llama_forward(D, d->dround.ids, d->dround.pos, d->dround.slot, d->dround.vis, dk + k, base + n0, nb, nullptr, st));
-        } else {
-          ATS_TRY(llama_forward(D, tin.ids, tin.pos, tin.slot, tin.vis, n0, base + n0, nb, nullptr, st));
-        }
-      } else {
-        n_src = dk;
-        TokBuf b = tb_offset(tin, n0 + (i - 1) * dk, W);
-        ATS_TRY(llama_forward(D, b.ids, b.pos, b.slot, b.vis, dk, base + n0 + i * dk, dk, nullptr, st));
-      }
-      s.n_draft_forwards++;
-      ATS_TRY(ats_lse_rows(D->logits, n_src, V, D->logits_ld, d->lse, st));
-      BeamStepArgs a{};
-      a.src = i == 0 ? beams : d->blk[i]; a.n_src = n_src; a.gen_len = gen + i;
-      a.logits = D->logits; a.ld = D->logits_ld; a.lse = d->lse; a.fsm = fsm->dev; a.k = dk;
-      a.dst = d->blk[i + 1]; a.emit = 1;
-      a.in = tin; a.in_row0 = i == 0 ? n0 - nb : n0 + (i - 1) * dk;
-      a.out = tin; a.out_row0 = n0 + i * dk; a.out_slot0 = base + n0 + i * dk; a.vis_words = W;
-      a.mail = d->mail_dev;
-      ATS_TRY(ats_beam_step(a, st));
-    }
-    ev_marks.push_back(mark());
-    // ---- 2. target: ONE forward over round inputs ++ all draft blocks (:190-232)
-    const int Tn = n0 + dl * dk, rows = nb + dl * dk;
-    ATS_TRY(llama_forward(T, tin.ids, tin.pos, tin.slot, tin.vis, Tn, base + Tn, rows, nullptr, st));
-    s.n_target_forwards++;
-    ev_marks.push_back(mark());
-    // ---- 3. verify (:242-456)
-    ATS_TRY(ats_lse_rows(T->logits, rows, V, T->logits_ld, d->lse, st));
-    VerifyArgs va{};
-    va.blk[0] = beams;
-    for (int i = 1; i <= dl; ++i) va.blk[i] = d->blk[i];
-    va.nb = nb; va.dl = dl; va.k = k; va.dk = dk; va.gen_len0 = gen;
-    va.logits = T->logits; va.ld = T->logits_ld; va.lse = d->lse; va.fsm = fsm->dev;
-    va.cur = tin; va.n0 = n0; va.next = d->tin[cur ^ 1]; va.dnext = d->dround; va.vis_words = W;
-    va.res = d->round_beams[cur ^ 1]; va.mail = d->mail_dev;
-    ATS_TRY(ats_verify_walk(va, st));
-    ev_marks.push_back(mark());
-    // trace of the draft's flat ids for parity tests (tiny copies, same stream)
-    for (int i = 1; i <= dl; ++i)
-      ATS_HIP(hipMemcpyAsync(d->trace_host + (i - 1) * MAXB, d->blk[i].flat, sizeof(int32_t) * dk, hipMemcpyDeviceToHost, st));
-    ATS_TRY(read_mailbox(d, st));                                                     // the round's only sync
-    const int nm = d->mail_host->n_matches;
-    d->trace.push_back(dl); d->trace.push_back(nm); d->trace.push_back(nb);
-    for (int i = 0; i < dl; ++i) for (int j = 0; j < dk; ++j) d->trace.push_back(d->trace_host[i * MAXB + j]);
-    if (s.n_run < ATSPEED_MAX_NEW_TOKENS) s.accept_steps[s.n_run] = nm;
-    s.n_run++;
-    s.total_accept_steps += nm;
-    base += n0 + nm * dk;                 // compact: keep up to the end of block nm
-    n0 = k; nb = k;
-    gen += nm + 1;                        // :522
-    draft_reingest = (nm == dl);
-    cur ^= 1;
-  }
-  ATS_TRY(ats_export_beams(d->round_beams[cur], k, max_new, out_tokens, out_scores, st));
-  int e_end = mark();
-  ATS_TRY(read_mailbox(d, st));
-  s.n_valid = d->mail_host->n_valid;
-  if (nev <= kMaxEvents) {
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, d->ev[e_begin], d->ev[e_end]); s.total_ms = ms;
-    for (size_t r = 0; r + 3 < ev_marks.size(); r += 4) {
-      hipEventElapsedTime(&ms, d->ev[ev_marks[r]], d->ev[ev_marks[r + 1]]); s.draft_ms += ms;
-      hipEventElapsedTime(&ms, d->ev[ev_marks[r + 1]], d->ev[ev_marks[r + 2]]); s.target_ms += ms;
-      hipEventElapsedTime(&ms, d->ev[ev_marks[r + 2]], d->ev[ev_marks[r + 3]]); s.verify_ms += ms;
-    }
-  }
-  if (stats) *stats = s;
+  ATS_TRY(ats_init_prompt(d->tin[0], prompt, P, d->W, d->round_beams[0], start_node, d->target->cfg.vocab_size, d->mail_dev, st));
+  r.e_begin = run_mark(d);
   return ATSPEED_OK;
+}
+
+// enqueue everything up to the next point where the host must look at the device (no synchronisation here)
+static int bssd_enqueue_round(atspeed_decoder* d) {
+  atspeed_decoder::Run& r = d->run;
+  hipStream_t st = r.st;
+  atspeed_llama *T = d->target, *D = d->draft;
+  const int W = d->W, V = T->cfg.vocab_size, k = r.k, dk = r.dk;
+  if (r.gen >= r.max_new) {                                                          // nothing left: export
+    r.final_step = true;
+  } else {
+    r.dl = std::min(r.gamma, r.max_new - r.gen - 1);                                 // beamSD.py:504
+    TokBuf& tin = d->tin[r.cur];
+    BeamSet& beams = d->round_beams[r.cur];
+    if (r.dl == 0) {                                                                 // :505-509
+      ATS_TRY(llama_forward(T, d->tctx, tin.ids, tin.pos, tin.slot, tin.vis, r.n0, r.base + r.n0, r.nb, nullptr, st));
+      r.s.n_target_forwards++;
+      ATS_TRY(ats_lse_rows(d->tctx->logits, r.nb, V, T->logits_ld, d->lse, st));
+      BeamStepArgs a{};
+      a.src = beams; a.n_src = r.nb; a.gen_len = r.gen;
+      a.logits = d->tctx->logits; a.ld = T->logits_ld; a.lse = d->lse; a.fsm = r.fsm->dev; a.k = k;
+      a.dst = d->round_beams[r.cur ^ 1]; a.emit = 0; a.mail = d->mail_dev; a.vis_words = W;
+      ATS_TRY(ats_beam_step(a, st));
+      r.cur ^= 1;
+      r.gen += 1;
+      r.final_step = true;
+    } else {
+      const int n0 = r.n0, nb = r.nb, dl = r.dl, base = r.base;
+      ATS_REQUIRE(n0 + dl * dk <= d->tok_cap && n0 + dl * dk <= T->cfg.max_tokens, ATSPEED_ERR_CAPACITY, "bssd: packed target input too long");
+      ATS_REQUIRE(base + n0 + dl * dk <= T->cfg.max_slots, ATSPEED_ERR_CAPACITY, "bssd: KV slots exhausted (%d needed, %d available)",
+                  base + n0 + dl * dk, T->cfg.max_slots);
+      ATS_REQUIRE(nb + dl * dk <= T->cfg.max_logit_rows, ATSPEED_ERR_CAPACITY, "bssd: %d logit rows exceed max_logit_rows", nb + dl * dk);
+      r.ev_marks.push_back(run_mark(d));
+      // ---- 1. draft: dl steps of one_step_beam_search (:108-179)
+      for (int i = 0; i < dl; ++i) {
+        int n_src;
+        if (i == 0) {
+          n_src = nb;
+          if (r.reingest) {
+            ATS_TRY(llama_forward(D, d->dctx, d->dround.ids, d->dround.pos, d->dround.slot, d->dround.vis, dk + k, base + n0, nb, nullptr, st));
+          } else {
+            ATS_TRY(llama_forward(D, d->dctx, tin.ids, tin.pos, tin.slot, tin.vis, n0, base + n0, nb, nullptr, st));
+          }
+        } else {
+          n_src = dk;
+          TokBuf b = tb_offset(tin, n0 + (i - 1) * dk, W);
+          ATS_TRY(llama_forward(D, d->dctx, b.ids, b.pos, b.slot, b.vis, dk, base + n0 + i * dk, dk, nullptr, st));
+        }
+        r.s.n_draft_forwards++;
+        ATS_TRY(ats_lse_rows(d->dctx->logits, n_src, V, D->logits_ld, d->lse, st));
+        BeamStepArgs a{};
+        a.src = i == 0 ? beams : d->blk[i]; a.n_src = n_src; a.gen_len = r.gen + i;
+        a.logits = d->dctx->logits; a.ld = D->logits_ld; a.lse = d->lse; a.fsm = r.fsm->dev; a.k = dk;
+        a.dst = d->blk[i + 1]; a.emit = 1;
+        a.in = tin; a.in_row0 = i == 0 ? n0 - nb : n0 + (i - 1) * dk;
+        a.out = tin; a.out_row0 = n0 + i * dk; a.out_slot0 = base + n0 + i * dk; a.vis_words = W;
+        a.mail = d->mail_dev;
+        ATS_TRY(ats_beam_step(a, st));
+      }
+      r.ev_marks.push_back(run_mark(d));
+      // ---- 2. target: ONE forward over round inputs ++ all draft blocks (:190-232)
+      const int Tn = n0 + dl * dk, rows = nb + dl * dk;
+      ATS_TRY(llama_forward(T, d->tctx, tin.ids, tin.pos, tin.slot, tin.vis, Tn, base + Tn, rows, nullptr, st));
+      r.s.n_target_forwards++;
+      r.ev_marks.push_back(run_mark(d));
+      // ---- 3. verify (:242-456)
+      ATS_TRY(ats_lse_rows(d->tctx->logits, rows, V, T->logits_ld, d->lse, st));
+      VerifyArgs va{};
+      va.blk[0] = beams;
+      for (int i = 1; i <= dl; ++i) va.blk[i] = d->blk[i];
+      va.nb = nb; va.dl = dl; va.k = k; va.dk = dk; va.gen_len0 = r.gen;
+      va.logits = d->tctx->logits; va.ld = T->logits_ld; va.lse = d->lse; va.fsm = r.fsm->dev;
+      va.cur = tin; va.n0 = n0; va.next = d->tin[r.cur ^ 1]; va.dnext = d->dround; va.vis_words = W;
+      va.res = d->round_beams[r.cur ^ 1]; va.mail = d->mail_dev;
+      ATS_TRY(ats_verify_walk(va, st));
+      r.ev_marks.push_back(run_mark(d));
+      for (int i = 1; i <= dl; ++i)   // trace of the draft's flat ids for parity tests (tiny copies, same stream)
+        ATS_HIP(hipMemcpyAsync(d->trace_host + (i - 1) * MAXB, d->blk[i].flat, sizeof(int32_t) * dk, hipMemcpyDeviceToHost, st));
+    }
+  }
+  if (r.final_step && !r.exported) {
+    ATS_TRY(ats_export_beams(d->round_beams[r.cur], k, r.max_new, r.out_tokens, r.out_scores, st));
+    r.e_end = run_mark(d);
+    r.exported = true;
+  }
+  ATS_HIP(hipMemcpyAsync(d->mail_host, d->mail_dev, sizeof(Mailbox), hipMemcpyDeviceToHost, st));
+  return ATSPEED_OK;
+}
+
+// wait for the enqueued work, read the mailbox, advance the state; sets run.done after the final step
+static int bssd_finish_round(atspeed_decoder* d) {
+  atspeed_decoder::Run& r = d->run;
+  ATS_TRY(read_mailbox(d, r.st));                                                   // the round's only sync
+  if (r.final_step) {
+    r.s.n_valid = d->mail_host->n_valid;
+    if (r.nev <= kMaxEvents) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, d->ev[r.e_begin], d->ev[r.e_end]); r.s.total_ms = ms;
+      for (size_t i = 0; i + 3 < r.ev_marks.size(); i += 4) {
+        hipEventElapsedTime(&ms, d->ev[r.ev_marks[i]], d->ev[r.ev_marks[i + 1]]); r.s.draft_ms += ms;
+        hipEventElapsedTime(&ms, d->ev[r.ev_marks[i + 1]], d->ev[r.ev_marks[i + 2]]); r.s.target_ms += ms;
+        hipEventElapsedTime(&ms, d->ev[r.ev_marks[i + 2]], d->ev[r.ev_marks[i + 3]]); r.s.verify_ms += ms;
+      }
+    }
+    if (r.stats_out) *r.stats_out = r.s;
+    r.done = true;
+    return ATSPEED_OK;
+  }
+  const int nm = d->mail_host->n_matches, dl = r.dl, dk = r.dk;
+  d->trace.push_back(dl); d->trace.push_back(nm); d->trace.push_back(r.nb);
+  for (int i = 0; i < dl; ++i) for (int j = 0; j < dk; ++j) d->trace.push_back(d->trace_host[i * MAXB + j]);
+  if (r.s.n_run < ATSPEED_MAX_NEW_TOKENS) r.s.accept_steps[r.s.n_run] = nm;
+  r.s.n_run++;
+  r.s.total_accept_steps += nm;
+  r.base += r.n0 + nm * dk;             // compact: keep up to the end of block nm
+  r.n0 = r.k; r.nb = r.k;
+  r.gen += nm + 1;                      // :522
+  r.reingest = (nm == dl);
+  r.cur ^= 1;
+  return ATSPEED_OK;
+}
+
+extern "C" int atspeed_bssd_generate(atspeed_decoder* d, const int32_t* prompt, int32_t P, const atspeed_fsm* fsm,
+                                     int32_t start_node, int32_t gamma, int32_t max_new, int32_t k, int32_t dk,
+                                     int32_t* out_tokens, float* out_scores, atspeed_gen_stats* stats, void* stream) {
+  ATS_TRY(bssd_begin(d, prompt, P, fsm, start_node, gamma, max_new, k, dk, out_tokens, out_scores, stats, (hipStream_t)stream));
+  while (!d->run.done) {
+    ATS_TRY(bssd_enqueue_round(d));
+    ATS_TRY(bssd_finish_round(d));
+  }
+  return ATSPEED_OK;
+}
+
+// Several independent users interleaved on the decoders' own streams: while the host waits for user A's mailbox,
+// users B, C, ... already have their rounds queued, so neither the per-round sync nor the launch latency of the
+// small-M forwards leaves the GPU idle, and forwards of different users overlap on the chip.  Results are
+// identical to n sequential atspeed_bssd_generate calls.  `stream` is the caller's stream: the call begins after
+// its pending work and ends synchronised with it.
+extern "C" int atspeed_bssd_generate_batch(atspeed_decoder** decs, int32_t n, const int32_t* const* prompts,
+                                           const int32_t* prompt_lens, const atspeed_fsm* fsm, const int32_t* start_nodes,
+                                           int32_t gamma, int32_t max_new, int32_t k, int32_t dk, int32_t* const* out_tokens,
+                                           float* const* out_scores, atspeed_gen_stats* stats, void* stream) {
+  ATS_REQUIRE(decs && prompts && prompt_lens && start_nodes && out_tokens && out_scores && n >= 1, ATSPEED_ERR_INVALID,
+              "bssd_batch: bad arguments");
+  hipStream_t caller = (hipStream_t)stream;
+  hipEvent_t ready;
+  ATS_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+  ATS_HIP(hipEventRecord(ready, caller));
+  int rc = ATSPEED_OK;
+  for (int i = 0; i < n && rc == ATSPEED_OK; ++i) {
+    for (int j = 0; j < i; ++j) ATS_REQUIRE(decs[i] != decs[j], ATSPEED_ERR_INVALID, "bssd_batch: decoder %d used twice", i);
+    ATS_HIP(hipStreamWaitEvent(decs[i]->own_stream, ready, 0));
+    rc = bssd_begin(decs[i], prompts[i], prompt_lens[i], fsm, start_nodes[i], gamma, max_new, k, dk, out_tokens[i], out_scores[i],
+                    stats ? &stats[i] : nullptr, decs[i]->own_stream);
+    if (rc == ATSPEED_OK) rc = bssd_enqueue_round(decs[i]);
+  }
+  int active = n;
+  while (rc == ATSPEED_OK && active > 0) {
+    active = 0;
+    for (int i = 0; i < n && rc == ATSPEED_OK; ++i) {
+      atspeed_decoder* d = decs[i];
+      if (d->run.done) continue;
+      rc = bssd_finish_round(d);
+      if (rc == ATSPEED_OK && !d->run.done) { rc = bssd_enqueue_round(d); ++active; }
+    }
+  }
+  for (int i = 0; i < n; ++i) hipStreamSynchronize(decs[i]->own_stream);
+  hipEventDestroy(ready);
+  if (rc == ATSPEED_OK) ATS_HIP(hipStreamSynchronize(caller));
+  return rc;
 }
 
 extern "C" int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt, int32_t P, const atspeed_fsm* fsm,
@@ -545,12 +667,12 @@ extern "C" int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt
   int cur = 0, row0 = 0, n_in = P, nb = 1, base = 0;
   for (int g = 0; g < max_new; ++g) {                                                // beamSD.py:579-588
     TokBuf b = tb_offset(tin, row0, W);
-    ATS_TRY(llama_forward(T, b.ids, b.pos, b.slot, b.vis, n_in, base + n_in, nb, nullptr, st));
+    ATS_TRY(llama_forward(T, d->tctx, b.ids, b.pos, b.slot, b.vis, n_in, base + n_in, nb, nullptr, st));
     s.n_target_forwards++;
-    ATS_TRY(ats_lse_rows(T->logits, nb, V, T->logits_ld, d->lse, st));
+    ATS_TRY(ats_lse_rows(d->tctx->logits, nb, V, T->logits_ld, d->lse, st));
     BeamStepArgs a{};
     a.src = d->round_beams[cur]; a.n_src = nb; a.gen_len = g;
-    a.logits = T->logits; a.ld = T->logits_ld; a.lse = d->lse; a.fsm = fsm->dev; a.k = k;
+    a.logits = d->tctx->logits; a.ld = T->logits_ld; a.lse = d->lse; a.fsm = fsm->dev; a.k = k;
     a.dst = d->round_beams[cur ^ 1]; a.emit = 1;
     a.in = tin; a.in_row0 = row0 + n_in - nb;
     a.out = tin; a.out_row0 = row0 + n_in; a.out_slot0 = base + n_in; a.vis_words = W;
@@ -560,6 +682,7 @@ extern "C" int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt
   }
   ATS_TRY(ats_export_beams(d->round_beams[cur], k, max_new, out_tokens, out_scores, st));
   hipEventRecord(d->ev[1], st);
+  ATS_HIP(hipMemcpyAsync(d->mail_host, d->mail_dev, sizeof(Mailbox), hipMemcpyDeviceToHost, st));
   ATS_TRY(read_mailbox(d, st));
   s.n_valid = d->mail_host->n_valid;
   hipEventElapsedTime(&s.total_ms, d->ev[0], d->ev[1]);

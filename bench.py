@@ -34,7 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from atspeed_amd import synth                      # noqa: E402
-from atspeed_amd.beamSD import BSSD                # noqa: E402
+from atspeed_amd.beamSD import BSSD, BSSD_batch    # noqa: E402
 from atspeed_amd.dist import Counters, aggregate, all_gather_counters   # noqa: E402
 from atspeed_amd.generation_trie import PositionSetConstraint   # noqa: E402
 from atspeed_amd.model import HipLlama             # noqa: E402
@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--gamma", type=int, default=4)
     ap.add_argument("--new-tokens", type=int, default=4)
     ap.add_argument("--seed", type=int, default=2025)
+    ap.add_argument("--streams", type=int, default=4, help="concurrent user streams (decoder lanes) per GPU; 1 = the reference's one-user-at-a-time loop")
     ap.add_argument("--cpu-baseline-users", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -122,8 +123,21 @@ def main():
     prompts = [synth.synthetic_prompt(int(plens[first + u]), synth.tensor_seed(args.seed, f"user{first + u}")) for u in range(n_local)]
     dprompts = [{"input_ids": torch.from_numpy(p)[None].to(dev)} for p in prompts]   # resident in HBM before timing
 
-    for u in range(args.warmup):
-        BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
+    def run_users(lo, hi):
+        """users [lo, hi): groups of --streams interleaved lanes (1 = plain per-user BSSD calls)"""
+        res = []
+        if args.streams <= 1:
+            for u in range(lo, hi):
+                res.append(BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn))
+            return res
+        for g in range(lo, hi, args.streams):
+            res += BSSD_batch(target, draft, dprompts[g:min(hi, g + args.streams)], args.gamma, args.new_tokens,
+                              prefix_allowed_tokens_fn=fn)
+        return res
+
+    run_users(0, args.warmup)
+    if args.streams > 1:                         # warm every lane (decoder creation, first-touch) outside the timed region
+        BSSD_batch(target, draft, dprompts[:args.streams], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
     target.profile(1)
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -133,8 +147,7 @@ def main():
     stage = np.zeros(3)
     n_tf = n_df = 0
     outs = []
-    for u in range(args.warmup, n_local):
-        o = BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
+    for o in run_users(args.warmup, n_local):
         n_run += o["n_run"]; acc += o["total_accept_steps"]
         stage += (o["draft_time_cost"], o["target_time_cost"], o["verify_time_cost"])
         n_tf += o["n_target_forwards"]; n_df += o["n_draft_forwards"]
@@ -180,8 +193,8 @@ def main():
         "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (hash-PRNG weights, Beauty-shaped vocabulary and prompts)",
         "config": {"workload": f"Beauty V={V}, Llama-68M draft / Llama-7B({args.target_layers}L) target, K={args.beam}, DK={args.draft_beam}, "
-                               f"gamma={args.gamma}, L={args.new_tokens}, batch=1 user stream per GPU, position-set mask",
-                   "users_per_gpu": args.steps, "mean_prompt_len": float(np.mean([len(p) for p in prompts[args.warmup:]])),
+                               f"gamma={args.gamma}, L={args.new_tokens}, {args.streams} interleaved user stream(s) per GPU, position-set mask",
+                   "users_per_gpu": args.steps, "streams": args.streams, "mean_prompt_len": float(np.mean([len(p) for p in prompts[args.warmup:]])),
                    "parallelism": f"user-shard x{world}"},
         "mean_accept_len": mean_accept,
         "accept_note": "unrelated random draft/target weights accept ~0 draft steps: worst-case bracket (4 target forwards per user)",

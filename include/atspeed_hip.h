@@ -176,6 +176,15 @@ int atspeed_bssd_generate(atspeed_decoder* d, const int32_t* prompt_ids_dev, int
                           int32_t k, int32_t dk, int32_t* out_tokens_dev, float* out_scores_dev,
                           atspeed_gen_stats* stats_host, void* stream);
 
+/* n independent users, one decoder each, interleaved on the decoders' private streams (the reference runs users
+ * strictly one after another, inference.py:162-176): hides the per-round mailbox sync and the launch latency of
+ * the small forwards, and lets forwards of different users overlap.  Results equal n sequential calls. */
+int atspeed_bssd_generate_batch(atspeed_decoder** decoders, int32_t n, const int32_t* const* prompt_ids_dev,
+                                const int32_t* prompt_lens, const atspeed_fsm* fsm, const int32_t* start_nodes,
+                                int32_t gamma, int32_t max_new_tokens, int32_t k, int32_t dk,
+                                int32_t* const* out_tokens_dev, float* const* out_scores_dev,
+                                atspeed_gen_stats* stats_host /* [n] */, void* stream);
+
 int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt_ids_dev, int32_t prompt_len,
                             const atspeed_fsm* fsm, int32_t start_node, int32_t max_new_tokens, int32_t k,
                             int32_t* out_tokens_dev, float* out_scores_dev, atspeed_gen_stats* stats_host,
