@@ -195,6 +195,7 @@ def BSSD(target_model, draft_model, inputs: Dict, gamma: int, max_new_tokens: in
 
 
 beam_sd_generate = BSSD
+MAX_USERS_PER_CALL = 16
 
 
 @torch.no_grad()
@@ -202,11 +203,18 @@ def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_token
                prefix_allowed_tokens_fn=None):
     """BSSD for several independent users at once (one result dict per user, same keys as BSSD).
 
-    The reference decodes users strictly one after another (inference.py:162-176).  Here each user gets its own
-    decoder lane (private KV cache + activations, own HIP stream) and the lanes are interleaved by
-    `atspeed_bssd_generate_batch`, so the per-round host read-back of one user overlaps the kernels of the
-    others.  Results are identical to calling BSSD() per user."""
+    The reference decodes users strictly one after another (inference.py:162-176).  Here the users advance in
+    lock step: each has its own decoder (private KV caches and beam state) and every draft step / target
+    verification of a round is ONE forward over the tokens of all users (`atspeed_bssd_generate_batch`), so the
+    weights are streamed once per forward instead of once per user.  Token ids, n_matches and draft candidates
+    are identical to calling BSSD() per user (scores agree to fp32 rounding: the GEMM tiling depends on the batch)."""
     _check_models(target_model, draft_model)
+    if len(inputs_list) > MAX_USERS_PER_CALL:            # the library batches up to 16 users per forward
+        outs = []
+        for i in range(0, len(inputs_list), MAX_USERS_PER_CALL):
+            outs += BSSD_batch(target_model, draft_model, inputs_list[i:i + MAX_USERS_PER_CALL], gamma, max_new_tokens,
+                               prefix_allowed_tokens_fn)
+        return outs
     lib = _lib.load()
     dev = target_model.device
     n = len(inputs_list)

@@ -20,13 +20,20 @@ namespace {
 constexpr int kMaxSlots = 2048;
 
 template <typename T>
-__global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ kc,
-                                                        const T* __restrict__ vc, const uint64_t* __restrict__ vis,
-                                                        int vis_words, T* __restrict__ out, int ldo, int n_slots,
+__global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q, int ldq, SegTable tab, size_t layer_off,
+                                                        int vis_words, T* __restrict__ out, int ldo,
                                                         int n_heads, int head_dim, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int t = blockIdx.x;
+  const int t = blockIdx.x;                        // global row
+  int si = 0;
+#pragma unroll 1
+  for (int i = 1; i < tab.n; ++i) if (t >= tab.seg[i].row0) si = i;
+  const Seg& sg = tab.seg[si];
+  const T* kc = reinterpret_cast<const T*>(reinterpret_cast<const char*>(sg.kc) + layer_off);
+  const T* vc = reinterpret_cast<const T*>(reinterpret_cast<const char*>(sg.vc) + layer_off);
+  const uint64_t* vis_row = sg.vis + (size_t)(t - sg.row0) * vis_words;
+  const int n_slots = sg.n_slots;
   const int h = blockIdx.y * 4 + wave;
   // per-wave LDS: q vector (head_dim f32), slot list (n_cap int32), probs (n_cap f32)
   const int n_cap = vis_words * 64;
@@ -43,7 +50,7 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q,
   int n_vis = 0;
   const int words = (n_slots + 63) >> 6;
   for (int w = 0; w < words; ++w) {
-    uint64_t bits = vis[(size_t)t * vis_words + w];
+    uint64_t bits = vis_row[w];
     if (w == words - 1 && (n_slots & 63)) bits &= (~0ull) >> (64 - (n_slots & 63));
     if ((bits >> lane) & 1ull) slot_list[n_vis + __popcll(bits & ((1ull << lane) - 1ull))] = w * 64 + lane;
     n_vis += __popcll(bits);
@@ -96,11 +103,13 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q,
 }
 
 // ---------------------------------------------------------------------------- MFMA kernel (bf16)
+// blockIdx.x walks the 64-row query tiles of all segments (tile -> segment through the table's tile prefix)
+struct AttnTiles { int n_tiles; unsigned char seg_of_tile[ATS_MAX_SEGS * 8]; unsigned char tile_in_seg[ATS_MAX_SEGS * 8]; };
+
 template <int DH>
-__global__ __launch_bounds__(256) void tree_attn_mfma_kernel(const bf16_t* __restrict__ q, int ldq,
-                                                             const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
-                                                             const uint64_t* __restrict__ vis, int vis_words,
-                                                             bf16_t* __restrict__ out, int ldo, int n_tokens, int n_slots,
+__global__ __launch_bounds__(256) void tree_attn_mfma_kernel(const bf16_t* __restrict__ q, int ldq, SegTable tab, AttnTiles tiles,
+                                                             size_t layer_off, int vis_words,
+                                                             bf16_t* __restrict__ out, int ldo,
                                                              int n_heads, float scale) {
   constexpr int KCH = DH / 8;                 // 16-byte chunks per K row
   constexpr int VT_LD = 68;                   // padded row (elements) of the transposed V tile
@@ -112,8 +121,14 @@ __global__ __launch_bounds__(256) void tree_attn_mfma_kernel(const bf16_t* __res
   const int g = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y;
   const int hidden = n_heads * DH;
-  const int qrow = blockIdx.x * 64 + wave * 16 + lq;
-  const bool qok = qrow < n_tokens;
+  const Seg& sg = tab.seg[tiles.seg_of_tile[blockIdx.x]];
+  const bf16_t* kc = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(sg.kc) + layer_off);
+  const bf16_t* vc = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(sg.vc) + layer_off);
+  const int n_slots = sg.n_slots;
+  const int lrow = tiles.tile_in_seg[blockIdx.x] * 64 + wave * 16 + lq;      // row inside the segment
+  const bool qok = lrow < sg.n_tok;
+  const int qrow = sg.row0 + lrow;                                           // row in the batched buffers
+  const uint64_t* vis_row = sg.vis + (size_t)lrow * vis_words;
 
   s16x8_t qf[KS];
 #pragma unroll
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(256) void tree_attn_mfma_kernel(const bf16_t* __res
       for (int e = 0; e < 8; ++e) vt_lds[(c * 8 + e) * VT_LD + r] = ve[e];
     }
     __syncthreads();
-    uint64_t word = qok ? vis[(size_t)qrow * vis_words + kt] : 0ull;
+    uint64_t word = qok ? vis_row[kt] : 0ull;
     if (kt == n_tiles - 1 && (n_slots & 63)) word &= (~0ull) >> (64 - (n_slots & 63));
     if (__ballot(word != 0ull) == 0ull) continue;      // this wave's 16 rows see nothing here (wave-uniform)
 
@@ -221,35 +236,51 @@ __global__ __launch_bounds__(256) void tree_attn_mfma_kernel(const bf16_t* __res
 
 }  // namespace
 
-int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* vcache, const uint64_t* vis,
-                       int vis_words, void* out, int ldo, int n_tokens, int n_slots, int n_heads, int head_dim,
-                       int dtype, hipStream_t st) {
-  if (n_tokens <= 0) return ATSPEED_OK;
+int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, size_t layer_off_bytes, int vis_words, void* out,
+                            int ldo, int n_heads, int head_dim, int dtype, hipStream_t st) {
+  if (t.total_tok <= 0) return ATSPEED_OK;
   ATS_REQUIRE(head_dim % 8 == 0 && head_dim <= 256, ATSPEED_ERR_INVALID, "attention: head_dim %d unsupported", head_dim);
-  ATS_REQUIRE(n_slots <= vis_words * 64 && vis_words * 64 <= kMaxSlots, ATSPEED_ERR_CAPACITY,
-              "attention: %d slots exceed the visibility bitset (%d words)", n_slots, vis_words);
+  ATS_REQUIRE(vis_words * 64 <= kMaxSlots, ATSPEED_ERR_CAPACITY, "attention: visibility bitset too wide (%d words)", vis_words);
+  for (int i = 0; i < t.n; ++i)
+    ATS_REQUIRE(t.seg[i].n_slots <= vis_words * 64, ATSPEED_ERR_CAPACITY, "attention: %d slots exceed the visibility bitset", t.seg[i].n_slots);
   float scale = 1.0f / sqrtf((float)head_dim);
   if (dtype == ATSPEED_BF16 && (head_dim == 64 || head_dim == 128) && (ldq % 8) == 0 && (ldo % 4) == 0) {
-    dim3 mgrid((n_tokens + 63) / 64, n_heads);
+    AttnTiles tiles;
+    tiles.n_tiles = 0;
+    const int cap = (int)sizeof(tiles.seg_of_tile);
+    for (int i = 0; i < t.n; ++i)
+      for (int j = 0; j * 64 < t.seg[i].n_tok; ++j) {
+        ATS_REQUIRE(tiles.n_tiles < cap, ATSPEED_ERR_CAPACITY, "attention: too many query tiles");
+        tiles.seg_of_tile[tiles.n_tiles] = (unsigned char)i;
+        tiles.tile_in_seg[tiles.n_tiles++] = (unsigned char)j;
+      }
+    dim3 mgrid(tiles.n_tiles, n_heads);
     if (head_dim == 128)
-      tree_attn_mfma_kernel<128><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)kcache, (const bf16_t*)vcache, vis,
-                                                        vis_words, (bf16_t*)out, ldo, n_tokens, n_slots, n_heads, scale);
+      tree_attn_mfma_kernel<128><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, t, tiles, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
     else
-      tree_attn_mfma_kernel<64><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)kcache, (const bf16_t*)vcache, vis,
-                                                       vis_words, (bf16_t*)out, ldo, n_tokens, n_slots, n_heads, scale);
+      tree_attn_mfma_kernel<64><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, t, tiles, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
     ATS_LAUNCH_CHECK();
     return ATSPEED_OK;
   }
-  dim3 grid(n_tokens, (n_heads + 3) / 4);
+  dim3 grid(t.total_tok, (n_heads + 3) / 4);
   size_t lds = (size_t)4 * (head_dim + 2 * vis_words * 64) * sizeof(float);
   if (dtype == ATSPEED_F32)
-    tree_attn_kernel<float><<<grid, 256, lds, st>>>((const float*)q, ldq, (const float*)kcache, (const float*)vcache, vis,
-                                                    vis_words, (float*)out, ldo, n_slots, n_heads, head_dim, scale);
+    tree_attn_kernel<float><<<grid, 256, lds, st>>>((const float*)q, ldq, t, layer_off_bytes, vis_words, (float*)out, ldo, n_heads, head_dim, scale);
   else
-    tree_attn_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)q, ldq, (const bf16_t*)kcache, (const bf16_t*)vcache,
-                                                     vis, vis_words, (bf16_t*)out, ldo, n_slots, n_heads, head_dim, scale);
+    tree_attn_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)q, ldq, t, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, head_dim, scale);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
+}
+
+int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* vcache, const uint64_t* vis,
+                       int vis_words, void* out, int ldo, int n_tokens, int n_slots, int n_heads, int head_dim,
+                       int dtype, hipStream_t st) {
+  SegTable t{};
+  t.n = 1; t.total_tok = n_tokens; t.total_logit = 0;
+  t.seg[0].vis = vis; t.seg[0].kc = const_cast<void*>(kcache); t.seg[0].vc = const_cast<void*>(vcache);
+  t.seg[0].row0 = 0; t.seg[0].n_tok = n_tokens; t.seg[0].n_slots = n_slots;
+  ATS_REQUIRE(n_slots <= vis_words * 64, ATSPEED_ERR_CAPACITY, "attention: %d slots exceed the visibility bitset (%d words)", n_slots, vis_words);
+  return ats_tree_attention_segs(q, ldq, t, 0, vis_words, out, ldo, n_heads, head_dim, dtype, st);
 }
 
 extern "C" int atspeed_tree_attention(const void* q, int32_t ldq, const void* kcache, const void* vcache,

@@ -106,12 +106,16 @@ extern "C" int atspeed_trie_flatten(const int32_t* seq_tokens, const int32_t* se
 }
 
 // ---------------------------------------------------------------------------- model
-// Weights/config/RoPE tables are shared and read-only; everything a forward WRITES lives in a LlamaCtx, so several
-// user streams can run the same model concurrently (one context per decoder).
-struct LlamaCtx {
-  void *kcache = nullptr, *vcache = nullptr;     // [n_layers][max_slots][hidden]
-  void *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *act = nullptr;   // activations
-  float* logits = nullptr;                       // [max_logit_rows][logits_ld]
+// Weights / config / RoPE tables are shared and read-only.  What a forward WRITES is split in two:
+//   KvCache — per user (decoder): the slot-addressed K/V arena;
+//   ActCtx  — per forward batch: activations, logits, split-K slabs, sized for the tokens of ALL users of the batch.
+struct KvCache { void* k = nullptr; void* v = nullptr; };
+
+struct ActCtx {
+  int cap_tok = 0, cap_rows = 0;
+  void *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *act = nullptr, *gath = nullptr;
+  float* logits = nullptr;                       // [cap_rows][logits_ld]
+  float* lse = nullptr;                          // [cap_rows]
   void* ws = nullptr; size_t ws_bytes = 0;       // split-K slabs
   // optional per-GEMM hipEvent brackets (bench.py roofline): 0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head
   bool prof_pending = false;
@@ -124,17 +128,19 @@ struct atspeed_llama {
   const void *embed, *final_norm, *lm_head;
   std::vector<atspeed_llama_layer_weights> layers;
   int esz, head_dim, vis_words, logits_ld;
+  size_t layer_kv_bytes;
   float *cos_tab, *sin_tab;                      // [max_slots][head_dim/2]
-  LlamaCtx* ctx0;                                // context of the plain atspeed_llama_forward API
-  std::vector<LlamaCtx*> ctxs;                   // every live context (profiling harvest)
+  KvCache kv0;                                   // cache of the plain atspeed_llama_forward API
+  ActCtx* act;                                   // grown on demand (ensure_act)
   bool prof_on = false;
   double prof_ms[5] = {0, 0, 0, 0, 0};
   long prof_cnt[5] = {0, 0, 0, 0, 0};
   long prof_rows[5] = {0, 0, 0, 0, 0};           // sum of M over the bracketed launches
 };
 
-static void prof_harvest(atspeed_llama* m, LlamaCtx* cx) {
-  if (!cx->prof_pending) return;
+static void prof_harvest(atspeed_llama* m) {
+  ActCtx* cx = m->act;
+  if (!cx || !cx->prof_pending) return;
   for (size_t b = 0; b < cx->prof_kind.size(); ++b) {
     float ms = 0.f;
     if (hipEventSynchronize(cx->prof_ev[2 * b + 1]) == hipSuccess &&
@@ -148,8 +154,8 @@ static void prof_harvest(atspeed_llama* m, LlamaCtx* cx) {
 }
 
 struct ProfBracket {
-  LlamaCtx* cx; hipStream_t st; bool on; size_t idx;
-  ProfBracket(atspeed_llama* m, LlamaCtx* cx_, int kind, int rows, hipStream_t st_) : cx(cx_), st(st_), on(m->prof_on), idx(0) {
+  ActCtx* cx; hipStream_t st; bool on; size_t idx;
+  ProfBracket(atspeed_llama* m, int kind, int rows, hipStream_t st_) : cx(m->act), st(st_), on(m->prof_on), idx(0) {
     if (!on) return;
     idx = cx->prof_kind.size();
     while (cx->prof_ev.size() < 2 * (idx + 1)) { hipEvent_t e; hipEventCreate(&e); cx->prof_ev.push_back(e); }
@@ -159,49 +165,58 @@ struct ProfBracket {
   ~ProfBracket() { if (on) { hipEventRecord(cx->prof_ev[2 * idx + 1], st); cx->prof_pending = true; } }
 };
 
-static size_t gemm_ws_for(const atspeed_llama_config& c) {
+static size_t gemm_ws_for(const atspeed_llama_config& c, int max_tok, int max_rows) {
   size_t best = 0;
-  for (int m = 1; m <= c.max_tokens; ++m) {      // the split-K plan depends on the exact M: take the true maximum
+  for (int m = 1; m <= max_tok; ++m) {          // the split-K plan depends on the exact M: take the true maximum
     best = std::max(best, ats_gemm_workspace_bytes(m, 3 * c.hidden, c.hidden, c.dtype));
     best = std::max(best, ats_gemm_workspace_bytes(m, c.hidden, c.hidden, c.dtype));
     best = std::max(best, ats_gemm_workspace_bytes(m, 2 * c.ffn, c.hidden, c.dtype));
     best = std::max(best, ats_gemm_workspace_bytes(m, c.hidden, c.ffn, c.dtype));
-    int lm = std::min(m, c.max_logit_rows);
-    best = std::max(best, ats_gemm_workspace_bytes(lm, c.vocab_size, c.hidden, c.dtype));
+    if (m <= max_rows) best = std::max(best, ats_gemm_workspace_bytes(m, c.vocab_size, c.hidden, c.dtype));
   }
   return best + (1 << 20);
 }
 
-static int ctx_create(atspeed_llama* m, LlamaCtx** out) {
+static void act_free(ActCtx* cx) {
+  if (!cx) return;
+  hipFree(cx->h); hipFree(cx->xn); hipFree(cx->qkv); hipFree(cx->att); hipFree(cx->act); hipFree(cx->gath);
+  hipFree(cx->logits); hipFree(cx->lse); hipFree(cx->ws);
+  for (hipEvent_t e : cx->prof_ev) hipEventDestroy(e);
+  delete cx;
+}
+
+// make sure the model's activation context can hold `tok` tokens and `rows` logit rows (device must be idle on it)
+static int ensure_act(atspeed_llama* m, int tok, int rows) {
+  if (m->act && m->act->cap_tok >= tok && m->act->cap_rows >= rows) return ATSPEED_OK;
+  if (m->act) { prof_harvest(m); ATS_HIP(hipDeviceSynchronize()); act_free(m->act); m->act = nullptr; }
   const atspeed_llama_config& c = m->cfg;
-  LlamaCtx* cx = new LlamaCtx();
-  size_t T = c.max_tokens, H = c.hidden, e = m->esz;
-  size_t kv = (size_t)c.n_layers * c.max_slots * H * e;
-  ATS_HIP(hipMalloc(&cx->kcache, kv));
-  ATS_HIP(hipMalloc(&cx->vcache, kv));
-  ATS_HIP(hipMemset(cx->kcache, 0, kv));
-  ATS_HIP(hipMemset(cx->vcache, 0, kv));
+  ActCtx* cx = new ActCtx();
+  cx->cap_tok = std::max(tok, c.max_tokens);
+  cx->cap_rows = std::max(rows, c.max_logit_rows);
+  size_t T = cx->cap_tok, H = c.hidden, e = m->esz;
   ATS_HIP(hipMalloc(&cx->h, T * H * e));
   ATS_HIP(hipMalloc(&cx->xn, T * H * e));
   ATS_HIP(hipMalloc(&cx->qkv, T * 3 * H * e));
   ATS_HIP(hipMalloc(&cx->att, T * H * e));
   ATS_HIP(hipMalloc(&cx->act, T * (size_t)c.ffn * e));
-  ATS_HIP(hipMalloc((void**)&cx->logits, (size_t)c.max_logit_rows * m->logits_ld * sizeof(float)));
-  cx->ws_bytes = gemm_ws_for(c);
+  ATS_HIP(hipMalloc(&cx->gath, (size_t)cx->cap_rows * H * e));
+  ATS_HIP(hipMalloc((void**)&cx->logits, (size_t)cx->cap_rows * m->logits_ld * sizeof(float)));
+  ATS_HIP(hipMalloc((void**)&cx->lse, (size_t)cx->cap_rows * sizeof(float)));
+  cx->ws_bytes = gemm_ws_for(c, cx->cap_tok, cx->cap_rows);
   ATS_HIP(hipMalloc(&cx->ws, cx->ws_bytes));
-  m->ctxs.push_back(cx);
-  *out = cx;
+  m->act = cx;
   return ATSPEED_OK;
 }
 
-static void ctx_destroy(atspeed_llama* m, LlamaCtx* cx) {
-  if (!cx) return;
-  hipFree(cx->kcache); hipFree(cx->vcache); hipFree(cx->h); hipFree(cx->xn); hipFree(cx->qkv); hipFree(cx->att);
-  hipFree(cx->act); hipFree(cx->logits); hipFree(cx->ws);
-  for (hipEvent_t e : cx->prof_ev) hipEventDestroy(e);
-  if (m) m->ctxs.erase(std::remove(m->ctxs.begin(), m->ctxs.end(), cx), m->ctxs.end());
-  delete cx;
+static int kv_create(atspeed_llama* m, KvCache* kv) {
+  size_t bytes = (size_t)m->cfg.n_layers * m->layer_kv_bytes;
+  ATS_HIP(hipMalloc(&kv->k, bytes));
+  ATS_HIP(hipMalloc(&kv->v, bytes));
+  ATS_HIP(hipMemset(kv->k, 0, bytes));
+  ATS_HIP(hipMemset(kv->v, 0, bytes));
+  return ATSPEED_OK;
 }
+static void kv_free(KvCache* kv) { hipFree(kv->k); hipFree(kv->v); kv->k = kv->v = nullptr; }
 
 extern "C" int atspeed_llama_create(const atspeed_llama_config* cfg, const void* embed, const void* final_norm,
                                     const void* lm_head, const atspeed_llama_layer_weights* layers, atspeed_llama** out) {
@@ -223,7 +238,10 @@ extern "C" int atspeed_llama_create(const atspeed_llama_config* cfg, const void*
   m->head_dim = hd;
   m->vis_words = cfg->max_slots / 64;
   m->logits_ld = (cfg->vocab_size + 63) / 64 * 64;
-  ATS_TRY(ctx_create(m, &m->ctx0));
+  m->layer_kv_bytes = (size_t)cfg->max_slots * cfg->hidden * m->esz;
+  m->act = nullptr;
+  ATS_TRY(kv_create(m, &m->kv0));
+  ATS_TRY(ensure_act(m, cfg->max_tokens, cfg->max_logit_rows));
   // RoPE tables: HF computes inv_freq and the angle in fp32; cos/sin of that angle in double, rounded once
   int half = hd / 2;
   std::vector<float> ct((size_t)cfg->max_slots * half), stv((size_t)cfg->max_slots * half);
@@ -244,14 +262,15 @@ extern "C" int atspeed_llama_create(const atspeed_llama_config* cfg, const void*
 
 extern "C" void atspeed_llama_destroy(atspeed_llama* m) {
   if (!m) return;
-  while (!m->ctxs.empty()) ctx_destroy(m, m->ctxs.back());
+  kv_free(&m->kv0);
+  act_free(m->act);
   hipFree(m->cos_tab); hipFree(m->sin_tab);
   delete m;
 }
 
 extern "C" int atspeed_llama_profile(atspeed_llama* m, int32_t enable, double* ms_out, int64_t* count_out, int64_t* rows_out) {
   ATS_REQUIRE(m, ATSPEED_ERR_INVALID, "profile: null model");
-  for (LlamaCtx* cx : m->ctxs) prof_harvest(m, cx);
+  prof_harvest(m);
   for (int i = 0; i < 5; ++i) {
     if (ms_out) ms_out[i] = m->prof_ms[i];
     if (count_out) count_out[i] = m->prof_cnt[i];
@@ -264,36 +283,40 @@ extern "C" int atspeed_llama_profile(atspeed_llama* m, int32_t enable, double* m
   return ATSPEED_OK;
 }
 
-extern "C" float* atspeed_llama_logits(atspeed_llama* m) { return m ? m->ctx0->logits : nullptr; }
+extern "C" float* atspeed_llama_logits(atspeed_llama* m) { return m && m->act ? m->act->logits : nullptr; }
 extern "C" int32_t atspeed_llama_logits_ld(const atspeed_llama* m) { return m ? m->logits_ld : 0; }
 
-static int llama_forward(atspeed_llama* m, LlamaCtx* cx, const int32_t* ids, const int32_t* pos, const int32_t* slots,
-                         const uint64_t* vis, int T, int S, int n_logit_rows, float* logits_out, hipStream_t st) {
+// One forward over the tokens of every segment (user) of the table.  Logits of each segment's last n_logit rows land
+// in act->logits rows [logit_row0, ..) (or in logits_out), their log-sum-exp in act->lse.
+static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits_out, hipStream_t st) {
   const atspeed_llama_config& c = m->cfg;
-  ATS_REQUIRE(T >= 1 && T <= c.max_tokens, ATSPEED_ERR_CAPACITY, "forward: %d tokens exceed max_tokens %d", T, c.max_tokens);
-  ATS_REQUIRE(S >= 1 && S <= c.max_slots, ATSPEED_ERR_CAPACITY, "forward: %d slots exceed max_slots %d", S, c.max_slots);
-  ATS_REQUIRE(n_logit_rows >= 0 && n_logit_rows <= T && n_logit_rows <= c.max_logit_rows, ATSPEED_ERR_CAPACITY,
-              "forward: %d logit rows exceed the limit %d", n_logit_rows, c.max_logit_rows);
+  ActCtx* cx = m->act;
+  const int T = t.total_tok;
+  ATS_REQUIRE(T >= 1 && T <= cx->cap_tok, ATSPEED_ERR_CAPACITY, "forward: %d tokens exceed the activation capacity %d", T, cx->cap_tok);
+  ATS_REQUIRE(t.total_logit >= 0 && t.total_logit <= cx->cap_rows, ATSPEED_ERR_CAPACITY, "forward: %d logit rows exceed the capacity %d",
+              t.total_logit, cx->cap_rows);
+  for (int i = 0; i < t.n; ++i) {
+    ATS_REQUIRE(t.seg[i].n_tok >= 1 && t.seg[i].n_slots >= 1 && t.seg[i].n_slots <= c.max_slots, ATSPEED_ERR_CAPACITY,
+                "forward: segment %d has %d tokens / %d slots (max_slots %d)", i, t.seg[i].n_tok, t.seg[i].n_slots, c.max_slots);
+    ATS_REQUIRE(t.seg[i].n_logit >= 0 && t.seg[i].n_logit <= t.seg[i].n_tok, ATSPEED_ERR_INVALID, "forward: bad logit row count");
+  }
   const int H = c.hidden, dt = c.dtype;
-  const size_t e = m->esz;
-  if (m->prof_on) prof_harvest(m, cx);
-  const size_t layer_kv = (size_t)c.max_slots * H * e;
-  ATS_TRY(ats_embed(m->embed, ids, cx->h, T, H, c.vocab_size, dt, st));
+  if (m->prof_on) prof_harvest(m);
+  ATS_TRY(ats_embed_segs(m->embed, t, cx->h, H, c.vocab_size, dt, st));
   ATS_TRY(ats_rmsnorm(cx->h, m->layers[0].input_norm, cx->xn, T, H, c.rms_eps, dt, st));
   for (int l = 0; l < c.n_layers; ++l) {
     const atspeed_llama_layer_weights& w = m->layers[l];
-    char* kc = (char*)cx->kcache + l * layer_kv;
-    char* vc = (char*)cx->vcache + l * layer_kv;
+    const size_t loff = (size_t)l * m->layer_kv_bytes;
     // cx->xn holds rmsnorm(h) * input_norm here (from the embed above or the previous layer's fused down_proj epilogue)
-    { ProfBracket pb(m, cx, 0, T, st);
+    { ProfBracket pb(m, 0, T, st);
       ATS_TRY(ats_gemm(cx->xn, w.wqkv, cx->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, cx->ws, cx->ws_bytes, st)); }
-    ATS_TRY(ats_rope_kv(cx->qkv, pos, slots, m->cos_tab, m->sin_tab, kc, vc, T, c.n_heads, m->head_dim, c.max_slots, dt, st));
-    ATS_TRY(ats_tree_attention(cx->qkv, 3 * H, kc, vc, vis, m->vis_words, cx->att, H, T, S, c.n_heads, m->head_dim, dt, st));
-    { ProfBracket pb(m, cx, 1, T, st);     // h += att Wo^T ; xn = rmsnorm(h) * post_norm
+    ATS_TRY(ats_rope_kv_segs(cx->qkv, t, m->cos_tab, m->sin_tab, loff, c.n_heads, m->head_dim, c.max_slots, dt, st));
+    ATS_TRY(ats_tree_attention_segs(cx->qkv, 3 * H, t, loff, m->vis_words, cx->att, H, c.n_heads, m->head_dim, dt, st));
+    { ProfBracket pb(m, 1, T, st);     // h += att Wo^T ; xn = rmsnorm(h) * post_norm
       ATS_TRY(ats_gemm_resid_norm(cx->att, w.wo, cx->h, T, H, H, H, H, dt, w.post_norm, cx->xn, c.rms_eps, cx->ws, cx->ws_bytes, st)); }
-    { ProfBracket pb(m, cx, 2, T, st);
+    { ProfBracket pb(m, 2, T, st);
       ATS_TRY(ats_gemm(cx->xn, w.wgu, cx->act, T, 2 * c.ffn, H, H, c.ffn, dt, EPI_SWIGLU, cx->ws, cx->ws_bytes, st)); }
-    { ProfBracket pb(m, cx, 3, T, st);     // h += act Wd^T ; xn = rmsnorm(h) * next layer's input_norm
+    { ProfBracket pb(m, 3, T, st);     // h += act Wd^T ; xn = rmsnorm(h) * next layer's input_norm
       if (l + 1 < c.n_layers) {
         ATS_TRY(ats_gemm_resid_norm(cx->act, w.wd, cx->h, T, H, c.ffn, c.ffn, H, dt, m->layers[l + 1].input_norm, cx->xn, c.rms_eps,
                                     cx->ws, cx->ws_bytes, st));
@@ -301,12 +324,14 @@ static int llama_forward(atspeed_llama* m, LlamaCtx* cx, const int32_t* ids, con
         ATS_TRY(ats_gemm(cx->act, w.wd, cx->h, T, H, c.ffn, c.ffn, H, dt, EPI_RESID, cx->ws, cx->ws_bytes, st));
       } }
   }
-  if (n_logit_rows > 0) {
-    char* hrows = (char*)cx->h + (size_t)(T - n_logit_rows) * H * e;
-    ATS_TRY(ats_rmsnorm(hrows, m->final_norm, cx->xn, n_logit_rows, H, c.rms_eps, dt, st));
+  if (t.total_logit > 0) {
+    const int R = t.total_logit;
+    ATS_TRY(ats_gather_logit_rows(cx->h, t, cx->gath, H, dt, st));
+    ATS_TRY(ats_rmsnorm(cx->gath, m->final_norm, cx->xn, R, H, c.rms_eps, dt, st));
     float* lo = logits_out ? logits_out : cx->logits;
-    ProfBracket pb(m, cx, 4, n_logit_rows, st);
-    ATS_TRY(ats_gemm(cx->xn, m->lm_head, lo, n_logit_rows, c.vocab_size, H, H, m->logits_ld, dt, EPI_F32, cx->ws, cx->ws_bytes, st));
+    { ProfBracket pb(m, 4, R, st);
+      ATS_TRY(ats_gemm(cx->xn, m->lm_head, lo, R, c.vocab_size, H, H, m->logits_ld, dt, EPI_F32, cx->ws, cx->ws_bytes, st)); }
+    ATS_TRY(ats_lse_rows(lo, R, c.vocab_size, m->logits_ld, cx->lse, st));     // beamSD.py:58,285: full-vocab normaliser
   }
   return ATSPEED_OK;
 }
@@ -315,7 +340,15 @@ extern "C" int atspeed_llama_forward(atspeed_llama* m, const int32_t* ids, const
                                      const uint64_t* vis, int32_t n_tokens, int32_t n_slots_visible, int32_t n_logit_rows,
                                      float* logits_out, void* stream) {
   ATS_REQUIRE(m && ids && pos && slots && vis, ATSPEED_ERR_INVALID, "forward: null argument");
-  return llama_forward(m, m->ctx0, ids, pos, slots, vis, n_tokens, n_slots_visible, n_logit_rows, logits_out, (hipStream_t)stream);
+  ATS_REQUIRE(n_tokens >= 1 && n_tokens <= m->cfg.max_tokens, ATSPEED_ERR_CAPACITY, "forward: %d tokens exceed max_tokens %d", n_tokens, m->cfg.max_tokens);
+  ATS_REQUIRE(n_logit_rows >= 0 && n_logit_rows <= n_tokens && n_logit_rows <= m->cfg.max_logit_rows, ATSPEED_ERR_CAPACITY,
+              "forward: %d logit rows exceed the limit %d", n_logit_rows, m->cfg.max_logit_rows);
+  SegTable t{};
+  t.n = 1; t.total_tok = n_tokens; t.total_logit = n_logit_rows;
+  Seg& s = t.seg[0];
+  s.ids = ids; s.pos = pos; s.slot = slots; s.vis = vis; s.kc = m->kv0.k; s.vc = m->kv0.v;
+  s.row0 = 0; s.n_tok = n_tokens; s.n_slots = n_slots_visible; s.logit_row0 = 0; s.n_logit = n_logit_rows;
+  return llama_forward_segs(m, t, logits_out, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------- decoder
@@ -323,35 +356,28 @@ namespace {
 constexpr int MAXB = ATSPEED_MAX_BEAMS;
 constexpr int LMAX = ATSPEED_MAX_NEW_TOKENS;
 constexpr int NBLK = ATSPEED_MAX_GAMMA + 1;
-constexpr int kMaxEvents = 4 * (ATSPEED_MAX_NEW_TOKENS + 2);
+constexpr int kArgSlots = 4 * (ATSPEED_MAX_GAMMA + 2);     // argument blocks a user needs per round
 }  // namespace
 
-// One user stream: private forward contexts (KV + activations) for target and draft, device-side beam state, a
-// pinned mailbox, and the bookkeeping of the call in flight (so several decoders can be interleaved, see
-// atspeed_bssd_generate_batch).
+// One user: private KV caches for target and draft, device-side beam state, pinned mailbox and argument staging,
+// plus the bookkeeping of the generate call in flight.  Forwards of several users are batched (SegTable).
 struct atspeed_decoder {
   atspeed_llama *target, *draft;
-  LlamaCtx *tctx, *dctx;
+  KvCache tkv, dkv;
   int max_prompt, tok_cap, W;
   char* arena;
   TokBuf tin[2], dround;
   BeamSet round_beams[2], blk[NBLK];
-  float* lse;
   Mailbox* mail_dev;
   Mailbox* mail_host;       // pinned
   int32_t* trace_host;      // pinned: per round [dl][MAXB] draft flat ids
   std::vector<int32_t> trace;   // rounds: {dl, n_matches, nb, flat ids...}
-  hipEvent_t ev[kMaxEvents];
-  hipStream_t own_stream;   // used by the batch API
-  // ---- state of the generate call in flight
   struct Run {
     const atspeed_fsm* fsm; int gamma, max_new, k, dk;
     int32_t* out_tokens; float* out_scores; atspeed_gen_stats* stats_out;
-    hipStream_t st;
     atspeed_gen_stats s;
-    int cur, gen, base, n0, nb, dl, nev, e_begin, e_end;
-    bool reingest, final_step, exported, done;
-    std::vector<int> ev_marks;
+    int cur, gen, base, n0, nb, dl;
+    bool reingest, final_step, export_only, done;
   } run;
 };
 
@@ -380,15 +406,14 @@ extern "C" int atspeed_decoder_create(atspeed_llama* target, atspeed_llama* draf
   }
   atspeed_decoder* d = new atspeed_decoder();
   d->target = target; d->draft = draft;
-  d->tctx = nullptr; d->dctx = nullptr;
-  ATS_TRY(ctx_create(target, &d->tctx));
-  if (draft) ATS_TRY(ctx_create(draft, &d->dctx));
+  ATS_TRY(kv_create(target, &d->tkv));
+  if (draft) ATS_TRY(kv_create(draft, &d->dkv));
   d->max_prompt = max_prompt;
   d->W = target->vis_words;
   d->tok_cap = max_prompt + ATSPEED_MAX_GAMMA * MAXB + MAXB;
   size_t tb_bytes = 3 * align_up((size_t)d->tok_cap * 4, 256) + align_up((size_t)d->tok_cap * d->W * 8, 256);
   size_t bs_bytes = 5 * 256 + align_up((size_t)MAXB * LMAX * 4, 256);
-  size_t total = 3 * tb_bytes + (2 + NBLK) * bs_bytes + align_up((size_t)target->cfg.max_logit_rows * 4, 256) + 256;
+  size_t total = 3 * tb_bytes + (2 + NBLK) * bs_bytes + 256;
   ATS_HIP(hipMalloc((void**)&d->arena, total));
   ATS_HIP(hipMemset(d->arena, 0, total));
   char* p = d->arena;
@@ -398,12 +423,9 @@ extern "C" int atspeed_decoder_create(atspeed_llama* target, atspeed_llama* draf
   carve_beams(p, d->round_beams[0]);
   carve_beams(p, d->round_beams[1]);
   for (int i = 0; i < NBLK; ++i) carve_beams(p, d->blk[i]);
-  d->lse = (float*)p; p += align_up((size_t)target->cfg.max_logit_rows * 4, 256);
   d->mail_dev = (Mailbox*)p; p += 256;
   ATS_HIP(hipHostMalloc((void**)&d->mail_host, sizeof(Mailbox)));
   ATS_HIP(hipHostMalloc((void**)&d->trace_host, sizeof(int32_t) * ATSPEED_MAX_GAMMA * MAXB));
-  for (int i = 0; i < kMaxEvents; ++i) ATS_HIP(hipEventCreate(&d->ev[i]));
-  ATS_HIP(hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking));
   d->run.done = true;
   *out = d;
   return ATSPEED_OK;
@@ -411,14 +433,12 @@ extern "C" int atspeed_decoder_create(atspeed_llama* target, atspeed_llama* draf
 
 extern "C" void atspeed_decoder_destroy(atspeed_decoder* d) {
   if (!d) return;
-  hipStreamSynchronize(d->own_stream);
-  hipStreamDestroy(d->own_stream);
-  ctx_destroy(d->target, d->tctx);
-  if (d->draft) ctx_destroy(d->draft, d->dctx);
+  hipDeviceSynchronize();
+  kv_free(&d->tkv);
+  if (d->draft) kv_free(&d->dkv);
   hipFree(d->arena);
   hipHostFree(d->mail_host);
   hipHostFree(d->trace_host);
-  for (int i = 0; i < kMaxEvents; ++i) hipEventDestroy(d->ev[i]);
   delete d;
 }
 
@@ -440,8 +460,7 @@ static int check_common(atspeed_decoder* d, const int32_t* prompt, int P, const 
   return ATSPEED_OK;
 }
 
-static int read_mailbox(atspeed_decoder* d, hipStream_t st) {
-  ATS_HIP(hipStreamSynchronize(st));
+static int mailbox_status(atspeed_decoder* d) {
   if (d->mail_host->status == ATSPEED_ERR_CONSTRAINT) {
     atspeed_set_error("`prefix_allowed_tokens_fn` returned an empty list for batch ID 0. This means that the constraint is unsatisfiable.");
     return ATSPEED_ERR_CONSTRAINT;
@@ -453,13 +472,50 @@ static int read_mailbox(atspeed_decoder* d, hipStream_t st) {
   return ATSPEED_OK;
 }
 
-static int run_mark(atspeed_decoder* d) {
-  atspeed_decoder::Run& r = d->run;
-  if (r.nev < kMaxEvents) hipEventRecord(d->ev[r.nev], r.st);
-  return r.nev++;
+// ---- a group of users decoded in lock step ----------------------------------------------------------------------
+// Pinned + device staging for the per-user argument blocks of the multi-user scan kernels; one slot per launch,
+// recycled after the round's synchronisation.
+struct ArgStage {
+  char *host = nullptr, *dev = nullptr;
+  size_t cap = 0, used = 0;
+  int reserve(size_t bytes) {
+    if (cap >= bytes) return ATSPEED_OK;
+    if (host) hipHostFree(host);
+    if (dev) hipFree(dev);
+    ATS_HIP(hipHostMalloc((void**)&host, bytes));
+    ATS_HIP(hipMalloc((void**)&dev, bytes));
+    cap = bytes;
+    return ATSPEED_OK;
+  }
+  template <typename A>
+  int push(const std::vector<A>& v, const A** dev_out, hipStream_t st) {
+    size_t bytes = align_up(v.size() * sizeof(A), 256);
+    ATS_REQUIRE(used + bytes <= cap, ATSPEED_ERR_CAPACITY, "argument staging exhausted");
+    memcpy(host + used, v.data(), v.size() * sizeof(A));
+    ATS_HIP(hipMemcpyAsync(dev + used, host + used, v.size() * sizeof(A), hipMemcpyHostToDevice, st));
+    *dev_out = reinterpret_cast<const A*>(dev + used);
+    used += bytes;
+    return ATSPEED_OK;
+  }
+};
+static thread_local ArgStage g_args;
+static thread_local hipEvent_t g_ev[8];
+static thread_local bool g_ev_init = false;
+
+static Seg make_seg(const TokBuf& tb, int n_tok, int n_slots, int n_logit, const KvCache& kv) {
+  Seg s{};
+  s.ids = tb.ids; s.pos = tb.pos; s.slot = tb.slot; s.vis = tb.vis; s.kc = kv.k; s.vc = kv.v;
+  s.n_tok = n_tok; s.n_slots = n_slots; s.n_logit = n_logit;
+  return s;
+}
+static void seg_finish(SegTable& t) {
+  t.total_tok = t.total_logit = 0;
+  for (int i = 0; i < t.n; ++i) {
+    t.seg[i].row0 = t.total_tok; t.total_tok += t.seg[i].n_tok;
+    t.seg[i].logit_row0 = t.total_logit; t.total_logit += t.seg[i].n_logit;
+  }
 }
 
-// -- BSSD as a resumable state machine: begin -> (enqueue_round -> finish_round)* ------------------------------
 static int bssd_begin(atspeed_decoder* d, const int32_t* prompt, int P, const atspeed_fsm* fsm, int start_node, int gamma,
                       int max_new, int k, int dk, int32_t* out_tokens, float* out_scores, atspeed_gen_stats* stats,
                       hipStream_t st) {
@@ -469,185 +525,221 @@ static int bssd_begin(atspeed_decoder* d, const int32_t* prompt, int P, const at
   ATS_REQUIRE(gamma >= 1 && gamma <= ATSPEED_MAX_GAMMA, ATSPEED_ERR_CAPACITY, "bssd: gamma %d out of [1,%d]", gamma, ATSPEED_MAX_GAMMA);
   atspeed_decoder::Run& r = d->run;
   r.fsm = fsm; r.gamma = gamma; r.max_new = max_new; r.k = k; r.dk = dk;
-  r.out_tokens = out_tokens; r.out_scores = out_scores; r.stats_out = stats; r.st = st;
+  r.out_tokens = out_tokens; r.out_scores = out_scores; r.stats_out = stats;
   memset(&r.s, 0, sizeof(r.s));
-  r.cur = 0; r.gen = 0; r.base = 0; r.n0 = P; r.nb = 1; r.dl = 0; r.nev = 0;
-  r.reingest = false; r.final_step = false; r.exported = false; r.done = false;
-  r.ev_marks.clear();
+  r.cur = 0; r.gen = 0; r.base = 0; r.n0 = P; r.nb = 1; r.dl = 0;
+  r.reingest = false; r.final_step = false; r.export_only = false; r.done = false;
   d->trace.clear();
   ATS_TRY(ats_init_prompt(d->tin[0], prompt, P, d->W, d->round_beams[0], start_node, d->target->cfg.vocab_size, d->mail_dev, st));
-  r.e_begin = run_mark(d);
   return ATSPEED_OK;
 }
 
-// enqueue everything up to the next point where the host must look at the device (no synchronisation here)
-static int bssd_enqueue_round(atspeed_decoder* d) {
-  atspeed_decoder::Run& r = d->run;
-  hipStream_t st = r.st;
-  atspeed_llama *T = d->target, *D = d->draft;
-  const int W = d->W, V = T->cfg.vocab_size, k = r.k, dk = r.dk;
-  if (r.gen >= r.max_new) {                                                          // nothing left: export
-    r.final_step = true;
-  } else {
-    r.dl = std::min(r.gamma, r.max_new - r.gen - 1);                                 // beamSD.py:504
-    TokBuf& tin = d->tin[r.cur];
-    BeamSet& beams = d->round_beams[r.cur];
-    if (r.dl == 0) {                                                                 // :505-509
-      ATS_TRY(llama_forward(T, d->tctx, tin.ids, tin.pos, tin.slot, tin.vis, r.n0, r.base + r.n0, r.nb, nullptr, st));
-      r.s.n_target_forwards++;
-      ATS_TRY(ats_lse_rows(d->tctx->logits, r.nb, V, T->logits_ld, d->lse, st));
-      BeamStepArgs a{};
-      a.src = beams; a.n_src = r.nb; a.gen_len = r.gen;
-      a.logits = d->tctx->logits; a.ld = T->logits_ld; a.lse = d->lse; a.fsm = r.fsm->dev; a.k = k;
-      a.dst = d->round_beams[r.cur ^ 1]; a.emit = 0; a.mail = d->mail_dev; a.vis_words = W;
-      ATS_TRY(ats_beam_step(a, st));
-      r.cur ^= 1;
-      r.gen += 1;
-      r.final_step = true;
-    } else {
-      const int n0 = r.n0, nb = r.nb, dl = r.dl, base = r.base;
-      ATS_REQUIRE(n0 + dl * dk <= d->tok_cap && n0 + dl * dk <= T->cfg.max_tokens, ATSPEED_ERR_CAPACITY, "bssd: packed target input too long");
-      ATS_REQUIRE(base + n0 + dl * dk <= T->cfg.max_slots, ATSPEED_ERR_CAPACITY, "bssd: KV slots exhausted (%d needed, %d available)",
-                  base + n0 + dl * dk, T->cfg.max_slots);
-      ATS_REQUIRE(nb + dl * dk <= T->cfg.max_logit_rows, ATSPEED_ERR_CAPACITY, "bssd: %d logit rows exceed max_logit_rows", nb + dl * dk);
-      r.ev_marks.push_back(run_mark(d));
-      // ---- 1. draft: dl steps of one_step_beam_search (:108-179)
-      for (int i = 0; i < dl; ++i) {
-        int n_src;
-        if (i == 0) {
-          n_src = nb;
-          if (r.reingest) {
-            ATS_TRY(llama_forward(D, d->dctx, d->dround.ids, d->dround.pos, d->dround.slot, d->dround.vis, dk + k, base + n0, nb, nullptr, st));
-          } else {
-            ATS_TRY(llama_forward(D, d->dctx, tin.ids, tin.pos, tin.slot, tin.vis, n0, base + n0, nb, nullptr, st));
-          }
-        } else {
-          n_src = dk;
-          TokBuf b = tb_offset(tin, n0 + (i - 1) * dk, W);
-          ATS_TRY(llama_forward(D, d->dctx, b.ids, b.pos, b.slot, b.vis, dk, base + n0 + i * dk, dk, nullptr, st));
-        }
+// BSSD (beamSD.py:458-542) for n users in lock step: every draft step and every target verification of the round
+// is ONE forward over the tokens of all users that need it (weights are streamed once per forward, not per user).
+static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
+  atspeed_llama *T = decs[0]->target, *D = decs[0]->draft;
+  const int W = decs[0]->W, V = T->cfg.vocab_size;
+  if (!g_ev_init) { for (auto& e : g_ev) ATS_HIP(hipEventCreate(&e)); g_ev_init = true; }
+  ATS_TRY(g_args.reserve((size_t)kArgSlots * ATS_MAX_SEGS * (sizeof(VerifyArgs) + 256)));
+  // capacity for the largest possible batched forward of this group
+  int cap_t = 0, cap_r = 0, cap_d = 0;
+  for (int u = 0; u < n; ++u) {
+    const atspeed_decoder::Run& r = decs[u]->run;
+    cap_t += std::max(r.n0, r.k) + r.gamma * r.dk;
+    cap_r += MAXB + r.gamma * r.dk;
+    cap_d += std::max(std::max(r.n0, r.dk + r.k), r.dk);
+  }
+  ATS_TRY(ensure_act(T, cap_t, cap_r));
+  ATS_TRY(ensure_act(D, cap_d, n * MAXB));
+  bool any = true;
+  while (any) {
+    g_args.used = 0;
+    std::vector<atspeed_decoder*> ver, fin;          // users doing a verify round / the final single step this round
+    int max_dl = 0;
+    for (int u = 0; u < n; ++u) {
+      atspeed_decoder* d = decs[u];
+      atspeed_decoder::Run& r = d->run;
+      if (r.done) continue;
+      r.final_step = r.export_only = false;
+      if (r.gen >= r.max_new) { r.final_step = r.export_only = true; continue; }
+      r.dl = std::min(r.gamma, r.max_new - r.gen - 1);                               // beamSD.py:504
+      if (r.dl == 0) { r.final_step = true; fin.push_back(d); continue; }            // :505-509
+      ATS_REQUIRE(r.n0 + r.dl * r.dk <= d->tok_cap, ATSPEED_ERR_CAPACITY, "bssd: packed target input too long");
+      ATS_REQUIRE(r.base + r.n0 + r.dl * r.dk <= T->cfg.max_slots, ATSPEED_ERR_CAPACITY,
+                  "bssd: KV slots exhausted (%d needed, %d available)", r.base + r.n0 + r.dl * r.dk, T->cfg.max_slots);
+      ver.push_back(d);
+      max_dl = std::max(max_dl, r.dl);
+    }
+    hipEventRecord(g_ev[0], st);
+    // ---- 1. draft: step i of one_step_beam_search for every user that still drafts (:108-179)
+    for (int i = 0; i < max_dl; ++i) {
+      SegTable t{};
+      std::vector<BeamStepArgs> args;
+      std::vector<atspeed_decoder*> us;
+      for (atspeed_decoder* d : ver) if (d->run.dl > i) us.push_back(d);
+      for (atspeed_decoder* d : us) {
+        atspeed_decoder::Run& r = d->run;
+        TokBuf& tin = d->tin[r.cur];
+        Seg sg;
+        if (i == 0) sg = r.reingest ? make_seg(d->dround, r.dk + r.k, r.base + r.n0, r.nb, d->dkv)
+                                    : make_seg(tin, r.n0, r.base + r.n0, r.nb, d->dkv);
+        else        sg = make_seg(tb_offset(tin, r.n0 + (i - 1) * r.dk, W), r.dk, r.base + r.n0 + i * r.dk, r.dk, d->dkv);
+        t.seg[t.n++] = sg;
         r.s.n_draft_forwards++;
-        ATS_TRY(ats_lse_rows(d->dctx->logits, n_src, V, D->logits_ld, d->lse, st));
-        BeamStepArgs a{};
-        a.src = i == 0 ? beams : d->blk[i]; a.n_src = n_src; a.gen_len = r.gen + i;
-        a.logits = d->dctx->logits; a.ld = D->logits_ld; a.lse = d->lse; a.fsm = r.fsm->dev; a.k = dk;
-        a.dst = d->blk[i + 1]; a.emit = 1;
-        a.in = tin; a.in_row0 = i == 0 ? n0 - nb : n0 + (i - 1) * dk;
-        a.out = tin; a.out_row0 = n0 + i * dk; a.out_slot0 = base + n0 + i * dk; a.vis_words = W;
-        a.mail = d->mail_dev;
-        ATS_TRY(ats_beam_step(a, st));
       }
-      r.ev_marks.push_back(run_mark(d));
-      // ---- 2. target: ONE forward over round inputs ++ all draft blocks (:190-232)
-      const int Tn = n0 + dl * dk, rows = nb + dl * dk;
-      ATS_TRY(llama_forward(T, d->tctx, tin.ids, tin.pos, tin.slot, tin.vis, Tn, base + Tn, rows, nullptr, st));
-      r.s.n_target_forwards++;
-      r.ev_marks.push_back(run_mark(d));
-      // ---- 3. verify (:242-456)
-      ATS_TRY(ats_lse_rows(d->tctx->logits, rows, V, T->logits_ld, d->lse, st));
-      VerifyArgs va{};
-      va.blk[0] = beams;
-      for (int i = 1; i <= dl; ++i) va.blk[i] = d->blk[i];
-      va.nb = nb; va.dl = dl; va.k = k; va.dk = dk; va.gen_len0 = r.gen;
-      va.logits = d->tctx->logits; va.ld = T->logits_ld; va.lse = d->lse; va.fsm = r.fsm->dev;
-      va.cur = tin; va.n0 = n0; va.next = d->tin[r.cur ^ 1]; va.dnext = d->dround; va.vis_words = W;
-      va.res = d->round_beams[r.cur ^ 1]; va.mail = d->mail_dev;
-      ATS_TRY(ats_verify_walk(va, st));
-      r.ev_marks.push_back(run_mark(d));
-      for (int i = 1; i <= dl; ++i)   // trace of the draft's flat ids for parity tests (tiny copies, same stream)
-        ATS_HIP(hipMemcpyAsync(d->trace_host + (i - 1) * MAXB, d->blk[i].flat, sizeof(int32_t) * dk, hipMemcpyDeviceToHost, st));
+      seg_finish(t);
+      ATS_TRY(llama_forward_segs(D, t, nullptr, st));
+      for (size_t j = 0; j < us.size(); ++j) {
+        atspeed_decoder* d = us[j];
+        atspeed_decoder::Run& r = d->run;
+        TokBuf& tin = d->tin[r.cur];
+        BeamStepArgs a{};
+        a.src = i == 0 ? d->round_beams[r.cur] : d->blk[i]; a.n_src = t.seg[j].n_logit; a.gen_len = r.gen + i;
+        a.logits = D->act->logits + (size_t)t.seg[j].logit_row0 * D->logits_ld; a.ld = D->logits_ld;
+        a.lse = D->act->lse + t.seg[j].logit_row0; a.fsm = r.fsm->dev; a.k = r.dk;
+        a.dst = d->blk[i + 1]; a.emit = 1;
+        a.in = tin; a.in_row0 = i == 0 ? r.n0 - r.nb : r.n0 + (i - 1) * r.dk;
+        a.out = tin; a.out_row0 = r.n0 + i * r.dk; a.out_slot0 = r.base + r.n0 + i * r.dk; a.vis_words = W;
+        a.mail = d->mail_dev;
+        args.push_back(a);
+      }
+      const BeamStepArgs* dev_args = nullptr;
+      ATS_TRY(g_args.push(args, &dev_args, st));
+      ATS_TRY(ats_beam_step_multi(dev_args, (int)args.size(), st));
+    }
+    hipEventRecord(g_ev[1], st);
+    // ---- 2. target: ONE forward over (round inputs ++ draft blocks) of every verifying user and the inputs of
+    //         every user on its final step (:190-232, :505-509)
+    if (!ver.empty() || !fin.empty()) {
+      SegTable t{};
+      for (atspeed_decoder* d : ver) {
+        atspeed_decoder::Run& r = d->run;
+        int Tn = r.n0 + r.dl * r.dk;
+        t.seg[t.n++] = make_seg(d->tin[r.cur], Tn, r.base + Tn, r.nb + r.dl * r.dk, d->tkv);
+        r.s.n_target_forwards++;
+      }
+      for (atspeed_decoder* d : fin) {
+        atspeed_decoder::Run& r = d->run;
+        t.seg[t.n++] = make_seg(d->tin[r.cur], r.n0, r.base + r.n0, r.nb, d->tkv);
+        r.s.n_target_forwards++;
+      }
+      seg_finish(t);
+      ATS_TRY(llama_forward_segs(T, t, nullptr, st));
+      hipEventRecord(g_ev[2], st);
+      // ---- 3. verify (:242-456) for the verifying users, one workgroup each
+      std::vector<VerifyArgs> vargs;
+      for (size_t j = 0; j < ver.size(); ++j) {
+        atspeed_decoder* d = ver[j];
+        atspeed_decoder::Run& r = d->run;
+        VerifyArgs va{};
+        va.blk[0] = d->round_beams[r.cur];
+        for (int i = 1; i <= r.dl; ++i) va.blk[i] = d->blk[i];
+        va.nb = r.nb; va.dl = r.dl; va.k = r.k; va.dk = r.dk; va.gen_len0 = r.gen;
+        va.logits = T->act->logits + (size_t)t.seg[j].logit_row0 * T->logits_ld; va.ld = T->logits_ld;
+        va.lse = T->act->lse + t.seg[j].logit_row0; va.fsm = r.fsm->dev;
+        va.cur = d->tin[r.cur]; va.n0 = r.n0; va.next = d->tin[r.cur ^ 1]; va.dnext = d->dround; va.vis_words = W;
+        va.res = d->round_beams[r.cur ^ 1]; va.mail = d->mail_dev;
+        vargs.push_back(va);
+      }
+      if (!vargs.empty()) {
+        const VerifyArgs* dv = nullptr;
+        ATS_TRY(g_args.push(vargs, &dv, st));
+        ATS_TRY(ats_verify_walk_multi(dv, (int)vargs.size(), st));
+      }
+      std::vector<BeamStepArgs> fargs;
+      for (size_t j = 0; j < fin.size(); ++j) {
+        atspeed_decoder* d = fin[j];
+        atspeed_decoder::Run& r = d->run;
+        const Seg& sg = t.seg[ver.size() + j];
+        BeamStepArgs a{};
+        a.src = d->round_beams[r.cur]; a.n_src = r.nb; a.gen_len = r.gen;
+        a.logits = T->act->logits + (size_t)sg.logit_row0 * T->logits_ld; a.ld = T->logits_ld;
+        a.lse = T->act->lse + sg.logit_row0; a.fsm = r.fsm->dev; a.k = r.k;
+        a.dst = d->round_beams[r.cur ^ 1]; a.emit = 0; a.mail = d->mail_dev; a.vis_words = W;
+        fargs.push_back(a);
+      }
+      if (!fargs.empty()) {
+        const BeamStepArgs* df = nullptr;
+        ATS_TRY(g_args.push(fargs, &df, st));
+        ATS_TRY(ats_beam_step_multi(df, (int)fargs.size(), st));
+      }
+      for (atspeed_decoder* d : fin) { d->run.cur ^= 1; d->run.gen += 1; }
+    } else {
+      hipEventRecord(g_ev[2], st);
+    }
+    hipEventRecord(g_ev[3], st);
+    // ---- 4. outputs of finished users, mailboxes, the round's single synchronisation
+    for (int u = 0; u < n; ++u) {
+      atspeed_decoder* d = decs[u];
+      atspeed_decoder::Run& r = d->run;
+      if (r.done) continue;
+      if (r.final_step) ATS_TRY(ats_export_beams(d->round_beams[r.cur], r.k, r.max_new, r.out_tokens, r.out_scores, st));
+      else
+        for (int i = 1; i <= r.dl; ++i)     // trace of the draft's flat ids for parity tests (tiny copies, same stream)
+          ATS_HIP(hipMemcpyAsync(d->trace_host + (i - 1) * MAXB, d->blk[i].flat, sizeof(int32_t) * r.dk, hipMemcpyDeviceToHost, st));
+      ATS_HIP(hipMemcpyAsync(d->mail_host, d->mail_dev, sizeof(Mailbox), hipMemcpyDeviceToHost, st));
+    }
+    ATS_HIP(hipStreamSynchronize(st));
+    float ms_d = 0.f, ms_t = 0.f, ms_v = 0.f;
+    hipEventElapsedTime(&ms_d, g_ev[0], g_ev[1]);
+    hipEventElapsedTime(&ms_t, g_ev[1], g_ev[2]);
+    hipEventElapsedTime(&ms_v, g_ev[2], g_ev[3]);
+    int n_act = 0;
+    for (int u = 0; u < n; ++u) if (!decs[u]->run.done) ++n_act;
+    any = false;
+    for (int u = 0; u < n; ++u) {
+      atspeed_decoder* d = decs[u];
+      atspeed_decoder::Run& r = d->run;
+      if (r.done) continue;
+      ATS_TRY(mailbox_status(d));
+      // stage times: the group's stage time shared equally by the users that were active in the round
+      r.s.draft_ms += ms_d / n_act; r.s.target_ms += ms_t / n_act; r.s.verify_ms += ms_v / n_act;
+      if (r.final_step) {
+        r.s.n_valid = d->mail_host->n_valid;
+        r.s.total_ms = r.s.draft_ms + r.s.target_ms + r.s.verify_ms;
+        if (r.stats_out) *r.stats_out = r.s;
+        r.done = true;
+        continue;
+      }
+      const int nm = d->mail_host->n_matches, dl = r.dl, dk = r.dk;
+      d->trace.push_back(dl); d->trace.push_back(nm); d->trace.push_back(r.nb);
+      for (int i = 0; i < dl; ++i) for (int j = 0; j < dk; ++j) d->trace.push_back(d->trace_host[i * MAXB + j]);
+      if (r.s.n_run < ATSPEED_MAX_NEW_TOKENS) r.s.accept_steps[r.s.n_run] = nm;
+      r.s.n_run++;
+      r.s.total_accept_steps += nm;
+      r.base += r.n0 + nm * dk;             // compact: keep up to the end of block nm
+      r.n0 = r.k; r.nb = r.k;
+      r.gen += nm + 1;                      // :522
+      r.reingest = (nm == dl);
+      r.cur ^= 1;
+      any = true;
     }
   }
-  if (r.final_step && !r.exported) {
-    ATS_TRY(ats_export_beams(d->round_beams[r.cur], k, r.max_new, r.out_tokens, r.out_scores, st));
-    r.e_end = run_mark(d);
-    r.exported = true;
-  }
-  ATS_HIP(hipMemcpyAsync(d->mail_host, d->mail_dev, sizeof(Mailbox), hipMemcpyDeviceToHost, st));
   return ATSPEED_OK;
 }
 
-// wait for the enqueued work, read the mailbox, advance the state; sets run.done after the final step
-static int bssd_finish_round(atspeed_decoder* d) {
-  atspeed_decoder::Run& r = d->run;
-  ATS_TRY(read_mailbox(d, r.st));                                                   // the round's only sync
-  if (r.final_step) {
-    r.s.n_valid = d->mail_host->n_valid;
-    if (r.nev <= kMaxEvents) {
-      float ms = 0.f;
-      hipEventElapsedTime(&ms, d->ev[r.e_begin], d->ev[r.e_end]); r.s.total_ms = ms;
-      for (size_t i = 0; i + 3 < r.ev_marks.size(); i += 4) {
-        hipEventElapsedTime(&ms, d->ev[r.ev_marks[i]], d->ev[r.ev_marks[i + 1]]); r.s.draft_ms += ms;
-        hipEventElapsedTime(&ms, d->ev[r.ev_marks[i + 1]], d->ev[r.ev_marks[i + 2]]); r.s.target_ms += ms;
-        hipEventElapsedTime(&ms, d->ev[r.ev_marks[i + 2]], d->ev[r.ev_marks[i + 3]]); r.s.verify_ms += ms;
-      }
-    }
-    if (r.stats_out) *r.stats_out = r.s;
-    r.done = true;
-    return ATSPEED_OK;
+extern "C" int atspeed_bssd_generate_batch(atspeed_decoder** decs, int32_t n, const int32_t* const* prompts,
+                                           const int32_t* prompt_lens, const atspeed_fsm* fsm, const int32_t* start_nodes,
+                                           int32_t gamma, int32_t max_new, int32_t k, int32_t dk, int32_t* const* out_tokens,
+                                           float* const* out_scores, atspeed_gen_stats* stats, void* stream) {
+  ATS_REQUIRE(decs && prompts && prompt_lens && start_nodes && out_tokens && out_scores, ATSPEED_ERR_INVALID, "bssd_batch: null argument");
+  ATS_REQUIRE(n >= 1 && n <= ATS_MAX_SEGS, ATSPEED_ERR_CAPACITY, "bssd_batch: %d users per call (max %d)", n, ATS_MAX_SEGS);
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < n; ++i) {
+    ATS_REQUIRE(decs[i] && decs[i]->target == decs[0]->target && decs[i]->draft == decs[0]->draft, ATSPEED_ERR_INVALID,
+                "bssd_batch: decoders must share one target/draft pair");
+    for (int j = 0; j < i; ++j) ATS_REQUIRE(decs[i] != decs[j], ATSPEED_ERR_INVALID, "bssd_batch: decoder %d used twice", i);
+    ATS_TRY(bssd_begin(decs[i], prompts[i], prompt_lens[i], fsm, start_nodes[i], gamma, max_new, k, dk, out_tokens[i], out_scores[i],
+                       stats ? &stats[i] : nullptr, st));
   }
-  const int nm = d->mail_host->n_matches, dl = r.dl, dk = r.dk;
-  d->trace.push_back(dl); d->trace.push_back(nm); d->trace.push_back(r.nb);
-  for (int i = 0; i < dl; ++i) for (int j = 0; j < dk; ++j) d->trace.push_back(d->trace_host[i * MAXB + j]);
-  if (r.s.n_run < ATSPEED_MAX_NEW_TOKENS) r.s.accept_steps[r.s.n_run] = nm;
-  r.s.n_run++;
-  r.s.total_accept_steps += nm;
-  r.base += r.n0 + nm * dk;             // compact: keep up to the end of block nm
-  r.n0 = r.k; r.nb = r.k;
-  r.gen += nm + 1;                      // :522
-  r.reingest = (nm == dl);
-  r.cur ^= 1;
-  return ATSPEED_OK;
+  return bssd_group_run(decs, n, st);
 }
 
 extern "C" int atspeed_bssd_generate(atspeed_decoder* d, const int32_t* prompt, int32_t P, const atspeed_fsm* fsm,
                                      int32_t start_node, int32_t gamma, int32_t max_new, int32_t k, int32_t dk,
                                      int32_t* out_tokens, float* out_scores, atspeed_gen_stats* stats, void* stream) {
   ATS_TRY(bssd_begin(d, prompt, P, fsm, start_node, gamma, max_new, k, dk, out_tokens, out_scores, stats, (hipStream_t)stream));
-  while (!d->run.done) {
-    ATS_TRY(bssd_enqueue_round(d));
-    ATS_TRY(bssd_finish_round(d));
-  }
-  return ATSPEED_OK;
-}
-
-// Several independent users interleaved on the decoders' own streams: while the host waits for user A's mailbox,
-// users B, C, ... already have their rounds queued, so neither the per-round sync nor the launch latency of the
-// small-M forwards leaves the GPU idle, and forwards of different users overlap on the chip.  Results are
-// identical to n sequential atspeed_bssd_generate calls.  `stream` is the caller's stream: the call begins after
-// its pending work and ends synchronised with it.
-extern "C" int atspeed_bssd_generate_batch(atspeed_decoder** decs, int32_t n, const int32_t* const* prompts,
-                                           const int32_t* prompt_lens, const atspeed_fsm* fsm, const int32_t* start_nodes,
-                                           int32_t gamma, int32_t max_new, int32_t k, int32_t dk, int32_t* const* out_tokens,
-                                           float* const* out_scores, atspeed_gen_stats* stats, void* stream) {
-  ATS_REQUIRE(decs && prompts && prompt_lens && start_nodes && out_tokens && out_scores && n >= 1, ATSPEED_ERR_INVALID,
-              "bssd_batch: bad arguments");
-  hipStream_t caller = (hipStream_t)stream;
-  hipEvent_t ready;
-  ATS_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-  ATS_HIP(hipEventRecord(ready, caller));
-  int rc = ATSPEED_OK;
-  for (int i = 0; i < n && rc == ATSPEED_OK; ++i) {
-    for (int j = 0; j < i; ++j) ATS_REQUIRE(decs[i] != decs[j], ATSPEED_ERR_INVALID, "bssd_batch: decoder %d used twice", i);
-    ATS_HIP(hipStreamWaitEvent(decs[i]->own_stream, ready, 0));
-    rc = bssd_begin(decs[i], prompts[i], prompt_lens[i], fsm, start_nodes[i], gamma, max_new, k, dk, out_tokens[i], out_scores[i],
-                    stats ? &stats[i] : nullptr, decs[i]->own_stream);
-    if (rc == ATSPEED_OK) rc = bssd_enqueue_round(decs[i]);
-  }
-  int active = n;
-  while (rc == ATSPEED_OK && active > 0) {
-    active = 0;
-    for (int i = 0; i < n && rc == ATSPEED_OK; ++i) {
-      atspeed_decoder* d = decs[i];
-      if (d->run.done) continue;
-      rc = bssd_finish_round(d);
-      if (rc == ATSPEED_OK && !d->run.done) { rc = bssd_enqueue_round(d); ++active; }
-    }
-  }
-  for (int i = 0; i < n; ++i) hipStreamSynchronize(decs[i]->own_stream);
-  hipEventDestroy(ready);
-  if (rc == ATSPEED_OK) ATS_HIP(hipStreamSynchronize(caller));
-  return rc;
+  return bssd_group_run(&d, 1, (hipStream_t)stream);
 }
 
 extern "C" int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt, int32_t P, const atspeed_fsm* fsm,
@@ -657,22 +749,27 @@ extern "C" int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt
   hipStream_t st = (hipStream_t)stream;
   atspeed_llama* T = d->target;
   const int W = d->W, V = T->cfg.vocab_size;
+  (void)V;
   atspeed_gen_stats s;
   memset(&s, 0, sizeof(s));
   ATS_REQUIRE(P + max_new * k <= T->cfg.max_slots, ATSPEED_ERR_CAPACITY, "target_generate: KV slots exhausted");
-  ATS_REQUIRE(P + max_new * k <= d->tok_cap && P <= T->cfg.max_tokens, ATSPEED_ERR_CAPACITY, "target_generate: token buffer too small");
+  ATS_REQUIRE(P + max_new * k <= d->tok_cap, ATSPEED_ERR_CAPACITY, "target_generate: token buffer too small");
+  ATS_TRY(ensure_act(T, std::max(P, k), MAXB));
+  if (!g_ev_init) { for (auto& e : g_ev) ATS_HIP(hipEventCreate(&e)); g_ev_init = true; }
   TokBuf& tin = d->tin[0];
-  ATS_TRY(ats_init_prompt(tin, prompt, P, W, d->round_beams[0], start_node, V, d->mail_dev, st));
-  hipEventRecord(d->ev[0], st);
+  ATS_TRY(ats_init_prompt(tin, prompt, P, W, d->round_beams[0], start_node, T->cfg.vocab_size, d->mail_dev, st));
+  hipEventRecord(g_ev[0], st);
   int cur = 0, row0 = 0, n_in = P, nb = 1, base = 0;
   for (int g = 0; g < max_new; ++g) {                                                // beamSD.py:579-588
-    TokBuf b = tb_offset(tin, row0, W);
-    ATS_TRY(llama_forward(T, d->tctx, b.ids, b.pos, b.slot, b.vis, n_in, base + n_in, nb, nullptr, st));
+    SegTable t{};
+    t.n = 1;
+    t.seg[0] = make_seg(tb_offset(tin, row0, W), n_in, base + n_in, nb, d->tkv);
+    seg_finish(t);
+    ATS_TRY(llama_forward_segs(T, t, nullptr, st));
     s.n_target_forwards++;
-    ATS_TRY(ats_lse_rows(d->tctx->logits, nb, V, T->logits_ld, d->lse, st));
     BeamStepArgs a{};
     a.src = d->round_beams[cur]; a.n_src = nb; a.gen_len = g;
-    a.logits = d->tctx->logits; a.ld = T->logits_ld; a.lse = d->lse; a.fsm = fsm->dev; a.k = k;
+    a.logits = T->act->logits; a.ld = T->logits_ld; a.lse = T->act->lse; a.fsm = fsm->dev; a.k = k;
     a.dst = d->round_beams[cur ^ 1]; a.emit = 1;
     a.in = tin; a.in_row0 = row0 + n_in - nb;
     a.out = tin; a.out_row0 = row0 + n_in; a.out_slot0 = base + n_in; a.vis_words = W;
@@ -681,11 +778,12 @@ extern "C" int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt
     row0 += n_in; base += n_in; n_in = k; nb = k; cur ^= 1;
   }
   ATS_TRY(ats_export_beams(d->round_beams[cur], k, max_new, out_tokens, out_scores, st));
-  hipEventRecord(d->ev[1], st);
+  hipEventRecord(g_ev[1], st);
   ATS_HIP(hipMemcpyAsync(d->mail_host, d->mail_dev, sizeof(Mailbox), hipMemcpyDeviceToHost, st));
-  ATS_TRY(read_mailbox(d, st));
+  ATS_HIP(hipStreamSynchronize(st));
+  ATS_TRY(mailbox_status(d));
   s.n_valid = d->mail_host->n_valid;
-  hipEventElapsedTime(&s.total_ms, d->ev[0], d->ev[1]);
+  hipEventElapsedTime(&s.total_ms, g_ev[0], g_ev[1]);
   s.target_ms = s.total_ms;
   if (stats) *stats = s;
   return ATSPEED_OK;

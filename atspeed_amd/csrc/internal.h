@@ -2,7 +2,24 @@
 #pragma once
 #include "common.h"
 
+// ---- segment table: one forward over the tokens of several users ----------------------
+// Each user (decoder) contributes a contiguous run of rows; its KV cache, visibility bitsets, positions
+// and slots stay private.  Passed to kernels BY VALUE (about 1 KB of kernel arguments).
+constexpr int ATS_MAX_SEGS = 16;
+struct Seg {
+  const int32_t* ids; const int32_t* pos; const int32_t* slot; const uint64_t* vis;   // this user's per-token arrays
+  void* kc; void* vc;          // this user's KV cache (layer 0 base)
+  int row0, n_tok;             // rows [row0, row0 + n_tok) of the batched activations
+  int n_slots;                 // slots visible to this user's rows
+  int logit_row0, n_logit;     // the last n_logit tokens get logits, at rows [logit_row0, ..) of the logits buffer
+};
+struct SegTable { int n, total_tok, total_logit; Seg seg[ATS_MAX_SEGS]; };
+
 // ---- fill.hip / elementwise.hip -------------------------------------------------------
+int ats_embed_segs(const void* table, const SegTable& t, void* out, int hidden, int vocab, int dtype, hipStream_t st);
+int ats_rope_kv_segs(void* qkv, const SegTable& t, const float* cos_tab, const float* sin_tab, size_t layer_off_bytes,
+                     int n_heads, int head_dim, int max_pos, int dtype, hipStream_t st);
+int ats_gather_logit_rows(const void* h, const SegTable& t, void* out, int hidden, int dtype, hipStream_t st);
 int ats_embed(const void* table, const int32_t* ids, void* out, int n_tokens, int hidden, int vocab, int dtype,
               hipStream_t st);
 int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, float eps, int dtype, hipStream_t st);
@@ -24,6 +41,9 @@ int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int
 int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* vcache, const uint64_t* vis,
                        int vis_words, void* out, int ldo, int n_tokens, int n_slots, int n_heads, int head_dim,
                        int dtype, hipStream_t st);
+
+int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, size_t layer_off_bytes, int vis_words, void* out,
+                            int ldo, int n_heads, int head_dim, int dtype, hipStream_t st);
 
 // ---- scan.hip -------------------------------------------------------------------------
 struct FsmDev {
@@ -72,6 +92,8 @@ struct BeamStepArgs {
   Mailbox* mail;                              // status only
 };
 int ats_beam_step(const BeamStepArgs& a, hipStream_t st);
+// one workgroup per user; `dev_args` is a DEVICE array of n argument blocks
+int ats_beam_step_multi(const BeamStepArgs* dev_args, int n, hipStream_t st);
 
 struct VerifyArgs {
   BeamSet blk[ATSPEED_MAX_GAMMA + 1];         // blk[0] round beams, blk[i] draft step i
@@ -86,6 +108,7 @@ struct VerifyArgs {
   Mailbox* mail;
 };
 int ats_verify_walk(const VerifyArgs& a, hipStream_t st);
+int ats_verify_walk_multi(const VerifyArgs* dev_args, int n, hipStream_t st);
 
 int ats_init_prompt(TokBuf tb, const int32_t* prompt, int prompt_len, int vis_words, BeamSet beams, int start_node,
                     int vocab, Mailbox* mail, hipStream_t st);

@@ -208,7 +208,19 @@ __device__ void emit_vis(const int* parents /*LDS*/, int k, const TokBuf& in, in
 }
 
 // ---------------------------------------------------------------------------- beam step
-__global__ __launch_bounds__(kScanThreads) void beam_step_kernel(BeamStepArgs a) {
+__device__ void beam_step_body(const BeamStepArgs& a);
+
+__global__ __launch_bounds__(kScanThreads) void beam_step_kernel(BeamStepArgs a) { beam_step_body(a); }
+__global__ __launch_bounds__(kScanThreads) void beam_step_multi_kernel(const BeamStepArgs* __restrict__ args) {
+  __shared__ BeamStepArgs a;                       // one workgroup per user: copy its argument block first
+  const int words = sizeof(BeamStepArgs) / 4;
+  for (int i = threadIdx.x; i < words; i += blockDim.x)
+    reinterpret_cast<uint32_t*>(&a)[i] = reinterpret_cast<const uint32_t*>(args + blockIdx.x)[i];
+  __syncthreads();
+  beam_step_body(a);
+}
+
+__device__ void beam_step_body(const BeamStepArgs& a) {
   __shared__ ExpandShared sh;
   __shared__ int parents[MAXB];
   const int tid = threadIdx.x;
@@ -239,7 +251,19 @@ __global__ __launch_bounds__(kScanThreads) void beam_step_kernel(BeamStepArgs a)
 }
 
 // ---------------------------------------------------------------------------- verify
-__global__ __launch_bounds__(kScanThreads) void verify_walk_kernel(VerifyArgs a) {
+__device__ void verify_walk_body(const VerifyArgs& a);
+
+__global__ __launch_bounds__(kScanThreads) void verify_walk_kernel(VerifyArgs a) { verify_walk_body(a); }
+__global__ __launch_bounds__(kScanThreads) void verify_walk_multi_kernel(const VerifyArgs* __restrict__ args) {
+  __shared__ VerifyArgs a;
+  const int words = sizeof(VerifyArgs) / 4;
+  for (int i = threadIdx.x; i < words; i += blockDim.x)
+    reinterpret_cast<uint32_t*>(&a)[i] = reinterpret_cast<const uint32_t*>(args + blockIdx.x)[i];
+  __syncthreads();
+  verify_walk_body(a);
+}
+
+__device__ void verify_walk_body(const VerifyArgs& a) {
   __shared__ ExpandShared sh;
   __shared__ int t_parent[MAXB], t_pos[MAXB], hit[MAXB];
   __shared__ float sbh[MAXB];
@@ -374,6 +398,20 @@ int ats_beam_step(const BeamStepArgs& a, hipStream_t st) {
   ATS_REQUIRE(a.k >= 1 && a.k <= MAXB && a.n_src >= 1 && a.n_src <= MAXB, ATSPEED_ERR_CAPACITY,
               "beam step: k=%d / rows=%d exceed %d", a.k, a.n_src, MAXB);
   beam_step_kernel<<<1, kScanThreads, 0, st>>>(a);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+int ats_beam_step_multi(const BeamStepArgs* dev_args, int n, hipStream_t st) {
+  if (n <= 0) return ATSPEED_OK;
+  beam_step_multi_kernel<<<n, kScanThreads, 0, st>>>(dev_args);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+int ats_verify_walk_multi(const VerifyArgs* dev_args, int n, hipStream_t st) {
+  if (n <= 0) return ATSPEED_OK;
+  verify_walk_multi_kernel<<<n, kScanThreads, 0, st>>>(dev_args);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }

@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s sp
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24, help="users per GPU in the timed region")
+    ap.add_argument("--steps", type=int, default=64, help="users per GPU in the timed region")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--target-layers", type=int, default=32, help="32 = Llama-7B (the metric's config)")
     ap.add_argument("--beam", type=int, default=20)
@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--gamma", type=int, default=4)
     ap.add_argument("--new-tokens", type=int, default=4)
     ap.add_argument("--seed", type=int, default=2025)
-    ap.add_argument("--streams", type=int, default=4, help="concurrent user streams (decoder lanes) per GPU; 1 = the reference's one-user-at-a-time loop")
+    ap.add_argument("--streams", type=int, default=16, help="users decoded in lock step per GPU (one batched forward per draft step / verification); 1 = the reference's one-user-at-a-time loop")
     ap.add_argument("--cpu-baseline-users", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -136,7 +136,7 @@ def main():
         return res
 
     run_users(0, args.warmup)
-    if args.streams > 1:                         # warm every lane (decoder creation, first-touch) outside the timed region
+    if args.streams > 1:                         # create every decoder / grow the batch buffers outside the timed region
         BSSD_batch(target, draft, dprompts[:args.streams], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
     target.profile(1)
     torch.cuda.synchronize(dev)
@@ -193,7 +193,7 @@ def main():
         "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (hash-PRNG weights, Beauty-shaped vocabulary and prompts)",
         "config": {"workload": f"Beauty V={V}, Llama-68M draft / Llama-7B({args.target_layers}L) target, K={args.beam}, DK={args.draft_beam}, "
-                               f"gamma={args.gamma}, L={args.new_tokens}, {args.streams} interleaved user stream(s) per GPU, position-set mask",
+                               f"gamma={args.gamma}, L={args.new_tokens}, {args.streams} user(s) per lock-step batch per GPU, position-set mask",
                    "users_per_gpu": args.steps, "streams": args.streams, "mean_prompt_len": float(np.mean([len(p) for p in prompts[args.warmup:]])),
                    "parallelism": f"user-shard x{world}"},
         "mean_accept_len": mean_accept,

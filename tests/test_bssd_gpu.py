@@ -123,7 +123,7 @@ def test_bssd_batch_equals_sequential_calls(bssd_golden):
     assert len(bat) == len(seq)
     for a, b in zip(seq, bat):
         assert torch.equal(a["beam_sequence"], b["beam_sequence"])
-        assert torch.equal(a["beam_scores"], b["beam_scores"])
+        np.testing.assert_allclose(a["beam_scores"].cpu().numpy(), b["beam_scores"].cpu().numpy(), atol=1e-4, rtol=0)
         assert (a["n_run"], a["total_accept_steps"], a["accept_steps"]) == (b["n_run"], b["total_accept_steps"], b["accept_steps"])
     gold = bssd_golden[case["name"]]
     P = len(ci["prompt"])
