@@ -195,7 +195,7 @@ def BSSD(target_model, draft_model, inputs: Dict, gamma: int, max_new_tokens: in
 
 
 beam_sd_generate = BSSD
-MAX_USERS_PER_CALL = 16
+MAX_USERS_PER_CALL = 64
 
 
 @torch.no_grad()
@@ -209,7 +209,7 @@ def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_token
     weights are streamed once per forward instead of once per user.  Token ids, n_matches and draft candidates
     are identical to calling BSSD() per user (scores agree to fp32 rounding: the GEMM tiling depends on the batch)."""
     _check_models(target_model, draft_model)
-    if len(inputs_list) > MAX_USERS_PER_CALL:            # the library batches up to 16 users per forward
+    if len(inputs_list) > MAX_USERS_PER_CALL:            # the library batches up to 64 users per forward
         outs = []
         for i in range(0, len(inputs_list), MAX_USERS_PER_CALL):
             outs += BSSD_batch(target_model, draft_model, inputs_list[i:i + MAX_USERS_PER_CALL], gamma, max_new_tokens,

@@ -20,16 +20,15 @@ namespace {
 constexpr int kMaxSlots = 2048;
 
 template <typename T>
-__global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q, int ldq, SegTable tab, size_t layer_off,
+__global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q, int ldq, const SegTable* __restrict__ tab, size_t layer_off,
                                                         int vis_words, T* __restrict__ out, int ldo,
                                                         int n_heads, int head_dim, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int t = blockIdx.x;                        // global row
-  int si = 0;
-#pragma unroll 1
-  for (int i = 1; i < tab.n; ++i) if (t >= tab.seg[i].row0) si = i;
-  const Seg& sg = tab.seg[si];
+  int si = 0, hi = tab->n;
+  while (hi - si > 1) { int mid = (si + hi) >> 1; if (tab->seg[mid].row0 <= t) si = mid; else hi = mid; }
+  const Seg& sg = tab->seg[si];
   const T* kc = reinterpret_cast<const T*>(reinterpret_cast<const char*>(sg.kc) + layer_off);
   const T* vc = reinterpret_cast<const T*>(reinterpret_cast<const char*>(sg.vc) + layer_off);
   const uint64_t* vis_row = sg.vis + (size_t)(t - sg.row0) * vis_words;
@@ -103,11 +102,9 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q,
 }
 
 // ---------------------------------------------------------------------------- MFMA kernel (bf16)
-// blockIdx.x walks the 64-row query tiles of all segments (tile -> segment through the table's tile prefix)
-struct AttnTiles { int n_tiles; unsigned char seg_of_tile[ATS_MAX_SEGS * 8]; unsigned char tile_in_seg[ATS_MAX_SEGS * 8]; };
-
+// blockIdx.x walks the 64-row query tiles of all segments (tile -> segment through the table's qtile arrays)
 template <int DH>
-__global__ __launch_bounds__(256) void tree_attn_mfma_kernel(const bf16_t* __restrict__ q, int ldq, SegTable tab, AttnTiles tiles,
+__global__ __launch_bounds__(256) void tree_attn_mfma_kernel(const bf16_t* __restrict__ q, int ldq, const SegTable* __restrict__ tab,
                                                              size_t layer_off, int vis_words,
                                                              bf16_t* __restrict__ out, int ldo,
                                                              int n_heads, float scale) {
@@ -121,11 +118,11 @@ __global__ __launch_bounds__(256) void tree_attn_mfma_kernel(const bf16_t* __res
   const int g = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y;
   const int hidden = n_heads * DH;
-  const Seg& sg = tab.seg[tiles.seg_of_tile[blockIdx.x]];
+  const Seg& sg = tab->seg[tab->qtile_seg[blockIdx.x]];
   const bf16_t* kc = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(sg.kc) + layer_off);
   const bf16_t* vc = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(sg.vc) + layer_off);
   const int n_slots = sg.n_slots;
-  const int lrow = tiles.tile_in_seg[blockIdx.x] * 64 + wave * 16 + lq;      // row inside the segment
+  const int lrow = tab->qtile_idx[blockIdx.x] * 64 + wave * 16 + lq;         // row inside the segment
   const bool qok = lrow < sg.n_tok;
   const int qrow = sg.row0 + lrow;                                           // row in the batched buffers
   const uint64_t* vis_row = sg.vis + (size_t)lrow * vis_words;
@@ -236,8 +233,8 @@ __global__ __launch_bounds__(256) void tree_attn_mfma_kernel(const bf16_t* __res
 
 }  // namespace
 
-int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, size_t layer_off_bytes, int vis_words, void* out,
-                            int ldo, int n_heads, int head_dim, int dtype, hipStream_t st) {
+int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const SegTable* dt, size_t layer_off_bytes, int vis_words,
+                            void* out, int ldo, int n_heads, int head_dim, int dtype, hipStream_t st) {
   if (t.total_tok <= 0) return ATSPEED_OK;
   ATS_REQUIRE(head_dim % 8 == 0 && head_dim <= 256, ATSPEED_ERR_INVALID, "attention: head_dim %d unsupported", head_dim);
   ATS_REQUIRE(vis_words * 64 <= kMaxSlots, ATSPEED_ERR_CAPACITY, "attention: visibility bitset too wide (%d words)", vis_words);
@@ -245,29 +242,20 @@ int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, size_t la
     ATS_REQUIRE(t.seg[i].n_slots <= vis_words * 64, ATSPEED_ERR_CAPACITY, "attention: %d slots exceed the visibility bitset", t.seg[i].n_slots);
   float scale = 1.0f / sqrtf((float)head_dim);
   if (dtype == ATSPEED_BF16 && (head_dim == 64 || head_dim == 128) && (ldq % 8) == 0 && (ldo % 4) == 0) {
-    AttnTiles tiles;
-    tiles.n_tiles = 0;
-    const int cap = (int)sizeof(tiles.seg_of_tile);
-    for (int i = 0; i < t.n; ++i)
-      for (int j = 0; j * 64 < t.seg[i].n_tok; ++j) {
-        ATS_REQUIRE(tiles.n_tiles < cap, ATSPEED_ERR_CAPACITY, "attention: too many query tiles");
-        tiles.seg_of_tile[tiles.n_tiles] = (unsigned char)i;
-        tiles.tile_in_seg[tiles.n_tiles++] = (unsigned char)j;
-      }
-    dim3 mgrid(tiles.n_tiles, n_heads);
+    dim3 mgrid(t.n_qtiles, n_heads);
     if (head_dim == 128)
-      tree_attn_mfma_kernel<128><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, t, tiles, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+      tree_attn_mfma_kernel<128><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
     else
-      tree_attn_mfma_kernel<64><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, t, tiles, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+      tree_attn_mfma_kernel<64><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
     ATS_LAUNCH_CHECK();
     return ATSPEED_OK;
   }
   dim3 grid(t.total_tok, (n_heads + 3) / 4);
   size_t lds = (size_t)4 * (head_dim + 2 * vis_words * 64) * sizeof(float);
   if (dtype == ATSPEED_F32)
-    tree_attn_kernel<float><<<grid, 256, lds, st>>>((const float*)q, ldq, t, layer_off_bytes, vis_words, (float*)out, ldo, n_heads, head_dim, scale);
+    tree_attn_kernel<float><<<grid, 256, lds, st>>>((const float*)q, ldq, dt, layer_off_bytes, vis_words, (float*)out, ldo, n_heads, head_dim, scale);
   else
-    tree_attn_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)q, ldq, t, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, head_dim, scale);
+    tree_attn_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, head_dim, scale);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -280,7 +268,12 @@ int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* v
   t.seg[0].vis = vis; t.seg[0].kc = const_cast<void*>(kcache); t.seg[0].vc = const_cast<void*>(vcache);
   t.seg[0].row0 = 0; t.seg[0].n_tok = n_tokens; t.seg[0].n_slots = n_slots;
   ATS_REQUIRE(n_slots <= vis_words * 64, ATSPEED_ERR_CAPACITY, "attention: %d slots exceed the visibility bitset (%d words)", n_slots, vis_words);
-  return ats_tree_attention_segs(q, ldq, t, 0, vis_words, out, ldo, n_heads, head_dim, dtype, st);
+  ATS_REQUIRE((n_tokens + 63) / 64 <= ATS_MAX_QTILES, ATSPEED_ERR_CAPACITY, "attention: too many query rows");
+  t.n_qtiles = 0;
+  for (int j = 0; j * 64 < n_tokens; ++j) { t.qtile_seg[t.n_qtiles] = 0; t.qtile_idx[t.n_qtiles++] = (unsigned char)j; }
+  const void* dt = nullptr;
+  ATS_TRY(ats_stage(&t, sizeof(t), &dt, st));
+  return ats_tree_attention_segs(q, ldq, t, (const SegTable*)dt, 0, vis_words, out, ldo, n_heads, head_dim, dtype, st);
 }
 
 extern "C" int atspeed_tree_attention(const void* q, int32_t ldq, const void* kcache, const void* vcache,

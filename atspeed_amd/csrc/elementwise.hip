@@ -149,44 +149,43 @@ int ats_rope_kv(void* qkv, const int32_t* pos, const int32_t* slots, const float
 }
 
 // ---------------------------------------------------------------------------- multi-user (segment) variants
-__device__ __forceinline__ int seg_of_row(const SegTable& t, int row) {
-  int s = 0;
-#pragma unroll 1
-  for (int i = 1; i < t.n; ++i) if (row >= t.seg[i].row0) s = i;
-  return s;
+__device__ __forceinline__ int seg_of_row(const SegTable* t, int row) {
+  int lo = 0, hi = t->n;                           // last segment with row0 <= row
+  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (t->seg[mid].row0 <= row) lo = mid; else hi = mid; }
+  return lo;
 }
 
-__global__ void embed_segs_kernel(const uint4* __restrict__ table, SegTable t, uint4* __restrict__ out, int chunks_per_row,
-                                  int vocab) {
+__global__ void embed_segs_kernel(const uint4* __restrict__ table, const SegTable* __restrict__ t, uint4* __restrict__ out,
+                                  int chunks_per_row, int vocab) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= t.total_tok * chunks_per_row) return;
+  if (i >= t->total_tok * chunks_per_row) return;
   int row = i / chunks_per_row, c = i - row * chunks_per_row;
-  const Seg& sg = t.seg[seg_of_row(t, row)];
+  const Seg& sg = t->seg[seg_of_row(t, row)];
   int id = sg.ids[row - sg.row0];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   out[i] = table[(size_t)id * chunks_per_row + c];
 }
 
-int ats_embed_segs(const void* table, const SegTable& t, void* out, int hidden, int vocab, int dtype, hipStream_t st) {
+int ats_embed_segs(const void* table, const SegTable& t, const SegTable* dt, void* out, int hidden, int vocab, int dtype, hipStream_t st) {
   int cpr = hidden * (dtype == ATSPEED_F32 ? 4 : 2) / 16;
   int total = t.total_tok * cpr;
   if (total <= 0) return ATSPEED_OK;
-  embed_segs_kernel<<<(total + 255) / 256, 256, 0, st>>>((const uint4*)table, t, (uint4*)out, cpr, vocab);
+  embed_segs_kernel<<<(total + 255) / 256, 256, 0, st>>>((const uint4*)table, dt, (uint4*)out, cpr, vocab);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
 
 template <typename T>
-__global__ void rope_kv_segs_kernel(T* __restrict__ qkv, SegTable t, const float* __restrict__ cos_tab,
+__global__ void rope_kv_segs_kernel(T* __restrict__ qkv, const SegTable* __restrict__ t, const float* __restrict__ cos_tab,
                                     const float* __restrict__ sin_tab, size_t layer_off, int n_heads, int head_dim, int max_pos) {
   int half = head_dim >> 1;
   int hidden = n_heads * head_dim;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= t.total_tok * n_heads * half) return;
+  if (i >= t->total_tok * n_heads * half) return;
   int p = i % half;
   int h = (i / half) % n_heads;
   int row = i / (half * n_heads);
-  const Seg& sg = t.seg[seg_of_row(t, row)];
+  const Seg& sg = t->seg[seg_of_row(t, row)];
   int lt = row - sg.row0;
   int ps = sg.pos[lt];
   ps = ps < 0 ? 0 : (ps >= max_pos ? max_pos - 1 : ps);
@@ -205,36 +204,36 @@ __global__ void rope_kv_segs_kernel(T* __restrict__ qkv, SegTable t, const float
   vc[d1] = r[2 * hidden + d1];
 }
 
-int ats_rope_kv_segs(void* qkv, const SegTable& t, const float* cos_tab, const float* sin_tab, size_t layer_off_bytes,
+int ats_rope_kv_segs(void* qkv, const SegTable& t, const SegTable* dt, const float* cos_tab, const float* sin_tab, size_t layer_off_bytes,
                      int n_heads, int head_dim, int max_pos, int dtype, hipStream_t st) {
   int total = t.total_tok * n_heads * (head_dim / 2);
   if (total <= 0) return ATSPEED_OK;
   if (dtype == ATSPEED_F32)
-    rope_kv_segs_kernel<float><<<(total + 255) / 256, 256, 0, st>>>((float*)qkv, t, cos_tab, sin_tab, layer_off_bytes, n_heads, head_dim, max_pos);
+    rope_kv_segs_kernel<float><<<(total + 255) / 256, 256, 0, st>>>((float*)qkv, dt, cos_tab, sin_tab, layer_off_bytes, n_heads, head_dim, max_pos);
   else
-    rope_kv_segs_kernel<bf16_t><<<(total + 255) / 256, 256, 0, st>>>((bf16_t*)qkv, t, cos_tab, sin_tab, layer_off_bytes, n_heads, head_dim, max_pos);
+    rope_kv_segs_kernel<bf16_t><<<(total + 255) / 256, 256, 0, st>>>((bf16_t*)qkv, dt, cos_tab, sin_tab, layer_off_bytes, n_heads, head_dim, max_pos);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
 
 // copy the last n_logit rows of every segment to consecutive rows (input of the final norm + lm_head)
-__global__ void gather_logit_rows_kernel(const uint4* __restrict__ h, SegTable t, uint4* __restrict__ out, int chunks_per_row) {
+__global__ void gather_logit_rows_kernel(const uint4* __restrict__ h, const SegTable* __restrict__ t, uint4* __restrict__ out,
+                                         int chunks_per_row) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= t.total_logit * chunks_per_row) return;
+  if (i >= t->total_logit * chunks_per_row) return;
   int lr = i / chunks_per_row, c = i - lr * chunks_per_row;
-  int s = 0;
-#pragma unroll 1
-  for (int j = 1; j < t.n; ++j) if (lr >= t.seg[j].logit_row0) s = j;
-  const Seg& sg = t.seg[s];
+  int lo = 0, hi = t->n;
+  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (t->seg[mid].logit_row0 <= lr) lo = mid; else hi = mid; }
+  const Seg& sg = t->seg[lo];
   int src_row = sg.row0 + sg.n_tok - sg.n_logit + (lr - sg.logit_row0);
   out[i] = h[(size_t)src_row * chunks_per_row + c];
 }
 
-int ats_gather_logit_rows(const void* h, const SegTable& t, void* out, int hidden, int dtype, hipStream_t st) {
+int ats_gather_logit_rows(const void* h, const SegTable& t, const SegTable* dt, void* out, int hidden, int dtype, hipStream_t st) {
   int cpr = hidden * (dtype == ATSPEED_F32 ? 4 : 2) / 16;
   int total = t.total_logit * cpr;
   if (total <= 0) return ATSPEED_OK;
-  gather_logit_rows_kernel<<<(total + 255) / 256, 256, 0, st>>>((const uint4*)h, t, (uint4*)out, cpr);
+  gather_logit_rows_kernel<<<(total + 255) / 256, 256, 0, st>>>((const uint4*)h, dt, (uint4*)out, cpr);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }

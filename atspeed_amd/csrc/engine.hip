@@ -31,6 +31,37 @@ extern "C" int atspeed_device_count(void) {
   return n;
 }
 
+// ---------------------------------------------------------------------------- host->device staging ring
+// Small host-built tables (segment tables, per-user argument blocks) travel through one pinned buffer and one
+// device buffer; a slot is reused only after ats_stage_reset() (called after a stream synchronisation) or, if the
+// ring fills up, after an explicit synchronisation of the stream.
+namespace {
+struct StageRing {
+  char *host = nullptr, *dev = nullptr;
+  size_t cap = 0, used = 0;
+};
+thread_local StageRing g_stage;
+constexpr size_t kStageBytes = 8u << 20;
+}  // namespace
+
+int ats_stage(const void* host_obj, size_t bytes, const void** dev_out, hipStream_t st) {
+  StageRing& r = g_stage;
+  if (!r.host) {
+    ATS_HIP(hipHostMalloc((void**)&r.host, kStageBytes));
+    ATS_HIP(hipMalloc((void**)&r.dev, kStageBytes));
+    r.cap = kStageBytes; r.used = 0;
+  }
+  size_t need = (bytes + 255) / 256 * 256;
+  ATS_REQUIRE(need <= r.cap, ATSPEED_ERR_CAPACITY, "staging: object of %zu bytes too large", bytes);
+  if (r.used + need > r.cap) { ATS_HIP(hipStreamSynchronize(st)); r.used = 0; }
+  memcpy(r.host + r.used, host_obj, bytes);
+  ATS_HIP(hipMemcpyAsync(r.dev + r.used, r.host + r.used, bytes, hipMemcpyHostToDevice, st));
+  *dev_out = r.dev + r.used;
+  r.used += need;
+  return ATSPEED_OK;
+}
+void ats_stage_reset() { g_stage.used = 0; }
+
 // ---------------------------------------------------------------------------- FSM
 extern "C" int atspeed_fsm_create(const int32_t* row_ptr, const int32_t* tok, const int32_t* nxt, int32_t n_nodes,
                                   int32_t n_edges, int32_t vocab_size, atspeed_fsm** out) {
@@ -302,7 +333,10 @@ static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits
   }
   const int H = c.hidden, dt = c.dtype;
   if (m->prof_on) prof_harvest(m);
-  ATS_TRY(ats_embed_segs(m->embed, t, cx->h, H, c.vocab_size, dt, st));
+  const void* dtab_v = nullptr;
+  ATS_TRY(ats_stage(&t, sizeof(t), &dtab_v, st));
+  const SegTable* dtab = (const SegTable*)dtab_v;
+  ATS_TRY(ats_embed_segs(m->embed, t, dtab, cx->h, H, c.vocab_size, dt, st));
   ATS_TRY(ats_rmsnorm(cx->h, m->layers[0].input_norm, cx->xn, T, H, c.rms_eps, dt, st));
   for (int l = 0; l < c.n_layers; ++l) {
     const atspeed_llama_layer_weights& w = m->layers[l];
@@ -310,8 +344,8 @@ static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits
     // cx->xn holds rmsnorm(h) * input_norm here (from the embed above or the previous layer's fused down_proj epilogue)
     { ProfBracket pb(m, 0, T, st);
       ATS_TRY(ats_gemm(cx->xn, w.wqkv, cx->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, cx->ws, cx->ws_bytes, st)); }
-    ATS_TRY(ats_rope_kv_segs(cx->qkv, t, m->cos_tab, m->sin_tab, loff, c.n_heads, m->head_dim, c.max_slots, dt, st));
-    ATS_TRY(ats_tree_attention_segs(cx->qkv, 3 * H, t, loff, m->vis_words, cx->att, H, c.n_heads, m->head_dim, dt, st));
+    ATS_TRY(ats_rope_kv_segs(cx->qkv, t, dtab, m->cos_tab, m->sin_tab, loff, c.n_heads, m->head_dim, c.max_slots, dt, st));
+    ATS_TRY(ats_tree_attention_segs(cx->qkv, 3 * H, t, dtab, loff, m->vis_words, cx->att, H, c.n_heads, m->head_dim, dt, st));
     { ProfBracket pb(m, 1, T, st);     // h += att Wo^T ; xn = rmsnorm(h) * post_norm
       ATS_TRY(ats_gemm_resid_norm(cx->att, w.wo, cx->h, T, H, H, H, H, dt, w.post_norm, cx->xn, c.rms_eps, cx->ws, cx->ws_bytes, st)); }
     { ProfBracket pb(m, 2, T, st);
@@ -326,7 +360,7 @@ static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits
   }
   if (t.total_logit > 0) {
     const int R = t.total_logit;
-    ATS_TRY(ats_gather_logit_rows(cx->h, t, cx->gath, H, dt, st));
+    ATS_TRY(ats_gather_logit_rows(cx->h, t, dtab, cx->gath, H, dt, st));
     ATS_TRY(ats_rmsnorm(cx->gath, m->final_norm, cx->xn, R, H, c.rms_eps, dt, st));
     float* lo = logits_out ? logits_out : cx->logits;
     { ProfBracket pb(m, 4, R, st);
@@ -348,6 +382,8 @@ extern "C" int atspeed_llama_forward(atspeed_llama* m, const int32_t* ids, const
   Seg& s = t.seg[0];
   s.ids = ids; s.pos = pos; s.slot = slots; s.vis = vis; s.kc = m->kv0.k; s.vc = m->kv0.v;
   s.row0 = 0; s.n_tok = n_tokens; s.n_slots = n_slots_visible; s.logit_row0 = 0; s.n_logit = n_logit_rows;
+  t.n_qtiles = 0;
+  for (int j = 0; j * 64 < n_tokens; ++j) { t.qtile_seg[t.n_qtiles] = 0; t.qtile_idx[t.n_qtiles++] = (unsigned char)j; }
   return llama_forward_segs(m, t, logits_out, (hipStream_t)stream);
 }
 
@@ -356,7 +392,6 @@ namespace {
 constexpr int MAXB = ATSPEED_MAX_BEAMS;
 constexpr int LMAX = ATSPEED_MAX_NEW_TOKENS;
 constexpr int NBLK = ATSPEED_MAX_GAMMA + 1;
-constexpr int kArgSlots = 4 * (ATSPEED_MAX_GAMMA + 2);     // argument blocks a user needs per round
 }  // namespace
 
 // One user: private KV caches for target and draft, device-side beam state, pinned mailbox and argument staging,
@@ -473,34 +508,16 @@ static int mailbox_status(atspeed_decoder* d) {
 }
 
 // ---- a group of users decoded in lock step ----------------------------------------------------------------------
-// Pinned + device staging for the per-user argument blocks of the multi-user scan kernels; one slot per launch,
-// recycled after the round's synchronisation.
-struct ArgStage {
-  char *host = nullptr, *dev = nullptr;
-  size_t cap = 0, used = 0;
-  int reserve(size_t bytes) {
-    if (cap >= bytes) return ATSPEED_OK;
-    if (host) hipHostFree(host);
-    if (dev) hipFree(dev);
-    ATS_HIP(hipHostMalloc((void**)&host, bytes));
-    ATS_HIP(hipMalloc((void**)&dev, bytes));
-    cap = bytes;
-    return ATSPEED_OK;
-  }
-  template <typename A>
-  int push(const std::vector<A>& v, const A** dev_out, hipStream_t st) {
-    size_t bytes = align_up(v.size() * sizeof(A), 256);
-    ATS_REQUIRE(used + bytes <= cap, ATSPEED_ERR_CAPACITY, "argument staging exhausted");
-    memcpy(host + used, v.data(), v.size() * sizeof(A));
-    ATS_HIP(hipMemcpyAsync(dev + used, host + used, v.size() * sizeof(A), hipMemcpyHostToDevice, st));
-    *dev_out = reinterpret_cast<const A*>(dev + used);
-    used += bytes;
-    return ATSPEED_OK;
-  }
-};
-static thread_local ArgStage g_args;
 static thread_local hipEvent_t g_ev[8];
 static thread_local bool g_ev_init = false;
+
+template <typename A>
+static int stage_args(const std::vector<A>& v, const A** dev_out, hipStream_t st) {
+  const void* p = nullptr;
+  ATS_TRY(ats_stage(v.data(), v.size() * sizeof(A), &p, st));
+  *dev_out = (const A*)p;
+  return ATSPEED_OK;
+}
 
 static Seg make_seg(const TokBuf& tb, int n_tok, int n_slots, int n_logit, const KvCache& kv) {
   Seg s{};
@@ -508,12 +525,17 @@ static Seg make_seg(const TokBuf& tb, int n_tok, int n_slots, int n_logit, const
   s.n_tok = n_tok; s.n_slots = n_slots; s.n_logit = n_logit;
   return s;
 }
-static void seg_finish(SegTable& t) {
-  t.total_tok = t.total_logit = 0;
+static int seg_finish(SegTable& t) {
+  t.total_tok = t.total_logit = t.n_qtiles = 0;
   for (int i = 0; i < t.n; ++i) {
     t.seg[i].row0 = t.total_tok; t.total_tok += t.seg[i].n_tok;
     t.seg[i].logit_row0 = t.total_logit; t.total_logit += t.seg[i].n_logit;
+    for (int j = 0; j * 64 < t.seg[i].n_tok; ++j) {
+      ATS_REQUIRE(t.n_qtiles < ATS_MAX_QTILES, ATSPEED_ERR_CAPACITY, "forward: too many query tiles in one batch");
+      t.qtile_seg[t.n_qtiles] = (unsigned char)i; t.qtile_idx[t.n_qtiles++] = (unsigned char)j;
+    }
   }
+  return ATSPEED_OK;
 }
 
 static int bssd_begin(atspeed_decoder* d, const int32_t* prompt, int P, const atspeed_fsm* fsm, int start_node, int gamma,
@@ -540,7 +562,6 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
   atspeed_llama *T = decs[0]->target, *D = decs[0]->draft;
   const int W = decs[0]->W, V = T->cfg.vocab_size;
   if (!g_ev_init) { for (auto& e : g_ev) ATS_HIP(hipEventCreate(&e)); g_ev_init = true; }
-  ATS_TRY(g_args.reserve((size_t)kArgSlots * ATS_MAX_SEGS * (sizeof(VerifyArgs) + 256)));
   // capacity for the largest possible batched forward of this group
   int cap_t = 0, cap_r = 0, cap_d = 0;
   for (int u = 0; u < n; ++u) {
@@ -553,7 +574,6 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
   ATS_TRY(ensure_act(D, cap_d, n * MAXB));
   bool any = true;
   while (any) {
-    g_args.used = 0;
     std::vector<atspeed_decoder*> ver, fin;          // users doing a verify round / the final single step this round
     int max_dl = 0;
     for (int u = 0; u < n; ++u) {
@@ -587,7 +607,7 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
         t.seg[t.n++] = sg;
         r.s.n_draft_forwards++;
       }
-      seg_finish(t);
+      ATS_TRY(seg_finish(t));
       ATS_TRY(llama_forward_segs(D, t, nullptr, st));
       for (size_t j = 0; j < us.size(); ++j) {
         atspeed_decoder* d = us[j];
@@ -604,7 +624,7 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
         args.push_back(a);
       }
       const BeamStepArgs* dev_args = nullptr;
-      ATS_TRY(g_args.push(args, &dev_args, st));
+      ATS_TRY(stage_args(args, &dev_args, st));
       ATS_TRY(ats_beam_step_multi(dev_args, (int)args.size(), st));
     }
     hipEventRecord(g_ev[1], st);
@@ -623,7 +643,7 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
         t.seg[t.n++] = make_seg(d->tin[r.cur], r.n0, r.base + r.n0, r.nb, d->tkv);
         r.s.n_target_forwards++;
       }
-      seg_finish(t);
+      ATS_TRY(seg_finish(t));
       ATS_TRY(llama_forward_segs(T, t, nullptr, st));
       hipEventRecord(g_ev[2], st);
       // ---- 3. verify (:242-456) for the verifying users, one workgroup each
@@ -643,7 +663,7 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
       }
       if (!vargs.empty()) {
         const VerifyArgs* dv = nullptr;
-        ATS_TRY(g_args.push(vargs, &dv, st));
+        ATS_TRY(stage_args(vargs, &dv, st));
         ATS_TRY(ats_verify_walk_multi(dv, (int)vargs.size(), st));
       }
       std::vector<BeamStepArgs> fargs;
@@ -660,7 +680,7 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
       }
       if (!fargs.empty()) {
         const BeamStepArgs* df = nullptr;
-        ATS_TRY(g_args.push(fargs, &df, st));
+        ATS_TRY(stage_args(fargs, &df, st));
         ATS_TRY(ats_beam_step_multi(df, (int)fargs.size(), st));
       }
       for (atspeed_decoder* d : fin) { d->run.cur ^= 1; d->run.gen += 1; }
@@ -680,6 +700,7 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
       ATS_HIP(hipMemcpyAsync(d->mail_host, d->mail_dev, sizeof(Mailbox), hipMemcpyDeviceToHost, st));
     }
     ATS_HIP(hipStreamSynchronize(st));
+    ats_stage_reset();
     float ms_d = 0.f, ms_t = 0.f, ms_v = 0.f;
     hipEventElapsedTime(&ms_d, g_ev[0], g_ev[1]);
     hipEventElapsedTime(&ms_t, g_ev[1], g_ev[2]);
@@ -764,7 +785,7 @@ extern "C" int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt
     SegTable t{};
     t.n = 1;
     t.seg[0] = make_seg(tb_offset(tin, row0, W), n_in, base + n_in, nb, d->tkv);
-    seg_finish(t);
+    ATS_TRY(seg_finish(t));
     ATS_TRY(llama_forward_segs(T, t, nullptr, st));
     s.n_target_forwards++;
     BeamStepArgs a{};

@@ -530,6 +530,173 @@ __global__ __launch_bounds__(256, 2) void gemm_wsr_kernel(const bf16_t* __restri
   ws_epilogue<MT, RT, EPI, SPLIT>(acc, Cv, partial, M, N, ldc, 0, n_wave, lq, g);
 }
 
+// =====================================================================================
+// Large-M GEMM (bf16) for the lock-step multi-user forwards (M = tokens of all users, 1-4 k rows).
+//
+//   C^T[N, M] = W[N, K] * X^T[K, M],  workgroup tile 256 (n) x 256 (m) x 64 (k), 8 waves as 4 (n) x 2 (m),
+//   wave tile 64 x 128 = 4 x 8 MFMA 16x16x32 tiles (128 accumulator registers).
+// Both operands are staged by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, 1 KB per wave-instruction)
+// into two 64 KB stages; LDS rows are 128 B with the 16-byte chunk XOR-swizzle applied on the per-lane SOURCE
+// address (the DMA destination is lane-linear) and again on the fragment reads.  Per k-tile a wave first pulls
+// all its fragments of the current stage into registers, then issues the DMA of the next stage, then runs its 64
+// MFMAs under that DMA, then waits (vmcnt(0)) and meets the others at the barrier — the one barrier per k-tile
+// both publishes the new stage and retires the reads of the old one.
+// Workgroup ids are remapped so that each XCD (private L2) walks a contiguous band of tiles.
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_big_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                          void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
+                                                          int tiles_n, int tiles_m) {
+  constexpr int BT = 256, BK = 64;
+  constexpr int STAGE = 2 * BT * kRowBytes;                      // W tile then X tile: 64 KB
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, g = lane >> 4;
+  // XCD-aware, bijective remap: ids b, b+8, b+16, ... share an XCD; give each XCD a contiguous run of tiles
+  const int nwg = tiles_n * tiles_m;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;              // consecutive ids share the X panel (same tm)
+  const int n0 = tn * BT, m0 = tm * BT;
+  const int wn = wave >> 1, wm = wave & 1;                       // 4 x 2 waves
+  const int nk = K / BK;
+
+  // DMA source pointers: 4 wave-instructions for W and 4 for X per stage; instruction j of this wave moves rows
+  // (wave*4 + j)*8 .. +8; lane i -> row +(i>>3), stored position p = i&7 carries logical chunk p ^ (row&7)
+  const bf16_t* wsrc[4]; const bf16_t* xsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (row & 7);
+    wsrc[j] = W + (size_t)min(n0 + row, N - 1) * K + c * 8;
+    xsrc[j] = X + (size_t)min(m0 + row, M - 1) * ldx + c * 8;
+  }
+  auto dma_stage = [&](int buf, int kt) {
+    unsigned char* sw = smem + buf * STAGE;
+    unsigned char* sx = sw + BT * kRowBytes;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sw + (wave * 4 + j) * 8 * kRowBytes), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[j] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sx + (wave * 4 + j) * 8 * kRowBytes), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  dma_stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const unsigned char* sw = smem + buf * STAGE + (wn * 64) * kRowBytes;
+    const unsigned char* sx = smem + buf * STAGE + BT * kRowBytes + (wm * 128) * kRowBytes;
+    s16x8_t af[2][4], bfr[2][8];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const s16x8_t*>(sw + swz(i * 16 + lq, ks * 4 + g));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bfr[ks][j] = *reinterpret_cast<const s16x8_t*>(sx + swz(j * 16 + lq, ks * 4 + g));
+    }
+    if (kt + 1 < nk) dma_stage(buf ^ 1, kt + 1);               // next stage flies under the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[ks][i]),
+                                                              __builtin_bit_cast(bf16x8_t, bfr[ks][j]), acc[i][j], 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // acc[i][j][r] = C[m = m0 + wm*128 + j*16 + lq][n = n0 + wn*64 + i*16 + g*4 + r]
+  const bool vec = (ldc & 3) == 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int gm = m0 + wm * 128 + j * 16 + lq;
+    if (gm >= M) continue;
+    if constexpr (EPI == EPI_SWIGLU) {
+      bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        const int gn = n0 + wn * 64 + i * 16;                    // 32-row group start: [16 gate | 16 up]
+        if (gn >= N) continue;
+        ushort4 o;
+        bf16_t* op = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float gt = bf2f(f2bf(acc[i][j][r])), up = bf2f(f2bf(acc[i + 1][j][r]));
+          op[r] = f2bf(gt / (1.f + __expf(-gt)) * up);
+        }
+        *reinterpret_cast<ushort4*>(C + (size_t)gm * ldc + (gn >> 1) + g * 4) = o;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gn = n0 + wn * 64 + i * 16 + g * 4;
+        if (gn >= N) continue;
+        if constexpr (EPI == EPI_F32) {
+          float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
+          if (gn + 3 < N && vec) *reinterpret_cast<float4*>(C) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          else
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[i][j][r];
+        } else {
+          bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
+          if (gn + 3 < N && vec) {
+            ushort4 o;
+            bf16_t* op = reinterpret_cast<bf16_t*>(&o);
+            if constexpr (EPI == EPI_RESID) {
+              ushort4 rs = *reinterpret_cast<const ushort4*>(C);
+              const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) op[r] = f2bf(bf2f(rp[r]) + bf2f(f2bf(acc[i][j][r])));
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) op[r] = f2bf(acc[i][j][r]);
+            }
+            *reinterpret_cast<ushort4*>(C) = o;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (gn + r < N) {
+                float v = acc[i][j][r];
+                if constexpr (EPI == EPI_RESID) v = bf2f(C[r]) + bf2f(f2bf(v));
+                C[r] = f2bf(v);
+              }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st) {
+  const int tiles_n = (n + 255) / 256, tiles_m = (m + 255) / 256;
+  auto kern = gemm_big_kernel<EPI>;
+  static thread_local bool attr_done = false;
+  if (!attr_done) {
+    ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_n * tiles_m), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, tiles_m);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
 struct WsPlan { int mt; int rt; int splits; int k_per_split; bool resident; };
 
 WsPlan make_ws_plan(int m, int n, int k, int epi) {
@@ -818,6 +985,20 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
   if (dtype == ATSPEED_BF16) {
     // weight-streaming kernel needs whole 64-wide k steps and 8-byte aligned SwiGLU rows; odd shapes
     // (only the tiny test models have them) take the LDS-tiled kernel
+    // 256x256 tiles pay off when they fill the 256 CUs evenly (measured, tools/sweep_big.sh): >= ~85 % of the last
+    // wave of workgroups busy; otherwise the 128-wide LDS-tiled kernel (with split-K) is faster
+    static const int big_min_m = env_int("ATSPEED_GEMM_BIG_MIN_M", 768);
+    const int big_tiles = ((n + 255) / 256) * ((m + 255) / 256);
+    const bool big_fills = big_tiles * 100 >= ((big_tiles + 255) / 256) * 256 * 85;
+    if (m >= big_min_m && big_fills && k % 64 == 0 && (lda % 8) == 0 && (epilogue != EPI_SWIGLU || ((ldc & 3) == 0 && n % 32 == 0))) {
+      const bf16_t* X = (const bf16_t*)a; const bf16_t* Wt = (const bf16_t*)w;
+      switch (epilogue) {
+        case EPI_STORE:  return launch_big<EPI_STORE>(X, Wt, c, m, n, k, lda, ldc, st);
+        case EPI_F32:    return launch_big<EPI_F32>(X, Wt, c, m, n, k, lda, ldc, st);
+        case EPI_RESID:  return launch_big<EPI_RESID>(X, Wt, c, m, n, k, lda, ldc, st);
+        case EPI_SWIGLU: return launch_big<EPI_SWIGLU>(X, Wt, c, m, n, k, lda, ldc, st);
+      }
+    }
     static const bool use_ws = getenv("ATSPEED_GEMM_WS") != nullptr;     // experimental weight-streaming kernels (tools/gemm_bench.py)
     if (use_ws && k % 64 == 0 && (epilogue != EPI_SWIGLU || (ldc & 3) == 0))
       return launch_ws(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st);

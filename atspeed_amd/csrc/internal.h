@@ -4,8 +4,10 @@
 
 // ---- segment table: one forward over the tokens of several users ----------------------
 // Each user (decoder) contributes a contiguous run of rows; its KV cache, visibility bitsets, positions
-// and slots stay private.  Passed to kernels BY VALUE (about 1 KB of kernel arguments).
-constexpr int ATS_MAX_SEGS = 16;
+// and slots stay private.  The host builds the table, stages it to device memory (ats_stage) and kernels read it
+// through a pointer (64 users x 72 B does not fit the 4 KB kernel-argument block).
+constexpr int ATS_MAX_SEGS = 64;
+constexpr int ATS_MAX_QTILES = ATS_MAX_SEGS * 8;
 struct Seg {
   const int32_t* ids; const int32_t* pos; const int32_t* slot; const uint64_t* vis;   // this user's per-token arrays
   void* kc; void* vc;          // this user's KV cache (layer 0 base)
@@ -13,13 +15,22 @@ struct Seg {
   int n_slots;                 // slots visible to this user's rows
   int logit_row0, n_logit;     // the last n_logit tokens get logits, at rows [logit_row0, ..) of the logits buffer
 };
-struct SegTable { int n, total_tok, total_logit; Seg seg[ATS_MAX_SEGS]; };
+struct SegTable {
+  int n, total_tok, total_logit;
+  int n_qtiles;                                   // 64-row query tiles of all segments (attention grid)
+  Seg seg[ATS_MAX_SEGS];
+  unsigned char qtile_seg[ATS_MAX_QTILES], qtile_idx[ATS_MAX_QTILES];
+};
+// copy a host object to device memory, stream ordered (pinned staging ring); returns the device address
+int ats_stage(const void* host_obj, size_t bytes, const void** dev_out, hipStream_t st);
+void ats_stage_reset();                           // after a stream synchronisation: every staged copy has landed
 
 // ---- fill.hip / elementwise.hip -------------------------------------------------------
-int ats_embed_segs(const void* table, const SegTable& t, void* out, int hidden, int vocab, int dtype, hipStream_t st);
-int ats_rope_kv_segs(void* qkv, const SegTable& t, const float* cos_tab, const float* sin_tab, size_t layer_off_bytes,
+// `t` = host copy (sizes), `dt` = the staged device copy the kernels read
+int ats_embed_segs(const void* table, const SegTable& t, const SegTable* dt, void* out, int hidden, int vocab, int dtype, hipStream_t st);
+int ats_rope_kv_segs(void* qkv, const SegTable& t, const SegTable* dt, const float* cos_tab, const float* sin_tab, size_t layer_off_bytes,
                      int n_heads, int head_dim, int max_pos, int dtype, hipStream_t st);
-int ats_gather_logit_rows(const void* h, const SegTable& t, void* out, int hidden, int dtype, hipStream_t st);
+int ats_gather_logit_rows(const void* h, const SegTable& t, const SegTable* dt, void* out, int hidden, int dtype, hipStream_t st);
 int ats_embed(const void* table, const int32_t* ids, void* out, int n_tokens, int hidden, int vocab, int dtype,
               hipStream_t st);
 int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, float eps, int dtype, hipStream_t st);
@@ -42,8 +53,8 @@ int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* v
                        int vis_words, void* out, int ldo, int n_tokens, int n_slots, int n_heads, int head_dim,
                        int dtype, hipStream_t st);
 
-int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, size_t layer_off_bytes, int vis_words, void* out,
-                            int ldo, int n_heads, int head_dim, int dtype, hipStream_t st);
+int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const SegTable* dt, size_t layer_off_bytes, int vis_words,
+                            void* out, int ldo, int n_heads, int head_dim, int dtype, hipStream_t st);
 
 // ---- scan.hip -------------------------------------------------------------------------
 struct FsmDev {

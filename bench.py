@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--gamma", type=int, default=4)
     ap.add_argument("--new-tokens", type=int, default=4)
     ap.add_argument("--seed", type=int, default=2025)
-    ap.add_argument("--streams", type=int, default=16, help="users decoded in lock step per GPU (one batched forward per draft step / verification); 1 = the reference's one-user-at-a-time loop")
+    ap.add_argument("--streams", type=int, default=32, help="users decoded in lock step per GPU (one batched forward per draft step / verification); 1 = the reference's one-user-at-a-time loop")
     ap.add_argument("--cpu-baseline-users", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()

@@ -69,7 +69,7 @@ def _gemm(lib, a, w, epi, dtype, resid=None, n_out=None):
     return c
 
 
-SHAPES = [(1, 128, 128), (5, 200, 96), (16, 384, 352), (20, 4096, 768), (40, 2304, 768), (61, 768, 3072),
+SHAPES = [(900, 1000, 512), (1024, 2304, 768), (1543, 300, 1024), (1, 128, 128), (5, 200, 96), (16, 384, 352), (20, 4096, 768), (40, 2304, 768), (61, 768, 3072),
           (100, 512, 4096), (228, 1024, 1024), (228, 4096, 4096), (130, 32256, 128), (121, 32859, 768),
           (257, 640, 1376)]
 
@@ -89,7 +89,7 @@ def test_gemm_store_and_f32(lib, m, n, k, dtype):
     np.testing.assert_allclose(c.double().cpu().numpy(), ref.numpy(), atol=tol2, rtol=0)
 
 
-@pytest.mark.parametrize("m,n,k", [(7, 256, 128), (40, 768, 768), (228, 4096, 11008), (228, 4096, 4096)])
+@pytest.mark.parametrize("m,n,k", [(7, 256, 128), (40, 768, 768), (228, 4096, 11008), (228, 4096, 4096), (1100, 768, 1024), (2000, 500, 256)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_residual(lib, m, n, k, dtype):
     a = _rand((m, k), 3).to(dtype).cuda()
@@ -101,7 +101,7 @@ def test_gemm_residual(lib, m, n, k, dtype):
     np.testing.assert_allclose(c.double().cpu().numpy(), ref.numpy(), atol=tol, rtol=0)
 
 
-@pytest.mark.parametrize("m,ffn,k", [(3, 32, 64), (40, 352, 128), (228, 11008, 4096), (20, 3072, 768)])
+@pytest.mark.parametrize("m,ffn,k", [(3, 32, 64), (40, 352, 128), (228, 11008, 4096), (20, 3072, 768), (1300, 1376, 512), (800, 496, 256)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_swiglu(lib, m, ffn, k, dtype):
     from atspeed_amd.model import _interleave_gate_up

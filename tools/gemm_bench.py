@@ -11,7 +11,7 @@ SHAPES = {"qkv": (12288, 4096, _lib.EPI_STORE), "o_proj": (4096, 4096, _lib.EPI_
           "gate_up": (22016, 4096, _lib.EPI_SWIGLU), "down": (4096, 11008, _lib.EPI_RESID),
           "lm_head": (32859, 4096, _lib.EPI_F32)}
 Ms = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [20, 60, 100, 228]
-ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+ws = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
 st = _lib.stream_ptr()
 # several weight copies so that consecutive launches do not hit a cache-resident matrix
 for name, (n, k, epi) in SHAPES.items():
