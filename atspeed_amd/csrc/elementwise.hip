@@ -204,8 +204,54 @@ __global__ void rope_kv_segs_kernel(T* __restrict__ qkv, const SegTable* __restr
   vc[d1] = r[2 * hidden + d1];
 }
 
+// bf16, head_dim % 16 == 0: a thread rotates 8 consecutive (i, i + dh/2) pairs of q and k with 16-byte accesses
+__global__ void rope_kv_segs_vec_kernel(bf16_t* __restrict__ qkv, const SegTable* __restrict__ t, const float* __restrict__ cos_tab,
+                                        const float* __restrict__ sin_tab, size_t layer_off, int n_heads, int head_dim, int max_pos) {
+  const int half = head_dim >> 1, groups = half >> 3;
+  const int hidden = n_heads * head_dim;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t->total_tok * n_heads * groups) return;
+  const int gi = i % groups;
+  const int h = (i / groups) % n_heads;
+  const int row = i / (groups * n_heads);
+  const Seg& sg = t->seg[seg_of_row(t, row)];
+  const int lt = row - sg.row0;
+  int ps = sg.pos[lt];
+  ps = ps < 0 ? 0 : (ps >= max_pos ? max_pos - 1 : ps);
+  const float* cp = cos_tab + (size_t)ps * half + gi * 8;
+  const float* sp = sin_tab + (size_t)ps * half + gi * 8;
+  bf16_t* r = qkv + (size_t)row * 3 * hidden;
+  const int d0 = h * head_dim + gi * 8, d1 = d0 + half;
+  const size_t co = (size_t)sg.slot[lt] * hidden;
+  bf16_t* kc = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(sg.kc) + layer_off) + co;
+  bf16_t* vc = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(sg.vc) + layer_off) + co;
+  uint4 q0v = *reinterpret_cast<const uint4*>(r + d0), q1v = *reinterpret_cast<const uint4*>(r + d1);
+  uint4 k0v = *reinterpret_cast<const uint4*>(r + hidden + d0), k1v = *reinterpret_cast<const uint4*>(r + hidden + d1);
+  uint4 qo0, qo1, ko0, ko1;
+  const bf16_t *q0 = (const bf16_t*)&q0v, *q1 = (const bf16_t*)&q1v, *k0 = (const bf16_t*)&k0v, *k1 = (const bf16_t*)&k1v;
+  bf16_t *a0 = (bf16_t*)&qo0, *a1 = (bf16_t*)&qo1, *b0 = (bf16_t*)&ko0, *b1 = (bf16_t*)&ko1;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float c = cp[e], s = sp[e];
+    const float x0 = bf2f(q0[e]), x1 = bf2f(q1[e]), y0 = bf2f(k0[e]), y1 = bf2f(k1[e]);
+    a0[e] = f2bf(x0 * c - x1 * s); a1[e] = f2bf(x1 * c + x0 * s);
+    b0[e] = f2bf(y0 * c - y1 * s); b1[e] = f2bf(y1 * c + y0 * s);
+  }
+  *reinterpret_cast<uint4*>(r + d0) = qo0; *reinterpret_cast<uint4*>(r + d1) = qo1;
+  *reinterpret_cast<uint4*>(kc + d0) = ko0; *reinterpret_cast<uint4*>(kc + d1) = ko1;
+  *reinterpret_cast<uint4*>(vc + d0) = *reinterpret_cast<const uint4*>(r + 2 * hidden + d0);
+  *reinterpret_cast<uint4*>(vc + d1) = *reinterpret_cast<const uint4*>(r + 2 * hidden + d1);
+}
+
 int ats_rope_kv_segs(void* qkv, const SegTable& t, const SegTable* dt, const float* cos_tab, const float* sin_tab, size_t layer_off_bytes,
                      int n_heads, int head_dim, int max_pos, int dtype, hipStream_t st) {
+  if (dtype == ATSPEED_BF16 && head_dim % 16 == 0) {
+    int totalv = t.total_tok * n_heads * (head_dim / 16);
+    if (totalv <= 0) return ATSPEED_OK;
+    rope_kv_segs_vec_kernel<<<(totalv + 255) / 256, 256, 0, st>>>((bf16_t*)qkv, dt, cos_tab, sin_tab, layer_off_bytes, n_heads, head_dim, max_pos);
+    ATS_LAUNCH_CHECK();
+    return ATSPEED_OK;
+  }
   int total = t.total_tok * n_heads * (head_dim / 2);
   if (total <= 0) return ATSPEED_OK;
   if (dtype == ATSPEED_F32)

@@ -973,6 +973,8 @@ size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype) {
   return p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
 }
 
+static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype, int epilogue);
+
 int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int dtype, int epilogue,
              void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (m <= 0 || n <= 0) return ATSPEED_OK;
@@ -985,12 +987,7 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
   if (dtype == ATSPEED_BF16) {
     // weight-streaming kernel needs whole 64-wide k steps and 8-byte aligned SwiGLU rows; odd shapes
     // (only the tiny test models have them) take the LDS-tiled kernel
-    // 256x256 tiles pay off when they fill the 256 CUs evenly (measured, tools/sweep_big.sh): >= ~85 % of the last
-    // wave of workgroups busy; otherwise the 128-wide LDS-tiled kernel (with split-K) is faster
-    static const int big_min_m = env_int("ATSPEED_GEMM_BIG_MIN_M", 768);
-    const int big_tiles = ((n + 255) / 256) * ((m + 255) / 256);
-    const bool big_fills = big_tiles * 100 >= ((big_tiles + 255) / 256) * 256 * 85;
-    if (m >= big_min_m && big_fills && k % 64 == 0 && (lda % 8) == 0 && (epilogue != EPI_SWIGLU || ((ldc & 3) == 0 && n % 32 == 0))) {
+    if (big_kernel_applies(m, n, k, lda, ldc, dtype, epilogue)) {
       const bf16_t* X = (const bf16_t*)a; const bf16_t* Wt = (const bf16_t*)w;
       switch (epilogue) {
         case EPI_STORE:  return launch_big<EPI_STORE>(X, Wt, c, m, n, k, lda, ldc, st);
@@ -1009,13 +1006,23 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
 }
 
 // h += a * w^T, then xn = rmsnorm(h) * norm_w  (split-K path fuses the reduce, the residual and the norm)
+static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype, int epilogue) {
+  // 256x256 tiles pay off when they fill the 256 CUs evenly (measured, tools/sweep_big.sh): >= ~85 % of the last
+  // wave of workgroups busy; otherwise the 128-wide LDS-tiled kernel (with split-K) is faster
+  static const int big_min_m = env_int("ATSPEED_GEMM_BIG_MIN_M", 768);
+  if (dtype != ATSPEED_BF16 || m < big_min_m || k % 64 != 0 || (lda % 8) != 0) return false;
+  if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
+  const int big_tiles = ((n + 255) / 256) * ((m + 255) / 256);
+  return big_tiles * 100 >= ((big_tiles + 255) / 256) * 256 * 85;
+}
+
 int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int k, int lda, int ldh, int dtype,
                         const void* norm_w, void* xn, float eps, void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (m <= 0) return ATSPEED_OK;
   FusedNorm fn{norm_w, xn, eps, false};
   static const bool use_ws = getenv("ATSPEED_GEMM_WS") != nullptr;
   int epc = dtype == ATSPEED_F32 ? 4 : 8;
-  if (!use_ws && k % epc == 0 && lda % epc == 0) {
+  if (!use_ws && !big_kernel_applies(m, n, k, lda, ldh, dtype, EPI_RESID) && k % epc == 0 && lda % epc == 0) {
     int rc;
     if (dtype == ATSPEED_F32)
       rc = launch_epi<float, EPI_RESID>((const float*)a, (const float*)w, h, m, n, k, lda, ldh, (float*)workspace, workspace_bytes, st, &fn);
