@@ -25,6 +25,8 @@
 
 namespace {
 
+static int env_int(const char* name, int dflt);
+
 constexpr int kThreads = 256;
 constexpr int kRowBytes = 128;      // bytes of K per LDS row
 constexpr int kChunks = 8;          // 16-byte chunks per row
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wsr_kernel(const bf16_t* __restri
 // MFMAs under that DMA, then waits (vmcnt(0)) and meets the others at the barrier — the one barrier per k-tile
 // both publishes the new stage and retires the reads of the old one.
 // Workgroup ids are remapped so that each XCD (private L2) walks a contiguous band of tiles.
-template <int EPI>
+template <int EPI, int DBG = 0>   // DBG (tuning only): 1 = no DMA inside the loop, 2 = no fragment reads inside the loop
 __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                           void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
                                                           int tiles_n, int tiles_m) {
@@ -600,6 +602,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const bf16_t* __restri
     const unsigned char* sw = smem + buf * STAGE + (wn * 64) * kRowBytes;
     const unsigned char* sx = smem + buf * STAGE + BT * kRowBytes + (wm * 128) * kRowBytes;
     s16x8_t af[2][4], bfr[2][8];
+    if (DBG != 2 || kt == 0) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -607,7 +610,8 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const bf16_t* __restri
 #pragma unroll
       for (int j = 0; j < 8; ++j) bfr[ks][j] = *reinterpret_cast<const s16x8_t*>(sx + swz(j * 16 + lq, ks * 4 + g));
     }
-    if (kt + 1 < nk) dma_stage(buf ^ 1, kt + 1);               // next stage flies under the MFMAs below
+    }
+    if (DBG != 1 && kt + 1 < nk) dma_stage(buf ^ 1, kt + 1);   // next stage flies under the MFMAs below
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -683,14 +687,178 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const bf16_t* __restri
   }
 }
 
+// ---- deeper-pipelined variant -----------------------------------------------------------------------------------
+// Ablation on MI355X (tools/sweep_big.sh): the loop above runs at 1.26-1.5 PF without its DMA and ~0.85 PF with it:
+// a 64 KB stage per ~1.6 us of MFMAs is right at the ~65 GB/s a CU can pull from L2, so a DMA issued just before the
+// MFMAs of tile t and awaited right after them is exposed.  Here the fragments of tile t are pulled into registers
+// first; once every wave has them (barrier B) the stage is dead and the DMA of tile t+2 is issued into it, so two
+// tiles are always in flight with the same 128 KB of LDS.  The fragment reads are inline asm: hipcc would otherwise
+// put s_waitcnt vmcnt(0) in front of any ds_read while an LDS-DMA is pending and drain the pipeline.  Waits are
+// counted by hand: 8 LDS-DMA instructions per wave per tile.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+#define ATS_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                           void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
+                                                           int tiles_n, int tiles_m) {
+  constexpr int BT = 256, BK = 64;
+  constexpr int STAGE = 2 * BT * kRowBytes;                      // W tile then X tile: 64 KB
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, g = lane >> 4;
+  const int nwg = tiles_n * tiles_m;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int n0 = tn * BT, m0 = tm * BT;
+  const int wn = wave >> 1, wm = wave & 1;
+  const int nk = K / BK;
+
+  const bf16_t* wsrc[4]; const bf16_t* xsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (row & 7);
+    wsrc[j] = W + (size_t)min(n0 + row, N - 1) * K + c * 8;
+    xsrc[j] = X + (size_t)min(m0 + row, M - 1) * ldx + c * 8;
+  }
+  auto dma_stage = [&](int buf, int kt) {
+    unsigned char* sw = smem + buf * STAGE;
+    unsigned char* sx = sw + BT * kRowBytes;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sw + (wave * 4 + j) * 8 * kRowBytes), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[j] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sx + (wave * 4 + j) * 8 * kRowBytes), 16, 0, 0);
+    }
+  };
+  // per-lane fragment addresses inside stage 0 (row lq of the wave's first tile; tile i adds i*16 rows = i*2048 B)
+  unsigned a_addr[2], b_addr[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int sl = ((ks * 4 + g) ^ (lq & 7)) * 16 + lq * kRowBytes;
+    a_addr[ks] = lds_addr(smem) + (wn * 64) * kRowBytes + sl;
+    b_addr[ks] = lds_addr(smem) + BT * kRowBytes + (wm * 128) * kRowBytes + sl;
+  }
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  dma_stage(0, 0);
+  if (nk > 1) dma_stage(1, 1);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned boff = (kt & 1) * STAGE;
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // tile kt landed (this wave's part); kt+1 may fly
+    else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                           // A: tile kt published by every wave
+    u32x4_t af[2][4], bfr[2][8];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned aa = a_addr[ks] + boff, ba = b_addr[ks] + boff;
+      ATS_DS_READ_B128(af[ks][0], aa, 0);     ATS_DS_READ_B128(af[ks][1], aa, 2048);
+      ATS_DS_READ_B128(af[ks][2], aa, 4096);  ATS_DS_READ_B128(af[ks][3], aa, 6144);
+      ATS_DS_READ_B128(bfr[ks][0], ba, 0);     ATS_DS_READ_B128(bfr[ks][1], ba, 2048);
+      ATS_DS_READ_B128(bfr[ks][2], ba, 4096);  ATS_DS_READ_B128(bfr[ks][3], ba, 6144);
+      ATS_DS_READ_B128(bfr[ks][4], ba, 8192);  ATS_DS_READ_B128(bfr[ks][5], ba, 10240);
+      ATS_DS_READ_B128(bfr[ks][6], ba, 12288); ATS_DS_READ_B128(bfr[ks][7], ba, 14336);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // fragments are in registers
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                                           // B: nobody reads this stage any more
+    if (kt + 2 < nk) dma_stage(kt & 1, kt + 2);                             // refill it two tiles ahead
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[ks][i]),
+                                                              __builtin_bit_cast(bf16x8_t, bfr[ks][j]), acc[i][j], 0, 0, 0);
+  }
+
+  // ------------------------------------------------------------------ epilogue (as gemm_big_kernel)
+  const bool vec = (ldc & 3) == 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int gm = m0 + wm * 128 + j * 16 + lq;
+    if (gm >= M) continue;
+    if constexpr (EPI == EPI_SWIGLU) {
+      bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        const int gn = n0 + wn * 64 + i * 16;
+        if (gn >= N) continue;
+        ushort4 o;
+        bf16_t* op = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float gt = bf2f(f2bf(acc[i][j][r])), up = bf2f(f2bf(acc[i + 1][j][r]));
+          op[r] = f2bf(gt / (1.f + __expf(-gt)) * up);
+        }
+        *reinterpret_cast<ushort4*>(C + (size_t)gm * ldc + (gn >> 1) + g * 4) = o;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gn = n0 + wn * 64 + i * 16 + g * 4;
+        if (gn >= N) continue;
+        if constexpr (EPI == EPI_F32) {
+          float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
+          if (gn + 3 < N && vec) *reinterpret_cast<float4*>(C) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          else
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[i][j][r];
+        } else {
+          bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
+          if (gn + 3 < N && vec) {
+            ushort4 o;
+            bf16_t* op = reinterpret_cast<bf16_t*>(&o);
+            if constexpr (EPI == EPI_RESID) {
+              ushort4 rs = *reinterpret_cast<const ushort4*>(C);
+              const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) op[r] = f2bf(bf2f(rp[r]) + bf2f(f2bf(acc[i][j][r])));
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) op[r] = f2bf(acc[i][j][r]);
+            }
+            *reinterpret_cast<ushort4*>(C) = o;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (gn + r < N) {
+                float v = acc[i][j][r];
+                if constexpr (EPI == EPI_RESID) v = bf2f(C[r]) + bf2f(f2bf(v));
+                C[r] = f2bf(v);
+              }
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int EPI>
 int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st) {
   const int tiles_n = (n + 255) / 256, tiles_m = (m + 255) / 256;
-  auto kern = gemm_big_kernel<EPI>;
-  static thread_local bool attr_done = false;
-  if (!attr_done) {
+  static const int dbg = env_int("ATSPEED_GEMM_BIG_DBG", 0);       // tuning: 1/2 = ablations of the simple loop, 3 = simple loop
+  auto kern = dbg == 1 ? gemm_big_kernel<EPI, 1> : (dbg == 2 ? gemm_big_kernel<EPI, 2> : (dbg == 3 ? gemm_big_kernel<EPI, 0> : gemm_big2_kernel<EPI>));
+  static thread_local std::set<const void*> attr_done;
+  if (!attr_done.count((const void*)kern)) {
     ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    attr_done = true;
+    attr_done.insert((const void*)kern);
   }
   hipLaunchKernelGGL(kern, dim3(tiles_n * tiles_m), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, tiles_m);
   ATS_LAUNCH_CHECK();
@@ -1013,7 +1181,7 @@ static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype,
   if (dtype != ATSPEED_BF16 || m < big_min_m || k % 64 != 0 || (lda % 8) != 0) return false;
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
   const int big_tiles = ((n + 255) / 256) * ((m + 255) / 256);
-  return big_tiles * 100 >= ((big_tiles + 255) / 256) * 256 * 85;
+  return big_tiles * 100 >= ((big_tiles + 255) / 256) * 256 * 80;
 }
 
 int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int k, int lda, int ldh, int dtype,
