@@ -715,7 +715,12 @@ __global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restr
     const int q = nwg / 8, r = nwg % 8, x = bid % 8;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
   }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  // grouped order: bands of GM tile rows, W-panel-major inside a band, so the ~32 tiles an XCD runs at once form a
+  // GM x 8 block sharing GM X panels and 8 W panels (PMC: FETCH_SIZE showed every W panel missing the 4 MB L2)
+  constexpr int GM = 4;
+  const int band = bid / (GM * tiles_n), rem = bid % (GM * tiles_n);
+  const int band_rows = min(GM, tiles_m - band * GM);
+  const int tn = rem / band_rows, tm = band * GM + rem % band_rows;
   const int n0 = tn * BT, m0 = tm * BT;
   const int wn = wave >> 1, wm = wave & 1;
   const int nk = K / BK;

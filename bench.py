@@ -188,7 +188,6 @@ def main():
     else:
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         bound, peak, unit = "hbm", HBM_PEAK_GBS, "GB/s"
-    tf_total = 2.0 * tdims.n_params_streamed() * sum(pk2["rows"] for k2, pk2 in prof.items() if k2 == "qkv") / max(1, prof["qkv"]["count"])
     roofline = dict(bound=bound, kernel=f"projection GEMM [{kind}] N={N} K={K} avg_M={avg_m:.0f} (gemm_big2_kernel / gemm_kernel<bf16>)",
                     achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
                     traffic=traffic_from_profiles(kind), avg_launch_us=avg_ms * 1e3, launches=pk["count"],

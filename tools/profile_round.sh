@@ -1,0 +1,9 @@
+# run on the GPU box: default bench line, kernel stats, PMC traffic passes
+set -x
+mkdir -p gpurun_out/final
+python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final/stats -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/final/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final/pmc_fetch -- python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/final/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final/pmc_write -- python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/final/pmc_write.log 2>&1
+ls -R $GRAFT_REPO_ROOT/gpurun_out/final | head -30
