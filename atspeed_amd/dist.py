@@ -43,7 +43,7 @@ class Counters:
 def all_gather_counters(c: Counters, device="cpu") -> List[Counters]:
     """The path's single collective: int64[4] per rank."""
     t = c.tensor(device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [c]
     outs = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(outs, t)

@@ -135,6 +135,49 @@ def test_bssd_batch_equals_sequential_calls(bssd_golden):
         assert torch.equal(a["beam_sequence"], b["beam_sequence"])
 
 
+def test_games_strict_trie_many_users_batch():
+    """BASELINE config 3 shape (Games vocabulary, strict item trie, many users per batch) on small models: every user
+    of a 48-user lock-step batch must equal its own single-user decode, a few users are checked against the oracle,
+    and every recommended item must be a real item of the index (the trie allows nothing else)."""
+    from atspeed_amd.beamSD import BSSD_batch
+    from atspeed_amd.generation_trie import SuffixTrieConstraint, Trie
+    vocab = synth.GAMES
+    V = vocab.vocab_size
+    tdims = synth.LlamaDims(V, 256, 2, 4, 704)
+    ddims = synth.LlamaDims(V, 128, 2, 2, 352)
+    tsd = synth.synthetic_state_dict(tdims, 21, std=0.05, head_std=0.3)
+    dsd = synth.synthetic_state_dict(ddims, 22, std=0.05, head_std=0.3)
+    kw = dict(max_slots=512, max_tokens=512, max_logit_rows=448)
+    tgt = HipLlama.from_state_dict(tdims, tsd, torch.float32, num_beams=20, **kw)
+    drf = HipLlama.from_state_dict(ddims, dsd, torch.float32, num_beams=40, **kw)
+    items = synth.synthetic_items(vocab)
+    item_set = {tuple(int(t) for t in it) for it in items}
+    fn = SuffixTrieConstraint(Trie([[1] + [int(t) for t in it] + [2] for it in items]), synth.RESPONSE_SEP, 1)
+    n_users = 48
+    prompts = [synth.synthetic_prompt(20 + (7 * u) % 40, 5000 + u) for u in range(n_users)]
+    inputs = [{"input_ids": torch.from_numpy(p)[None].cuda()} for p in prompts]
+    bat = BSSD_batch(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=fn)
+    assert len(bat) == n_users
+    for u in (0, 7, 23, 47):
+        one = BSSD(tgt, drf, inputs[u], 4, 4, prefix_allowed_tokens_fn=fn)
+        assert torch.equal(one["beam_sequence"], bat[u]["beam_sequence"])
+        assert (one["n_run"], one["accept_steps"]) == (bat[u]["n_run"], bat[u]["accept_steps"])
+    for u in (3, 31):
+        ref = R.BSSD(RefLlama(tdims, tsd), RefLlama(ddims, dsd), prompts[u], 4, 4, 20, 40, fn)
+        P = len(prompts[u])
+        nv = bat[u]["n_valid"]
+        assert bat[u]["beam_sequence"][:nv, P:].cpu().tolist() == ref["beam_sequence"][:, P:].tolist()[:nv]
+        assert bat[u]["n_run"] == ref["n_run"] and bat[u]["total_accept_steps"] == ref["total_accept_steps"]
+    for u in range(n_users):
+        P = len(prompts[u])
+        toks = bat[u]["beam_sequence"][: bat[u]["n_valid"], P:].cpu().tolist()
+        assert bat[u]["n_valid"] >= 1
+        assert all(tuple(t) in item_set for t in toks), "a beam left the item trie"
+        assert len({tuple(t) for t in toks}) == len(toks), "duplicate items in one user's beams"
+        sc = bat[u]["beam_scores"][: bat[u]["n_valid"]].cpu().numpy()
+        assert np.all(np.diff(sc) <= 1e-6), "beams must be sorted by score"
+
+
 def test_api_errors():
     ci = build_case_inputs(CASES[0])
     tgt, drf = _models(ci, CASES[0])
