@@ -26,6 +26,8 @@
 namespace {
 
 static int env_int(const char* name, int dflt);
+// share of the last wave of 256 CUs a grid of `tiles` workgroups keeps busy, in percent
+static int big_fill_pct(int tiles) { return tiles * 100 / (((tiles + 255) / 256) * 256); }
 
 constexpr int kThreads = 256;
 constexpr int kRowBytes = 128;      // bytes of K per LDS row
@@ -700,12 +702,15 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 }
 #define ATS_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 
-template <int EPI>
+// MT2 = 16-row token tiles per wave: 8 -> 256x256 workgroup tile, 4 -> 256 (n) x 128 (m) for the mid-size rounds
+template <int EPI, int MT2>
 __global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                            void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
-                                                           int tiles_n, int tiles_m) {
+                                                           int tiles_n, int tiles_m, int GM) {
   constexpr int BT = 256, BK = 64;
-  constexpr int STAGE = 2 * BT * kRowBytes;                      // W tile then X tile: 64 KB
+  constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
+  constexpr int XJ = XR / 64;                                    // X DMA instructions per wave per stage
+  constexpr int STAGE = (BT + XR) * kRowBytes;                   // W tile then X tile: 64 or 48 KB
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, g = lane >> 4;
@@ -717,32 +722,35 @@ __global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restr
   }
   // grouped order: bands of GM tile rows, W-panel-major inside a band, so the ~32 tiles an XCD runs at once form a
   // GM x 8 block sharing GM X panels and 8 W panels (PMC: FETCH_SIZE showed every W panel missing the 4 MB L2)
-  constexpr int GM = 4;
   const int band = bid / (GM * tiles_n), rem = bid % (GM * tiles_n);
   const int band_rows = min(GM, tiles_m - band * GM);
   const int tn = rem / band_rows, tm = band * GM + rem % band_rows;
-  const int n0 = tn * BT, m0 = tm * BT;
+  const int n0 = tn * BT, m0 = tm * XR;
   const int wn = wave >> 1, wm = wave & 1;
   const int nk = K / BK;
 
-  const bf16_t* wsrc[4]; const bf16_t* xsrc[4];
+  const bf16_t* wsrc[4]; const bf16_t* xsrc[XJ];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int row = (wave * 4 + j) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ (row & 7);
-    wsrc[j] = W + (size_t)min(n0 + row, N - 1) * K + c * 8;
-    xsrc[j] = X + (size_t)min(m0 + row, M - 1) * ldx + c * 8;
+    wsrc[j] = W + (size_t)min(n0 + row, N - 1) * K + ((lane & 7) ^ (row & 7)) * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < XJ; ++j) {
+    const int row = (wave * XJ + j) * 8 + (lane >> 3);
+    xsrc[j] = X + (size_t)min(m0 + row, M - 1) * ldx + ((lane & 7) ^ (row & 7)) * 8;
   }
   auto dma_stage = [&](int buf, int kt) {
     unsigned char* sw = smem + buf * STAGE;
     unsigned char* sx = sw + BT * kRowBytes;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + kt * BK),
                                        (__attribute__((address_space(3))) void*)(sw + (wave * 4 + j) * 8 * kRowBytes), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < XJ; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[j] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sx + (wave * 4 + j) * 8 * kRowBytes), 16, 0, 0);
-    }
+                                       (__attribute__((address_space(3))) void*)(sx + (wave * XJ + j) * 8 * kRowBytes), 16, 0, 0);
   };
   // per-lane fragment addresses inside stage 0 (row lq of the wave's first tile; tile i adds i*16 rows = i*2048 B)
   unsigned a_addr[2], b_addr[2];
@@ -750,24 +758,28 @@ __global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restr
   for (int ks = 0; ks < 2; ++ks) {
     const int sl = ((ks * 4 + g) ^ (lq & 7)) * 16 + lq * kRowBytes;
     a_addr[ks] = lds_addr(smem) + (wn * 64) * kRowBytes + sl;
-    b_addr[ks] = lds_addr(smem) + BT * kRowBytes + (wm * 128) * kRowBytes + sl;
+    b_addr[ks] = lds_addr(smem) + BT * kRowBytes + (wm * MT2 * 16) * kRowBytes + sl;
   }
 
-  f32x4_t acc[4][8];
+  f32x4_t acc[4][MT2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   dma_stage(0, 0);
   if (nk > 1) dma_stage(1, 1);
 
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned boff = (kt & 1) * STAGE;
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // tile kt landed (this wave's part); kt+1 may fly
-    else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (kt + 1 < nk) {                                                      // tile kt landed (this wave's part); kt+1 may fly
+      if constexpr (MT2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                                           // A: tile kt published by every wave
-    u32x4_t af[2][4], bfr[2][8];
+    u32x4_t af[2][4], bfr[2][MT2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const unsigned aa = a_addr[ks] + boff, ba = b_addr[ks] + boff;
@@ -775,8 +787,10 @@ __global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restr
       ATS_DS_READ_B128(af[ks][2], aa, 4096);  ATS_DS_READ_B128(af[ks][3], aa, 6144);
       ATS_DS_READ_B128(bfr[ks][0], ba, 0);     ATS_DS_READ_B128(bfr[ks][1], ba, 2048);
       ATS_DS_READ_B128(bfr[ks][2], ba, 4096);  ATS_DS_READ_B128(bfr[ks][3], ba, 6144);
-      ATS_DS_READ_B128(bfr[ks][4], ba, 8192);  ATS_DS_READ_B128(bfr[ks][5], ba, 10240);
-      ATS_DS_READ_B128(bfr[ks][6], ba, 12288); ATS_DS_READ_B128(bfr[ks][7], ba, 14336);
+      if constexpr (MT2 == 8) {
+        ATS_DS_READ_B128(bfr[ks][4], ba, 8192);  ATS_DS_READ_B128(bfr[ks][5], ba, 10240);
+        ATS_DS_READ_B128(bfr[ks][6], ba, 12288); ATS_DS_READ_B128(bfr[ks][7], ba, 14336);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // fragments are in registers
     __builtin_amdgcn_sched_barrier(0);
@@ -788,7 +802,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restr
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < MT2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[ks][i]),
                                                               __builtin_bit_cast(bf16x8_t, bfr[ks][j]), acc[i][j], 0, 0, 0);
   }
@@ -796,8 +810,8 @@ __global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restr
   // ------------------------------------------------------------------ epilogue (as gemm_big_kernel)
   const bool vec = (ldc & 3) == 0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int gm = m0 + wm * 128 + j * 16 + lq;
+  for (int j = 0; j < MT2; ++j) {
+    const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
     if (gm >= M) continue;
     if constexpr (EPI == EPI_SWIGLU) {
       bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
@@ -857,14 +871,29 @@ __global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restr
 
 template <int EPI>
 int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st) {
-  const int tiles_n = (n + 255) / 256, tiles_m = (m + 255) / 256;
   static const int dbg = env_int("ATSPEED_GEMM_BIG_DBG", 0);       // tuning: 1/2 = ablations of the simple loop, 3 = simple loop
-  auto kern = dbg == 1 ? gemm_big_kernel<EPI, 1> : (dbg == 2 ? gemm_big_kernel<EPI, 2> : (dbg == 3 ? gemm_big_kernel<EPI, 0> : gemm_big2_kernel<EPI>));
-  static thread_local std::set<const void*> attr_done;
-  if (!attr_done.count((const void*)kern)) {
-    ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    attr_done.insert((const void*)kern);
+  static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
+  const int tiles_n = (n + 255) / 256;
+  static thread_local bool attr_done = false;
+  if (!attr_done) {
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_done = true;
   }
+  if (dbg == 0) {
+    // 256-row token tiles when they fill the chip at least as well as 128-row ones (fewer bytes per flop), else 128
+    const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
+    const bool use256 = big_fill_pct(t256) >= 80 && big_fill_pct(t256) + 8 >= big_fill_pct(t128);
+    if (use256) hipLaunchKernelGGL((gemm_big2_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
+    else        hipLaunchKernelGGL((gemm_big2_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
+    ATS_LAUNCH_CHECK();
+    return ATSPEED_OK;
+  }
+  const int tiles_m = (m + 255) / 256;
+  auto kern = dbg == 1 ? gemm_big_kernel<EPI, 1> : (dbg == 2 ? gemm_big_kernel<EPI, 2> : gemm_big_kernel<EPI, 0>);
   hipLaunchKernelGGL(kern, dim3(tiles_n * tiles_m), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, tiles_m);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
@@ -1147,7 +1176,6 @@ size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype) {
 }
 
 static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype, int epilogue);
-
 int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int dtype, int epilogue,
              void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (m <= 0 || n <= 0) return ATSPEED_OK;
@@ -1182,11 +1210,11 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
 static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype, int epilogue) {
   // 256x256 tiles pay off when they fill the 256 CUs evenly (measured, tools/sweep_big.sh): >= ~85 % of the last
   // wave of workgroups busy; otherwise the 128-wide LDS-tiled kernel (with split-K) is faster
-  static const int big_min_m = env_int("ATSPEED_GEMM_BIG_MIN_M", 768);
+  static const int big_min_m = env_int("ATSPEED_GEMM_BIG_MIN_M", 512);
   if (dtype != ATSPEED_BF16 || m < big_min_m || k % 64 != 0 || (lda % 8) != 0) return false;
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
-  const int big_tiles = ((n + 255) / 256) * ((m + 255) / 256);
-  return big_tiles * 100 >= ((big_tiles + 255) / 256) * 256 * 80;
+  const int tn = (n + 255) / 256;
+  return big_fill_pct(tn * ((m + 255) / 256)) >= 80 || big_fill_pct(tn * ((m + 127) / 128)) >= 80;
 }
 
 int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int k, int lda, int ldh, int dtype,
