@@ -12,6 +12,8 @@ typedef unsigned short bf16_t;   // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+// 16-byte register value as an SSA vector: HIP's uint4 STRUCT in a register ring ended up in scratch (hipcc 7.2)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- host error plumbing
 void atspeed_set_error(const char* fmt, ...);

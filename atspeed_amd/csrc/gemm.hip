@@ -2,20 +2,16 @@
 //
 //   C[M,N] (+)= A[M,K] * W[N,K]^T      A, W row-major with K contiguous (HF nn.Linear layout)
 //
-// M is the number of tokens in the forward (<= a few hundred: prompt + gamma*DK draft beams),
-// so every launch streams the weight matrix W exactly once from HBM and is bound by that
-// stream: algorithmic bytes = N*K*sizeof(T) (+ the small A and C).  Structure:
-//   * workgroup = 256 threads = 4 waves, tile BM x 128 x (128 bytes of K), LDS double buffered,
-//     register-staged 16-byte global loads issued one tile ahead of the MFMAs;
-//   * LDS rows are 128 B; 16-B chunk c of row r is stored at chunk c ^ (r & 7) so that the
-//     ds_read_b128 fragment reads of 16 consecutive rows spread over all banks;
-//   * bf16: v_mfma_f32_16x16x32_bf16 (A/B fragment = 8 consecutive k of one row = one chunk);
-//     f32 (parity mode): v_mfma_f32_16x16x4_f32 with the k order permuted so that a lane's
-//     four k-steps come from one 16-byte chunk (same permutation on A and W);
-//   * split-K over blockIdx.z into fp32 partial slabs when M*N tiles alone cannot fill the
-//     256 CUs; a second kernel reduces the slabs and applies the epilogue.
-// Epilogues: store (dtype), fp32 store (logits), residual add, SwiGLU over interleaved
-// gate/up 16-column groups.
+// Two regimes, two kernels (dispatch in ats_gemm / big_kernel_applies):
+//   * gemm_kernel<T,...>  — M = one user's tokens (tens to a few hundred): every launch is one pass over W and is
+//     bound by that HBM stream.  256 threads = 4 waves, tile BM x {64,128} x (128 bytes of K), LDS double buffered,
+//     register-staged 16-byte loads one tile ahead; 16-byte chunk c of LDS row r lives at chunk c ^ (r & 7);
+//     bf16: v_mfma_f32_16x16x32_bf16, fp32 parity mode: v_mfma_f32_16x16x4_f32 with a k permutation that lets a
+//     lane take its four k-steps from one chunk; split-K into fp32 slabs sized for >= 2-3 workgroups per CU, reduced
+//     by a second kernel that also applies the epilogue (and, for the residual projections, the next RMSNorm).
+//   * gemm_big2_kernel<EPI,MT2> — M = tokens of all users of a lock-step batch (thousands): MFMA-bound.  256 x
+//     {256,128} tile, 8 waves, both operands by LDS-DMA, two tiles in flight (see the kernel's comment).
+// Epilogues: store (dtype), fp32 store (logits), residual add, SwiGLU over interleaved gate/up 16-row groups.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -251,288 +247,6 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, void* __
   }
 }
 
-
-// =====================================================================================
-// Weight-streaming GEMMs (bf16), the production path for the forward's projections.
-//
-//   C^T[N, M] = W[N, K] * X^T[K, M]          (same math as above, operands swapped)
-//
-// M (tokens) is small, so every launch is a single pass over W.  Each wave OWNS 16*RT rows of W
-// and streams them global -> VGPR through a 4-step register ring (no LDS round trip: a weight
-// element is used by exactly one wave), while the token block X — shared by all waves and
-// L2-resident — goes through LDS.  W is the MFMA A operand, X^T the B operand; the accumulator
-// has the W row on the register index and the token on the lane, so the epilogue writes 4
-// consecutive output columns per lane (8-byte stores) and the SwiGLU pair (gate tile, up
-// tile) sits in one lane.  Two variants, by how X reaches LDS:
-//   * gemm_wsr_kernel ("resident X", M <= 64): the workgroup's whole K-slice of X is staged
-//     once; the main loop has NO barrier — pure weight streaming with 16 KB per wave in flight.
-//   * gemm_ws_kernel ("ring X", M <= 320): X tiles of 64 k are prefetched FOUR steps ahead in
-//     registers and handed through a double-buffered LDS tile, one barrier per step.
-// All loads are unconditional and in bounds (steps past the end re-read the last tile, rows past
-// M or N re-read the last row: those products are never stored) — a "load or zero" select makes
-// hipcc branch around the load and drain vmcnt.
-
-__device__ __forceinline__ int swz16(int row, int chunk, int chunks_per_row) {   // 16-row conflict-free image
-  return (row * chunks_per_row + (chunk ^ (row & 15))) * 16;
-}
-
-template <int MT, int RT, int EPI, bool SPLIT>
-__device__ __forceinline__ void ws_epilogue(const f32x4_t (&acc)[RT][MT], void* __restrict__ Cv, float* __restrict__ partial,
-                                            int M, int N, int ldc, int m0, int n_wave, int lq, int g) {
-  // acc[rt][mt][r] = C[m = m0 + mt*16 + lq][n = n_wave + rt*16 + g*4 + r]
-  if constexpr (SPLIT) {
-    float* P = partial + (size_t)blockIdx.z * M * N;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        int gm = m0 + mt * 16 + lq, gn = n_wave + rt * 16 + g * 4;
-        if (gm < M) {
-          if (gn + 3 < N && (N & 3) == 0) {
-            *reinterpret_cast<float4*>(P + (size_t)gm * N + gn) = make_float4(acc[rt][mt][0], acc[rt][mt][1], acc[rt][mt][2], acc[rt][mt][3]);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (gn + r < N) P[(size_t)gm * N + gn + r] = acc[rt][mt][r];
-          }
-        }
-      }
-  } else if constexpr (EPI == EPI_SWIGLU) {
-    static_assert(RT == 2 || EPI != EPI_SWIGLU, "SwiGLU needs the gate and up tiles in one wave");
-    bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      int gm = m0 + mt * 16 + lq, gn = n_wave;                      // 32-row group start
-      if (gm < M && gn < N) {
-        ushort4 o;
-        bf16_t* op = reinterpret_cast<bf16_t*>(&o);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float gt = bf2f(f2bf(acc[0][mt][r])), up = bf2f(f2bf(acc[RT - 1][mt][r]));
-          op[r] = f2bf(gt / (1.f + __expf(-gt)) * up);
-        }
-        *reinterpret_cast<ushort4*>(C + (size_t)gm * ldc + (gn >> 1) + g * 4) = o;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        int gm = m0 + mt * 16 + lq, gn = n_wave + rt * 16 + g * 4;
-        if (gm >= M || gn >= N) continue;
-        if constexpr (EPI == EPI_F32) {
-          float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
-          if (gn + 3 < N && (ldc & 3) == 0) *reinterpret_cast<float4*>(C) = make_float4(acc[rt][mt][0], acc[rt][mt][1], acc[rt][mt][2], acc[rt][mt][3]);
-          else
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[rt][mt][r];
-        } else {
-          bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
-          if (gn + 3 < N && (ldc & 3) == 0) {
-            ushort4 o;
-            bf16_t* op = reinterpret_cast<bf16_t*>(&o);
-            if constexpr (EPI == EPI_RESID) {
-              ushort4 rs = *reinterpret_cast<const ushort4*>(C);
-              const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) op[r] = f2bf(bf2f(rp[r]) + bf2f(f2bf(acc[rt][mt][r])));
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) op[r] = f2bf(acc[rt][mt][r]);
-            }
-            *reinterpret_cast<ushort4*>(C) = o;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (gn + r < N) {
-                float v = acc[rt][mt][r];
-                if constexpr (EPI == EPI_RESID) v = bf2f(C[r]) + bf2f(f2bf(v));
-                C[r] = f2bf(v);
-              }
-          }
-        }
-      }
-  }
-}
-
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));   // SSA vector (HIP's uint4 struct copies kept the ring in scratch)
-
-// ---- ring-X variant -------------------------------------------------------------------
-// (free functions + one named array per ring slot: lambdas over a [D][..] array kept the ring in scratch)
-template <int RT>
-__device__ __forceinline__ void ws_load_w(u32x4_t (&dst)[2][RT], const bf16_t* const (&wrow)[RT], int step, int nsteps) {
-  const int kb = min(step, nsteps - 1) * 64;
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) dst[ks][rt] = *reinterpret_cast<const u32x4_t*>(wrow[rt] + kb + ks * 32);
-}
-template <int XCH>
-__device__ __forceinline__ void ws_load_x(u32x4_t (&dst)[XCH], const bf16_t* const (&xrow)[XCH], int step, int nsteps) {
-  const int kb = min(step, nsteps - 1) * 64;
-#pragma unroll
-  for (int i = 0; i < XCH; ++i) dst[i] = *reinterpret_cast<const u32x4_t*>(xrow[i] + kb);
-}
-template <int XCH>
-__device__ __forceinline__ void ws_store_x(const u32x4_t (&src)[XCH], unsigned char* sx, int tid) {
-#pragma unroll
-  for (int i = 0; i < XCH; ++i) {
-    int qi = tid + i * 256;
-    *reinterpret_cast<u32x4_t*>(sx + swz(qi >> 3, qi & 7)) = src[i];
-  }
-}
-template <int MT, int RT>
-__device__ __forceinline__ void ws_compute(f32x4_t (&acc)[RT][MT], const u32x4_t (&wf)[2][RT], const unsigned char* sx, int lq, int g) {
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      s16x8_t xf = *reinterpret_cast<const s16x8_t*>(sx + swz(mt * 16 + lq, ks * 4 + g));
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        acc[rt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[ks][rt]),
-                                                              __builtin_bit_cast(bf16x8_t, xf), acc[rt][mt], 0, 0, 0);
-    }
-}
-
-template <int MT, int RT, int EPI, bool SPLIT>
-__global__ __launch_bounds__(256, 1) void gemm_ws_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
-                                                         void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
-                                                         int k_per_split, float* __restrict__ partial) {
-  constexpr int D = 4;                          // ring depth (BK steps) of both register rings
-  constexpr int BK = 64;
-  constexpr int MP = MT * 16;                   // padded token rows per workgroup
-  constexpr int XCH = MP * 8 / 256;             // 16-byte chunks of one X tile per thread
-  constexpr int BN = 4 * 16 * RT;
-  constexpr int XBUF = MP * kRowBytes;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 15, g = lane >> 4;
-  const int n_wave = blockIdx.x * BN + wave * 16 * RT;
-  const int m0 = blockIdx.y * MP;
-  const int kz0 = blockIdx.z * k_per_split;
-  const int kz1 = min(K, kz0 + k_per_split);
-  const int nsteps = (kz1 - kz0) / BK;
-
-  const bf16_t* wrow[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) wrow[rt] = W + (size_t)min(n_wave + rt * 16 + lq, N - 1) * K + kz0 + g * 8;
-  const bf16_t* xrow[XCH];
-#pragma unroll
-  for (int i = 0; i < XCH; ++i) {
-    int qi = tid + i * 256;
-    xrow[i] = X + (size_t)min(m0 + (qi >> 3), M - 1) * ldx + kz0 + (qi & 7) * 8;
-  }
-
-  u32x4_t wr0[2][RT], wr1[2][RT], wr2[2][RT], wr3[2][RT];     // W ring: [k-step][row tile] per slot
-  u32x4_t xr0[XCH], xr1[XCH], xr2[XCH], xr3[XCH];             // X ring
-  f32x4_t acc[RT][MT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[rt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  // prologue: X steps 0..3 and W steps 0..3 in flight; X(0) handed to LDS, its slot refilled with X(4)
-  ws_load_x<XCH>(xr0, xrow, 0, nsteps); ws_load_x<XCH>(xr1, xrow, 1, nsteps);
-  ws_load_x<XCH>(xr2, xrow, 2, nsteps); ws_load_x<XCH>(xr3, xrow, 3, nsteps);
-  ws_load_w<RT>(wr0, wrow, 0, nsteps); ws_load_w<RT>(wr1, wrow, 1, nsteps);
-  ws_load_w<RT>(wr2, wrow, 2, nsteps); ws_load_w<RT>(wr3, wrow, 3, nsteps);
-  ws_store_x<XCH>(xr0, smem, tid);
-  ws_load_x<XCH>(xr0, xrow, D, nsteps);
-  __syncthreads();
-
-#define WS_STEP(SLOT, NEXT)                                                                        \
-  {                                                                                                \
-    const int s = s0 + SLOT;                                                                       \
-    if (s < nsteps) {                                                                              \
-      ws_store_x<XCH>(xr##NEXT, smem + ((s + 1) & 1) * XBUF, tid);  /* X(s+1), loaded >= 3 steps ago */ \
-      ws_load_x<XCH>(xr##NEXT, xrow, s + 1 + D, nsteps);                                           \
-      ws_compute<MT, RT>(acc, wr##SLOT, smem + (s & 1) * XBUF, lq, g);                             \
-      ws_load_w<RT>(wr##SLOT, wrow, s + D, nsteps);                 /* refill the slot just consumed */ \
-      __syncthreads();                                                                             \
-    }                                                                                              \
-  }
-  for (int s0 = 0; s0 < nsteps; s0 += D) {
-    WS_STEP(0, 1) WS_STEP(1, 2) WS_STEP(2, 3) WS_STEP(3, 0)
-  }
-#undef WS_STEP
-  ws_epilogue<MT, RT, EPI, SPLIT>(acc, Cv, partial, M, N, ldc, m0, n_wave, lq, g);
-}
-
-// ---- resident-X variant -----------------------------------------------------------------
-// LDS image: [MP rows][k_per_split] bf16, 16-byte chunk c of row r at chunk c ^ (r & 15).
-template <int MT, int RT, int EPI, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void gemm_wsr_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
-                                                          void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
-                                                          int k_per_split, float* __restrict__ partial) {
-  constexpr int D = 4;
-  constexpr int BK = 64;
-  constexpr int MP = MT * 16;
-  constexpr int BN = 4 * 16 * RT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 15, g = lane >> 4;
-  const int n_wave = blockIdx.x * BN + wave * 16 * RT;
-  const int kz0 = blockIdx.z * k_per_split;
-  const int kz1 = min(K, kz0 + k_per_split);
-  const int klen = kz1 - kz0;                   // multiple of 64
-  const int nsteps = klen / BK;
-  const int cpr = k_per_split / 8;              // chunks per LDS row (>= 16)
-
-  const bf16_t* wrow[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) wrow[rt] = W + (size_t)min(n_wave + rt * 16 + lq, N - 1) * K + kz0 + g * 8;
-  u32x4_t wr0[2][RT], wr1[2][RT], wr2[2][RT], wr3[2][RT];
-  ws_load_w<RT>(wr0, wrow, 0, nsteps); ws_load_w<RT>(wr1, wrow, 1, nsteps);   // weights start flowing before X is staged
-  ws_load_w<RT>(wr2, wrow, 2, nsteps); ws_load_w<RT>(wr3, wrow, 3, nsteps);
-
-  // stage the whole X slice: rows past M re-read row M-1 (never stored)
-  {
-    const int cprl = klen / 8;                           // chunks actually present per row
-    const int total = MP * cprl;
-    for (int q0 = 0; q0 < total; q0 += 256 * 4) {
-      u32x4_t v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int qi = min(q0 + u * 256 + tid, total - 1);
-        int r = qi / cprl, c = qi - r * cprl;
-        v[u] = *reinterpret_cast<const u32x4_t*>(X + (size_t)min(r, M - 1) * ldx + kz0 + c * 8);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int qi = min(q0 + u * 256 + tid, total - 1);
-        int r = qi / cprl, c = qi - r * cprl;
-        *reinterpret_cast<u32x4_t*>(smem + swz16(r, c, cpr)) = v[u];
-      }
-    }
-  }
-  f32x4_t acc[RT][MT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[rt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-
-#define WSR_STEP(SLOT)                                                                         \
-  {                                                                                            \
-    const int s = s0 + SLOT;                                                                   \
-    if (s < nsteps) {                                                                          \
-      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                         \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                    \
-          s16x8_t xf = *reinterpret_cast<const s16x8_t*>(smem + swz16(mt * 16 + lq, s * 8 + ks * 4 + g, cpr)); \
-          _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                    \
-            acc[rt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wr##SLOT[ks][rt]), \
-                                                                  __builtin_bit_cast(bf16x8_t, xf), acc[rt][mt], 0, 0, 0); \
-        }                                                                                      \
-      ws_load_w<RT>(wr##SLOT, wrow, s + D, nsteps);                                            \
-    }                                                                                          \
-  }
-  for (int s0 = 0; s0 < nsteps; s0 += D) {
-    WSR_STEP(0) WSR_STEP(1) WSR_STEP(2) WSR_STEP(3)
-  }
-#undef WSR_STEP
-  ws_epilogue<MT, RT, EPI, SPLIT>(acc, Cv, partial, M, N, ldc, 0, n_wave, lq, g);
-}
 
 // =====================================================================================
 // Large-M GEMM (bf16) for the lock-step multi-user forwards (M = tokens of all users, 1-4 k rows).
@@ -899,108 +613,6 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
   return ATSPEED_OK;
 }
 
-struct WsPlan { int mt; int rt; int splits; int k_per_split; bool resident; };
-
-WsPlan make_ws_plan(int m, int n, int k, int epi) {
-  WsPlan p;
-  const int mts[] = {2, 4, 8, 12, 16, 20};
-  p.mt = 20;
-  for (int c : mts) if (c * 16 >= m) { p.mt = c; break; }
-  const int ksteps = k / 64;
-  p.resident = p.mt <= 4;
-  if (p.resident) {
-    // whole K-slice of X in LDS (<= 64 KB so two workgroups share a CU); aim at >= 512 workgroups
-    p.rt = 2;
-    const int wgs = (n + 127) / 128;
-    const int max_slice_steps = (64 * 1024) / (p.mt * 16 * 128);          // steps whose X fits in 64 KB
-    int splits = (512 + wgs - 1) / wgs;
-    int min_splits = (ksteps + max_slice_steps - 1) / max_slice_steps;
-    int max_splits = std::max(1, ksteps / 8);
-    splits = std::max(min_splits, std::min(splits, max_splits));
-    if (splits > 32) splits = std::max(min_splits, 32);
-    int sps = (ksteps + splits - 1) / splits;
-    sps = (std::max(sps, 2) + 1) & ~1;                                    // even: LDS rows are multiples of 16 chunks (swz16)
-    if (sps > max_slice_steps) sps = max_slice_steps & ~1;
-    p.k_per_split = sps * 64;
-    p.splits = (k + p.k_per_split - 1) / p.k_per_split;
-    return p;
-  }
-  p.rt = 2;
-  int wgs = ((n + 127) / 128) * ((m + p.mt * 16 - 1) / (p.mt * 16));
-  int splits = 1;
-  if (wgs < 160) {
-    splits = (256 + wgs - 1) / wgs;
-    int max_splits = ksteps / 8;
-    if (splits > max_splits) splits = max_splits;
-    if (splits > 16) splits = 16;
-    if (splits < 1) splits = 1;
-  }
-  int kps = ((ksteps + splits - 1) / splits) * 64;
-  p.splits = (k + kps - 1) / kps;
-  p.k_per_split = kps;
-  return p;
-}
-
-template <int MT, int RT, int EPI, bool RESIDENT>
-int launch_ws_cfg(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, const WsPlan& p,
-                  float* partial, hipStream_t st) {
-  constexpr int BN = 64 * RT;
-  dim3 grid((n + BN - 1) / BN, RESIDENT ? 1 : (m + MT * 16 - 1) / (MT * 16), p.splits);
-  size_t lds = RESIDENT ? (size_t)MT * 16 * p.k_per_split * 2 : 2 * (size_t)MT * 16 * kRowBytes;
-  auto launch = [&](auto kern) -> int {
-    static thread_local std::set<const void*> big_lds_done;           // one attribute call per kernel, not per launch
-    if (lds > 48 * 1024 && !big_lds_done.count((const void*)kern)) {
-      ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      big_lds_done.insert((const void*)kern);
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, w, c, m, n, k, ldx, ldc, p.k_per_split, partial);
-    ATS_LAUNCH_CHECK();
-    return ATSPEED_OK;
-  };
-  if (p.splits > 1) {
-    if constexpr (RESIDENT) { ATS_TRY(launch(gemm_wsr_kernel<MT, RT, EPI, true>)); }
-    else { ATS_TRY(launch(gemm_ws_kernel<MT, RT, EPI, true>)); }
-    size_t outs = EPI == EPI_SWIGLU ? (size_t)m * (n / 2) : (size_t)m * n;
-    splitk_reduce_kernel<bf16_t, EPI><<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(partial, c, m, n, ldc, p.splits);
-    ATS_LAUNCH_CHECK();
-  } else {
-    if constexpr (RESIDENT) { ATS_TRY(launch(gemm_wsr_kernel<MT, RT, EPI, false>)); }
-    else { ATS_TRY(launch(gemm_ws_kernel<MT, RT, EPI, false>)); }
-  }
-  return ATSPEED_OK;
-}
-
-template <int EPI>
-int launch_ws_epi(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, float* partial,
-                  size_t ws_bytes, hipStream_t st) {
-  WsPlan p = make_ws_plan(m, n, k, EPI);
-  ATS_REQUIRE(p.splits == 1 || (size_t)p.splits * m * n * sizeof(float) <= ws_bytes, ATSPEED_ERR_CAPACITY,
-              "gemm: split-K workspace too small (%zu bytes needed)", (size_t)p.splits * m * n * sizeof(float));
-  switch (p.mt) {
-    case 2:  return launch_ws_cfg<2, 2, EPI, true>(x, w, c, m, n, k, ldx, ldc, p, partial, st);
-    case 4:  return launch_ws_cfg<4, 2, EPI, true>(x, w, c, m, n, k, ldx, ldc, p, partial, st);
-    case 8:  return launch_ws_cfg<8, 2, EPI, false>(x, w, c, m, n, k, ldx, ldc, p, partial, st);
-    case 12: return launch_ws_cfg<12, 2, EPI, false>(x, w, c, m, n, k, ldx, ldc, p, partial, st);
-    case 16: return launch_ws_cfg<16, 2, EPI, false>(x, w, c, m, n, k, ldx, ldc, p, partial, st);
-    case 20: return launch_ws_cfg<20, 2, EPI, false>(x, w, c, m, n, k, ldx, ldc, p, partial, st);
-  }
-  atspeed_set_error("gemm: no weight-streaming configuration for M=%d", m);
-  return ATSPEED_ERR_INVALID;
-}
-
-int launch_ws(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int epi, void* ws,
-              size_t ws_bytes, hipStream_t st) {
-  const bf16_t* X = (const bf16_t*)a; const bf16_t* Wt = (const bf16_t*)w; float* P = (float*)ws;
-  switch (epi) {
-    case EPI_STORE:  return launch_ws_epi<EPI_STORE>(X, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
-    case EPI_F32:    return launch_ws_epi<EPI_F32>(X, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
-    case EPI_RESID:  return launch_ws_epi<EPI_RESID>(X, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
-    case EPI_SWIGLU: return launch_ws_epi<EPI_SWIGLU>(X, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
-  }
-  atspeed_set_error("gemm: unknown epilogue %d", epi);
-  return ATSPEED_ERR_INVALID;
-}
-
 // split-K reduce + residual add + RMSNorm of the updated row, one workgroup per token row:
 //   h[m][:] += sum_z partial[z][m][:]        (the o_proj / down_proj epilogue)
 //   xn[m][:] = w * (h[m][:] * rsqrt(mean(h^2) + eps))   (the NEXT op's input norm)
@@ -1162,16 +774,7 @@ int launch_typed(const void* a, const void* w, void* c, int m, int n, int k, int
 }  // namespace
 
 size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype) {
-  if (dtype == ATSPEED_BF16) {
-    Plan po = make_plan<bf16_t>(m, n, k);
-    size_t best = po.splits > 1 ? (size_t)po.splits * m * n * sizeof(float) : 0;
-    for (int epi = 0; epi < 4; ++epi) {
-      WsPlan p = make_ws_plan(m, n, k, epi);
-      if (p.splits > 1) best = std::max(best, (size_t)p.splits * m * n * sizeof(float));
-    }
-    return best;
-  }
-  Plan p = make_plan<float>(m, n, k);
+  Plan p = dtype == ATSPEED_BF16 ? make_plan<bf16_t>(m, n, k) : make_plan<float>(m, n, k);
   return p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
 }
 
@@ -1186,8 +789,6 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
   ATS_REQUIRE(epilogue != EPI_SWIGLU || n % 32 == 0, ATSPEED_ERR_INVALID, "gemm: SwiGLU needs N %% 32 == 0 (N=%d)", n);
   if (dtype == ATSPEED_F32) return launch_typed<float>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st);
   if (dtype == ATSPEED_BF16) {
-    // weight-streaming kernel needs whole 64-wide k steps and 8-byte aligned SwiGLU rows; odd shapes
-    // (only the tiny test models have them) take the LDS-tiled kernel
     if (big_kernel_applies(m, n, k, lda, ldc, dtype, epilogue)) {
       const bf16_t* X = (const bf16_t*)a; const bf16_t* Wt = (const bf16_t*)w;
       switch (epilogue) {
@@ -1197,9 +798,6 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
         case EPI_SWIGLU: return launch_big<EPI_SWIGLU>(X, Wt, c, m, n, k, lda, ldc, st);
       }
     }
-    static const bool use_ws = getenv("ATSPEED_GEMM_WS") != nullptr;     // experimental weight-streaming kernels (tools/gemm_bench.py)
-    if (use_ws && k % 64 == 0 && (epilogue != EPI_SWIGLU || (ldc & 3) == 0))
-      return launch_ws(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st);
     return launch_typed<bf16_t>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st);
   }
   atspeed_set_error("gemm: unknown dtype %d", dtype);
@@ -1221,9 +819,8 @@ int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int
                         const void* norm_w, void* xn, float eps, void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (m <= 0) return ATSPEED_OK;
   FusedNorm fn{norm_w, xn, eps, false};
-  static const bool use_ws = getenv("ATSPEED_GEMM_WS") != nullptr;
   int epc = dtype == ATSPEED_F32 ? 4 : 8;
-  if (!use_ws && !big_kernel_applies(m, n, k, lda, ldh, dtype, EPI_RESID) && k % epc == 0 && lda % epc == 0) {
+  if (!big_kernel_applies(m, n, k, lda, ldh, dtype, EPI_RESID) && k % epc == 0 && lda % epc == 0) {
     int rc;
     if (dtype == ATSPEED_F32)
       rc = launch_epi<float, EPI_RESID>((const float*)a, (const float*)w, h, m, n, k, lda, ldh, (float*)workspace, workspace_bytes, st, &fn);
