@@ -14,9 +14,11 @@ The models are `HipLlama` objects; the whole loop runs in libatspeed_hip
 (`atspeed_bssd_generate`) with one host read-back per verification round instead of the
 reference's per-beam mask calls and `.tolist()` syncs (beamSD.py:62-64,371-372).
 
-Not on this path (raise): sampling (`do_sample`, beamSD.py:293-321,332-369 — SURVEY 8a V'),
-extra `logits_processor` entries (the reference always passes None, inference.py:175-176),
-and mask callables that cannot be compiled to the device automaton.
+Mask functions that can `compile()` (PositionSetConstraint, SuffixTrieConstraint, prefix_allowed_tokens_fn(trie)) run
+as a device automaton; any other callable is served by `hostmask.py` the way the reference does it (one host call per
+beam per step, all arithmetic still in HIP).  Not on this path (raise): sampling (`do_sample`, beamSD.py:293-321,
+332-369 — SURVEY 8a V'), extra `logits_processor` entries (the reference always passes None, inference.py:175-176),
+and no mask at all.
 """
 from __future__ import annotations
 
@@ -82,6 +84,15 @@ class _DeviceFSM:
         self.handle = h
         self.src = fsm.row_ptr       # keeps id() stable while cached
 
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                _lib.load().atspeed_fsm_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
     @classmethod
     def get(cls, fsm: ConstraintFSM, vocab_size: int) -> "_DeviceFSM":
         key = (id(fsm.row_ptr), id(fsm.tok), vocab_size)
@@ -104,6 +115,15 @@ class _Decoder:
         self.handle, self.max_prompt = h, max_prompt
         self.models = (target, draft)
 
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                _lib.load().atspeed_decoder_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
     @classmethod
     def get(cls, target: HipLlama, draft: Optional[HipLlama], prompt_len: int, lane: int = 0) -> "_Decoder":
         """One decoder (= one user stream: private KV + activations) per (model pair, lane)."""
@@ -120,11 +140,6 @@ def _compile_constraint(fn, prompt):
         raise NotImplementedError(
             "unconstrained beam search is not on the MI355X hot path: the reference's harness always installs a "
             "prefix_allowed_tokens_fn (code/inference.py:131,175)")
-    if not hasattr(fn, "compile"):
-        raise TypeError(
-            "prefix_allowed_tokens_fn must be compilable to the device automaton: use atspeed_amd.PositionSetConstraint "
-            "(code/data.py:84-104), SuffixTrieConstraint or prefix_allowed_tokens_fn(trie); arbitrary Python callables "
-            "would need the reference's per-beam host round trip")
     return fn.compile(prompt)
 
 
@@ -161,6 +176,15 @@ def BSSD(target_model, draft_model, inputs: Dict, gamma: int, max_new_tokens: in
     P = int(prompt.numel())
     k = int(target_model.generation_config.num_beams)                 # beamSD.py:482
     dk = int(draft_model.generation_config.num_beams)                 # beamSD.py:483
+    if prefix_allowed_tokens_fn is not None and not hasattr(prefix_allowed_tokens_fn, "compile"):
+        # arbitrary Python callable: served like the reference does, one host call per beam per step (hostmask.py)
+        from .hostmask import bssd_host_mask
+        r = bssd_host_mask(target_model, draft_model, prompt.cpu().numpy().astype(np.int64), int(gamma), int(max_new_tokens),
+                           prefix_allowed_tokens_fn)
+        out = {"beam_sequence": torch.from_numpy(r["beam_sequence"]).to(dev), "beam_scores": torch.from_numpy(r["beam_scores"]).to(dev)}
+        out.update({kk: r[kk] for kk in ("n_run", "total_accept_steps", "total_accept_tokens", "ave_accept_tokens", "accept_steps")})
+        out.update({"draft_time_cost": 0.0, "target_time_cost": 0.0, "verify_time_cost": 0.0, "n_valid": int(len(r["beam_scores"]))})
+        return out
     # the mask functions look at the prompt (position of "Response:", data.py:97-102): one D2H copy per
     # user, where the reference does one per beam per step (generation_trie.py:94, data.py:98)
     fsm = _compile_constraint(prefix_allowed_tokens_fn, prompt.tolist())
@@ -268,6 +292,11 @@ def target_generate(model, inputs: Dict, max_new_tokens: int, logits_processor=N
     prompt = _prompt_row(inputs).to(dev)
     P = int(prompt.numel())
     k = int(model.generation_config.num_beams)                        # beamSD.py:553
+    if prefix_allowed_tokens_fn is not None and not hasattr(prefix_allowed_tokens_fn, "compile"):
+        from .hostmask import target_generate_host_mask
+        r = target_generate_host_mask(model, prompt.cpu().numpy().astype(np.int64), int(max_new_tokens), prefix_allowed_tokens_fn)
+        return {"beam_sequence": torch.from_numpy(r["beam_sequence"]).to(dev), "beam_scores": torch.from_numpy(r["beam_scores"]).to(dev),
+                "n_valid": int(len(r["beam_scores"]))}
     fsm = _compile_constraint(prefix_allowed_tokens_fn, prompt.tolist())
     dfsm = _DeviceFSM.get(fsm, model.dims.vocab_size)
     dec = _Decoder.get(model, None, P)

@@ -1,0 +1,234 @@
+"""Compatibility path for ARBITRARY `prefix_allowed_tokens_fn(batch_id, sentence) -> List[int]` callables.
+
+The fast path compiles the mask into a device automaton (`generation_trie.ConstraintFSM`).  A callable that
+cannot be compiled (any closure, e.g. the one `BaseDataset.get_prefix_allowed_tokens_fn` returns at
+`code/data.py:96-104`) is served here the way the reference serves every mask: the function is called on the host
+once per beam per step (`code/beamSD.py:60-64,286-291` through HF's `PrefixConstrainedLogitsProcessor`).  All
+arithmetic still runs in libatspeed_hip — forwards (`atspeed_llama_forward`), the full-vocabulary normaliser
+(`atspeed_lse_rows`), mask + expand + top-K (`atspeed_beam_expand_prune` over a per-step automaton whose node r
+holds row r's allowed list) and the acceptance test (`atspeed_accept`); only the mask lists and the small beam
+tables cross PCIe, with one synchronisation per step like the reference.  One user at a time.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model import HipLlama
+
+
+class _Inputs:
+    """Host-side description of one forward: tokens, positions, KV slots and visibility rows (bool [T, S])."""
+
+    def __init__(self, ids, pos, slots, vis):
+        self.ids = np.asarray(ids, np.int32)
+        self.pos = np.asarray(pos, np.int32)
+        self.slots = np.asarray(slots, np.int32)
+        self.vis = np.asarray(vis, bool)
+
+
+def _pad(v: np.ndarray, width: int) -> np.ndarray:
+    if v.shape[1] >= width:
+        return v[:, :width]
+    return np.concatenate((v, np.zeros((v.shape[0], width - v.shape[1]), bool)), axis=1)
+
+
+def _vis_bits(vis: np.ndarray, max_slots: int) -> np.ndarray:
+    T, S = vis.shape
+    full = np.zeros((T, max_slots), bool)
+    full[:, :S] = vis
+    return np.packbits(full.reshape(T, max_slots // 64, 64), axis=-1, bitorder="little").view(np.uint64).reshape(T, max_slots // 64).view(np.int64)
+
+
+def _forward(model: HipLlama, inp: _Inputs, n_rows: int):
+    """-> (logits [n_rows, ld] device view with row stride ld, lse [n_rows] device)."""
+    dev = model.device
+    lib = _lib.load()
+    T = len(inp.ids)
+    S = inp.vis.shape[1]
+    with torch.cuda.device(dev):
+        ids = torch.from_numpy(inp.ids).to(dev)
+        pos = torch.from_numpy(inp.pos).to(dev)
+        slots = torch.from_numpy(inp.slots).to(dev)
+        bits = torch.from_numpy(_vis_bits(inp.vis, model.max_slots)).to(dev)
+        ld = model.logits_ld
+        logits = torch.empty(n_rows * ld, dtype=torch.float32, device=dev)
+        _lib.check(lib.atspeed_llama_forward(model._handle, ids.data_ptr(), pos.data_ptr(), slots.data_ptr(), bits.data_ptr(),
+                                             T, S, n_rows, logits.data_ptr(), _lib.stream_ptr(dev)))
+        lse = torch.empty(n_rows, dtype=torch.float32, device=dev)
+        _lib.check(lib.atspeed_lse_rows(logits.data_ptr(), n_rows, model.dims.vocab_size, ld, lse.data_ptr(), _lib.stream_ptr(dev)))
+    return logits, lse
+
+
+def _allowed_lists(fn: Callable, seqs: np.ndarray) -> List[List[int]]:
+    out = []
+    for r in range(seqs.shape[0]):
+        al = fn(0, torch.from_numpy(seqs[r]))        # batch id 0: _num_beams is poked to the row count (beamSD.py:56,281)
+        if len(al) == 0:                              # TypeError when fn returned None, like the HF processor
+            raise ValueError("`prefix_allowed_tokens_fn` returned an empty list for batch ID 0."
+                             "This means that the constraint is unsatisfiable. Please check your implementation"
+                             "of `prefix_allowed_tokens_fn` ")
+        out.append(sorted({int(t) for t in al}))
+    return out
+
+
+def _expand_prune(model: HipLlama, logits, lse, row_ids: Sequence[int], beam_scores: np.ndarray,
+                  allowed: List[List[int]], k: int):
+    """Mask + add beam scores + top-k on the device (beamSD.py:60-78).  `row_ids[r]` = logits row of candidate row r.
+    Returns host arrays (score, parent(row index r), token, flat = r*V + token), only real beams (finite scores)."""
+    lib = _lib.load()
+    dev = model.device
+    V = model.dims.vocab_size
+    n = len(allowed)
+    row_ptr = np.zeros(n + 1, np.int32)
+    row_ptr[1:] = np.cumsum([len(a) for a in allowed])
+    tok = np.asarray([t for a in allowed for t in a], np.int32)
+    nxt = np.zeros(len(tok), np.int32)
+    fsm = C.c_void_p()
+    _lib.check(lib.atspeed_fsm_create(row_ptr.ctypes.data, tok.ctypes.data, nxt.ctypes.data, n, len(tok), V, C.byref(fsm)))
+    try:
+        with torch.cuda.device(dev):
+            ld = model.logits_ld
+            rows = torch.as_tensor(list(row_ids), dtype=torch.int64, device=dev)
+            lg = logits.view(-1, ld)[rows].contiguous()               # gather the candidate rows (verify keeps only hit beams)
+            ls = lse[rows].contiguous()
+            bs = torch.from_numpy(np.asarray(beam_scores, np.float32)).to(dev)
+            nd = torch.arange(n, dtype=torch.int32, device=dev)
+            o_s = torch.empty(k, dtype=torch.float32, device=dev)
+            o_p, o_t, o_n, o_f = (torch.empty(k, dtype=torch.int32, device=dev) for _ in range(4))
+            _lib.check(lib.atspeed_beam_expand_prune(lg.data_ptr(), ld, ls.data_ptr(), bs.data_ptr(), nd.data_ptr(), n, fsm, k,
+                                                     o_s.data_ptr(), o_p.data_ptr(), o_t.data_ptr(), o_n.data_ptr(), o_f.data_ptr(),
+                                                     _lib.stream_ptr(dev)))
+            s, p, t, f = (x.cpu().numpy() for x in (o_s, o_p, o_t, o_f))
+    finally:
+        lib.atspeed_fsm_destroy(fsm)
+    keep = f >= 0
+    return s[keep], p[keep].astype(np.int64), t[keep].astype(np.int64), f[keep].astype(np.int64)
+
+
+def _one_step(model: HipLlama, inp: _Inputs, k: int, beam_scores: np.ndarray, beam_seq: np.ndarray, fn: Callable) -> Dict:
+    """one_step_beam_search (beamSD.py:40-106)."""
+    n = len(beam_scores)
+    logits, lse = _forward(model, inp, n)
+    seqs = beam_seq[:1] if (n == 1 and k != 1) else beam_seq                       # :61-64
+    s, p, t, f = _expand_prune(model, logits, lse, range(n), beam_scores, _allowed_lists(fn, seqs), k)
+    keep = (t >= 32000) | (t == 2)                                                  # :80-86 (hard-coded Llama vocab / EOS)
+    s, p, t, f = s[keep], p[keep], t[keep], f[keep]
+    m = len(t)
+    S = inp.vis.shape[1]
+    vis = np.concatenate((inp.vis[-n:][p], np.eye(m, dtype=bool)), axis=1)          # :89
+    nxt = _Inputs(t, np.full(m, inp.pos[-1] + 1), np.arange(S, S + m), vis)         # :91
+    return dict(flat=f, scores=s, parents=p, tokens=t, seq=np.concatenate((beam_seq[p], t[:, None]), axis=1), next=nxt)
+
+
+def _causal(ids: np.ndarray) -> _Inputs:
+    n = len(ids)
+    return _Inputs(ids, np.arange(n), np.arange(n), np.tril(np.ones((n, n), bool)))
+
+
+def target_generate_host_mask(model: HipLlama, prompt: np.ndarray, max_new_tokens: int, fn: Callable) -> Dict:
+    k = int(model.generation_config.num_beams)
+    inp = _causal(prompt)
+    scores = np.zeros(1, np.float32)
+    seq = np.repeat(prompt[None, :], k, axis=0)
+    for _ in range(max_new_tokens):                                                 # beamSD.py:579-588
+        o = _one_step(model, inp, k, scores, seq, fn)
+        inp, scores, seq = o["next"], o["scores"], o["seq"]
+    return dict(beam_sequence=seq, beam_scores=scores)
+
+
+def bssd_host_mask(target: HipLlama, draft: HipLlama, prompt: np.ndarray, gamma: int, max_new_tokens: int, fn: Callable) -> Dict:
+    """BSSD (beamSD.py:458-542) with the mask function on the host."""
+    lib = _lib.load()
+    k, dk = int(target.generation_config.num_beams), int(draft.generation_config.num_beams)
+    V = target.dims.vocab_size
+    cur_len, max_len = len(prompt), len(prompt) + max_new_tokens
+    tin = din = _causal(prompt)
+    scores = np.zeros(1, np.float32)
+    seq = np.repeat(prompt[None, :], k, axis=0)
+    accept_steps: List[int] = []
+    while cur_len < max_len:
+        dl = min(gamma, max_len - cur_len - 1)                                      # :504
+        if dl == 0:                                                                 # :505-509
+            o = _one_step(target, tin, k, scores, seq, fn)
+            seq, scores = o["seq"], o["scores"]
+            break
+        # ---- draft (:108-179)
+        steps, inp, d_scores, d_seq = [], din, scores, seq
+        step_len, step_seq = [len(scores)], [seq]
+        for _ in range(dl):
+            o = _one_step(draft, inp, dk, d_scores, d_seq, fn)
+            inp, d_scores, d_seq = o["next"], o["scores"], o["seq"]
+            steps.append(o)
+            step_len.append(len(d_scores))
+            step_seq.append(d_seq)
+        # ---- target: one forward over round inputs ++ every draft block (:190-232)
+        blocks = [tin] + [o["next"] for o in steps]
+        width = max(b.vis.shape[1] for b in blocks)
+        packed = _Inputs(np.concatenate([b.ids for b in blocks]), np.concatenate([b.pos for b in blocks]),
+                         np.concatenate([b.slots for b in blocks]), np.concatenate([_pad(b.vis, width) for b in blocks], axis=0))
+        n_rows = sum(step_len)
+        logits, lse = _forward(target, packed, n_rows)
+        # ---- verify (:242-456, greedy)
+        n0 = len(tin.ids)
+        nm, lo, hi = 0, 0, step_len[0]
+        hit = hit4 = None
+        v_scores = scores
+        for i in range(dl + 1):
+            rows = list(range(lo, hi))
+            if nm != dl:
+                lo, hi = hi, hi + step_len[i + 1]
+            seqs = step_seq[i]
+            if i > 0:
+                rows = [rows[h] for h in hit]
+                seqs = seqs[hit]
+                v_scores = v_scores[hit4]
+            if i == 0 and len(rows) == 1 and k != 1:
+                seqs = seqs[:1]
+            s, p, t, f = _expand_prune(target, logits, lse, rows, v_scores, _allowed_lists(fn, seqs), k)
+            v_scores = s
+            parents = hit[p] if i > 0 else p
+            flat = parents * V + t
+            if nm == dl:
+                break
+            d_flat = steps[i]["flat"]
+            kk, dd = len(flat), len(d_flat)
+            with torch.cuda.device(target.device):                                  # acceptance on the device (:371-380)
+                tf = torch.from_numpy(flat.astype(np.int32)).cuda()
+                ts = torch.from_numpy(np.asarray(s, np.float32)).cuda()
+                df = torch.from_numpy(d_flat.astype(np.int32)).cuda()
+                h_out = torch.empty(kk, dtype=torch.int32, device="cuda")
+                sb = torch.empty(kk, dtype=torch.float32, device="cuda")
+                acc = torch.empty(1, dtype=torch.int32, device="cuda")
+                _lib.check(lib.atspeed_accept(tf.data_ptr(), ts.data_ptr(), kk, df.data_ptr(), dd, h_out.data_ptr(), sb.data_ptr(),
+                                              acc.data_ptr(), _lib.stream_ptr(target.device)))
+                accepted = bool(acc.item()) and kk == k
+                if accepted:
+                    hit = h_out.cpu().numpy().astype(np.int64)
+            if not accepted:
+                break
+            pos_of = {int(d): j for j, d in enumerate(d_flat)}
+            hit4 = np.argsort(np.asarray([pos_of[int(y)] for y in flat]), kind="stable")
+            nm += 1
+        seq = np.concatenate((step_seq[nm][parents], t[:, None]), axis=1)           # :383
+        scores = v_scores
+        blk_lo = n0 - step_len[0] + sum(step_len[:nm])
+        blk_rows = packed.vis[blk_lo: blk_lo + step_len[nm]]
+        base = int(packed.slots[blk_lo + step_len[nm] - 1]) + 1
+        m = len(t)
+        vis = np.concatenate((_pad(blk_rows, base)[parents], np.eye(m, dtype=bool)), axis=1)
+        tin = _Inputs(t, np.full(m, packed.pos[blk_lo] + 1), np.arange(base, base + m), vis)
+        din = tin
+        if nm == dl:                                                                # :402-416: the draft re-ingests its last block
+            last = steps[dl - 1]["next"]
+            din = _Inputs(np.concatenate((last.ids, tin.ids)), np.concatenate((last.pos, tin.pos)),
+                          np.concatenate((last.slots, tin.slots)), np.concatenate((_pad(last.vis, base + m), vis), axis=0))
+        cur_len += nm + 1
+        accept_steps.append(nm)
+    n_run, total = len(accept_steps), sum(accept_steps)
+    return dict(beam_sequence=seq, beam_scores=scores, n_run=n_run, total_accept_steps=total, total_accept_tokens=total * k,
+                ave_accept_tokens=total * k / n_run if n_run else 0.0, accept_steps=accept_steps)

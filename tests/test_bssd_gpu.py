@@ -182,8 +182,6 @@ def test_api_errors():
     ci = build_case_inputs(CASES[0])
     tgt, drf = _models(ci, CASES[0])
     inputs = {"input_ids": torch.from_numpy(ci["prompt"])[None, :].cuda()}
-    with pytest.raises(TypeError):
-        BSSD(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=lambda b, s: [1])
     with pytest.raises(NotImplementedError):
         BSSD(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=None)
     with pytest.raises(TypeError):       # separator absent: the reference's fn returns None -> TypeError in HF
@@ -195,3 +193,85 @@ def test_api_errors():
     # position-set mask exhausted (5th generated token after EOS): HF raises ValueError on the empty list
     with pytest.raises((ValueError, KeyError)):
         target_generate(tgt, inputs, 6, prefix_allowed_tokens_fn=ci["fn"])
+
+
+def test_capacity_limits_are_reported_not_faulted():
+    """Sizes beyond the handles' limits must come back as status codes (AtSpeedError), never as a device fault."""
+    from atspeed_amd._lib import AtSpeedError
+    case = CASES[0]
+    ci = build_case_inputs(case)
+    kw = dict(max_slots=128, max_tokens=128, max_logit_rows=128)
+    t = HipLlama.from_state_dict(ci["target_dims"], ci["target_sd"], torch.float32, num_beams=20, **kw)
+    d = HipLlama.from_state_dict(ci["draft_dims"], ci["draft_sd"], torch.float32, num_beams=40, **kw)
+    inputs = {"input_ids": torch.from_numpy(ci["prompt"])[None, :].cuda()}
+    with pytest.raises(AtSpeedError) as e:           # 24 + 3*40 tokens need 144 KV slots > 128
+        BSSD(t, d, inputs, 4, 4, prefix_allowed_tokens_fn=ci["fn"])
+    assert e.value.status == -3
+    t.generation_config.num_beams = 65               # > ATSPEED_MAX_BEAMS
+    with pytest.raises(AtSpeedError):
+        target_generate(t, inputs, 4, prefix_allowed_tokens_fn=ci["fn"])
+    t.generation_config.num_beams = 20
+    d.generation_config.num_beams = 10               # draft beams < target beams
+    with pytest.raises(AtSpeedError):
+        BSSD(t, d, inputs, 4, 4, prefix_allowed_tokens_fn=ci["fn"])
+    d.generation_config.num_beams = 40
+    with pytest.raises(AtSpeedError):                # gamma beyond ATSPEED_MAX_GAMMA
+        BSSD(t, d, inputs, 9, 4, prefix_allowed_tokens_fn=ci["fn"])
+    long_prompt = synth.synthetic_prompt(600, 1)
+    with pytest.raises(AtSpeedError):                # prompt longer than the decoder was built for
+        target_generate(t, {"input_ids": torch.from_numpy(long_prompt)[None].cuda()}, 4, prefix_allowed_tokens_fn=ci["fn"])
+    # and the handles still work afterwards
+    t2 = HipLlama.from_state_dict(ci["target_dims"], ci["target_sd"], torch.float32, num_beams=5, max_slots=256, max_tokens=256, max_logit_rows=128)
+    out = target_generate(t2, inputs, 4, prefix_allowed_tokens_fn=ci["fn"])
+    assert out["beam_sequence"].shape == (5, len(ci["prompt"]) + 4)
+
+
+def test_max_beams_and_long_generation():
+    """K = DK = 64 (ATSPEED_MAX_BEAMS) and 7 generated positions on the tiny models: lossless vs plain beam search."""
+    case = [c for c in CASES if c["name"] == "k20_dk40_new7_gamma2"][0]
+    ci = build_case_inputs(case)
+    kw = dict(max_slots=1024, max_tokens=640, max_logit_rows=512)
+    t = HipLlama.from_state_dict(ci["target_dims"], ci["target_sd"], torch.float32, num_beams=64, **kw)
+    d = HipLlama.from_state_dict(ci["draft_dims"], ci["draft_sd"], torch.float32, num_beams=64, **kw)
+    inputs = {"input_ids": torch.from_numpy(ci["prompt"])[None, :].cuda()}
+    a = BSSD(t, d, inputs, 3, 7, prefix_allowed_tokens_fn=ci["fn"])
+    b = target_generate(t, inputs, 7, prefix_allowed_tokens_fn=ci["fn"])
+    assert a["beam_sequence"].shape == (64, len(ci["prompt"]) + 7)
+    assert torch.equal(a["beam_sequence"], b["beam_sequence"])
+    np.testing.assert_allclose(a["beam_scores"].cpu().numpy(), b["beam_scores"].cpu().numpy(), atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["k20_dk40_sigma01_s7", "k20_dk40_sigma0", "k5_dk10_indep", "k20_dk40_trie", "k6_dk12_new7_gamma3_s9"])
+def test_arbitrary_python_mask_callable(name, bssd_golden):
+    """A plain closure (no compile()) takes the host-mask path: same answers as the reference."""
+    case = [c for c in CASES if c["name"] == name][0]
+    gold = bssd_golden[name]
+    ci = build_case_inputs(case)
+    tgt, drf = _models(ci, case)
+    con = ci["fn"]
+    calls = []
+    def closure(batch_id, sentence):                  # what BaseDataset.get_prefix_allowed_tokens_fn returns (data.py:96-104)
+        calls.append(batch_id)
+        return con(batch_id, sentence)
+    inputs = {"input_ids": torch.from_numpy(ci["prompt"])[None, :].cuda()}
+    P = len(ci["prompt"])
+    tg = target_generate(tgt, inputs, case["max_new_tokens"], prefix_allowed_tokens_fn=closure)
+    nv = len(gold["tg_tokens"])
+    assert tg["beam_sequence"][:, P:].cpu().tolist() == gold["tg_tokens"]
+    np.testing.assert_allclose(tg["beam_scores"].cpu().numpy(), gold["tg_scores"], atol=SCORE_TOL, rtol=0)
+    out = BSSD(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=closure)
+    assert out["beam_sequence"][:, P:].cpu().tolist() == gold["bssd_tokens"]
+    np.testing.assert_allclose(out["beam_scores"].cpu().numpy(), gold["bssd_scores"], atol=SCORE_TOL, rtol=0)
+    assert (out["n_run"], out["total_accept_steps"]) == (gold["n_run"], gold["total_accept_steps"])
+    assert out["accept_steps"] == [r["n_matches"] for r in gold["rounds"]]
+    assert calls and set(calls) == {0} and nv > 0
+
+
+def test_python_mask_callable_errors():
+    ci = build_case_inputs(CASES[0])
+    tgt, drf = _models(ci, CASES[0])
+    inputs = {"input_ids": torch.from_numpy(ci["prompt"])[None, :].cuda()}
+    with pytest.raises(ValueError):                   # HF: empty allowed list
+        target_generate(tgt, inputs, 2, prefix_allowed_tokens_fn=lambda b, s: [])
+    with pytest.raises(TypeError):                    # the reference's fn returns None when "Response:" is absent
+        target_generate(tgt, inputs, 2, prefix_allowed_tokens_fn=lambda b, s: None)
