@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--new-tokens", type=int, default=4)
     ap.add_argument("--seed", type=int, default=2025)
     ap.add_argument("--streams", type=int, default=32, help="users decoded in lock step per GPU (one batched forward per draft step / verification); 1 = the reference's one-user-at-a-time loop")
+    ap.add_argument("--single-stream-users", type=int, default=6, help="extra untimed-for-value pass: users decoded one at a time (the reference's loop)")
     ap.add_argument("--cpu-baseline-users", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -159,6 +160,30 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = target.profile(0)
 
+    # ---- the reference's own regime, for the record (not part of `value`): a few users strictly one at a time.
+    # Here every projection is one pass over the weights (M ~ 20-230 tokens): HBM-bound.
+    single = None
+    if rank == 0 and args.streams > 1 and args.single_stream_users > 0:
+        n1 = min(args.single_stream_users, args.steps)
+        BSSD(target, draft, dprompts[args.warmup], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
+        target.profile(1)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for u in range(args.warmup, args.warmup + n1):
+            BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
+        torch.cuda.synchronize(dev)
+        dt1 = time.perf_counter() - t1
+        p1 = target.profile(0)
+        k1 = max(p1, key=lambda k: p1[k]["ms"])
+        N1, K1 = target.gemm_shape(k1)
+        m1 = p1[k1]["rows"] / max(1, p1[k1]["count"])
+        b1 = N1 * K1 * 2 + m1 * K1 * 2 + m1 * (N1 // 2 if k1 == "gate_up" else N1) * (4 if k1 == "lm_head" else 2)
+        us1 = 1e3 * p1[k1]["ms"] / max(1, p1[k1]["count"])
+        single = dict(users=n1, items_per_s=n1 * args.beam / dt1, ms_per_user=1e3 * dt1 / n1,
+                      roofline=dict(bound="hbm", kernel=f"gemm_kernel<bf16>[{k1}] N={N1} K={K1} avg_M={m1:.0f}",
+                                    achieved=b1 / (us1 * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                    frac=b1 / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, avg_launch_us=us1))
+
     per_rank = all_gather_counters(Counters(args.steps, n_run, acc, int(elapsed * 1e9)), dev)   # the path's single collective
     if rank != 0:
         if world > 1:
@@ -213,6 +238,7 @@ def main():
         "per_user": {"n_run": total_runs / users, "target_forwards": n_tf / args.steps, "draft_forwards": n_df / args.steps,
                      "draft_ms": 1e3 * stage[0] / args.steps, "target_ms": 1e3 * stage[1] / args.steps, "verify_ms": 1e3 * stage[2] / args.steps},
         "roofline": roofline,
+        "single_user_stream": single,
     }
     if world == 1 and not args.no_cpu_baseline:
         cb, ref_outs = cpu_baseline(target, draft, prompts[args.warmup:], fn, args)
