@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q,
 
 // ---------------------------------------------------------------------------- MFMA kernel (bf16)
 // blockIdx.x walks the 64-row query tiles of all segments (tile -> segment through the table's qtile arrays)
-template <int DH>
-__global__ __launch_bounds__(256) void tree_attn_mfma_kernel(const bf16_t* __restrict__ q, int ldq, const SegTable* __restrict__ tab,
+template <int DH, int NW>   // NW waves per workgroup = 16*NW query rows per tile
+__global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* __restrict__ q, int ldq, const SegTable* __restrict__ tab,
                                                              size_t layer_off, int vis_words,
                                                              bf16_t* __restrict__ out, int ldo,
                                                              int n_heads, float scale) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void tree_attn_mfma_kernel(const bf16_t* __res
   const bf16_t* kc = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(sg.kc) + layer_off);
   const bf16_t* vc = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(sg.vc) + layer_off);
   const int n_slots = sg.n_slots;
-  const int lrow = tab->qtile_idx[blockIdx.x] * 64 + wave * 16 + lq;         // row inside the segment
+  const int lrow = tab->qtile_idx[blockIdx.x] * (16 * NW) + wave * 16 + lq;  // row inside the segment
   const bool qok = lrow < sg.n_tok;
   const int qrow = sg.row0 + lrow;                                           // row in the batched buffers
   const uint64_t* vis_row = sg.vis + (size_t)lrow * vis_words;
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(256) void tree_attn_mfma_kernel(const bf16_t* __res
     __syncthreads();                                   // previous tile fully consumed
     // ---- stage K (swizzled rows) and V^T
 #pragma unroll
-    for (int i = 0; i < (64 * KCH) / 256; ++i) {
-      int qi = tid + i * 256;
+    for (int i = 0; i < (64 * KCH) / (64 * NW); ++i) {
+      int qi = tid + i * (64 * NW);
       int r = qi / KCH, c = qi % KCH;
       int key = kt * 64 + r;
       uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
@@ -243,10 +243,18 @@ int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const Seg
   float scale = 1.0f / sqrtf((float)head_dim);
   if (dtype == ATSPEED_BF16 && (head_dim == 64 || head_dim == 128) && (ldq % 8) == 0 && (ldo % 4) == 0) {
     dim3 mgrid(t.n_qtiles, n_heads);
-    if (head_dim == 128)
-      tree_attn_mfma_kernel<128><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
-    else
-      tree_attn_mfma_kernel<64><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+    ATS_REQUIRE(t.qtile_rows == 64 || t.qtile_rows == 128, ATSPEED_ERR_INVALID, "attention: query tile of %d rows", t.qtile_rows);
+    if (t.qtile_rows == 128) {
+      if (head_dim == 128)
+        tree_attn_mfma_kernel<128, 8><<<mgrid, 512, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+      else
+        tree_attn_mfma_kernel<64, 8><<<mgrid, 512, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+    } else {
+      if (head_dim == 128)
+        tree_attn_mfma_kernel<128, 4><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+      else
+        tree_attn_mfma_kernel<64, 4><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+    }
     ATS_LAUNCH_CHECK();
     return ATSPEED_OK;
   }
@@ -268,9 +276,9 @@ int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* v
   t.seg[0].vis = vis; t.seg[0].kc = const_cast<void*>(kcache); t.seg[0].vc = const_cast<void*>(vcache);
   t.seg[0].row0 = 0; t.seg[0].n_tok = n_tokens; t.seg[0].n_slots = n_slots;
   ATS_REQUIRE(n_slots <= vis_words * 64, ATSPEED_ERR_CAPACITY, "attention: %d slots exceed the visibility bitset (%d words)", n_slots, vis_words);
-  ATS_REQUIRE((n_tokens + 63) / 64 <= ATS_MAX_QTILES, ATSPEED_ERR_CAPACITY, "attention: too many query rows");
-  t.n_qtiles = 0;
-  for (int j = 0; j * 64 < n_tokens; ++j) { t.qtile_seg[t.n_qtiles] = 0; t.qtile_idx[t.n_qtiles++] = (unsigned char)j; }
+  ATS_REQUIRE((n_tokens + 63) / 64 <= 255, ATSPEED_ERR_CAPACITY, "attention: too many query rows");
+  t.n_qtiles = 0; t.qtile_rows = n_tokens > 96 ? 128 : 64;
+  for (int j = 0; j * t.qtile_rows < n_tokens; ++j) { t.qtile_seg[t.n_qtiles] = 0; t.qtile_idx[t.n_qtiles++] = (unsigned char)j; }
   const void* dt = nullptr;
   ATS_TRY(ats_stage(&t, sizeof(t), &dt, st));
   return ats_tree_attention_segs(q, ldq, t, (const SegTable*)dt, 0, vis_words, out, ldo, n_heads, head_dim, dtype, st);

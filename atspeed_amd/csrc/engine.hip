@@ -382,8 +382,8 @@ extern "C" int atspeed_llama_forward(atspeed_llama* m, const int32_t* ids, const
   Seg& s = t.seg[0];
   s.ids = ids; s.pos = pos; s.slot = slots; s.vis = vis; s.kc = m->kv0.k; s.vc = m->kv0.v;
   s.row0 = 0; s.n_tok = n_tokens; s.n_slots = n_slots_visible; s.logit_row0 = 0; s.n_logit = n_logit_rows;
-  t.n_qtiles = 0;
-  for (int j = 0; j * 64 < n_tokens; ++j) { t.qtile_seg[t.n_qtiles] = 0; t.qtile_idx[t.n_qtiles++] = (unsigned char)j; }
+  t.n_qtiles = 0; t.qtile_rows = n_tokens > 96 ? 128 : 64;
+  for (int j = 0; j * t.qtile_rows < n_tokens; ++j) { t.qtile_seg[t.n_qtiles] = 0; t.qtile_idx[t.n_qtiles++] = (unsigned char)j; }
   return llama_forward_segs(m, t, logits_out, (hipStream_t)stream);
 }
 
@@ -527,10 +527,13 @@ static Seg make_seg(const TokBuf& tb, int n_tok, int n_slots, int n_logit, const
 }
 static int seg_finish(SegTable& t) {
   t.total_tok = t.total_logit = t.n_qtiles = 0;
+  int long_segs = 0;
+  for (int i = 0; i < t.n; ++i) long_segs += t.seg[i].n_tok > 96 ? 1 : 0;
+  t.qtile_rows = (2 * long_segs >= t.n) ? 128 : 64;       // 128-row tiles halve the K/V re-reads of long segments
   for (int i = 0; i < t.n; ++i) {
     t.seg[i].row0 = t.total_tok; t.total_tok += t.seg[i].n_tok;
     t.seg[i].logit_row0 = t.total_logit; t.total_logit += t.seg[i].n_logit;
-    for (int j = 0; j * 64 < t.seg[i].n_tok; ++j) {
+    for (int j = 0; j * t.qtile_rows < t.seg[i].n_tok; ++j) {
       ATS_REQUIRE(t.n_qtiles < ATS_MAX_QTILES, ATSPEED_ERR_CAPACITY, "forward: too many query tiles in one batch");
       t.qtile_seg[t.n_qtiles] = (unsigned char)i; t.qtile_idx[t.n_qtiles++] = (unsigned char)j;
     }

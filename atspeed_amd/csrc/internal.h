@@ -17,7 +17,8 @@ struct Seg {
 };
 struct SegTable {
   int n, total_tok, total_logit;
-  int n_qtiles;                                   // 64-row query tiles of all segments (attention grid)
+  int n_qtiles;                                   // query tiles of all segments (attention grid)
+  int qtile_rows;                                 // rows per query tile: 64 (4 waves) or 128 (8 waves, halves the K/V re-reads)
   Seg seg[ATS_MAX_SEGS];
   unsigned char qtile_seg[ATS_MAX_QTILES], qtile_idx[ATS_MAX_QTILES];
 };

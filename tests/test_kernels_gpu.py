@@ -270,10 +270,11 @@ def test_accept_equals_reference_logic(lib, k, dk, kind):
 
 # ------------------------------------------------------------------ attention
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T", [23, 150])            # 150 rows take the 8-wave / 128-row-tile kernel
 @pytest.mark.parametrize("heads,dh", [(4, 32), (12, 64), (32, 128)])
-def test_tree_attention(lib, dtype, heads, dh):
+def test_tree_attention(lib, dtype, heads, dh, T):
     from atspeed_amd.model import vis_bits_from_bool
-    T, S, max_slots = 23, 150, 256
+    S, max_slots = 150, 256
     H = heads * dh
     q = _rand((T, 3 * H), 31).to(dtype).cuda()
     kc = _rand((max_slots, H), 32).to(dtype).cuda()
