@@ -49,6 +49,9 @@ SIGNATURES = {
     "atspeed_llama_destroy": (None, [_P]),
     "atspeed_llama_forward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "atspeed_llama_logits": (_P, [_P]),
+    "atspeed_llama_enable_fp8": (C.c_int, [_P, _P]),
+    "atspeed_quant_rows_fp8": (C.c_int, [_P, _I, _I, _P, _P, _P]),
+    "atspeed_gemm_fp8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "atspeed_llama_profile": (C.c_int, [_P, _I, _P, _P, _P]),
     "atspeed_llama_logits_ld": (_I, [_P]),
     "atspeed_lse_rows": (C.c_int, [_P, _I, _I, _I, _P, _P]),

@@ -283,3 +283,54 @@ int ats_gather_logit_rows(const void* h, const SegTable& t, const SegTable* dt, 
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
+
+// ---------------------------------------------------------------------------- fp8 (OCP e4m3) row quantisation
+// q[r][c] = e4m3(x[r][c] / scale[r]),  scale[r] = max|x[r][:]| / 448  (per-row = per-token / per-output-channel scales).
+// One workgroup per row, 16-byte loads, 8-byte stores.  Used once for the weights and per forward for the activations
+// feeding the fp8 projections (BASELINE config 5).
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, int cols, int ld,
+                                                             unsigned char* __restrict__ q, float* __restrict__ scale) {
+  __shared__ float red[4];
+  const bf16_t* xr = x + (size_t)blockIdx.x * ld;
+  unsigned char* qr = q + (size_t)blockIdx.x * cols;
+  float amax = 0.f;
+  for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
+    uint4 v = *reinterpret_cast<const uint4*>(xr + c);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(bf2f(e[j])));
+  }
+  amax = wave_max_f32(amax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / sc;
+  if (threadIdx.x == 0) scale[blockIdx.x] = sc;
+  for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
+    uint4 v = *reinterpret_cast<const uint4*>(xr + c);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(bf2f(e[j]) * inv, -448.f), 448.f);
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    *reinterpret_cast<uint2*>(qr + c) = make_uint2((unsigned)lo, (unsigned)hi);
+  }
+}
+
+int ats_quant_rows_fp8(const void* x, int rows, int cols, int ld, void* q, float* scale, hipStream_t st) {
+  if (rows <= 0) return ATSPEED_OK;
+  ATS_REQUIRE(cols % 8 == 0 && ld % 8 == 0, ATSPEED_ERR_INVALID, "quant_fp8: cols=%d / ld=%d must be multiples of 8", cols, ld);
+  quant_rows_fp8_kernel<<<rows, 256, 0, st>>>((const bf16_t*)x, cols, ld, (unsigned char*)q, scale);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+extern "C" int atspeed_quant_rows_fp8(const void* x, int32_t rows, int32_t cols, void* q, float* scale, void* stream) {
+  ATS_REQUIRE(x && q && scale, ATSPEED_ERR_INVALID, "quant_fp8: null argument");
+  return ats_quant_rows_fp8(x, rows, cols, cols, q, scale, (hipStream_t)stream);
+}

@@ -147,6 +147,7 @@ struct ActCtx {
   void *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *act = nullptr, *gath = nullptr;
   float* logits = nullptr;                       // [cap_rows][logits_ld]
   float* lse = nullptr;                          // [cap_rows]
+  void* xq = nullptr; float* sx = nullptr;       // fp8 activations [cap_tok][max(hidden, ffn)] + per-token scales
   void* ws = nullptr; size_t ws_bytes = 0;       // split-K slabs
   // optional per-GEMM hipEvent brackets (bench.py roofline): 0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head
   bool prof_pending = false;
@@ -161,6 +162,9 @@ struct atspeed_llama {
   int esz, head_dim, vis_words, logits_ld;
   size_t layer_kv_bytes;
   float *cos_tab, *sin_tab;                      // [max_slots][head_dim/2]
+  // optional fp8 (e4m3, per-output-row scales) copies of the layer projections, library-owned (atspeed_llama_enable_fp8)
+  struct Fp8Layer { void *wqkv, *wo, *wgu, *wd; float *sqkv, *so, *sgu, *sd; };
+  std::vector<Fp8Layer> fp8;
   KvCache kv0;                                   // cache of the plain atspeed_llama_forward API
   ActCtx* act;                                   // grown on demand (ensure_act)
   bool prof_on = false;
@@ -211,7 +215,7 @@ static size_t gemm_ws_for(const atspeed_llama_config& c, int max_tok, int max_ro
 static void act_free(ActCtx* cx) {
   if (!cx) return;
   hipFree(cx->h); hipFree(cx->xn); hipFree(cx->qkv); hipFree(cx->att); hipFree(cx->act); hipFree(cx->gath);
-  hipFree(cx->logits); hipFree(cx->lse); hipFree(cx->ws);
+  hipFree(cx->logits); hipFree(cx->lse); hipFree(cx->ws); hipFree(cx->xq); hipFree(cx->sx);
   for (hipEvent_t e : cx->prof_ev) hipEventDestroy(e);
   delete cx;
 }
@@ -233,6 +237,8 @@ static int ensure_act(atspeed_llama* m, int tok, int rows) {
   ATS_HIP(hipMalloc(&cx->gath, (size_t)cx->cap_rows * H * e));
   ATS_HIP(hipMalloc((void**)&cx->logits, (size_t)cx->cap_rows * m->logits_ld * sizeof(float)));
   ATS_HIP(hipMalloc((void**)&cx->lse, (size_t)cx->cap_rows * sizeof(float)));
+  ATS_HIP(hipMalloc(&cx->xq, T * (size_t)std::max(c.hidden, c.ffn)));
+  ATS_HIP(hipMalloc((void**)&cx->sx, T * sizeof(float)));
   cx->ws_bytes = gemm_ws_for(c, cx->cap_tok, cx->cap_rows);
   ATS_HIP(hipMalloc(&cx->ws, cx->ws_bytes));
   m->act = cx;
@@ -295,6 +301,7 @@ extern "C" void atspeed_llama_destroy(atspeed_llama* m) {
   if (!m) return;
   kv_free(&m->kv0);
   act_free(m->act);
+  for (auto& f : m->fp8) { hipFree(f.wqkv); hipFree(f.wo); hipFree(f.wgu); hipFree(f.wd); hipFree(f.sqkv); hipFree(f.so); hipFree(f.sgu); hipFree(f.sd); }
   hipFree(m->cos_tab); hipFree(m->sin_tab);
   delete m;
 }
@@ -316,6 +323,39 @@ extern "C" int atspeed_llama_profile(atspeed_llama* m, int32_t enable, double* m
 
 extern "C" float* atspeed_llama_logits(atspeed_llama* m) { return m && m->act ? m->act->logits : nullptr; }
 extern "C" int32_t atspeed_llama_logits_ld(const atspeed_llama* m) { return m ? m->logits_ld : 0; }
+
+extern "C" int atspeed_llama_enable_fp8(atspeed_llama* m, void* stream) {
+  ATS_REQUIRE(m, ATSPEED_ERR_INVALID, "enable_fp8: null model");
+  ATS_REQUIRE(m->cfg.dtype == ATSPEED_BF16, ATSPEED_ERR_INVALID, "enable_fp8: the model must hold bf16 weights");
+  ATS_REQUIRE(m->cfg.hidden % 128 == 0 && m->cfg.ffn % 128 == 0, ATSPEED_ERR_INVALID, "enable_fp8: hidden and ffn must be multiples of 128");
+  if (!m->fp8.empty()) return ATSPEED_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int H = m->cfg.hidden, F = m->cfg.ffn;
+  auto quant = [&](const void* w, int rows, int cols, void** q, float** sc) -> int {
+    ATS_HIP(hipMalloc(q, (size_t)rows * cols));
+    ATS_HIP(hipMalloc((void**)sc, (size_t)rows * sizeof(float)));
+    return ats_quant_rows_fp8(w, rows, cols, cols, *q, *sc, st);
+  };
+  m->fp8.resize(m->cfg.n_layers);
+  for (int l = 0; l < m->cfg.n_layers; ++l) {
+    const atspeed_llama_layer_weights& w = m->layers[l];
+    atspeed_llama::Fp8Layer& f = m->fp8[l];
+    ATS_TRY(quant(w.wqkv, 3 * H, H, &f.wqkv, &f.sqkv));
+    ATS_TRY(quant(w.wo, H, H, &f.wo, &f.so));
+    ATS_TRY(quant(w.wgu, 2 * F, H, &f.wgu, &f.sgu));
+    ATS_TRY(quant(w.wd, H, F, &f.wd, &f.sd));
+  }
+  ATS_HIP(hipStreamSynchronize(st));
+  return ATSPEED_OK;
+}
+
+// fp8 projection when enabled and the shape is on the batched path: quantise the activations per token, then W8A8 GEMM
+static int proj_fp8(atspeed_llama* m, const void* x, const void* wq, const float* sw, void* out, int M, int N, int K, int ldc,
+                    int epi, hipStream_t st) {
+  ActCtx* cx = m->act;
+  ATS_TRY(ats_quant_rows_fp8(x, M, K, K, cx->xq, cx->sx, st));
+  return ats_gemm_fp8(cx->xq, cx->sx, wq, sw, out, M, N, K, ldc, epi, st);
+}
 
 // One forward over the tokens of every segment (user) of the table.  Logits of each segment's last n_logit rows land
 // in act->logits rows [logit_row0, ..) (or in logits_out), their log-sum-exp in act->lse.
@@ -342,16 +382,33 @@ static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits
     const atspeed_llama_layer_weights& w = m->layers[l];
     const size_t loff = (size_t)l * m->layer_kv_bytes;
     // cx->xn holds rmsnorm(h) * input_norm here (from the embed above or the previous layer's fused down_proj epilogue)
+    const bool f8 = !m->fp8.empty();
     { ProfBracket pb(m, 0, T, st);
-      ATS_TRY(ats_gemm(cx->xn, w.wqkv, cx->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, cx->ws, cx->ws_bytes, st)); }
+      if (f8 && ats_gemm_fp8_applies(T, 3 * H, H, 3 * H, EPI_STORE)) {
+        ATS_TRY(proj_fp8(m, cx->xn, m->fp8[l].wqkv, m->fp8[l].sqkv, cx->qkv, T, 3 * H, H, 3 * H, EPI_STORE, st));
+      } else {
+        ATS_TRY(ats_gemm(cx->xn, w.wqkv, cx->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, cx->ws, cx->ws_bytes, st));
+      } }
     ATS_TRY(ats_rope_kv_segs(cx->qkv, t, dtab, m->cos_tab, m->sin_tab, loff, c.n_heads, m->head_dim, c.max_slots, dt, st));
     ATS_TRY(ats_tree_attention_segs(cx->qkv, 3 * H, t, dtab, loff, m->vis_words, cx->att, H, c.n_heads, m->head_dim, dt, st));
     { ProfBracket pb(m, 1, T, st);     // h += att Wo^T ; xn = rmsnorm(h) * post_norm
-      ATS_TRY(ats_gemm_resid_norm(cx->att, w.wo, cx->h, T, H, H, H, H, dt, w.post_norm, cx->xn, c.rms_eps, cx->ws, cx->ws_bytes, st)); }
+      if (f8 && ats_gemm_fp8_applies(T, H, H, H, EPI_RESID)) {
+        ATS_TRY(proj_fp8(m, cx->att, m->fp8[l].wo, m->fp8[l].so, cx->h, T, H, H, H, EPI_RESID, st));
+        ATS_TRY(ats_rmsnorm(cx->h, w.post_norm, cx->xn, T, H, c.rms_eps, dt, st));
+      } else {
+        ATS_TRY(ats_gemm_resid_norm(cx->att, w.wo, cx->h, T, H, H, H, H, dt, w.post_norm, cx->xn, c.rms_eps, cx->ws, cx->ws_bytes, st));
+      } }
     { ProfBracket pb(m, 2, T, st);
-      ATS_TRY(ats_gemm(cx->xn, w.wgu, cx->act, T, 2 * c.ffn, H, H, c.ffn, dt, EPI_SWIGLU, cx->ws, cx->ws_bytes, st)); }
+      if (f8 && ats_gemm_fp8_applies(T, 2 * c.ffn, H, c.ffn, EPI_SWIGLU)) {
+        ATS_TRY(proj_fp8(m, cx->xn, m->fp8[l].wgu, m->fp8[l].sgu, cx->act, T, 2 * c.ffn, H, c.ffn, EPI_SWIGLU, st));
+      } else {
+        ATS_TRY(ats_gemm(cx->xn, w.wgu, cx->act, T, 2 * c.ffn, H, H, c.ffn, dt, EPI_SWIGLU, cx->ws, cx->ws_bytes, st));
+      } }
     { ProfBracket pb(m, 3, T, st);     // h += act Wd^T ; xn = rmsnorm(h) * next layer's input_norm
-      if (l + 1 < c.n_layers) {
+      if (f8 && ats_gemm_fp8_applies(T, H, c.ffn, H, EPI_RESID)) {
+        ATS_TRY(proj_fp8(m, cx->act, m->fp8[l].wd, m->fp8[l].sd, cx->h, T, H, c.ffn, H, EPI_RESID, st));
+        if (l + 1 < c.n_layers) ATS_TRY(ats_rmsnorm(cx->h, m->layers[l + 1].input_norm, cx->xn, T, H, c.rms_eps, dt, st));
+      } else if (l + 1 < c.n_layers) {
         ATS_TRY(ats_gemm_resid_norm(cx->act, w.wd, cx->h, T, H, c.ffn, c.ffn, H, dt, m->layers[l + 1].input_norm, cx->xn, c.rms_eps,
                                     cx->ws, cx->ws_bytes, st));
       } else {

@@ -583,6 +583,197 @@ __global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restr
   }
 }
 
+// ---- fp8 (OCP e4m3) variant: same structure, 1-byte operands with per-row scales (W8A8) ---------------------------
+// A stage row is still 128 bytes = 128 k, so DMA, swizzle and the 24 fragment reads per stage are unchanged while a
+// stage now carries twice the k: half the DMA and LDS bytes per flop (the bf16 kernel is limited by exactly that
+// ingest).  v_mfma_f32_16x16x32_fp8_fp8 takes 8 bytes per lane; a lane's 16-byte fragment chunk feeds two MFMAs (low
+// / high 8 bytes), i.e. the k order inside a 64-k group is permuted identically on both operands.
+// C[m][n] = (sum_k xq[m][k] wq[n][k]) * sx[m] * sw[n], then the usual epilogues.
+template <int EPI, int MT2>
+__global__ __launch_bounds__(512, 1) void gemm_big2_fp8_kernel(const unsigned char* __restrict__ X, const unsigned char* __restrict__ W,
+                                                               const float* __restrict__ sx, const float* __restrict__ sw,
+                                                               void* __restrict__ Cv, int M, int N, int K, int ldc,
+                                                               int tiles_n, int tiles_m, int GM) {
+  const int ldx = K;
+  constexpr int BT = 256, BK = 128;                              // BK in elements = bytes
+  constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
+  constexpr int XJ = XR / 64;                                    // X DMA instructions per wave per stage
+  constexpr int STAGE = (BT + XR) * kRowBytes;                   // W tile then X tile: 64 or 48 KB
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, g = lane >> 4;
+  const int nwg = tiles_n * tiles_m;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+  }
+  // grouped order: bands of GM tile rows, W-panel-major inside a band, so the ~32 tiles an XCD runs at once form a
+  // GM x 8 block sharing GM X panels and 8 W panels (PMC: FETCH_SIZE showed every W panel missing the 4 MB L2)
+  const int band = bid / (GM * tiles_n), rem = bid % (GM * tiles_n);
+  const int band_rows = min(GM, tiles_m - band * GM);
+  const int tn = rem / band_rows, tm = band * GM + rem % band_rows;
+  const int n0 = tn * BT, m0 = tm * XR;
+  const int wn = wave >> 1, wm = wave & 1;
+  const int nk = K / BK;
+
+  const unsigned char* wsrc[4]; const unsigned char* xsrc[XJ];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + (lane >> 3);
+    wsrc[j] = W + (size_t)min(n0 + row, N - 1) * K + ((lane & 7) ^ (row & 7)) * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < XJ; ++j) {
+    const int row = (wave * XJ + j) * 8 + (lane >> 3);
+    xsrc[j] = X + (size_t)min(m0 + row, M - 1) * ldx + ((lane & 7) ^ (row & 7)) * 16;
+  }
+  auto dma_stage = [&](int buf, int kt) {
+    unsigned char* sw = smem + buf * STAGE;
+    unsigned char* sx = sw + BT * kRowBytes;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sw + (wave * 4 + j) * 8 * kRowBytes), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < XJ; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[j] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sx + (wave * XJ + j) * 8 * kRowBytes), 16, 0, 0);
+  };
+  // per-lane fragment addresses inside stage 0 (row lq of the wave's first tile; tile i adds i*16 rows = i*2048 B)
+  unsigned a_addr[2], b_addr[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int sl = ((ks * 4 + g) ^ (lq & 7)) * 16 + lq * kRowBytes;
+    a_addr[ks] = lds_addr(smem) + (wn * 64) * kRowBytes + sl;
+    b_addr[ks] = lds_addr(smem) + BT * kRowBytes + (wm * MT2 * 16) * kRowBytes + sl;
+  }
+
+  f32x4_t acc[4][MT2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MT2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  dma_stage(0, 0);
+  if (nk > 1) dma_stage(1, 1);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned boff = (kt & 1) * STAGE;
+    if (kt + 1 < nk) {                                                      // tile kt landed (this wave's part); kt+1 may fly
+      if constexpr (MT2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                                           // A: tile kt published by every wave
+    u32x4_t af[2][4], bfr[2][MT2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned aa = a_addr[ks] + boff, ba = b_addr[ks] + boff;
+      ATS_DS_READ_B128(af[ks][0], aa, 0);     ATS_DS_READ_B128(af[ks][1], aa, 2048);
+      ATS_DS_READ_B128(af[ks][2], aa, 4096);  ATS_DS_READ_B128(af[ks][3], aa, 6144);
+      ATS_DS_READ_B128(bfr[ks][0], ba, 0);     ATS_DS_READ_B128(bfr[ks][1], ba, 2048);
+      ATS_DS_READ_B128(bfr[ks][2], ba, 4096);  ATS_DS_READ_B128(bfr[ks][3], ba, 6144);
+      if constexpr (MT2 == 8) {
+        ATS_DS_READ_B128(bfr[ks][4], ba, 8192);  ATS_DS_READ_B128(bfr[ks][5], ba, 10240);
+        ATS_DS_READ_B128(bfr[ks][6], ba, 12288); ATS_DS_READ_B128(bfr[ks][7], ba, 14336);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // fragments are in registers
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                                           // B: nobody reads this stage any more
+    if (kt + 2 < nk) dma_stage(kt & 1, kt + 2);                             // refill it two tiles ahead
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)                                        // low / high 8 bytes of the 16-byte fragments
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < MT2; ++j) {
+            const long av = ((long)af[ks][i][2 * hh + 1] << 32) | (long)af[ks][i][2 * hh];
+            const long bv = ((long)bfr[ks][j][2 * hh + 1] << 32) | (long)bfr[ks][j][2 * hh];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(av, bv, acc[i][j], 0, 0, 0);
+          }
+  }
+
+  // per-row scales: acc[i][j][r] *= sx[m] * sw[n]
+#pragma unroll
+  for (int j = 0; j < MT2; ++j) {
+    const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
+    const float fx = sx[min(gm, M - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gn = n0 + wn * 64 + i * 16 + g * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] *= fx * sw[min(gn + r, N - 1)];
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue (as gemm_big_kernel)
+  const bool vec = (ldc & 3) == 0;
+#pragma unroll
+  for (int j = 0; j < MT2; ++j) {
+    const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
+    if (gm >= M) continue;
+    if constexpr (EPI == EPI_SWIGLU) {
+      bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        const int gn = n0 + wn * 64 + i * 16;
+        if (gn >= N) continue;
+        ushort4 o;
+        bf16_t* op = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float gt = bf2f(f2bf(acc[i][j][r])), up = bf2f(f2bf(acc[i + 1][j][r]));
+          op[r] = f2bf(gt / (1.f + __expf(-gt)) * up);
+        }
+        *reinterpret_cast<ushort4*>(C + (size_t)gm * ldc + (gn >> 1) + g * 4) = o;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gn = n0 + wn * 64 + i * 16 + g * 4;
+        if (gn >= N) continue;
+        if constexpr (EPI == EPI_F32) {
+          float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
+          if (gn + 3 < N && vec) *reinterpret_cast<float4*>(C) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          else
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[i][j][r];
+        } else {
+          bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
+          if (gn + 3 < N && vec) {
+            ushort4 o;
+            bf16_t* op = reinterpret_cast<bf16_t*>(&o);
+            if constexpr (EPI == EPI_RESID) {
+              ushort4 rs = *reinterpret_cast<const ushort4*>(C);
+              const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) op[r] = f2bf(bf2f(rp[r]) + bf2f(f2bf(acc[i][j][r])));
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) op[r] = f2bf(acc[i][j][r]);
+            }
+            *reinterpret_cast<ushort4*>(C) = o;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (gn + r < N) {
+                float v = acc[i][j][r];
+                if constexpr (EPI == EPI_RESID) v = bf2f(C[r]) + bf2f(f2bf(v));
+                C[r] = f2bf(v);
+              }
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int EPI>
 int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st) {
   static const int dbg = env_int("ATSPEED_GEMM_BIG_DBG", 0);       // tuning: 1/2 = ablations of the simple loop, 3 = simple loop
@@ -666,6 +857,25 @@ __global__ __launch_bounds__(1024) void splitk_resid_rmsnorm_kernel(const float*
       Elt<T>::store(xn + (size_t)m * N + n, Elt<T>::load(norm_w + n) * v);
     }
   }
+}
+
+template <int EPI>
+int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char* w, const float* sw, void* c, int m, int n, int k,
+                   int ldc, hipStream_t st) {
+  static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
+  const int tiles_n = (n + 255) / 256;
+  static thread_local bool attr_done = false;
+  if (!attr_done) {
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_fp8_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_fp8_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_done = true;
+  }
+  const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
+  const bool use256 = big_fill_pct(t256) >= 80 && big_fill_pct(t256) + 8 >= big_fill_pct(t128);
+  if (use256) hipLaunchKernelGGL((gemm_big2_fp8_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, x, w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 255) / 256, gm);
+  else        hipLaunchKernelGGL((gemm_big2_fp8_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, x, w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 127) / 128, gm);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
 }
 
 struct Plan { int bm; int bn; int splits; int k_per_split; };
@@ -832,6 +1042,34 @@ int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int
   }
   if (!fn.done) return ats_rmsnorm(h, norm_w, xn, m, n, eps, dtype, st);
   return ATSPEED_OK;
+}
+
+bool ats_gemm_fp8_applies(int m, int n, int k, int ldc, int epilogue) {
+  if (m < 512 || k % 128 != 0) return false;
+  if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
+  const int tn = (n + 255) / 256;
+  return big_fill_pct(tn * ((m + 255) / 256)) >= 80 || big_fill_pct(tn * ((m + 127) / 128)) >= 80;
+}
+
+int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int m, int n, int k, int ldc,
+                 int epilogue, hipStream_t st) {
+  ATS_REQUIRE(xq && sx && wq && sw && c, ATSPEED_ERR_INVALID, "gemm_fp8: null argument");
+  ATS_REQUIRE(m >= 1 && n >= 1 && k % 128 == 0, ATSPEED_ERR_INVALID, "gemm_fp8: K=%d must be a multiple of 128", k);
+  ATS_REQUIRE(epilogue != EPI_SWIGLU || ((ldc & 3) == 0 && n % 32 == 0), ATSPEED_ERR_INVALID, "gemm_fp8: SwiGLU needs N %% 32 == 0 and ldc %% 4 == 0");
+  const unsigned char* X = (const unsigned char*)xq; const unsigned char* Wq = (const unsigned char*)wq;
+  switch (epilogue) {
+    case EPI_STORE:  return launch_big_fp8<EPI_STORE>(X, sx, Wq, sw, c, m, n, k, ldc, st);
+    case EPI_F32:    return launch_big_fp8<EPI_F32>(X, sx, Wq, sw, c, m, n, k, ldc, st);
+    case EPI_RESID:  return launch_big_fp8<EPI_RESID>(X, sx, Wq, sw, c, m, n, k, ldc, st);
+    case EPI_SWIGLU: return launch_big_fp8<EPI_SWIGLU>(X, sx, Wq, sw, c, m, n, k, ldc, st);
+  }
+  atspeed_set_error("gemm_fp8: unknown epilogue %d", epilogue);
+  return ATSPEED_ERR_INVALID;
+}
+
+extern "C" int atspeed_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int32_t m, int32_t n,
+                                int32_t k, int32_t ldc, int32_t epilogue, void* stream) {
+  return ats_gemm_fp8(xq, sx, wq, sw, c, m, n, k, ldc, epilogue, (hipStream_t)stream);
 }
 
 extern "C" int atspeed_gemm(const void* a, const void* w, void* c, int32_t m, int32_t n, int32_t k, int32_t lda,

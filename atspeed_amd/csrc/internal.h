@@ -49,6 +49,13 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
 int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int k, int lda, int ldh, int dtype,
                         const void* norm_w, void* xn, float eps, void* workspace, size_t workspace_bytes, hipStream_t st);
 
+// fp8 (e4m3, per-row scales) variants of the batched projections; returns ATSPEED_ERR_INVALID if the shape does not
+// qualify (ats_gemm_fp8_applies)
+int ats_quant_rows_fp8(const void* x, int rows, int cols, int ld, void* q, float* scale, hipStream_t st);
+bool ats_gemm_fp8_applies(int m, int n, int k, int ldc, int epilogue);
+int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int m, int n, int k, int ldc,
+                 int epilogue, hipStream_t st);
+
 // ---- attn.hip -------------------------------------------------------------------------
 int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* vcache, const uint64_t* vis,
                        int vis_words, void* out, int ldo, int n_tokens, int n_slots, int n_heads, int head_dim,

@@ -150,6 +150,13 @@ class HipLlama:
             del sd
         return cls(dims, packed, dtype, device, **kw)
 
+    def enable_fp8(self) -> "HipLlama":
+        """fp8 (e4m3, W8A8 with per-row scales) layer projections for the batched forwards (BASELINE config 5)."""
+        with torch.cuda.device(self._device):
+            _lib.check(_lib.load().atspeed_llama_enable_fp8(self._handle, _lib.stream_ptr(self._device)))
+        self.fp8 = True
+        return self
+
     # ---- measurement hooks --------------------------------------------------------------
     GEMM_KINDS = ("qkv", "o_proj", "gate_up", "down", "lm_head")
 

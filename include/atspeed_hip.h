@@ -123,6 +123,12 @@ float* atspeed_llama_logits(atspeed_llama* m);
  * enable < 0 only reads.  Measurement hook for bench.py's roofline (no reference counterpart). */
 int atspeed_llama_profile(atspeed_llama* m, int32_t enable, double* ms_out, int64_t* count_out, int64_t* rows_out);
 int32_t atspeed_llama_logits_ld(const atspeed_llama* m);
+/* BASELINE config 5 (fp8 target verification): build OCP-e4m3 copies of the layer projections (per-output-row scales,
+ * library-owned) from the bf16 weights.  From then on the batched forwards (M >= 512 tokens, shapes that fill the chip)
+ * quantise activations per token and run W8A8 MFMA GEMMs (v_mfma_f32_16x16x32_fp8_fp8, fp32 accumulate); smaller
+ * forwards, the lm_head, norms, attention and the KV cache stay bf16.  No reference counterpart (its target is int8
+ * weights via bitsandbytes, inference.py:88). */
+int atspeed_llama_enable_fp8(atspeed_llama* m, void* stream);
 
 /* ------------------------------------------------------------------ scan kernels
  * log-softmax normaliser over the FULL vocabulary, before masking (beamSD.py:58,285):
@@ -201,6 +207,10 @@ int atspeed_decoder_trace(atspeed_decoder* d, int32_t* rounds_out, int32_t cap);
 int atspeed_gemm(const void* a_dev, const void* w_dev, void* c_dev, int32_t m, int32_t n, int32_t k,
                  int32_t lda, int32_t ldc, int32_t dtype, int32_t epilogue, void* workspace_dev,
                  size_t workspace_bytes, void* stream);
+/* per-row e4m3 quantisation q = e4m3(x / scale[r]), scale[r] = max|x[r]| / 448, and the W8A8 GEMM over such operands */
+int atspeed_quant_rows_fp8(const void* x_bf16_dev, int32_t rows, int32_t cols, void* q_dev, float* scale_dev, void* stream);
+int atspeed_gemm_fp8(const void* xq_dev, const float* sx_dev, const void* wq_dev, const float* sw_dev, void* c_dev, int32_t m,
+                     int32_t n, int32_t k, int32_t ldc, int32_t epilogue, void* stream);
 int atspeed_rmsnorm(const void* x_dev, const void* w_dev, void* y_dev, int32_t rows, int32_t hidden,
                     float eps, int32_t dtype, void* stream);
 /* tree attention over a slot-addressed KV cache ([max_slots][hidden] per K and V) */

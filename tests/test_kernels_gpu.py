@@ -297,3 +297,60 @@ def test_tree_attention(lib, dtype, heads, dh, T):
     sc = sc.masked_fill(~vis[None], float("-inf"))
     ref = torch.einsum("hts,shd->thd", torch.softmax(sc, -1), vf).reshape(T, H)
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=2e-5 if dtype == torch.float32 else 3e-2, rtol=0)
+
+
+# ------------------------------------------------------------------ fp8 (BASELINE config 5)
+def _fp8_to_float(q_u8: torch.Tensor) -> torch.Tensor:
+    return q_u8.cpu().view(torch.float8_e4m3fn).to(torch.float32)
+
+
+def test_quant_rows_fp8(lib):
+    rows, cols = 37, 1152
+    x = (_rand((rows, cols), 41, 3.0) * torch.linspace(0.01, 30, rows)[:, None]).to(torch.bfloat16).cuda()
+    x[5] = 0                                                     # an all-zero row must not divide by zero
+    q = torch.empty(rows, cols, dtype=torch.uint8, device="cuda")
+    sc = torch.empty(rows, dtype=torch.float32, device="cuda")
+    _lib.check(lib.atspeed_quant_rows_fp8(x.data_ptr(), rows, cols, q.data_ptr(), sc.data_ptr(), _st()))
+    torch.cuda.synchronize()
+    xf = x.float().cpu()
+    amax = xf.abs().amax(1)
+    exp_scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    np.testing.assert_allclose(sc.cpu().numpy(), exp_scale.numpy(), rtol=1e-6)
+    deq = _fp8_to_float(q) * sc.cpu()[:, None]
+    # e4m3 has 3 mantissa bits: relative error <= 2^-4 of the value (plus the subnormal floor of the row)
+    err = (deq - xf).abs()
+    bound = xf.abs() * 2 ** -4 + exp_scale[:, None] * 2 ** -9 + 1e-30
+    assert bool((err <= bound * 1.001).all())
+    ref_codes = (xf / sc.cpu()[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert (ref_codes == q.cpu()).float().mean() > 0.999          # same rounding as torch's e4m3 conversion
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(1024, 2304, 768, 0), (640, 12288, 512, 0), (1300, 1024, 1280, 2), (900, 2752, 512, 3), (1543, 1000, 256, 1)])
+def test_gemm_fp8(lib, m, n, k, epi):
+    x = _rand((m, k), 51, 1.5).to(torch.bfloat16).cuda()
+    w = _rand((n, k), 52, 0.05).to(torch.bfloat16).cuda()
+    xq = torch.empty(m, k, dtype=torch.uint8, device="cuda"); sx = torch.empty(m, device="cuda")
+    wq = torch.empty(n, k, dtype=torch.uint8, device="cuda"); sw = torch.empty(n, device="cuda")
+    _lib.check(lib.atspeed_quant_rows_fp8(x.data_ptr(), m, k, xq.data_ptr(), sx.data_ptr(), _st()))
+    _lib.check(lib.atspeed_quant_rows_fp8(w.data_ptr(), n, k, wq.data_ptr(), sw.data_ptr(), _st()))
+    # exact reference of what the kernel must compute: dequantised operands, fp64 accumulate, per-row scales
+    ref = (_fp8_to_float(xq).double() @ _fp8_to_float(wq).double().T) * sx.cpu().double()[:, None] * sw.cpu().double()[None, :]
+    if epi == _lib.EPI_F32:
+        ldc = (n + 63) // 64 * 64
+        c = torch.zeros(m, ldc, dtype=torch.float32, device="cuda")
+    elif epi == _lib.EPI_SWIGLU:
+        ldc = n // 2
+        c = torch.zeros(m, ldc, dtype=torch.bfloat16, device="cuda")
+        g = ref.view(m, n // 32, 2, 16)
+        ref = (torch.nn.functional.silu(g[:, :, 0]) * g[:, :, 1]).reshape(m, n // 2)
+    else:
+        ldc = n
+        c = (_rand((m, n), 53).to(torch.bfloat16).cuda() if epi == _lib.EPI_RESID else torch.zeros(m, n, dtype=torch.bfloat16, device="cuda"))
+        if epi == _lib.EPI_RESID:
+            ref = ref + c.double().cpu()
+    _lib.check(lib.atspeed_gemm_fp8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), c.data_ptr(), m, n, k, ldc, epi, _st()))
+    torch.cuda.synchronize()
+    out = c.double().cpu()[:, : ref.shape[1]]
+    scale = float(ref.abs().max())
+    tol = 2e-5 * scale * np.sqrt(k) if epi == _lib.EPI_F32 else 2e-2 * scale
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=tol, rtol=0)
