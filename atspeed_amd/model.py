@@ -127,9 +127,16 @@ class HipLlama:
 
     @classmethod
     def from_synthetic(cls, dims: synth.LlamaDims, seed: int, std: float = 0.02, head_std: Optional[float] = None,
-                       norm_jitter: float = 0.1, dtype: torch.dtype = torch.bfloat16, device="cuda", **kw) -> "HipLlama":
+                       norm_jitter: float = 0.1, dtype: torch.dtype = torch.bfloat16, device="cuda",
+                       resid_scale: float = 1.0, align_to: Optional["HipLlama"] = None, **kw) -> "HipLlama":
         """Weights generated ON THE DEVICE by the same hash recipe as `synth.synthetic_state_dict`
-        (bit-identical values), so 7B-sized models need no host generation or PCIe transfer."""
+        (bit-identical values), so 7B-sized models need no host generation or PCIe transfer.
+
+        `resid_scale` / `align_to` build the high-acceptance bracket of SURVEY.md 8(d) without checkpoints: with the
+        o_proj / down_proj weights scaled by `resid_scale` << 1 a model is close to its own bigram table
+        head(norm(embed[tok])); `align_to=draft` copies the draft's embedding / final norm / head into the first
+        `draft.hidden` coordinates of this (wider) model, so both models rank next tokens almost alike while every
+        kernel still runs on dense weights of the full shapes."""
         device = torch.device(device)
         lib = _lib.load()
         head_std = std if head_std is None else head_std
@@ -143,9 +150,21 @@ class HipLlama:
                 if kind == "norm":
                     scale, add = float(synth.normal_scale(norm_jitter)), 1.0
                 else:
-                    scale, add = float(synth.normal_scale(synth.weight_std(name, dims, std, head_std))), 0.0
+                    w_std = synth.weight_std(name, dims, std, head_std)
+                    if "o_proj" in name or "down_proj" in name:
+                        w_std *= resid_scale
+                    scale, add = float(synth.normal_scale(w_std)), 0.0
                 _lib.check(lib.atspeed_fill_hash_normal(t.data_ptr(), t.numel(), s, scale, add, code, 0, st))
                 sd[name] = t
+            if align_to is not None:
+                src, hd = align_to._packed, align_to.dims.hidden
+                if align_to.dims.vocab_size != dims.vocab_size or hd > dims.hidden:
+                    raise ValueError("align_to: same vocabulary and a hidden size <= this model's are required")
+                sd["model.embed_tokens.weight"].zero_()
+                sd["model.embed_tokens.weight"][:, :hd] = src["embed"]
+                sd["lm_head.weight"][:, :hd] = src["lm_head"]
+                # RMS over `hidden` coordinates of which `hd` carry the signal: rescale so norm(x)[:hd] matches the draft's
+                sd["model.norm.weight"][:hd] = (src["final_norm"].float() * (hd / dims.hidden) ** 0.5).to(dtype)
             packed = cls._pack(sd, dims)
             del sd
         return cls(dims, packed, dtype, device, **kw)

@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=32, help="users decoded in lock step per GPU (one batched forward per draft step / verification); 1 = the reference's one-user-at-a-time loop")
     ap.add_argument("--target-fp8", action="store_true", help="BASELINE config 5: fp8 (e4m3 W8A8) target projections in the batched forwards")
     ap.add_argument("--single-stream-users", type=int, default=6, help="extra untimed-for-value pass: users decoded one at a time (the reference's loop)")
+    ap.add_argument("--aligned-resid-scale", type=str, default="3e-6,3e-5",
+                    help="extra brackets (SURVEY.md 8d 'oracle-draft'): same shapes and kernels, draft/target weights aligned through a "
+                         "shared bigram table with the layers' residual contributions scaled by each factor of this comma list "
+                         "(3e-6: every draft step accepted, 3e-5: about one step per verification); empty string skips the pass")
     ap.add_argument("--cpu-baseline-users", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -187,6 +191,38 @@ def main():
                                     achieved=b1 / (us1 * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                     frac=b1 / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, avg_launch_us=us1))
 
+    # ---- high-acceptance bracket: identical shapes / kernels / users, weights aligned so the draft's beams are mostly
+    # the target's (the natural bracket above accepts ~0 steps because the random weights are unrelated).
+    aligned = None
+    scales = [float(x) for x in args.aligned_resid_scale.split(",") if x.strip()]
+    if rank == 0 and scales:
+        aligned = []
+        grp = max(1, args.streams)
+        for rs in scales:
+            draft_a = HipLlama.from_synthetic(ddims, args.seed + 1, std=0.02, head_std=0.02, dtype=torch.bfloat16, num_beams=args.draft_beam,
+                                              resid_scale=rs, **kw)
+            target_a = HipLlama.from_synthetic(tdims, args.seed, std=0.02, head_std=0.02, dtype=torch.bfloat16, num_beams=args.beam,
+                                               resid_scale=rs, align_to=draft_a, **kw)
+            if args.target_fp8:
+                target_a.enable_fp8()
+
+            def run_aligned(lo, hi):
+                res = []
+                for g in range(lo, hi, grp):
+                    res += BSSD_batch(target_a, draft_a, dprompts[g:min(hi, g + grp)], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
+                return res
+            run_aligned(0, min(n_local, max(args.warmup, grp)))
+            torch.cuda.synchronize(dev)
+            ta = time.perf_counter()
+            ro = run_aligned(args.warmup, n_local)
+            torch.cuda.synchronize(dev)
+            dta = time.perf_counter() - ta
+            aligned.append(dict(resid_scale=rs, items_per_s=args.steps * args.beam / dta, ms_per_user=1e3 * dta / args.steps,
+                                mean_accept_len=sum(o["total_accept_steps"] for o in ro) / max(1, sum(o["n_run"] for o in ro)),
+                                n_run_per_user=sum(o["n_run"] for o in ro) / args.steps,
+                                target_forwards_per_user=sum(o["n_target_forwards"] for o in ro) / args.steps))
+            del target_a, draft_a, run_aligned
+
     per_rank = all_gather_counters(Counters(args.steps, n_run, acc, int(elapsed * 1e9)), dev)   # the path's single collective
     if rank != 0:
         if world > 1:
@@ -243,6 +279,7 @@ def main():
                      "draft_ms": 1e3 * stage[0] / args.steps, "target_ms": 1e3 * stage[1] / args.steps, "verify_ms": 1e3 * stage[2] / args.steps},
         "roofline": roofline,
         "single_user_stream": single,
+        "aligned_weight_brackets": aligned,   # same users, shapes and kernels as `value`; only the weights' agreement differs
     }
     if world == 1 and not args.no_cpu_baseline:
         cb, ref_outs = cpu_baseline(target, draft, prompts[args.warmup:], fn, args)

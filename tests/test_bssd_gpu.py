@@ -307,3 +307,27 @@ def test_fp8_target_batch_close_to_bf16():
           "accept steps bf16/fp8", sum(r["total_accept_steps"] for r in res["bf16"]), sum(r["total_accept_steps"] for r in res["fp8"]))
     assert np.mean(dscore) < 0.5
     assert np.mean(overlap) > 0.3
+
+
+def test_aligned_synthetic_pair_brackets_acceptance():
+    """HipLlama.from_synthetic(align_to=..): with the layers' residual writes scaled to ~0 a narrow draft and a wide target
+    share one bigram table, so every draft step is accepted (n_run=1, 3 steps: SURVEY.md 8c property iii); a large
+    scale decouples them.  Both stay lossless against target_generate on the same target."""
+    V = synth.TINY.vocab_size
+    fn = atspeed_amd.PositionSetConstraint(synth.TINY.allowed_tokens(), synth.RESPONSE_SEP)
+    ddims = synth.LlamaDims(V, 96, 2, 3, 256)
+    tdims = synth.LlamaDims(V, 128, 3, 4, 352)
+    kw = dict(dtype=torch.float32, max_slots=512, max_tokens=512, max_logit_rows=448)
+    prompt = synth.synthetic_prompt(30, 77)
+    inputs = {"input_ids": torch.from_numpy(prompt)[None].cuda()}
+    seen = {}
+    for rs in (1e-6, 1.0):
+        d = HipLlama.from_synthetic(ddims, 5, num_beams=40, resid_scale=rs, **kw)
+        t = HipLlama.from_synthetic(tdims, 6, num_beams=20, resid_scale=rs, align_to=d, **kw)
+        out = BSSD(t, d, inputs, 4, 4, prefix_allowed_tokens_fn=fn)
+        tg = target_generate(t, inputs, 4, prefix_allowed_tokens_fn=fn)
+        assert torch.equal(out["beam_sequence"], tg["beam_sequence"])
+        np.testing.assert_allclose(out["beam_scores"].cpu().numpy(), tg["beam_scores"].cpu().numpy(), atol=SCORE_TOL, rtol=0)
+        seen[rs] = (out["n_run"], out["total_accept_steps"])
+    assert seen[1e-6] == (1, 3)
+    assert seen[1.0][1] < 3 and seen[1.0][0] > 1
