@@ -403,6 +403,72 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const bf16_t* __restri
   }
 }
 
+// Epilogue of the 256-wide kernels: wave (wn, wm) holds 4 x MT2 accumulator tiles, n = n0 + wn*64 + i*16 + g*4 + r,
+// m = m0 + wm*MT2*16 + j*16 + lq.
+template <int EPI, int MT2>
+__device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[4][MT2], void* __restrict__ Cv, int M, int N, int ldc, int m0, int n0,
+                                             int wn, int wm, int lq, int g) {
+  const bool vec = (ldc & 3) == 0;
+#pragma unroll
+  for (int j = 0; j < MT2; ++j) {
+    const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
+    if (gm >= M) continue;
+    if constexpr (EPI == EPI_SWIGLU) {
+      bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        const int gn = n0 + wn * 64 + i * 16;
+        if (gn >= N) continue;
+        ushort4 o;
+        bf16_t* op = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float gt = bf2f(f2bf(acc[i][j][r])), up = bf2f(f2bf(acc[i + 1][j][r]));
+          op[r] = f2bf(gt / (1.f + __expf(-gt)) * up);
+        }
+        *reinterpret_cast<ushort4*>(C + (size_t)gm * ldc + (gn >> 1) + g * 4) = o;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gn = n0 + wn * 64 + i * 16 + g * 4;
+        if (gn >= N) continue;
+        if constexpr (EPI == EPI_F32) {
+          float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
+          if (gn + 3 < N && vec) *reinterpret_cast<float4*>(C) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          else
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[i][j][r];
+        } else {
+          bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
+          if (gn + 3 < N && vec) {
+            ushort4 o;
+            bf16_t* op = reinterpret_cast<bf16_t*>(&o);
+            if constexpr (EPI == EPI_RESID) {
+              ushort4 rs = *reinterpret_cast<const ushort4*>(C);
+              const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) op[r] = f2bf(bf2f(rp[r]) + bf2f(f2bf(acc[i][j][r])));
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) op[r] = f2bf(acc[i][j][r]);
+            }
+            *reinterpret_cast<ushort4*>(C) = o;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (gn + r < N) {
+                float v = acc[i][j][r];
+                if constexpr (EPI == EPI_RESID) v = bf2f(C[r]) + bf2f(f2bf(v));
+                C[r] = f2bf(v);
+              }
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---- deeper-pipelined variant -----------------------------------------------------------------------------------
 // Ablation on MI355X (tools/sweep_big.sh): the loop above runs at 1.26-1.5 PF without its DMA and ~0.85 PF with it:
 // a 64 KB stage per ~1.6 us of MFMAs is right at the ~65 GB/s a CU can pull from L2, so a DMA issued just before the
@@ -417,7 +483,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 #define ATS_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 
 // MT2 = 16-row token tiles per wave: 8 -> 256x256 workgroup tile, 4 -> 256 (n) x 128 (m) for the mid-size rounds
-template <int EPI, int MT2>
+template <int EPI, int MT2, int STAG = 0>
 __global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                            void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
                                                            int tiles_n, int tiles_m, int GM) {
@@ -481,19 +547,9 @@ __global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restr
 #pragma unroll
     for (int j = 0; j < MT2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  dma_stage(0, 0);
-  if (nk > 1) dma_stage(1, 1);
-
-  for (int kt = 0; kt < nk; ++kt) {
+  u32x4_t af[2][4], bfr[2][MT2];
+  auto read_frags = [&](int kt) {                                           // 24 (16) ds_read_b128: this wave's fragments of tile kt
     const unsigned boff = (kt & 1) * STAGE;
-    if (kt + 1 < nk) {                                                      // tile kt landed (this wave's part); kt+1 may fly
-      if constexpr (MT2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                                           // A: tile kt published by every wave
-    u32x4_t af[2][4], bfr[2][MT2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const unsigned aa = a_addr[ks] + boff, ba = b_addr[ks] + boff;
@@ -507,10 +563,8 @@ __global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restr
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // fragments are in registers
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                                           // B: nobody reads this stage any more
-    if (kt + 2 < nk) dma_stage(kt & 1, kt + 2);                             // refill it two tiles ahead
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfma_tile = [&]() {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -519,68 +573,249 @@ __global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restr
         for (int j = 0; j < MT2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[ks][i]),
                                                               __builtin_bit_cast(bf16x8_t, bfr[ks][j]), acc[i][j], 0, 0, 0);
-  }
-
-  // ------------------------------------------------------------------ epilogue (as gemm_big_kernel)
-  const bool vec = (ldc & 3) == 0;
+  };
+  // the same MFMAs with this wave's 4 + XJ DMA pieces of tile `kt` spread between them (one piece per 8 (6) MFMAs): a
+  // burst of pieces right after the barrier costs each wave 100-185 cycles of issue per piece (VMEM queue back-pressure)
+  auto mfma_tile_dma = [&](int buf, int kt) {
+    unsigned char* sw = smem + buf * STAGE;
+    unsigned char* sx = sw + BT * kRowBytes;
+    constexpr int NP = 4 + XJ, GAP = (2 * 4 * MT2) / NP;
 #pragma unroll
-  for (int j = 0; j < MT2; ++j) {
-    const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
-    if (gm >= M) continue;
-    if constexpr (EPI == EPI_SWIGLU) {
-      bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < 4; i += 2) {
-        const int gn = n0 + wn * 64 + i * 16;
-        if (gn >= N) continue;
-        ushort4 o;
-        bf16_t* op = reinterpret_cast<bf16_t*>(&o);
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float gt = bf2f(f2bf(acc[i][j][r])), up = bf2f(f2bf(acc[i + 1][j][r]));
-          op[r] = f2bf(gt / (1.f + __expf(-gt)) * up);
-        }
-        *reinterpret_cast<ushort4*>(C + (size_t)gm * ldc + (gn >> 1) + g * 4) = o;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gn = n0 + wn * 64 + i * 16 + g * 4;
-        if (gn >= N) continue;
-        if constexpr (EPI == EPI_F32) {
-          float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
-          if (gn + 3 < N && vec) *reinterpret_cast<float4*>(C) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-          else
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[i][j][r];
-        } else {
-          bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
-          if (gn + 3 < N && vec) {
-            ushort4 o;
-            bf16_t* op = reinterpret_cast<bf16_t*>(&o);
-            if constexpr (EPI == EPI_RESID) {
-              ushort4 rs = *reinterpret_cast<const ushort4*>(C);
-              const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) op[r] = f2bf(bf2f(rp[r]) + bf2f(f2bf(acc[i][j][r])));
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) op[r] = f2bf(acc[i][j][r]);
-            }
-            *reinterpret_cast<ushort4*>(C) = o;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (gn + r < N) {
-                float v = acc[i][j][r];
-                if constexpr (EPI == EPI_RESID) v = bf2f(C[r]) + bf2f(f2bf(v));
-                C[r] = f2bf(v);
-              }
+        for (int j = 0; j < MT2; ++j) {
+          const int idx = (ks * 4 + i) * MT2 + j;
+          if (idx % GAP == 0 && idx / GAP < NP) {
+            const int pc = idx / GAP;
+            if (pc < 4)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[pc] + kt * BK),
+                                               (__attribute__((address_space(3))) void*)(sw + (wave * 4 + pc) * 8 * kRowBytes), 16, 0, 0);
+            else
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[(pc - 4) % XJ] + kt * BK),
+                                               (__attribute__((address_space(3))) void*)(sx + (wave * XJ + (pc - 4)) * 8 * kRowBytes), 16, 0, 0);
           }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[ks][i]),
+                                                              __builtin_bit_cast(bf16x8_t, bfr[ks][j]), acc[i][j], 0, 0, 0);
         }
+  };
+
+  dma_stage(0, 0);
+  if (nk > 1) dma_stage(1, 1);
+
+  if constexpr (STAG == 4) {
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) {
+        if constexpr (MT2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      __builtin_amdgcn_s_barrier();                                         // A: tile kt published by every wave
+      read_frags(kt);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();                                         // B: nobody reads this stage any more
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < nk) mfma_tile_dma(kt & 1, kt + 2); else mfma_tile();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (STAG == 0) {
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) {                                                    // tile kt landed (this wave's part); kt+1 may fly
+        if constexpr (MT2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                                         // A: tile kt published by every wave
+      read_frags(kt);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();                                         // B: nobody reads this stage any more
+      if (kt + 2 < nk) dma_stage(kt & 1, kt + 2);                           // refill it two tiles ahead
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_tile();
+    }
+  } else {
+    // Staggered halves: waves 0-3 and their SIMD partners 4-7 alternate roles every phase, so on each SIMD one wave
+    // issues MFMAs while the other pulls its next fragments out of LDS (in lock step both read, then both compute, and
+    // the matrix pipe idles through every read burst).  Phase 2t: first half computes tile t, second half reads tile t.
+    // Phase 2t+1: second half computes tile t, first half reads tile t+1; the stage of tile t is dead at its start and
+    // takes the DMA of tile t+2, which has two phases to land.
+    const int half = wave >> 2;
+    if (nk > 1) {
+      if constexpr (MT2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                                           // tile 0 published
+    if (half == 0) read_frags(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();                                         // phase 2kt
+      __builtin_amdgcn_sched_barrier(0);
+      if (half == 0) mfma_tile(); else read_frags(kt);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (STAG != 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of tile kt+1 has landed
+      __builtin_amdgcn_s_barrier();                                         // phase 2kt+1: stage of tile kt is dead
+      if constexpr (STAG != 2) if (kt + 2 < nk) dma_stage(kt & 1, kt + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (half == 0) { if (kt + 1 < nk) read_frags(kt + 1); } else mfma_tile();
     }
   }
+
+  big_epilogue<EPI, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
+}
+
+// ---- ring variant: 32-k stages, four of them, everything in the loop hand-placed -------------------------------
+// Measured on the two-stage kernel above (tools/pmc_gemm.sh, ATSPEED_GEMM_STAG ablations): MFMA pipe 52 % busy, 1.3-1.6 PF
+// without the DMA, unchanged when the vmcnt wait is dropped -> what costs is not the landing latency but the burst
+// of 8 DMA pieces per wave (100-185 cycles of issue each while the VMEM queue is full) and the lock-step read burst.
+// hipcc sinks/serialises the builtin when asked to interleave it with MFMAs, so the loop body is inline asm:
+//   * a stage is one 32-deep k-step (64-byte LDS rows, 32 KB for a 256x256 tile), four stages form a ring, and the DMA
+//     of k-step s+4 is issued during the MFMAs of k-step s: three k-steps (96 KB per CU) are always in flight;
+//   * the 12 fragment reads of k-step s+1 and the 4 DMA pieces are spread between the 32 MFMAs of k-step s
+//     (register double buffering of the fragments), so neither is a burst;
+//   * one barrier per k-step both publishes k-step s+2 and retires the reads of k-step s+1.
+// LDS image of a stage: W rows then X rows, 64 B each; the 16-byte chunk c of row r sits at position c ^ f((r>>2)&3),
+// f = {2,0,1,3}: conflict-free for ds_read_b128's lane groups ({0-3,12-15,20-27},...) with 64-byte rows.
+#define ATS_MFMA_BF16(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
+#define ATS_DMA16(voff, sbase, m0v) \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory")
+
+template <int EPI, int MT2>
+__global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                           void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
+                                                           int tiles_n, int tiles_m, int GM) {
+  constexpr int BT = 256, BK = 32, RB = 64;
+  constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
+  constexpr int XP = XR / 128;                                   // X DMA pieces (16 rows each) per wave per k-step
+  constexpr int NP = 2 + XP;                                     // DMA pieces per wave per k-step
+  constexpr int STAGE = (BT + XR) * RB;                          // 32 or 24 KB
+  constexpr int NR = 4 + MT2;                                    // fragment reads per wave per k-step
+  constexpr int NMF = 4 * MT2;                                   // MFMAs per wave per k-step
+  constexpr int RG = (NMF * 3 / 4) / NR;                         // one read every RG MFMAs, from the segment's start
+  constexpr int DG = (NMF - NR * RG) / NP;                       // then one DMA piece every DG MFMAs
+  static_assert(RG >= 1 && DG >= 1, "segment too short for its reads and DMA pieces");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, g = lane >> 4;
+  const int nwg = tiles_n * tiles_m;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+  }
+  const int band = bid / (GM * tiles_n), rem = bid % (GM * tiles_n);
+  const int band_rows = min(GM, tiles_m - band * GM);
+  const int tn = rem / band_rows, tm = band * GM + rem % band_rows;
+  const int n0 = tn * BT, m0 = tm * XR;
+  const int wn = wave >> 1, wm = wave & 1;
+  const int nks = K / BK;                                        // launcher: K % 128 == 0, K >= 256
+
+  // per-lane DMA source offsets (bytes): piece = 16 rows x 64 B, lane l -> row l>>2, stored position l&3
+  auto swz = [](int row) { return (0xD2 >> (((row >> 2) & 3) * 2)) & 3; };   // f = {2,0,1,3} packed in 0b11010010
+  unsigned woff[2], xoff[XP];
+  int m0w[2], m0x[XP];
+  const unsigned lbase = lds_addr(smem);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave * 2 + j) * 16 + (lane >> 2);
+    woff[j] = (unsigned)min(n0 + row, N - 1) * (unsigned)(K * 2) + (((lane & 3) ^ swz(row)) * 16);
+    m0w[j] = __builtin_amdgcn_readfirstlane((int)lbase + (wave * 2 + j) * 1024);
+  }
+#pragma unroll
+  for (int j = 0; j < XP; ++j) {
+    const int row = (wave * XP + j) * 16 + (lane >> 2);
+    xoff[j] = (unsigned)min(m0 + row, M - 1) * (unsigned)(ldx * 2) + (((lane & 3) ^ swz(row)) * 16);
+    m0x[j] = __builtin_amdgcn_readfirstlane((int)lbase + BT * RB + (wave * XP + j) * 1024);
+  }
+  const unsigned long long wb = (unsigned long long)W, xb = (unsigned long long)X;
+  // fragment addresses: lane (lq, g) reads chunk g of row lq of each 16-row tile
+  const unsigned lp = lq * RB + ((g ^ swz(lq)) * 16);
+  unsigned aA[2], aB[2];                                          // stages {0,1} and {2,3}
+  aA[0] = lbase + (wn * 64) * RB + lp;
+  aB[0] = lbase + BT * RB + (wm * MT2 * 16) * RB + lp;
+  aA[1] = aA[0] + 2 * STAGE;
+  aB[1] = aB[0] + 2 * STAGE;
+
+  f32x4_t acc[4][MT2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MT2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  u32x4_t fa[2][4], fb[2][MT2];
+
+  auto dma_piece = [&](int q, int ks, int d) {                    // piece d of k-step ks into stage q (q, d compile-time after unrolling)
+    if (d < 2) ATS_DMA16(woff[d], wb + (unsigned long long)ks * (BK * 2), m0w[d] + q * STAGE);
+    else       ATS_DMA16(xoff[(d - 2) % XP], xb + (unsigned long long)ks * (BK * 2), m0x[(d - 2) % XP] + q * STAGE);
+  };
+  auto read_one = [&](int q, int buf, int r) {                    // fragment read r of stage q into register buffer buf
+    const unsigned a = aA[q >> 1], b = aB[q >> 1];
+    const int so = (q & 1) * STAGE;
+    switch (r) {
+      case 0: ATS_DS_READ_B128(fa[buf][0], a, so); break;
+      case 1: ATS_DS_READ_B128(fa[buf][1], a, so + 1024); break;
+      case 2: ATS_DS_READ_B128(fa[buf][2], a, so + 2048); break;
+      case 3: ATS_DS_READ_B128(fa[buf][3], a, so + 3072); break;
+      case 4: ATS_DS_READ_B128(fb[buf][0], b, so); break;
+      case 5: ATS_DS_READ_B128(fb[buf][1], b, so + 1024); break;
+      case 6: ATS_DS_READ_B128(fb[buf][2], b, so + 2048); break;
+      case 7: ATS_DS_READ_B128(fb[buf][3], b, so + 3072); break;
+      case 8: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][4], b, so + 4096); break;
+      case 9: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][5], b, so + 5120); break;
+      case 10: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][6], b, so + 6144); break;
+      case 11: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][7], b, so + 7168); break;
+      default: break;
+    }
+  };
+  // one k-step: MFMAs of stage Q from register buffer Q&1, reads of stage Q+1 into the other buffer, DMA of k-step
+  // ks+4 into stage Q; VM = vmcnt to wait for before the closing barrier (-1: no wait, no barrier)
+#define ATS_RING_SEGMENT(Q, DMA, RD, VM, ks)                                                            \
+  {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < MT2; ++j) {      \
+      const int idx = i * MT2 + j;                                                                       \
+      if (RD && idx % RG == 0 && idx / RG < NR) read_one(((Q) + 1) & 3, ((Q) + 1) & 1, idx / RG);       \
+      if (DMA && idx >= NR * RG && (idx - NR * RG) % DG == 0 && (idx - NR * RG) / DG < NP)              \
+        dma_piece((Q), (ks) + 4, (idx - NR * RG) / DG);                                                  \
+      ATS_MFMA_BF16(acc[i][j], fa[(Q) & 1][i], fb[(Q) & 1][j]);                                          \
+    }                                                                                                    \
+    if (RD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
+    if ((VM) >= 0) {                                                                                     \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VM) < 0 ? 0 : (VM)) : "memory");                         \
+      asm volatile("s_barrier" ::: "memory");                                                            \
+    }                                                                                                    \
+  }
+
+  // prologue: k-steps 0..3 into stages 0..3; fragments of k-step 0
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int d = 0; d < NP; ++d) dma_piece(q, q, d);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP) : "memory");
+  asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+  for (int r = 0; r < NR; ++r) read_one(0, 0, r);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+  asm volatile("s_barrier" ::: "memory");                          // k-step 1 published, stage 0 read by everyone
+
+  int ks = 0;
+  for (; ks + 4 < nks; ks += 4) {
+    ATS_RING_SEGMENT(0, true, true, 2 * NP, ks);
+    ATS_RING_SEGMENT(1, true, true, 2 * NP, ks + 1);
+    ATS_RING_SEGMENT(2, true, true, 2 * NP, ks + 2);
+    ATS_RING_SEGMENT(3, true, true, 2 * NP, ks + 3);
+  }
+  ATS_RING_SEGMENT(0, false, true, NP, ks);
+  ATS_RING_SEGMENT(1, false, true, 0, ks + 1);
+  ATS_RING_SEGMENT(2, false, true, -1, ks + 2);
+  ATS_RING_SEGMENT(3, false, false, -1, ks + 3);
+#undef ATS_RING_SEGMENT
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");               // MFMA results -> VALU reads (the compiler cannot see the asm MFMAs)
+
+  big_epilogue<EPI, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
 }
 
 // ---- fp8 (OCP e4m3) variant: same structure, 1-byte operands with per-row scales (W8A8) ---------------------------
@@ -778,11 +1013,18 @@ template <int EPI>
 int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st) {
   static const int dbg = env_int("ATSPEED_GEMM_BIG_DBG", 0);       // tuning: 1/2 = ablations of the simple loop, 3 = simple loop
   static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
+  static const int stag = env_int("ATSPEED_GEMM_STAG", 5);   // 5 = ring kernel (production); 0/1/4 = two-stage variants, 2/3 = ablations
   const int tiles_n = (n + 255) / 256;
   static thread_local bool attr_done = false;
   if (!attr_done) {
     ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     ATS_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     ATS_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     ATS_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -792,8 +1034,28 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
     // 256-row token tiles when they fill the chip at least as well as 128-row ones (fewer bytes per flop), else 128
     const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
     const bool use256 = big_fill_pct(t256) >= 80 && big_fill_pct(t256) + 8 >= big_fill_pct(t128);
-    if (use256) hipLaunchKernelGGL((gemm_big2_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
-    else        hipLaunchKernelGGL((gemm_big2_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
+    if (stag == 5 && k % 128 == 0 && k >= 256) {
+      static thread_local bool ring_attr = false;
+      if (!ring_attr) {
+        ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        ring_attr = true;
+      }
+      if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
+      else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
+    } else if (stag == 4) {
+      if (use256) hipLaunchKernelGGL((gemm_big2_kernel<EPI, 8, 4>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
+      else        hipLaunchKernelGGL((gemm_big2_kernel<EPI, 4, 4>), dim3(t128), dim3(512), 96 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
+    } else if (stag >= 2) {   // tuning ablations (wrong results): 2 = no DMA inside the loop, 3 = no vmcnt wait inside the loop
+      if (stag == 2) hipLaunchKernelGGL((gemm_big2_kernel<EPI, 8, 2>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
+      else           hipLaunchKernelGGL((gemm_big2_kernel<EPI, 8, 3>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
+    } else if (stag) {
+      if (use256) hipLaunchKernelGGL((gemm_big2_kernel<EPI, 8, 1>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
+      else        hipLaunchKernelGGL((gemm_big2_kernel<EPI, 4, 1>), dim3(t128), dim3(512), 96 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
+    } else {
+      if (use256) hipLaunchKernelGGL((gemm_big2_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
+      else        hipLaunchKernelGGL((gemm_big2_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
+    }
     ATS_LAUNCH_CHECK();
     return ATSPEED_OK;
   }
