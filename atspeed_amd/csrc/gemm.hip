@@ -18,9 +18,6 @@
 #include <set>
 
 #include "internal.h"
-#include <atomic>
-#include <map>
-#include <mutex>
 
 namespace {
 
@@ -821,198 +818,6 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const bf16_t* __restr
   big_epilogue<EPI, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
 }
 
-// ---- persistent ring kernel with a stream-K tail ----------------------------------------------------------------
-// One workgroup per CU walks 256x256 tiles: first the tiles that fill whole rounds of the grid (data parallel, XCD-grouped
-// order as above), then its share of the REMAINING tiles' k-range, cut at 128-k units so that every workgroup gets the same
-// number of units (stream-K): the last partial round of a tile grid no longer costs a whole round (1118 tiles of the
-// gate_up GEMM at 3200 tokens: 4.37 instead of 5 rounds).  A tile whose k-range is shared is owned by the workgroup
-// holding its first unit; the others store their fp32 accumulators to a slot of their own, release them at agent scope
-// and raise a flag (= the launch's epoch, so flags never need clearing); the owner, whose part is the LAST item of its
-// range while the others' parts are their FIRST, acquires, adds them in rank order and runs the epilogue.  Only owners
-// ever wait, and only on higher ranks, so the launch needs no co-residency guarantee beyond in-order dispatch.
-// The DMA of the next item's first four k-steps is issued before the current item's epilogue.
-struct SkItem { int o, k0, k1; };
-
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void gemm_ringp_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
-                                                            void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
-                                                            int tiles_n, int tiles_m, int GM, f32x4_t* __restrict__ part,
-                                                            unsigned* __restrict__ flags, unsigned epoch) {
-  constexpr int MT2 = 8, BT = 256, BK = 32, RB = 64, NP = 4, STAGE = 2 * BT * RB, NR = 12, RG = 2, DG = 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 15, g = lane >> 4;
-  const int wn = wave >> 1, wm = wave & 1;
-  const int G = gridDim.x;                                         // multiple of 8
-  const int p = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);   // rank: the 32 workgroups of an XCD are consecutive
-  const int T = tiles_n * tiles_m, upt = K / 128, nks = K / BK;
-  const int rounds = T / G, Tdp = rounds * G, Usk = (T - Tdp) * upt;
-  const int u_end = (int)((long long)(p + 1) * Usk / G);
-  int u_cur = (int)((long long)p * Usk / G), dp_r = 0;
-  auto next_item = [&](SkItem& it) -> bool {
-    if (dp_r < rounds) { it.o = dp_r * G + p; it.k0 = 0; it.k1 = nks; ++dp_r; return true; }
-    if (u_cur >= u_end) return false;
-    const int tau = u_cur / upt, ub = tau * upt, ue = min(u_end, ub + upt);
-    it.o = Tdp + tau; it.k0 = (u_cur - ub) * 4; it.k1 = (ue - ub) * 4;
-    u_cur = ue;
-    return true;
-  };
-  auto tile_origin = [&](int o, int& n0, int& m0) {
-    const int band = o / (GM * tiles_n), rem = o % (GM * tiles_n);
-    const int band_rows = min(GM, tiles_m - band * GM);
-    n0 = (rem / band_rows) * BT;
-    m0 = (band * GM + rem % band_rows) * BT;
-  };
-
-  auto swz = [](int row) { return (0xD2 >> (((row >> 2) & 3) * 2)) & 3; };
-  unsigned woff[2], xoff[2];
-  int m0w[2], m0x[2];
-  const unsigned lbase = lds_addr(smem);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    m0w[j] = __builtin_amdgcn_readfirstlane((int)lbase + (wave * 2 + j) * 1024);
-    m0x[j] = __builtin_amdgcn_readfirstlane((int)lbase + BT * RB + (wave * 2 + j) * 1024);
-  }
-  const unsigned long long wb = (unsigned long long)W, xb = (unsigned long long)X;
-  const unsigned lp = lq * RB + ((g ^ swz(lq)) * 16);
-  unsigned aA[2], aB[2];
-  aA[0] = lbase + (wn * 64) * RB + lp;
-  aB[0] = lbase + BT * RB + (wm * MT2 * 16) * RB + lp;
-  aA[1] = aA[0] + 2 * STAGE;
-  aB[1] = aB[0] + 2 * STAGE;
-
-  f32x4_t acc[4][MT2];
-  u32x4_t fa[2][4], fb[2][MT2];
-
-  auto dma_piece = [&](int q, int ks, int d) {
-    if (d < 2) ATS_DMA16(woff[d], wb + (unsigned long long)ks * (BK * 2), m0w[d] + q * STAGE);
-    else       ATS_DMA16(xoff[d - 2], xb + (unsigned long long)ks * (BK * 2), m0x[d - 2] + q * STAGE);
-  };
-  auto read_one = [&](int q, int buf, int r) {
-    const unsigned a = aA[q >> 1], b = aB[q >> 1];
-    const int so = (q & 1) * STAGE;
-    switch (r) {
-      case 0: ATS_DS_READ_B128(fa[buf][0], a, so); break;
-      case 1: ATS_DS_READ_B128(fa[buf][1], a, so + 1024); break;
-      case 2: ATS_DS_READ_B128(fa[buf][2], a, so + 2048); break;
-      case 3: ATS_DS_READ_B128(fa[buf][3], a, so + 3072); break;
-      case 4: ATS_DS_READ_B128(fb[buf][0], b, so); break;
-      case 5: ATS_DS_READ_B128(fb[buf][1], b, so + 1024); break;
-      case 6: ATS_DS_READ_B128(fb[buf][2], b, so + 2048); break;
-      case 7: ATS_DS_READ_B128(fb[buf][3], b, so + 3072); break;
-      case 8: ATS_DS_READ_B128(fb[buf][4], b, so + 4096); break;
-      case 9: ATS_DS_READ_B128(fb[buf][5], b, so + 5120); break;
-      case 10: ATS_DS_READ_B128(fb[buf][6], b, so + 6144); break;
-      case 11: ATS_DS_READ_B128(fb[buf][7], b, so + 7168); break;
-      default: break;
-    }
-  };
-  // per-lane source offsets of a tile and the DMA of an item's first four k-steps (the ring is empty at that point)
-  auto begin_item = [&](const SkItem& it) {
-    int n0, m0;
-    tile_origin(it.o, n0, m0);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = (wave * 2 + j) * 16 + (lane >> 2);
-      woff[j] = (unsigned)min(n0 + row, N - 1) * (unsigned)(K * 2) + (((lane & 3) ^ swz(row)) * 16);
-      xoff[j] = (unsigned)min(m0 + row, M - 1) * (unsigned)(ldx * 2) + (((lane & 3) ^ swz(row)) * 16);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int d = 0; d < NP; ++d) dma_piece(q, it.k0 + q, d);
-  };
-
-#define ATS_RINGP_SEGMENT(Q, DMA, RD, VM, ks)                                                           \
-  {                                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < MT2; ++j) {      \
-      const int idx = i * MT2 + j;                                                                       \
-      if (RD && idx % RG == 0 && idx / RG < NR) read_one(((Q) + 1) & 3, ((Q) + 1) & 1, idx / RG);       \
-      if (DMA && idx >= NR * RG && (idx - NR * RG) % DG == 0 && (idx - NR * RG) / DG < NP)              \
-        dma_piece((Q), (ks) + 4, (idx - NR * RG) / DG);                                                  \
-      ATS_MFMA_BF16(acc[i][j], fa[(Q) & 1][i], fb[(Q) & 1][j]);                                          \
-    }                                                                                                    \
-    if (RD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
-    if ((VM) >= 0) {                                                                                     \
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VM) < 0 ? 0 : (VM)) : "memory");                         \
-      asm volatile("s_barrier" ::: "memory");                                                            \
-    }                                                                                                    \
-  }
-
-  SkItem cur, nxt;
-  bool have = next_item(cur);
-  if (have) begin_item(cur);
-  while (have) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < MT2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP) : "memory");
-    asm volatile("s_barrier" ::: "memory");
-#pragma unroll
-    for (int r = 0; r < NR; ++r) read_one(0, 0, r);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-    asm volatile("s_barrier" ::: "memory");
-    int ks = cur.k0;
-    for (; ks + 4 < cur.k1; ks += 4) {
-      ATS_RINGP_SEGMENT(0, true, true, 2 * NP, ks);
-      ATS_RINGP_SEGMENT(1, true, true, 2 * NP, ks + 1);
-      ATS_RINGP_SEGMENT(2, true, true, 2 * NP, ks + 2);
-      ATS_RINGP_SEGMENT(3, true, true, 2 * NP, ks + 3);
-    }
-    ATS_RINGP_SEGMENT(0, false, true, NP, ks);
-    ATS_RINGP_SEGMENT(1, false, true, 0, ks + 1);
-    ATS_RINGP_SEGMENT(2, false, true, 0, ks + 2);                   // barrier: every wave has read the last stage
-    ATS_RINGP_SEGMENT(3, false, false, -1, ks + 3);
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");              // MFMA results -> VALU/stores (the compiler cannot see the asm MFMAs)
-
-    int n0, m0;
-    tile_origin(cur.o, n0, m0);
-    const bool more = next_item(nxt);
-    if (more) begin_item(nxt);                                      // lands under the epilogue below
-
-    if (cur.k0 != 0) {                                              // not the owner: hand the accumulators over
-      f32x4_t* dst = part + ((size_t)p * 8 + wave) * (4 * MT2 * 64) + lane;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MT2; ++j) dst[(i * MT2 + j) * 64] = acc[i][j];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(flags + p, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    } else {
-      if (cur.k1 != nks) {                                          // owner of a shared tile: add the other parts
-        const int tile_end_u = (cur.o - Tdp + 1) * upt;
-        for (int q = p + 1; q < G && (int)((long long)q * Usk / G) < tile_end_u; ++q) {
-          if (tid == 0) {
-            while (__hip_atomic_load(flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(4);
-          }
-          __syncthreads();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          const f32x4_t* src = part + ((size_t)q * 8 + wave) * (4 * MT2 * 64) + lane;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {                             // 8 loads in flight at a time: the accumulators leave ~100 registers
-#pragma unroll
-            for (int j = 0; j < MT2; ++j) acc[i][j] += src[(i * MT2 + j) * 64];
-            asm volatile("" ::: "memory");
-          }
-        }
-      }
-      big_epilogue<EPI, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
-    }
-    cur = nxt;
-    have = more;
-  }
-#undef ATS_RINGP_SEGMENT
-}
-
 // ---- fp8 (OCP e4m3) variant: same structure, 1-byte operands with per-row scales (W8A8) ---------------------------
 // A stage row is still 128 bytes = 128 k, so DMA, swizzle and the 24 fragment reads per stage are unchanged while a
 // stage now carries twice the k: half the DMA and LDS bytes per flop (the bf16 kernel is limited by exactly that
@@ -1204,29 +1009,6 @@ __global__ __launch_bounds__(512, 1) void gemm_big2_fp8_kernel(const unsigned ch
   }
 }
 
-// stream-K hand-off memory of the persistent kernel: one 256 KB accumulator slot and one flag per workgroup, per (device,
-// stream) so that launches on different streams never share them; flags carry the launch epoch and are never cleared
-struct SkWorkspace { f32x4_t* part = nullptr; unsigned* flags = nullptr; int grid = 0; };
-static int sk_workspace(hipStream_t st, SkWorkspace& out) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, SkWorkspace> table;
-  int dev = 0;
-  ATS_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lk(mu);
-  SkWorkspace& w = table[{dev, st}];
-  if (!w.part) {
-    hipDeviceProp_t prop;
-    ATS_HIP(hipGetDeviceProperties(&prop, dev));
-    w.grid = std::max(8, prop.multiProcessorCount / 8 * 8);
-    ATS_HIP(hipMalloc((void**)&w.part, (size_t)w.grid * 256 * 256 * sizeof(float)));
-    ATS_HIP(hipMalloc((void**)&w.flags, (size_t)w.grid * sizeof(unsigned)));
-    ATS_HIP(hipMemset(w.flags, 0, (size_t)w.grid * sizeof(unsigned)));
-  }
-  out = w;
-  return ATSPEED_OK;
-}
-static std::atomic<unsigned> g_sk_epoch{1};
-
 template <int EPI>
 int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st) {
   static const int dbg = env_int("ATSPEED_GEMM_BIG_DBG", 0);       // tuning: 1/2 = ablations of the simple loop, 3 = simple loop
@@ -1252,20 +1034,7 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
     // 256-row token tiles when they fill the chip at least as well as 128-row ones (fewer bytes per flop), else 128
     const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
     const bool use256 = big_fill_pct(t256) >= 80 && big_fill_pct(t256) + 8 >= big_fill_pct(t128);
-    static const int sk_min_tiles = env_int("ATSPEED_GEMM_SK_MIN_TILES", 128);
-    if (stag == 6 && k % 128 == 0 && k >= 256 && t256 >= sk_min_tiles) {
-      SkWorkspace sk;
-      ATS_TRY(sk_workspace(st, sk));
-      static thread_local bool ringp_attr = false;
-      if (!ringp_attr) {
-        ATS_HIP(hipFuncSetAttribute((const void*)gemm_ringp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        ringp_attr = true;
-      }
-      unsigned epoch = g_sk_epoch.fetch_add(1);
-      if (epoch == 0) epoch = g_sk_epoch.fetch_add(1);               // 0 is the cleared state
-      hipLaunchKernelGGL((gemm_ringp_kernel<EPI>), dim3(sk.grid), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n,
-                         (m + 255) / 256, gm, sk.part, sk.flags, epoch);
-    } else if (stag >= 5 && k % 128 == 0 && k >= 256) {
+    if (stag >= 5 && k % 128 == 0 && k >= 256) {
       static thread_local bool ring_attr = false;
       if (!ring_attr) {
         ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
