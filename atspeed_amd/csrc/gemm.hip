@@ -24,6 +24,14 @@ namespace {
 static int env_int(const char* name, int dflt);
 // share of the last wave of 256 CUs a grid of `tiles` workgroups keeps busy, in percent
 static int big_fill_pct(int tiles) { return tiles * 100 / (((tiles + 255) / 256) * 256); }
+// Tile height of the 256-wide kernels from a cost model fitted to tools/gemm_ab.py sweeps (MI355X, ring kernel): time ~
+// whole rounds of 256 workgroups + a partial round that costs 55 % of a round plus 45 % of its fill (the emptier chip
+// clocks higher), and a 128-row tile costs 0.65 of a 256-row one (half the flops, 1.5x the operand bytes per flop).
+static float big_rounds(int tiles) {
+  const int full = tiles / 256, rem = tiles % 256;
+  return (float)full + (rem ? 0.55f + 0.45f * (float)rem / 256.f : 0.f);
+}
+static bool big_use_256_rows(int t256, int t128) { return big_rounds(t256) <= 0.65f * big_rounds(t128); }
 
 constexpr int kThreads = 256;
 constexpr int kRowBytes = 128;      // bytes of K per LDS row
@@ -1033,7 +1041,8 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
   if (dbg == 0) {
     // 256-row token tiles when they fill the chip at least as well as 128-row ones (fewer bytes per flop), else 128
     const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
-    const bool use256 = big_fill_pct(t256) >= 80 && big_fill_pct(t256) + 8 >= big_fill_pct(t128);
+    static const int force_mt = env_int("ATSPEED_GEMM_FORCE_MT", 0);     // tuning: 8 / 4 = always 256- / 128-row token tiles
+    const bool use256 = force_mt ? force_mt == 8 : big_use_256_rows(t256, t128);
     if (stag >= 5 && k % 128 == 0 && k >= 256) {
       static thread_local bool ring_attr = false;
       if (!ring_attr) {
@@ -1133,7 +1142,7 @@ int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char*
     attr_done = true;
   }
   const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
-  const bool use256 = big_fill_pct(t256) >= 80 && big_fill_pct(t256) + 8 >= big_fill_pct(t128);
+  const bool use256 = big_use_256_rows(t256, t128);
   if (use256) hipLaunchKernelGGL((gemm_big2_fp8_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, x, w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 255) / 256, gm);
   else        hipLaunchKernelGGL((gemm_big2_fp8_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, x, w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 127) / 128, gm);
   ATS_LAUNCH_CHECK();
