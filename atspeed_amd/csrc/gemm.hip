@@ -689,14 +689,20 @@ __global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restr
 // LDS image of a stage: W rows then X rows, 64 B each; the 16-byte chunk c of row r sits at position c ^ f((r>>2)&3),
 // f = {2,0,1,3}: conflict-free for ds_read_b128's lane groups ({0-3,12-15,20-27},...) with 64-byte rows.
 #define ATS_MFMA_BF16(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
+#define ATS_MFMA_FP8(c, a, b) asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
 #define ATS_DMA16(voff, sbase, m0v) \
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory")
 
-template <int EPI, int MT2>
-__global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+// FP8: the operands are e4m3 bytes with per-row scales (W8A8); a 64-byte row then holds 64 k, a lane's 16-byte fragment
+// chunk feeds two v_mfma_f32_16x16x32_fp8_fp8 (low / high 8 bytes: the k order inside a 64-k group is permuted
+// identically on both operands), so a stage carries twice the flops for the same DMA and LDS bytes.
+template <int EPI, int MT2, bool FP8>
+__global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const void* __restrict__ X, const void* __restrict__ W,
+                                                           const float* __restrict__ sx, const float* __restrict__ sw,
                                                            void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
                                                            int tiles_n, int tiles_m, int GM) {
-  constexpr int BT = 256, BK = 32, RB = 64;
+  constexpr int BT = 256, RB = 64, ESZ = FP8 ? 1 : 2;
+  constexpr int BK = RB / ESZ;                                   // k per stage: 32 (bf16) or 64 (fp8)
   constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
   constexpr int XP = XR / 128;                                   // X DMA pieces (16 rows each) per wave per k-step
   constexpr int NP = 2 + XP;                                     // DMA pieces per wave per k-step
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const bf16_t* __restr
   const int tn = rem / band_rows, tm = band * GM + rem % band_rows;
   const int n0 = tn * BT, m0 = tm * XR;
   const int wn = wave >> 1, wm = wave & 1;
-  const int nks = K / BK;                                        // launcher: K % 128 == 0, K >= 256
+  const int nks = K / BK;                                        // launcher: K % (4 BK) == 0, K >= 8 BK
 
   // per-lane DMA source offsets (bytes): piece = 16 rows x 64 B, lane l -> row l>>2, stored position l&3
   auto swz = [](int row) { return (0xD2 >> (((row >> 2) & 3) * 2)) & 3; };   // f = {2,0,1,3} packed in 0b11010010
@@ -730,13 +736,13 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const bf16_t* __restr
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int row = (wave * 2 + j) * 16 + (lane >> 2);
-    woff[j] = (unsigned)min(n0 + row, N - 1) * (unsigned)(K * 2) + (((lane & 3) ^ swz(row)) * 16);
+    woff[j] = (unsigned)min(n0 + row, N - 1) * (unsigned)(K * ESZ) + (((lane & 3) ^ swz(row)) * 16);
     m0w[j] = __builtin_amdgcn_readfirstlane((int)lbase + (wave * 2 + j) * 1024);
   }
 #pragma unroll
   for (int j = 0; j < XP; ++j) {
     const int row = (wave * XP + j) * 16 + (lane >> 2);
-    xoff[j] = (unsigned)min(m0 + row, M - 1) * (unsigned)(ldx * 2) + (((lane & 3) ^ swz(row)) * 16);
+    xoff[j] = (unsigned)min(m0 + row, M - 1) * (unsigned)(ldx * ESZ) + (((lane & 3) ^ swz(row)) * 16);
     m0x[j] = __builtin_amdgcn_readfirstlane((int)lbase + BT * RB + (wave * XP + j) * 1024);
   }
   const unsigned long long wb = (unsigned long long)W, xb = (unsigned long long)X;
@@ -756,8 +762,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const bf16_t* __restr
   u32x4_t fa[2][4], fb[2][MT2];
 
   auto dma_piece = [&](int q, int ks, int d) {                    // piece d of k-step ks into stage q (q, d compile-time after unrolling)
-    if (d < 2) ATS_DMA16(woff[d], wb + (unsigned long long)ks * (BK * 2), m0w[d] + q * STAGE);
-    else       ATS_DMA16(xoff[(d - 2) % XP], xb + (unsigned long long)ks * (BK * 2), m0x[(d - 2) % XP] + q * STAGE);
+    if (d < 2) ATS_DMA16(woff[d], wb + (unsigned long long)ks * RB, m0w[d] + q * STAGE);
+    else       ATS_DMA16(xoff[(d - 2) % XP], xb + (unsigned long long)ks * RB, m0x[(d - 2) % XP] + q * STAGE);
   };
   auto read_one = [&](int q, int buf, int r) {                    // fragment read r of stage q into register buffer buf
     const unsigned a = aA[q >> 1], b = aB[q >> 1];
@@ -787,7 +793,14 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const bf16_t* __restr
       if (RD && idx % RG == 0 && idx / RG < NR) read_one(((Q) + 1) & 3, ((Q) + 1) & 1, idx / RG);       \
       if (DMA && idx >= NR * RG && (idx - NR * RG) % DG == 0 && (idx - NR * RG) / DG < NP)              \
         dma_piece((Q), (ks) + 4, (idx - NR * RG) / DG);                                                  \
-      ATS_MFMA_BF16(acc[i][j], fa[(Q) & 1][i], fb[(Q) & 1][j]);                                          \
+      if constexpr (FP8) {                                                                               \
+        ATS_MFMA_FP8(acc[i][j], __builtin_shufflevector(fa[(Q) & 1][i], fa[(Q) & 1][i], 0, 1),           \
+                     __builtin_shufflevector(fb[(Q) & 1][j], fb[(Q) & 1][j], 0, 1));                     \
+        ATS_MFMA_FP8(acc[i][j], __builtin_shufflevector(fa[(Q) & 1][i], fa[(Q) & 1][i], 2, 3),           \
+                     __builtin_shufflevector(fb[(Q) & 1][j], fb[(Q) & 1][j], 2, 3));                     \
+      } else {                                                                                           \
+        ATS_MFMA_BF16(acc[i][j], fa[(Q) & 1][i], fb[(Q) & 1][j]);                                        \
+      }                                                                                                  \
     }                                                                                                    \
     if (RD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
     if ((VM) >= 0) {                                                                                     \
@@ -823,6 +836,18 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const bf16_t* __restr
 #undef ATS_RING_SEGMENT
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");               // MFMA results -> VALU reads (the compiler cannot see the asm MFMAs)
 
+  if constexpr (FP8) {                                             // per-row scales: acc[i][j][r] *= sx[m] * sw[n]
+#pragma unroll
+    for (int j = 0; j < MT2; ++j) {
+      const float fx = sx[min(m0 + wm * (MT2 * 16) + j * 16 + lq, M - 1)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gn = n0 + wn * 64 + i * 16 + g * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] *= fx * sw[min(gn + r, N - 1)];
+      }
+    }
+  }
   big_epilogue<EPI, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
 }
 
@@ -1046,12 +1071,13 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
     if (stag >= 5 && k % 128 == 0 && k >= 256) {
       static thread_local bool ring_attr = false;
       if (!ring_attr) {
-        ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         ring_attr = true;
       }
-      if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
-      else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
+      const float* none = nullptr;
+      if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
+      else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
     } else if (stag == 4) {
       if (use256) hipLaunchKernelGGL((gemm_big2_kernel<EPI, 8, 4>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
       else        hipLaunchKernelGGL((gemm_big2_kernel<EPI, 4, 4>), dim3(t128), dim3(512), 96 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
@@ -1143,6 +1169,19 @@ int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char*
   }
   const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
   const bool use256 = big_use_256_rows(t256, t128);
+  static const int ring = env_int("ATSPEED_GEMM_FP8_RING", 1);
+  if (ring && k % 256 == 0 && k >= 512) {
+    static thread_local bool ring_attr = false;
+    if (!ring_attr) {
+      ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      ring_attr = true;
+    }
+    if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, true>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 255) / 256, gm);
+    else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, true>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 127) / 128, gm);
+    ATS_LAUNCH_CHECK();
+    return ATSPEED_OK;
+  }
   if (use256) hipLaunchKernelGGL((gemm_big2_fp8_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, x, w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 255) / 256, gm);
   else        hipLaunchKernelGGL((gemm_big2_fp8_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, x, w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 127) / 128, gm);
   ATS_LAUNCH_CHECK();
