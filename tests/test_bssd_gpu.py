@@ -331,3 +331,69 @@ def test_aligned_synthetic_pair_brackets_acceptance():
         seen[rs] = (out["n_run"], out["total_accept_steps"])
     assert seen[1e-6] == (1, 3)
     assert seen[1.0][1] < 3 and seen[1.0][0] > 1
+
+
+def test_harness_end_to_end_on_a_tiny_dataset():
+    """dataset -> prompts -> BSSD (lock-step batches) -> items -> ranking metrics (atspeed_amd.harness):
+    under the strict trie every returned beam is an item, beam-SD returns target_generate's ranking, and the aligned
+    weight pair accepts every draft step."""
+    from atspeed_amd.harness import ItemIndex, SeqRecTestData, run_inference
+    rng = np.random.default_rng(3)
+    # >= DK distinct first-level codes: fewer finite candidates than beams is the regime where the reference itself breaks (SURVEY.md 8a quirk 6)
+    idx = {str(i): [f"<a_{rng.integers(48)}>", f"<b_{rng.integers(8)}>", f"<c_{rng.integers(8)}>", f"<d_{rng.integers(8)}>"] for i in range(300)}
+    ix = ItemIndex(idx)
+    assert len(ix.allowed_tokens()[0]) >= 20
+    train = {u: rng.integers(0, 300, size=rng.integers(1, 12)).tolist() for u in range(12)}
+    valid = {u: rng.integers(0, 300, size=1).tolist() for u in range(12)}
+    test = {u: (rng.integers(0, 300, size=1).tolist() if u % 4 else []) for u in range(12)}
+    data = SeqRecTestData(ix, train, valid, test)
+    assert len(data) == 9
+    V = ix.vocab_size
+    kw = dict(dtype=torch.float32, max_slots=512, max_tokens=512, max_logit_rows=448)
+    d = HipLlama.from_synthetic(synth.LlamaDims(V, 96, 2, 3, 256), 5, num_beams=20, resid_scale=1e-6, **kw)
+    t = HipLlama.from_synthetic(synth.LlamaDims(V, 128, 3, 4, 352), 6, num_beams=10, resid_scale=1e-6, align_to=d, **kw)
+    strict = data.strict_trie_fn()
+    res = run_inference(t, d, data, gamma=4, max_new_tokens=4, users_per_batch=4, prefix_allowed_tokens_fn=strict, baseline=True)
+    assert len(res.predictions) == 9 and all(len(p) == 10 for p in res.predictions)
+    assert all(i >= 0 for p in res.predictions for i in p)               # strict trie: every beam names an item
+    assert all(len(set(p)) == len(p) for p in res.predictions)           # distinct beams -> distinct items
+    assert res.counters()["mean_accept_len"] == 3.0
+    assert all(set(r) >= {"speedup", "generalBS_time_cost", "overhead"} for r in res.rows)
+    from atspeed_amd.harness import CodeTokenEncoder, encode_prompt
+    enc = CodeTokenEncoder(ix)
+    for u, pred in zip(data.users, res.predictions):
+        ids = torch.from_numpy(encode_prompt(data, u, None, enc))[None].cuda()
+        tg = target_generate(t, {"input_ids": ids}, 4, prefix_allowed_tokens_fn=strict)
+        assert [ix.decode(g) for g in tg["beam_sequence"][:, ids.shape[1]:].cpu().tolist()] == pred
+    m = res.metrics(ix, topN=(1, 5, 10, 20))
+    assert m["topN"] == [1, 5, 10] and all(0.0 <= x <= 1.0 for key in ("precision", "recall", "ndcg", "mrr") for x in m[key])
+    # the position-set mask (what inference.py really uses) may compose code tuples that are no item
+    res2 = run_inference(t, d, data, users_per_batch=9)
+    assert len(res2.predictions) == 9 and any(i == -1 for p in res2.predictions for i in p)
+
+
+def test_inference_cli_on_generated_dataset(tmp_path):
+    """`python -m atspeed_amd.inference` end to end: dataset files in the reference's formats (index JSON + sequential_*.txt),
+    2-layer Llama-7B-dims target / Llama-68M-dims draft with aligned synthetic weights, summary JSON with timing and metrics."""
+    import json
+    from atspeed_amd import inference
+    rng = np.random.default_rng(5)
+    root = tmp_path / "data" / "toys"
+    root.mkdir(parents=True)
+    idx = {str(i): [f"<a_{rng.integers(64)}>", f"<b_{rng.integers(16)}>", f"<c_{rng.integers(16)}>", f"<d_{rng.integers(16)}>"] for i in range(500)}
+    (root / "toys.LCRec-1e-3lr.json").write_text(json.dumps(idx))
+    for name, n_lo, n_hi in (("train", 2, 25), ("valid", 1, 2), ("test", 0, 2)):
+        lines = []
+        for u in range(1, 21):
+            items = rng.integers(1, 501, size=rng.integers(n_lo, n_hi)).tolist()
+            lines.append(" ".join(str(x) for x in [u] + items))
+        (root / f"sequential_{name}.txt").write_text("\n".join(lines) + "\n")
+    out = inference.main(["--data_path", str(tmp_path / "data"), "--dataset", "toys", "--target_layers", "2", "--aligned", "3e-6",
+                          "--run_beam_sizes", "[5, 20]", "--users_per_batch", "8", "--strict_trie", "--baseline",
+                          "--output_dir", str(tmp_path / "AnaResult")])
+    assert [r["beam_size"] for r in out] == [5, 20]
+    for r in out:
+        assert r["users"] > 0 and r["items_per_s"] > 0 and r["mean_accept_len"] == 3.0
+        assert r["metrics"]["users"] == r["users"] and len(r["metrics"]["recall"]) == len(r["metrics"]["topN"])
+        assert {"draft_time_cost", "target_time_cost", "verify_time_cost", "total_time_cost", "speedup"} <= set(r["timing_mean_rank0"])
+    assert len(list((tmp_path / "AnaResult" / "toys").glob("timing_mean_*.json"))) == 2
