@@ -9,13 +9,13 @@ from .generation_trie import (ConstraintFSM, PositionSetConstraint, SuffixTrieCo
                               WholeSentenceTrieConstraint, prefix_allowed_tokens_fn)
 
 __all__ = ["Trie", "prefix_allowed_tokens_fn", "PositionSetConstraint", "SuffixTrieConstraint",
-           "WholeSentenceTrieConstraint", "ConstraintFSM", "BSSD", "BSSD_batch", "beam_sd_generate", "target_generate",
+           "WholeSentenceTrieConstraint", "ConstraintFSM", "BSSD", "BSSD_batch", "beam_sd_generate", "target_generate", "target_generate_batch",
            "Timer", "HipLlama"]
 
 
 def __getattr__(name):
     # the HIP-backed entry points import torch + the shared library lazily
-    if name in ("BSSD", "BSSD_batch", "beam_sd_generate", "target_generate", "Timer", "one_step_beam_search"):
+    if name in ("BSSD", "BSSD_batch", "beam_sd_generate", "target_generate", "target_generate_batch", "Timer", "one_step_beam_search"):
         from . import beamSD
         return getattr(beamSD, name)
     if name in ("HipLlama",):

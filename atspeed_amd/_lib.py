@@ -62,6 +62,7 @@ SIGNATURES = {
     "atspeed_bssd_generate": (C.c_int, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, C.POINTER(GenStats), _P]),
     "atspeed_bssd_generate_batch": (C.c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "atspeed_target_generate": (C.c_int, [_P, _P, _I, _P, _I, _I, _I, _P, _P, C.POINTER(GenStats), _P]),
+    "atspeed_target_generate_batch": (C.c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "atspeed_decoder_trace": (C.c_int, [_P, _P, _I]),
     "atspeed_gemm": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "atspeed_rmsnorm": (C.c_int, [_P, _P, _P, _I, _I, _F, _I, _P]),

@@ -313,6 +313,48 @@ def target_generate(model, inputs: Dict, max_new_tokens: int, logits_processor=N
     return out
 
 
+def target_generate_batch(model, inputs_list, max_new_tokens: int, prefix_allowed_tokens_fn=None):
+    """`target_generate` for several independent users in lock step (one result dict per user): position g of every
+    user's constrained beam search is ONE forward.  This is the loop `code/generate_teacher_data.py:211-244` runs over
+    a whole training set with HF `generate`; token ids equal per-user `target_generate` calls."""
+    _check_models(model)
+    if len(inputs_list) > MAX_USERS_PER_CALL:
+        outs = []
+        for i in range(0, len(inputs_list), MAX_USERS_PER_CALL):
+            outs += target_generate_batch(model, inputs_list[i:i + MAX_USERS_PER_CALL], max_new_tokens, prefix_allowed_tokens_fn)
+        return outs
+    lib = _lib.load()
+    dev = model.device
+    n = len(inputs_list)
+    k = int(model.generation_config.num_beams)
+    t0 = time.time()
+    prompts = [_prompt_row(inp).to(dev) for inp in inputs_list]
+    fsms = [_compile_constraint(prefix_allowed_tokens_fn, p.tolist()) for p in prompts]
+    dfsm = _DeviceFSM.get(fsms[0], model.dims.vocab_size)
+    for f in fsms[1:]:
+        if f.row_ptr is not fsms[0].row_ptr:
+            raise ValueError("target_generate_batch needs one shared constraint automaton (only the start node may differ per user)")
+    decs = [_Decoder.get(model, None, int(p.numel()), lane=i) for i, p in enumerate(prompts)]
+    with torch.cuda.device(dev):
+        ids32 = [p.to(torch.int32).contiguous() for p in prompts]
+        toks = [torch.empty(k, max_new_tokens, dtype=torch.int32, device=dev) for _ in range(n)]
+        scores = [torch.empty(k, dtype=torch.float32, device=dev) for _ in range(n)]
+        stats = (_lib.GenStats * n)()
+        arr_p = (C.c_void_p * n)
+        _lib.check(lib.atspeed_target_generate_batch(
+            arr_p(*[d.handle for d in decs]), n, arr_p(*[t.data_ptr() for t in ids32]),
+            (C.c_int32 * n)(*[int(p.numel()) for p in prompts]), dfsm.handle, (C.c_int32 * n)(*[f.start for f in fsms]),
+            int(max_new_tokens), k, arr_p(*[t.data_ptr() for t in toks]), arr_p(*[t.data_ptr() for t in scores]), stats,
+            _lib.stream_ptr(dev)))
+    wall = time.time() - t0
+    outs = []
+    for i in range(n):
+        out = _result(prompts[i], toks[i], scores[i], k)
+        out.update({"n_valid": int(stats[i].n_valid), "device_time_cost": stats[i].total_ms * 1e-3, "time_cost": wall / n})
+        outs.append(out)
+    return outs
+
+
 def last_trace(target_model, draft_model):
     """Per-round trace of the last BSSD call on this model pair (parity tests):
     list of dict(draft_len, n_matches, n_beams, draft_ids=[draft_len][dk])."""

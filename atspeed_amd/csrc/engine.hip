@@ -620,7 +620,7 @@ static int bssd_begin(atspeed_decoder* d, const int32_t* prompt, int P, const at
 // is ONE forward over the tokens of all users that need it (weights are streamed once per forward, not per user).
 static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
   atspeed_llama *T = decs[0]->target, *D = decs[0]->draft;
-  const int W = decs[0]->W, V = T->cfg.vocab_size;
+  const int W = decs[0]->W;
   if (!g_ev_init) { for (auto& e : g_ev) ATS_HIP(hipEventCreate(&e)); g_ev_init = true; }
   // capacity for the largest possible batched forward of this group
   int cap_t = 0, cap_r = 0, cap_d = 0;
@@ -867,6 +867,82 @@ extern "C" int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt
   hipEventElapsedTime(&s.total_ms, g_ev[0], g_ev[1]);
   s.target_ms = s.total_ms;
   if (stats) *stats = s;
+  return ATSPEED_OK;
+}
+
+// target_generate (beamSD.py:544-595) for n users in lock step: step g of every user is ONE forward + one beam-step launch
+// (the teacher-data job of generate_teacher_data.py:211-244 is exactly this loop over a whole training set).
+extern "C" int atspeed_target_generate_batch(atspeed_decoder** decs, int32_t n, const int32_t* const* prompts,
+                                             const int32_t* prompt_lens, const atspeed_fsm* fsm, const int32_t* start_nodes,
+                                             int32_t max_new, int32_t k, int32_t* const* out_tokens, float* const* out_scores,
+                                             atspeed_gen_stats* stats, void* stream) {
+  ATS_REQUIRE(decs && prompts && prompt_lens && start_nodes && out_tokens && out_scores, ATSPEED_ERR_INVALID, "target_generate_batch: null argument");
+  ATS_REQUIRE(n >= 1 && n <= ATS_MAX_SEGS, ATSPEED_ERR_CAPACITY, "target_generate_batch: %d users per call (max %d)", n, ATS_MAX_SEGS);
+  hipStream_t st = (hipStream_t)stream;
+  atspeed_llama* T = decs[0]->target;
+  const int W = decs[0]->W;
+  int cap_t = 0;
+  for (int u = 0; u < n; ++u) {
+    atspeed_decoder* d = decs[u];
+    ATS_REQUIRE(d && d->target == T, ATSPEED_ERR_INVALID, "target_generate_batch: decoders must share one target model");
+    for (int j = 0; j < u; ++j) ATS_REQUIRE(decs[u] != decs[j], ATSPEED_ERR_INVALID, "target_generate_batch: decoder %d used twice", u);
+    ATS_TRY(check_common(d, prompts[u], prompt_lens[u], fsm, start_nodes[u], max_new, k, out_tokens[u], out_scores[u]));
+    ATS_REQUIRE(prompt_lens[u] + max_new * k <= T->cfg.max_slots, ATSPEED_ERR_CAPACITY, "target_generate: KV slots exhausted");
+    ATS_REQUIRE(prompt_lens[u] + max_new * k <= d->tok_cap, ATSPEED_ERR_CAPACITY, "target_generate: token buffer too small");
+    cap_t += std::max(prompt_lens[u], k);
+  }
+  ATS_TRY(ensure_act(T, cap_t, n * MAXB));
+  if (!g_ev_init) { for (auto& e : g_ev) ATS_HIP(hipEventCreate(&e)); g_ev_init = true; }
+  for (int u = 0; u < n; ++u)
+    ATS_TRY(ats_init_prompt(decs[u]->tin[0], prompts[u], prompt_lens[u], W, decs[u]->round_beams[0], start_nodes[u], T->cfg.vocab_size,
+                            decs[u]->mail_dev, st));
+  hipEventRecord(g_ev[0], st);
+  struct St { int row0, n_in, nb, base, cur; };
+  std::vector<St> s(n);
+  for (int u = 0; u < n; ++u) s[u] = St{0, prompt_lens[u], 1, 0, 0};
+  for (int g = 0; g < max_new; ++g) {                                                // beamSD.py:579-588
+    SegTable t{};
+    for (int u = 0; u < n; ++u)
+      t.seg[t.n++] = make_seg(tb_offset(decs[u]->tin[0], s[u].row0, W), s[u].n_in, s[u].base + s[u].n_in, s[u].nb, decs[u]->tkv);
+    ATS_TRY(seg_finish(t));
+    ATS_TRY(llama_forward_segs(T, t, nullptr, st));
+    std::vector<BeamStepArgs> args;
+    for (int u = 0; u < n; ++u) {
+      atspeed_decoder* d = decs[u];
+      BeamStepArgs a{};
+      a.src = d->round_beams[s[u].cur]; a.n_src = s[u].nb; a.gen_len = g;
+      a.logits = T->act->logits + (size_t)t.seg[u].logit_row0 * T->logits_ld; a.ld = T->logits_ld;
+      a.lse = T->act->lse + t.seg[u].logit_row0; a.fsm = fsm->dev; a.k = k;
+      a.dst = d->round_beams[s[u].cur ^ 1]; a.emit = 1;
+      a.in = d->tin[0]; a.in_row0 = s[u].row0 + s[u].n_in - s[u].nb;
+      a.out = d->tin[0]; a.out_row0 = s[u].row0 + s[u].n_in; a.out_slot0 = s[u].base + s[u].n_in; a.vis_words = W;
+      a.mail = d->mail_dev;
+      args.push_back(a);
+      s[u].row0 += s[u].n_in; s[u].base += s[u].n_in; s[u].n_in = k; s[u].nb = k; s[u].cur ^= 1;
+    }
+    const BeamStepArgs* dev_args = nullptr;
+    ATS_TRY(stage_args(args, &dev_args, st));
+    ATS_TRY(ats_beam_step_multi(dev_args, n, st));
+  }
+  for (int u = 0; u < n; ++u) {
+    ATS_TRY(ats_export_beams(decs[u]->round_beams[s[u].cur], k, max_new, out_tokens[u], out_scores[u], st));
+    ATS_HIP(hipMemcpyAsync(decs[u]->mail_host, decs[u]->mail_dev, sizeof(Mailbox), hipMemcpyDeviceToHost, st));
+  }
+  hipEventRecord(g_ev[1], st);
+  ATS_HIP(hipStreamSynchronize(st));
+  ats_stage_reset();
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, g_ev[0], g_ev[1]);
+  for (int u = 0; u < n; ++u) {
+    ATS_TRY(mailbox_status(decs[u]));
+    if (stats) {
+      atspeed_gen_stats gs;
+      memset(&gs, 0, sizeof(gs));
+      gs.n_target_forwards = max_new; gs.n_valid = decs[u]->mail_host->n_valid;
+      gs.total_ms = gs.target_ms = ms / n;                      // the group's time shared equally by its users
+      stats[u] = gs;
+    }
+  }
   return ATSPEED_OK;
 }
 

@@ -196,6 +196,13 @@ int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt_ids_dev, i
                             int32_t* out_tokens_dev, float* out_scores_dev, atspeed_gen_stats* stats_host,
                             void* stream);
 
+/* target_generate for n users in lock step (one forward + one beam-step launch per generated position for all of
+ * them): the constrained beam search of generate_teacher_data.py:211-244 at scale.  Results equal n single calls. */
+int atspeed_target_generate_batch(atspeed_decoder** decoders, int32_t n, const int32_t* const* prompt_ids_dev,
+                                  const int32_t* prompt_lens, const atspeed_fsm* fsm, const int32_t* start_nodes,
+                                  int32_t max_new_tokens, int32_t k, int32_t* const* out_tokens_dev,
+                                  float* const* out_scores_dev, atspeed_gen_stats* stats_host /* [n] */, void* stream);
+
 /* per-round trace of the last atspeed_bssd_generate call (host memory, for parity tests):
  * for round r, step i: the draft's flat ids (dk entries, -1 = not a beam).  Returns the
  * number of ints written. */

@@ -397,3 +397,50 @@ def test_inference_cli_on_generated_dataset(tmp_path):
         assert r["metrics"]["users"] == r["users"] and len(r["metrics"]["recall"]) == len(r["metrics"]["topN"])
         assert {"draft_time_cost", "target_time_cost", "verify_time_cost", "total_time_cost", "speedup"} <= set(r["timing_mean_rank0"])
     assert len(list((tmp_path / "AnaResult" / "toys").glob("timing_mean_*.json"))) == 2
+
+
+def test_target_generate_batch_equals_single_calls(bssd_golden):
+    from atspeed_amd.beamSD import target_generate_batch
+    case = next(c for c in CASES if c["name"] == "k20_dk40_trie")
+    ci = build_case_inputs(case)
+    tgt, _ = _models(ci, case)
+    rng = np.random.default_rng(2)
+    prompts = [ci["prompt"]] + [np.concatenate([rng.integers(3, 31000, size=n), ci["prompt"][-6:]]) for n in (5, 40, 17)]
+    inputs = [{"input_ids": torch.from_numpy(p.astype(np.int64))[None].cuda()} for p in prompts]
+    outs = target_generate_batch(tgt, inputs, case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"])
+    for inp, o in zip(inputs, outs):
+        one = target_generate(tgt, inp, case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"])
+        assert torch.equal(o["beam_sequence"], one["beam_sequence"])
+        np.testing.assert_allclose(o["beam_scores"].cpu().numpy(), one["beam_scores"].cpu().numpy(), atol=SCORE_TOL, rtol=0)
+    gold = bssd_golden[case["name"]]
+    P = len(ci["prompt"])
+    assert outs[0]["beam_sequence"][:, P:].cpu().tolist() == gold["tg_tokens"]   # the real reference's output
+
+
+def test_teacher_data_tensors_match_the_oracle_forward():
+    """generate_teacher_data: beams from the lock-step constrained search; the packed tree-mask forward
+    returns, for the label and for every beam, the logits a plain causal forward over prompt ++ sequence gives (oracle Llama)."""
+    from atspeed_amd.harness import CodeTokenEncoder, ItemIndex, SeqRecTestData, encode_prompt
+    from atspeed_amd.teacher import generate_teacher_data
+    rng = np.random.default_rng(4)
+    idx = {str(i): [f"<a_{rng.integers(40)}>", f"<b_{rng.integers(8)}>", f"<c_{rng.integers(8)}>", f"<d_{rng.integers(8)}>"] for i in range(200)}
+    ix = ItemIndex(idx)
+    train = {u: rng.integers(0, 200, size=rng.integers(2, 9)).tolist() for u in range(3)}
+    data = SeqRecTestData(ix, train, {u: [] for u in range(3)}, {u: [int(rng.integers(200))] for u in range(3)})
+    dims = synth.LlamaDims(ix.vocab_size, 128, 2, 4, 352)
+    sd = synth.synthetic_state_dict(dims, 11, std=0.05, head_std=0.1)
+    m = HipLlama.from_state_dict(dims, sd, torch.float32, max_slots=512, max_tokens=512, max_logit_rows=512, num_beams=10)
+    ref = RefLlama(dims, sd, max_slots=512)
+    enc = CodeTokenEncoder(ix)
+    prompts = [encode_prompt(data, u, None, enc) for u in data.users]
+    labels = [list(ix.item_codes[u.labels[0]]) + [2] for u in data.users]
+    out = generate_teacher_data(m, prompts, labels, data.strict_trie_fn(), beam_size=10, max_new_token=5, users_per_batch=2)
+    for p, lab, tl, to, tol in zip(prompts, labels, out["teacher_logits"], out["teacher_output"], out["teacher_output_logits"]):
+        assert to.shape == (10, 5) and tl.shape == (5, ix.vocab_size) and tol.shape == (10, 5, ix.vocab_size - 32000)
+        assert all(ix.decode(b[:4]) >= 0 and b[4] == 2 for b in to.tolist())              # strict trie: item codes, then EOS
+        for seq, got in [(lab, tl)] + [(b, torch.cat([torch.zeros(5, 32000), g], 1)) for b, g in zip(to.tolist()[:3], tol[:3])]:
+            full = torch.from_numpy(np.concatenate([p, np.asarray(seq[:-1], dtype=np.int64)]))
+            inp = R._causal_inputs(full)
+            want = ref.forward(inp.ids, inp.pos, inp.slots, inp.vis)[len(p) - 1:]
+            cols = slice(32000, None) if got is not tl else slice(None)
+            np.testing.assert_allclose(got[:, cols].numpy(), want[:, cols].numpy(), atol=LOGIT_TOL, rtol=0)
