@@ -53,6 +53,7 @@ SIGNATURES = {
     "atspeed_quant_rows_fp8": (C.c_int, [_P, _I, _I, _P, _P, _P]),
     "atspeed_gemm_fp8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "atspeed_llama_profile": (C.c_int, [_P, _I, _P, _P, _P]),
+    "atspeed_llama_profile_big": (C.c_int, [_P, _P, _P, _P]),
     "atspeed_llama_logits_ld": (_I, [_P]),
     "atspeed_lse_rows": (C.c_int, [_P, _I, _I, _I, _P, _P]),
     "atspeed_beam_expand_prune": (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P]),

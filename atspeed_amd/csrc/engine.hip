@@ -171,7 +171,12 @@ struct atspeed_llama {
   double prof_ms[5] = {0, 0, 0, 0, 0};
   long prof_cnt[5] = {0, 0, 0, 0, 0};
   long prof_rows[5] = {0, 0, 0, 0, 0};           // sum of M over the bracketed launches
+  // the same, restricted to launches of at least ATS_PROF_BIG_ROWS tokens (these take the 256x256 ring kernel)
+  double prof_big_ms[5] = {0, 0, 0, 0, 0};
+  long prof_big_cnt[5] = {0, 0, 0, 0, 0};
+  long prof_big_rows[5] = {0, 0, 0, 0, 0};
 };
+constexpr int ATS_PROF_BIG_ROWS = 1024;
 
 static void prof_harvest(atspeed_llama* m) {
   ActCtx* cx = m->act;
@@ -182,6 +187,7 @@ static void prof_harvest(atspeed_llama* m) {
         hipEventElapsedTime(&ms, cx->prof_ev[2 * b], cx->prof_ev[2 * b + 1]) == hipSuccess) {
       int kd = cx->prof_kind[b];
       m->prof_ms[kd] += ms; m->prof_cnt[kd] += 1; m->prof_rows[kd] += cx->prof_m[b];
+      if (cx->prof_m[b] >= ATS_PROF_BIG_ROWS) { m->prof_big_ms[kd] += ms; m->prof_big_cnt[kd] += 1; m->prof_big_rows[kd] += cx->prof_m[b]; }
     }
   }
   cx->prof_kind.clear(); cx->prof_m.clear();
@@ -316,8 +322,18 @@ extern "C" int atspeed_llama_profile(atspeed_llama* m, int32_t enable, double* m
   }
   if (enable >= 0) {
     m->prof_on = enable != 0;
-    for (int i = 0; i < 5; ++i) { m->prof_ms[i] = 0; m->prof_cnt[i] = 0; m->prof_rows[i] = 0; }
+    for (int i = 0; i < 5; ++i) {
+      m->prof_ms[i] = 0; m->prof_cnt[i] = 0; m->prof_rows[i] = 0;
+      m->prof_big_ms[i] = 0; m->prof_big_cnt[i] = 0; m->prof_big_rows[i] = 0;
+    }
   }
+  return ATSPEED_OK;
+}
+
+extern "C" int atspeed_llama_profile_big(atspeed_llama* m, double* ms_out, int64_t* count_out, int64_t* rows_out) {
+  ATS_REQUIRE(m && ms_out && count_out && rows_out, ATSPEED_ERR_INVALID, "profile_big: null argument");
+  prof_harvest(m);
+  for (int i = 0; i < 5; ++i) { ms_out[i] = m->prof_big_ms[i]; count_out[i] = m->prof_big_cnt[i]; rows_out[i] = m->prof_big_rows[i]; }
   return ATSPEED_OK;
 }
 

@@ -187,6 +187,14 @@ class HipLlama:
         _lib.check(_lib.load().atspeed_llama_profile(self._handle, enable, ms, cnt, rows))
         return {k: dict(ms=ms[i], count=int(cnt[i]), rows=int(rows[i])) for i, k in enumerate(self.GEMM_KINDS)}
 
+    def profile_big(self) -> Dict[str, Dict[str, float]]:
+        """The brackets of launches with >= 1024 tokens only (one kernel: the 256x256 ring GEMM); read before `profile(0)` resets."""
+        ms = (C.c_double * 5)()
+        cnt = (C.c_int64 * 5)()
+        rows = (C.c_int64 * 5)()
+        _lib.check(_lib.load().atspeed_llama_profile_big(self._handle, ms, cnt, rows))
+        return {k: dict(ms=ms[i], count=int(cnt[i]), rows=int(rows[i])) for i, k in enumerate(self.GEMM_KINDS)}
+
     def gemm_shape(self, kind: str):
         """(N, K) of a GEMM kind."""
         d = self.dims

@@ -122,6 +122,10 @@ float* atspeed_llama_logits(atspeed_llama* m);
  * count_out[5] / rows_out[5] (sum of M); enable = 1/0 switches the brackets on/off and resets,
  * enable < 0 only reads.  Measurement hook for bench.py's roofline (no reference counterpart). */
 int atspeed_llama_profile(atspeed_llama* m, int32_t enable, double* ms_out, int64_t* count_out, int64_t* rows_out);
+/* The same accumulators restricted to launches of >= 1024 tokens (the 256x256 ring kernel's launches): read BEFORE the
+ * atspeed_llama_profile call that resets them.  bench.py's roofline uses these so that its average launch time is
+ * that of one kernel (gemm_ring_kernel<EPI, 8, false>) and can be checked against the rocprofv3 kernel summary. */
+int atspeed_llama_profile_big(atspeed_llama* m, double* ms_out, int64_t* count_out, int64_t* rows_out);
 int32_t atspeed_llama_logits_ld(const atspeed_llama* m);
 /* BASELINE config 5 (fp8 target verification): build OCP-e4m3 copies of the layer projections (per-output-row scales,
  * library-owned) from the bf16 weights.  From then on the batched forwards (M >= 512 tokens, shapes that fill the chip)
