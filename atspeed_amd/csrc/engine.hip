@@ -343,7 +343,7 @@ extern "C" int32_t atspeed_llama_logits_ld(const atspeed_llama* m) { return m ? 
 extern "C" int atspeed_llama_enable_fp8(atspeed_llama* m, void* stream) {
   ATS_REQUIRE(m, ATSPEED_ERR_INVALID, "enable_fp8: null model");
   ATS_REQUIRE(m->cfg.dtype == ATSPEED_BF16, ATSPEED_ERR_INVALID, "enable_fp8: the model must hold bf16 weights");
-  ATS_REQUIRE(m->cfg.hidden % 128 == 0 && m->cfg.ffn % 128 == 0, ATSPEED_ERR_INVALID, "enable_fp8: hidden and ffn must be multiples of 128");
+  ATS_REQUIRE(m->cfg.hidden % 256 == 0 && m->cfg.ffn % 256 == 0, ATSPEED_ERR_INVALID, "enable_fp8: hidden and ffn must be multiples of 256");
   if (!m->fp8.empty()) return ATSPEED_OK;
   hipStream_t st = (hipStream_t)stream;
   const int H = m->cfg.hidden, F = m->cfg.ffn;

@@ -9,8 +9,9 @@
 //     bf16: v_mfma_f32_16x16x32_bf16, fp32 parity mode: v_mfma_f32_16x16x4_f32 with a k permutation that lets a
 //     lane take its four k-steps from one chunk; split-K into fp32 slabs sized for >= 2-3 workgroups per CU, reduced
 //     by a second kernel that also applies the epilogue (and, for the residual projections, the next RMSNorm).
-//   * gemm_big2_kernel<EPI,MT2> — M = tokens of all users of a lock-step batch (thousands): MFMA-bound.  256 x
-//     {256,128} tile, 8 waves, both operands by LDS-DMA, two tiles in flight (see the kernel's comment).
+//   * gemm_ring_kernel<EPI,MT2,FP8> — M = tokens of all users of a lock-step batch (thousands): MFMA-bound.  256 x
+//     {256,128} tile, 8 waves, both operands by LDS-DMA into a four-stage ring of 32-deep k-steps, hand-placed inner
+//     loop (see the kernel's comment); the same kernel on e4m3 operands with per-row scales (W8A8).
 // Epilogues: store (dtype), fp32 store (logits), residual add, SwiGLU over interleaved gate/up 16-row groups.
 #include <stdlib.h>
 
@@ -256,161 +257,6 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, void* __
 }
 
 
-// =====================================================================================
-// Large-M GEMM (bf16) for the lock-step multi-user forwards (M = tokens of all users, 1-4 k rows).
-//
-//   C^T[N, M] = W[N, K] * X^T[K, M],  workgroup tile 256 (n) x 256 (m) x 64 (k), 8 waves as 4 (n) x 2 (m),
-//   wave tile 64 x 128 = 4 x 8 MFMA 16x16x32 tiles (128 accumulator registers).
-// Both operands are staged by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, 1 KB per wave-instruction)
-// into two 64 KB stages; LDS rows are 128 B with the 16-byte chunk XOR-swizzle applied on the per-lane SOURCE
-// address (the DMA destination is lane-linear) and again on the fragment reads.  Per k-tile a wave first pulls
-// all its fragments of the current stage into registers, then issues the DMA of the next stage, then runs its 64
-// MFMAs under that DMA, then waits (vmcnt(0)) and meets the others at the barrier — the one barrier per k-tile
-// both publishes the new stage and retires the reads of the old one.
-// Workgroup ids are remapped so that each XCD (private L2) walks a contiguous band of tiles.
-template <int EPI, int DBG = 0>   // DBG (tuning only): 1 = no DMA inside the loop, 2 = no fragment reads inside the loop
-__global__ __launch_bounds__(512, 1) void gemm_big_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
-                                                          void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
-                                                          int tiles_n, int tiles_m) {
-  constexpr int BT = 256, BK = 64;
-  constexpr int STAGE = 2 * BT * kRowBytes;                      // W tile then X tile: 64 KB
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 15, g = lane >> 4;
-  // XCD-aware, bijective remap: ids b, b+8, b+16, ... share an XCD; give each XCD a contiguous run of tiles
-  const int nwg = tiles_n * tiles_m;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
-  }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;              // consecutive ids share the X panel (same tm)
-  const int n0 = tn * BT, m0 = tm * BT;
-  const int wn = wave >> 1, wm = wave & 1;                       // 4 x 2 waves
-  const int nk = K / BK;
-
-  // DMA source pointers: 4 wave-instructions for W and 4 for X per stage; instruction j of this wave moves rows
-  // (wave*4 + j)*8 .. +8; lane i -> row +(i>>3), stored position p = i&7 carries logical chunk p ^ (row&7)
-  const bf16_t* wsrc[4]; const bf16_t* xsrc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (wave * 4 + j) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ (row & 7);
-    wsrc[j] = W + (size_t)min(n0 + row, N - 1) * K + c * 8;
-    xsrc[j] = X + (size_t)min(m0 + row, M - 1) * ldx + c * 8;
-  }
-  auto dma_stage = [&](int buf, int kt) {
-    unsigned char* sw = smem + buf * STAGE;
-    unsigned char* sx = sw + BT * kRowBytes;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sw + (wave * 4 + j) * 8 * kRowBytes), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[j] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sx + (wave * 4 + j) * 8 * kRowBytes), 16, 0, 0);
-    }
-  };
-
-  f32x4_t acc[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  dma_stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const unsigned char* sw = smem + buf * STAGE + (wn * 64) * kRowBytes;
-    const unsigned char* sx = smem + buf * STAGE + BT * kRowBytes + (wm * 128) * kRowBytes;
-    s16x8_t af[2][4], bfr[2][8];
-    if (DBG != 2 || kt == 0) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const s16x8_t*>(sw + swz(i * 16 + lq, ks * 4 + g));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bfr[ks][j] = *reinterpret_cast<const s16x8_t*>(sx + swz(j * 16 + lq, ks * 4 + g));
-    }
-    }
-    if (DBG != 1 && kt + 1 < nk) dma_stage(buf ^ 1, kt + 1);   // next stage flies under the MFMAs below
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[ks][i]),
-                                                              __builtin_bit_cast(bf16x8_t, bfr[ks][j]), acc[i][j], 0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  // ------------------------------------------------------------------ epilogue
-  // acc[i][j][r] = C[m = m0 + wm*128 + j*16 + lq][n = n0 + wn*64 + i*16 + g*4 + r]
-  const bool vec = (ldc & 3) == 0;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int gm = m0 + wm * 128 + j * 16 + lq;
-    if (gm >= M) continue;
-    if constexpr (EPI == EPI_SWIGLU) {
-      bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
-#pragma unroll
-      for (int i = 0; i < 4; i += 2) {
-        const int gn = n0 + wn * 64 + i * 16;                    // 32-row group start: [16 gate | 16 up]
-        if (gn >= N) continue;
-        ushort4 o;
-        bf16_t* op = reinterpret_cast<bf16_t*>(&o);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float gt = bf2f(f2bf(acc[i][j][r])), up = bf2f(f2bf(acc[i + 1][j][r]));
-          op[r] = f2bf(gt / (1.f + __expf(-gt)) * up);
-        }
-        *reinterpret_cast<ushort4*>(C + (size_t)gm * ldc + (gn >> 1) + g * 4) = o;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gn = n0 + wn * 64 + i * 16 + g * 4;
-        if (gn >= N) continue;
-        if constexpr (EPI == EPI_F32) {
-          float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
-          if (gn + 3 < N && vec) *reinterpret_cast<float4*>(C) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-          else
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[i][j][r];
-        } else {
-          bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
-          if (gn + 3 < N && vec) {
-            ushort4 o;
-            bf16_t* op = reinterpret_cast<bf16_t*>(&o);
-            if constexpr (EPI == EPI_RESID) {
-              ushort4 rs = *reinterpret_cast<const ushort4*>(C);
-              const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) op[r] = f2bf(bf2f(rp[r]) + bf2f(f2bf(acc[i][j][r])));
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) op[r] = f2bf(acc[i][j][r]);
-            }
-            *reinterpret_cast<ushort4*>(C) = o;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (gn + r < N) {
-                float v = acc[i][j][r];
-                if constexpr (EPI == EPI_RESID) v = bf2f(C[r]) + bf2f(f2bf(v));
-                C[r] = f2bf(v);
-              }
-          }
-        }
-      }
-    }
-  }
-}
-
 // Epilogue of the 256-wide kernels: wave (wn, wm) holds 4 x MT2 accumulator tiles, n = n0 + wn*64 + i*16 + g*4 + r,
 // m = m0 + wm*MT2*16 + j*16 + lq.
 template <int EPI, int MT2>
@@ -477,217 +323,36 @@ __device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[4][MT2], void* __res
   }
 }
 
-// ---- deeper-pipelined variant -----------------------------------------------------------------------------------
-// Ablation on MI355X (tools/sweep_big.sh): the loop above runs at 1.26-1.5 PF without its DMA and ~0.85 PF with it:
-// a 64 KB stage per ~1.6 us of MFMAs is right at the ~65 GB/s a CU can pull from L2, so a DMA issued just before the
-// MFMAs of tile t and awaited right after them is exposed.  Here the fragments of tile t are pulled into registers
-// first; once every wave has them (barrier B) the stage is dead and the DMA of tile t+2 is issued into it, so two
-// tiles are always in flight with the same 128 KB of LDS.  The fragment reads are inline asm: hipcc would otherwise
-// put s_waitcnt vmcnt(0) in front of any ds_read while an LDS-DMA is pending and drain the pipeline.  Waits are
-// counted by hand: 8 LDS-DMA instructions per wave per tile.
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
 }
+// inline asm: hipcc puts s_waitcnt vmcnt(0) in front of any ds_read it emits itself while an LDS-DMA is pending
 #define ATS_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 
-// MT2 = 16-row token tiles per wave: 8 -> 256x256 workgroup tile, 4 -> 256 (n) x 128 (m) for the mid-size rounds
-template <int EPI, int MT2, int STAG = 0>
-__global__ __launch_bounds__(512, 1) void gemm_big2_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
-                                                           void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
-                                                           int tiles_n, int tiles_m, int GM) {
-  constexpr int BT = 256, BK = 64;
-  constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
-  constexpr int XJ = XR / 64;                                    // X DMA instructions per wave per stage
-  constexpr int STAGE = (BT + XR) * kRowBytes;                   // W tile then X tile: 64 or 48 KB
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 15, g = lane >> 4;
-  const int nwg = tiles_n * tiles_m;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
-  }
-  // grouped order: bands of GM tile rows, W-panel-major inside a band, so the ~32 tiles an XCD runs at once form a
-  // GM x 8 block sharing GM X panels and 8 W panels (PMC: FETCH_SIZE showed every W panel missing the 4 MB L2)
-  const int band = bid / (GM * tiles_n), rem = bid % (GM * tiles_n);
-  const int band_rows = min(GM, tiles_m - band * GM);
-  const int tn = rem / band_rows, tm = band * GM + rem % band_rows;
-  const int n0 = tn * BT, m0 = tm * XR;
-  const int wn = wave >> 1, wm = wave & 1;
-  const int nk = K / BK;
-
-  const bf16_t* wsrc[4]; const bf16_t* xsrc[XJ];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (wave * 4 + j) * 8 + (lane >> 3);
-    wsrc[j] = W + (size_t)min(n0 + row, N - 1) * K + ((lane & 7) ^ (row & 7)) * 8;
-  }
-#pragma unroll
-  for (int j = 0; j < XJ; ++j) {
-    const int row = (wave * XJ + j) * 8 + (lane >> 3);
-    xsrc[j] = X + (size_t)min(m0 + row, M - 1) * ldx + ((lane & 7) ^ (row & 7)) * 8;
-  }
-  auto dma_stage = [&](int buf, int kt) {
-    unsigned char* sw = smem + buf * STAGE;
-    unsigned char* sx = sw + BT * kRowBytes;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sw + (wave * 4 + j) * 8 * kRowBytes), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < XJ; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[j] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sx + (wave * XJ + j) * 8 * kRowBytes), 16, 0, 0);
-  };
-  // per-lane fragment addresses inside stage 0 (row lq of the wave's first tile; tile i adds i*16 rows = i*2048 B)
-  unsigned a_addr[2], b_addr[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int sl = ((ks * 4 + g) ^ (lq & 7)) * 16 + lq * kRowBytes;
-    a_addr[ks] = lds_addr(smem) + (wn * 64) * kRowBytes + sl;
-    b_addr[ks] = lds_addr(smem) + BT * kRowBytes + (wm * MT2 * 16) * kRowBytes + sl;
-  }
-
-  f32x4_t acc[4][MT2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < MT2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  u32x4_t af[2][4], bfr[2][MT2];
-  auto read_frags = [&](int kt) {                                           // 24 (16) ds_read_b128: this wave's fragments of tile kt
-    const unsigned boff = (kt & 1) * STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const unsigned aa = a_addr[ks] + boff, ba = b_addr[ks] + boff;
-      ATS_DS_READ_B128(af[ks][0], aa, 0);     ATS_DS_READ_B128(af[ks][1], aa, 2048);
-      ATS_DS_READ_B128(af[ks][2], aa, 4096);  ATS_DS_READ_B128(af[ks][3], aa, 6144);
-      ATS_DS_READ_B128(bfr[ks][0], ba, 0);     ATS_DS_READ_B128(bfr[ks][1], ba, 2048);
-      ATS_DS_READ_B128(bfr[ks][2], ba, 4096);  ATS_DS_READ_B128(bfr[ks][3], ba, 6144);
-      if constexpr (MT2 == 8) {
-        ATS_DS_READ_B128(bfr[ks][4], ba, 8192);  ATS_DS_READ_B128(bfr[ks][5], ba, 10240);
-        ATS_DS_READ_B128(bfr[ks][6], ba, 12288); ATS_DS_READ_B128(bfr[ks][7], ba, 14336);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // fragments are in registers
-  };
-  auto mfma_tile = [&]() {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MT2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[ks][i]),
-                                                              __builtin_bit_cast(bf16x8_t, bfr[ks][j]), acc[i][j], 0, 0, 0);
-  };
-  // the same MFMAs with this wave's 4 + XJ DMA pieces of tile `kt` spread between them (one piece per 8 (6) MFMAs): a
-  // burst of pieces right after the barrier costs each wave 100-185 cycles of issue per piece (VMEM queue back-pressure)
-  auto mfma_tile_dma = [&](int buf, int kt) {
-    unsigned char* sw = smem + buf * STAGE;
-    unsigned char* sx = sw + BT * kRowBytes;
-    constexpr int NP = 4 + XJ, GAP = (2 * 4 * MT2) / NP;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MT2; ++j) {
-          const int idx = (ks * 4 + i) * MT2 + j;
-          if (idx % GAP == 0 && idx / GAP < NP) {
-            const int pc = idx / GAP;
-            if (pc < 4)
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[pc] + kt * BK),
-                                               (__attribute__((address_space(3))) void*)(sw + (wave * 4 + pc) * 8 * kRowBytes), 16, 0, 0);
-            else
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[(pc - 4) % XJ] + kt * BK),
-                                               (__attribute__((address_space(3))) void*)(sx + (wave * XJ + (pc - 4)) * 8 * kRowBytes), 16, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[ks][i]),
-                                                              __builtin_bit_cast(bf16x8_t, bfr[ks][j]), acc[i][j], 0, 0, 0);
-        }
-  };
-
-  dma_stage(0, 0);
-  if (nk > 1) dma_stage(1, 1);
-
-  if constexpr (STAG == 4) {
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) {
-        if constexpr (MT2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();                                         // A: tile kt published by every wave
-      read_frags(kt);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();                                         // B: nobody reads this stage any more
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 2 < nk) mfma_tile_dma(kt & 1, kt + 2); else mfma_tile();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else if constexpr (STAG == 0) {
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) {                                                    // tile kt landed (this wave's part); kt+1 may fly
-        if constexpr (MT2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();                                         // A: tile kt published by every wave
-      read_frags(kt);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();                                         // B: nobody reads this stage any more
-      if (kt + 2 < nk) dma_stage(kt & 1, kt + 2);                           // refill it two tiles ahead
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_tile();
-    }
-  } else {
-    // Staggered halves: waves 0-3 and their SIMD partners 4-7 alternate roles every phase, so on each SIMD one wave
-    // issues MFMAs while the other pulls its next fragments out of LDS (in lock step both read, then both compute, and
-    // the matrix pipe idles through every read burst).  Phase 2t: first half computes tile t, second half reads tile t.
-    // Phase 2t+1: second half computes tile t, first half reads tile t+1; the stage of tile t is dead at its start and
-    // takes the DMA of tile t+2, which has two phases to land.
-    const int half = wave >> 2;
-    if (nk > 1) {
-      if constexpr (MT2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                                           // tile 0 published
-    if (half == 0) read_frags(0);
-    for (int kt = 0; kt < nk; ++kt) {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();                                         // phase 2kt
-      __builtin_amdgcn_sched_barrier(0);
-      if (half == 0) mfma_tile(); else read_frags(kt);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (STAG != 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of tile kt+1 has landed
-      __builtin_amdgcn_s_barrier();                                         // phase 2kt+1: stage of tile kt is dead
-      if constexpr (STAG != 2) if (kt + 2 < nk) dma_stage(kt & 1, kt + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      if (half == 0) { if (kt + 1 < nk) read_frags(kt + 1); } else mfma_tile();
-    }
-  }
-
-  big_epilogue<EPI, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
-}
-
-// ---- ring variant: 32-k stages, four of them, everything in the loop hand-placed -------------------------------
-// Measured on the two-stage kernel above (tools/pmc_gemm.sh, ATSPEED_GEMM_STAG ablations): MFMA pipe 52 % busy, 1.3-1.6 PF
-// without the DMA, unchanged when the vmcnt wait is dropped -> what costs is not the landing latency but the burst
-// of 8 DMA pieces per wave (100-185 cycles of issue each while the VMEM queue is full) and the lock-step read burst.
-// hipcc sinks/serialises the builtin when asked to interleave it with MFMAs, so the loop body is inline asm:
-//   * a stage is one 32-deep k-step (64-byte LDS rows, 32 KB for a 256x256 tile), four stages form a ring, and the DMA
+// =====================================================================================
+// Large-M GEMM for the lock-step multi-user forwards (M = tokens of all users, 0.5-8 k rows): MFMA-bound.
+//
+//   C^T[n][m] = sum_k W[n][k] X[m][k]      A operand = W rows, B operand = X rows, both K-contiguous in HBM
+//   workgroup tile 256 (n) x 256 or 128 (m), 8 waves (4 x 2), wave tile 64 x 128 (64) = 4 x 8 (4) MFMA 16x16x32 tiles.
+//
+// How it got here (profiles/README.md has the numbers): a two-stage 256x256x64 LDS-DMA loop ran the MFMA pipe 52 % busy
+// (SQ counters), 1.3-1.6 PF without its DMA and unchanged when the vmcnt wait was dropped: what cost was the burst of
+// 8 LDS-DMA pieces per wave right after the barrier (100-185 cycles of issue each while the VMEM queue is full) and the
+// lock-step burst of 24 fragment reads, not the landing latency.  hipcc sinks and serialises the LDS-DMA builtin when
+// asked to interleave it with MFMAs, so the loop body is inline asm (volatile asm statements keep their order):
+//   * a stage is ONE 32-deep k-step (64-byte LDS rows, 32 KB for a 256x256 tile), four stages form a ring, and the DMA
 //     of k-step s+4 is issued during the MFMAs of k-step s: three k-steps (96 KB per CU) are always in flight;
-//   * the 12 fragment reads of k-step s+1 and the 4 DMA pieces are spread between the 32 MFMAs of k-step s
-//     (register double buffering of the fragments), so neither is a burst;
+//   * the 12 fragment reads of k-step s+1 (register double buffering) and the 4 DMA pieces are spread between the
+//     32 MFMAs of k-step s, so neither is a burst;
 //   * one barrier per k-step both publishes k-step s+2 and retires the reads of k-step s+1.
-// LDS image of a stage: W rows then X rows, 64 B each; the 16-byte chunk c of row r sits at position c ^ f((r>>2)&3),
-// f = {2,0,1,3}: conflict-free for ds_read_b128's lane groups ({0-3,12-15,20-27},...) with 64-byte rows.
+// Both operands arrive by LDS-DMA (global_load_lds_dwordx4, saddr + 32-bit lane offset, M0 = destination): no VGPR round
+// trip.  LDS image of a stage: W rows then X rows, 64 B each; the 16-byte chunk c of row r sits at position
+// c ^ f((r>>2)&3), f = {2,0,1,3}, applied on the per-lane SOURCE address (the DMA destination is lane-linear) and on the
+// fragment reads: conflict-free for ds_read_b128's lane groups ({0-3,12-15,20-27},...) with 64-byte rows (PMC: 0 conflicts).
+// Workgroup ids are remapped so that each XCD (private 4 MB L2) walks a contiguous run of tiles, inside it bands of GM
+// tile rows, W-panel-major: the ~32 tiles an XCD runs at once share GM X panels and 8 W panels.
+// Result on MI355X: MFMA pipe 74 % busy at ~1.55 GHz (the chip lowers its clock under this load), 1.15-1.25 PF on the
+// Llama-7B projections at 2-7 k tokens; hipBLASLt's stream-K 256x256x64 kernel reaches 1.05-1.39 PF on the same shapes.
 #define ATS_MFMA_BF16(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
 #define ATS_MFMA_FP8(c, a, b) asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
 #define ATS_DMA16(voff, sbase, m0v) \
@@ -851,252 +516,22 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const void* __restric
   big_epilogue<EPI, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
 }
 
-// ---- fp8 (OCP e4m3) variant: same structure, 1-byte operands with per-row scales (W8A8) ---------------------------
-// A stage row is still 128 bytes = 128 k, so DMA, swizzle and the 24 fragment reads per stage are unchanged while a
-// stage now carries twice the k: half the DMA and LDS bytes per flop (the bf16 kernel is limited by exactly that
-// ingest).  v_mfma_f32_16x16x32_fp8_fp8 takes 8 bytes per lane; a lane's 16-byte fragment chunk feeds two MFMAs (low
-// / high 8 bytes), i.e. the k order inside a 64-k group is permuted identically on both operands.
-// C[m][n] = (sum_k xq[m][k] wq[n][k]) * sx[m] * sw[n], then the usual epilogues.
-template <int EPI, int MT2>
-__global__ __launch_bounds__(512, 1) void gemm_big2_fp8_kernel(const unsigned char* __restrict__ X, const unsigned char* __restrict__ W,
-                                                               const float* __restrict__ sx, const float* __restrict__ sw,
-                                                               void* __restrict__ Cv, int M, int N, int K, int ldc,
-                                                               int tiles_n, int tiles_m, int GM) {
-  const int ldx = K;
-  constexpr int BT = 256, BK = 128;                              // BK in elements = bytes
-  constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
-  constexpr int XJ = XR / 64;                                    // X DMA instructions per wave per stage
-  constexpr int STAGE = (BT + XR) * kRowBytes;                   // W tile then X tile: 64 or 48 KB
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 15, g = lane >> 4;
-  const int nwg = tiles_n * tiles_m;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
-  }
-  // grouped order: bands of GM tile rows, W-panel-major inside a band, so the ~32 tiles an XCD runs at once form a
-  // GM x 8 block sharing GM X panels and 8 W panels (PMC: FETCH_SIZE showed every W panel missing the 4 MB L2)
-  const int band = bid / (GM * tiles_n), rem = bid % (GM * tiles_n);
-  const int band_rows = min(GM, tiles_m - band * GM);
-  const int tn = rem / band_rows, tm = band * GM + rem % band_rows;
-  const int n0 = tn * BT, m0 = tm * XR;
-  const int wn = wave >> 1, wm = wave & 1;
-  const int nk = K / BK;
-
-  const unsigned char* wsrc[4]; const unsigned char* xsrc[XJ];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (wave * 4 + j) * 8 + (lane >> 3);
-    wsrc[j] = W + (size_t)min(n0 + row, N - 1) * K + ((lane & 7) ^ (row & 7)) * 16;
-  }
-#pragma unroll
-  for (int j = 0; j < XJ; ++j) {
-    const int row = (wave * XJ + j) * 8 + (lane >> 3);
-    xsrc[j] = X + (size_t)min(m0 + row, M - 1) * ldx + ((lane & 7) ^ (row & 7)) * 16;
-  }
-  auto dma_stage = [&](int buf, int kt) {
-    unsigned char* sw = smem + buf * STAGE;
-    unsigned char* sx = sw + BT * kRowBytes;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sw + (wave * 4 + j) * 8 * kRowBytes), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < XJ; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[j] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sx + (wave * XJ + j) * 8 * kRowBytes), 16, 0, 0);
-  };
-  // per-lane fragment addresses inside stage 0 (row lq of the wave's first tile; tile i adds i*16 rows = i*2048 B)
-  unsigned a_addr[2], b_addr[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int sl = ((ks * 4 + g) ^ (lq & 7)) * 16 + lq * kRowBytes;
-    a_addr[ks] = lds_addr(smem) + (wn * 64) * kRowBytes + sl;
-    b_addr[ks] = lds_addr(smem) + BT * kRowBytes + (wm * MT2 * 16) * kRowBytes + sl;
-  }
-
-  f32x4_t acc[4][MT2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < MT2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  dma_stage(0, 0);
-  if (nk > 1) dma_stage(1, 1);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const unsigned boff = (kt & 1) * STAGE;
-    if (kt + 1 < nk) {                                                      // tile kt landed (this wave's part); kt+1 may fly
-      if constexpr (MT2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                                           // A: tile kt published by every wave
-    u32x4_t af[2][4], bfr[2][MT2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const unsigned aa = a_addr[ks] + boff, ba = b_addr[ks] + boff;
-      ATS_DS_READ_B128(af[ks][0], aa, 0);     ATS_DS_READ_B128(af[ks][1], aa, 2048);
-      ATS_DS_READ_B128(af[ks][2], aa, 4096);  ATS_DS_READ_B128(af[ks][3], aa, 6144);
-      ATS_DS_READ_B128(bfr[ks][0], ba, 0);     ATS_DS_READ_B128(bfr[ks][1], ba, 2048);
-      ATS_DS_READ_B128(bfr[ks][2], ba, 4096);  ATS_DS_READ_B128(bfr[ks][3], ba, 6144);
-      if constexpr (MT2 == 8) {
-        ATS_DS_READ_B128(bfr[ks][4], ba, 8192);  ATS_DS_READ_B128(bfr[ks][5], ba, 10240);
-        ATS_DS_READ_B128(bfr[ks][6], ba, 12288); ATS_DS_READ_B128(bfr[ks][7], ba, 14336);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // fragments are in registers
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                                           // B: nobody reads this stage any more
-    if (kt + 2 < nk) dma_stage(kt & 1, kt + 2);                             // refill it two tiles ahead
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)                                        // low / high 8 bytes of the 16-byte fragments
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < MT2; ++j) {
-            const long av = ((long)af[ks][i][2 * hh + 1] << 32) | (long)af[ks][i][2 * hh];
-            const long bv = ((long)bfr[ks][j][2 * hh + 1] << 32) | (long)bfr[ks][j][2 * hh];
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(av, bv, acc[i][j], 0, 0, 0);
-          }
-  }
-
-  // per-row scales: acc[i][j][r] *= sx[m] * sw[n]
-#pragma unroll
-  for (int j = 0; j < MT2; ++j) {
-    const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
-    const float fx = sx[min(gm, M - 1)];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int gn = n0 + wn * 64 + i * 16 + g * 4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] *= fx * sw[min(gn + r, N - 1)];
-    }
-  }
-
-  // ------------------------------------------------------------------ epilogue (as gemm_big_kernel)
-  const bool vec = (ldc & 3) == 0;
-#pragma unroll
-  for (int j = 0; j < MT2; ++j) {
-    const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
-    if (gm >= M) continue;
-    if constexpr (EPI == EPI_SWIGLU) {
-      bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
-#pragma unroll
-      for (int i = 0; i < 4; i += 2) {
-        const int gn = n0 + wn * 64 + i * 16;
-        if (gn >= N) continue;
-        ushort4 o;
-        bf16_t* op = reinterpret_cast<bf16_t*>(&o);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float gt = bf2f(f2bf(acc[i][j][r])), up = bf2f(f2bf(acc[i + 1][j][r]));
-          op[r] = f2bf(gt / (1.f + __expf(-gt)) * up);
-        }
-        *reinterpret_cast<ushort4*>(C + (size_t)gm * ldc + (gn >> 1) + g * 4) = o;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gn = n0 + wn * 64 + i * 16 + g * 4;
-        if (gn >= N) continue;
-        if constexpr (EPI == EPI_F32) {
-          float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
-          if (gn + 3 < N && vec) *reinterpret_cast<float4*>(C) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-          else
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[i][j][r];
-        } else {
-          bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
-          if (gn + 3 < N && vec) {
-            ushort4 o;
-            bf16_t* op = reinterpret_cast<bf16_t*>(&o);
-            if constexpr (EPI == EPI_RESID) {
-              ushort4 rs = *reinterpret_cast<const ushort4*>(C);
-              const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) op[r] = f2bf(bf2f(rp[r]) + bf2f(f2bf(acc[i][j][r])));
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) op[r] = f2bf(acc[i][j][r]);
-            }
-            *reinterpret_cast<ushort4*>(C) = o;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (gn + r < N) {
-                float v = acc[i][j][r];
-                if constexpr (EPI == EPI_RESID) v = bf2f(C[r]) + bf2f(f2bf(v));
-                C[r] = f2bf(v);
-              }
-          }
-        }
-      }
-    }
-  }
-}
-
 template <int EPI>
 int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st) {
-  static const int dbg = env_int("ATSPEED_GEMM_BIG_DBG", 0);       // tuning: 1/2 = ablations of the simple loop, 3 = simple loop
   static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
-  static const int stag = env_int("ATSPEED_GEMM_STAG", 5);   // 5 = ring kernel (production); 0/1/4 = two-stage variants, 2/3 = ablations
+  static const int force_mt = env_int("ATSPEED_GEMM_FORCE_MT", 0);     // tuning: 8 / 4 = always 256- / 128-row token tiles
   const int tiles_n = (n + 255) / 256;
   static thread_local bool attr_done = false;
   if (!attr_done) {
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_kernel<EPI, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_done = true;
   }
-  if (dbg == 0) {
-    // 256-row token tiles when they fill the chip at least as well as 128-row ones (fewer bytes per flop), else 128
-    const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
-    static const int force_mt = env_int("ATSPEED_GEMM_FORCE_MT", 0);     // tuning: 8 / 4 = always 256- / 128-row token tiles
-    const bool use256 = force_mt ? force_mt == 8 : big_use_256_rows(t256, t128);
-    if (stag >= 5 && k % 128 == 0 && k >= 256) {
-      static thread_local bool ring_attr = false;
-      if (!ring_attr) {
-        ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        ring_attr = true;
-      }
-      const float* none = nullptr;
-      if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
-      else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
-    } else if (stag == 4) {
-      if (use256) hipLaunchKernelGGL((gemm_big2_kernel<EPI, 8, 4>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
-      else        hipLaunchKernelGGL((gemm_big2_kernel<EPI, 4, 4>), dim3(t128), dim3(512), 96 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
-    } else if (stag >= 2) {   // tuning ablations (wrong results): 2 = no DMA inside the loop, 3 = no vmcnt wait inside the loop
-      if (stag == 2) hipLaunchKernelGGL((gemm_big2_kernel<EPI, 8, 2>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
-      else           hipLaunchKernelGGL((gemm_big2_kernel<EPI, 8, 3>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
-    } else if (stag) {
-      if (use256) hipLaunchKernelGGL((gemm_big2_kernel<EPI, 8, 1>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
-      else        hipLaunchKernelGGL((gemm_big2_kernel<EPI, 4, 1>), dim3(t128), dim3(512), 96 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
-    } else {
-      if (use256) hipLaunchKernelGGL((gemm_big2_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
-      else        hipLaunchKernelGGL((gemm_big2_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
-    }
-    ATS_LAUNCH_CHECK();
-    return ATSPEED_OK;
-  }
-  const int tiles_m = (m + 255) / 256;
-  auto kern = dbg == 1 ? gemm_big_kernel<EPI, 1> : (dbg == 2 ? gemm_big_kernel<EPI, 2> : gemm_big_kernel<EPI, 0>);
-  hipLaunchKernelGGL(kern, dim3(tiles_n * tiles_m), dim3(512), 128 * 1024, st, x, w, c, m, n, k, ldx, ldc, tiles_n, tiles_m);
+  const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
+  const bool use256 = force_mt ? force_mt == 8 : big_use_256_rows(t256, t128);
+  const float* none = nullptr;
+  if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
+  else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -1163,27 +598,15 @@ int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char*
   const int tiles_n = (n + 255) / 256;
   static thread_local bool attr_done = false;
   if (!attr_done) {
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_fp8_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_big2_fp8_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_done = true;
   }
   const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
-  const bool use256 = big_use_256_rows(t256, t128);
-  static const int ring = env_int("ATSPEED_GEMM_FP8_RING", 1);
-  if (ring && k % 256 == 0 && k >= 512) {
-    static thread_local bool ring_attr = false;
-    if (!ring_attr) {
-      ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      ring_attr = true;
-    }
-    if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, true>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 255) / 256, gm);
-    else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, true>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 127) / 128, gm);
-    ATS_LAUNCH_CHECK();
-    return ATSPEED_OK;
-  }
-  if (use256) hipLaunchKernelGGL((gemm_big2_fp8_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, x, w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 255) / 256, gm);
-  else        hipLaunchKernelGGL((gemm_big2_fp8_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, x, w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 127) / 128, gm);
+  if (big_use_256_rows(t256, t128))
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, true>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 255) / 256, gm);
+  else
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, true>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 127) / 128, gm);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -1329,7 +752,7 @@ static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype,
   // 256x256 tiles pay off when they fill the 256 CUs evenly (measured, tools/sweep_big.sh): >= ~85 % of the last
   // wave of workgroups busy; otherwise the 128-wide LDS-tiled kernel (with split-K) is faster
   static const int big_min_m = env_int("ATSPEED_GEMM_BIG_MIN_M", 512);
-  if (dtype != ATSPEED_BF16 || m < big_min_m || k % 64 != 0 || (lda % 8) != 0) return false;
+  if (dtype != ATSPEED_BF16 || m < big_min_m || k % 128 != 0 || (lda % 8) != 0) return false;
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
   const int tn = (n + 255) / 256;
   return big_fill_pct(tn * ((m + 255) / 256)) >= 80 || big_fill_pct(tn * ((m + 127) / 128)) >= 80;
@@ -1355,7 +778,7 @@ int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int
 }
 
 bool ats_gemm_fp8_applies(int m, int n, int k, int ldc, int epilogue) {
-  if (m < 512 || k % 128 != 0) return false;
+  if (m < 512 || k % 256 != 0) return false;
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
   const int tn = (n + 255) / 256;
   return big_fill_pct(tn * ((m + 255) / 256)) >= 80 || big_fill_pct(tn * ((m + 127) / 128)) >= 80;
@@ -1364,7 +787,7 @@ bool ats_gemm_fp8_applies(int m, int n, int k, int ldc, int epilogue) {
 int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int m, int n, int k, int ldc,
                  int epilogue, hipStream_t st) {
   ATS_REQUIRE(xq && sx && wq && sw && c, ATSPEED_ERR_INVALID, "gemm_fp8: null argument");
-  ATS_REQUIRE(m >= 1 && n >= 1 && k % 128 == 0, ATSPEED_ERR_INVALID, "gemm_fp8: K=%d must be a multiple of 128", k);
+  ATS_REQUIRE(m >= 1 && n >= 1 && k % 256 == 0, ATSPEED_ERR_INVALID, "gemm_fp8: K=%d must be a multiple of 256", k);
   ATS_REQUIRE(epilogue != EPI_SWIGLU || ((ldc & 3) == 0 && n % 32 == 0), ATSPEED_ERR_INVALID, "gemm_fp8: SwiGLU needs N %% 32 == 0 and ldc %% 4 == 0");
   const unsigned char* X = (const unsigned char*)xq; const unsigned char* Wq = (const unsigned char*)wq;
   switch (epilogue) {

@@ -282,7 +282,7 @@ def test_fp8_target_batch_close_to_bf16():
     construction; the check is that decoding still works end to end, scores stay close and the drift is reported."""
     from atspeed_amd.beamSD import BSSD_batch
     V = synth.BEAUTY.vocab_size
-    tdims = synth.LlamaDims(V, 512, 2, 4, 1408)
+    tdims = synth.LlamaDims(V, 512, 2, 4, 1536)
     ddims = synth.LlamaDims(V, 256, 2, 4, 704)
     kw = dict(max_slots=512, max_tokens=512, max_logit_rows=448)
     fn = atspeed_amd.PositionSetConstraint(synth.BEAUTY.allowed_tokens(), synth.RESPONSE_SEP)
