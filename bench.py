@@ -46,7 +46,7 @@ MFMA_PEAK_TFLOPS = 2500.0    # same guide: ~2.5 PF dense bf16
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64, help="users per GPU in the timed region")
+    ap.add_argument("--steps", type=int, default=128, help="users per GPU in the timed region")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--target-layers", type=int, default=32, help="32 = Llama-7B (the metric's config)")
     ap.add_argument("--beam", type=int, default=20)
@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--gamma", type=int, default=4)
     ap.add_argument("--new-tokens", type=int, default=4)
     ap.add_argument("--seed", type=int, default=2025)
-    ap.add_argument("--streams", type=int, default=32, help="users decoded in lock step per GPU (one batched forward per draft step / verification); 1 = the reference's one-user-at-a-time loop")
+    ap.add_argument("--streams", type=int, default=64, help="users decoded in lock step per GPU (one batched forward per draft step / verification); 1 = the reference's one-user-at-a-time loop")
     ap.add_argument("--target-fp8", action="store_true", help="BASELINE config 5: fp8 (e4m3 W8A8) target projections in the batched forwards")
     ap.add_argument("--single-stream-users", type=int, default=6, help="extra untimed-for-value pass: users decoded one at a time (the reference's loop)")
     ap.add_argument("--aligned-resid-scale", type=str, default="3e-6,3e-5",
@@ -224,6 +224,31 @@ def main():
                                 target_forwards_per_user=sum(o["n_target_forwards"] for o in ro) / args.steps))
             del target_a, draft_a, run_aligned
 
+    # ---- the verify step's scan (full-vocabulary log-sum-exp over the packed logit rows of one lock-step round, the HBM-bound
+    # kernel of beamSD.py:285): rows = users x (1 + 3*DK) at V fp32 logits, timed alone with events on its launch stream
+    scan = None
+    if rank == 0:
+        from atspeed_amd import _lib
+        lib = _lib.load()
+        rows = max(1, args.streams) * (1 + (args.new_tokens - 1) * args.draft_beam)
+        ld = target.logits_ld
+        lg = torch.randn(rows, ld, dtype=torch.float32, device=dev)
+        lse = torch.empty(rows, dtype=torch.float32, device=dev)
+        st = _lib.stream_ptr(dev)
+        run_lse = lambda: _lib.check(lib.atspeed_lse_rows(lg.data_ptr(), rows, V, ld, lse.data_ptr(), st))
+        for _ in range(3):
+            run_lse()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run_lse()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        scan = dict(kernel="lse_rows_kernel", rows=rows, bytes_per_launch=rows * V * 4, avg_launch_us=us, bound="hbm",
+                    achieved=rows * V * 4 / (us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=rows * V * 4 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+        del lg, lse
+
     per_rank = all_gather_counters(Counters(args.steps, n_run, acc, int(elapsed * 1e9)), dev)   # the path's single collective
     if rank != 0:
         if world > 1:
@@ -284,6 +309,7 @@ def main():
         "per_user": {"n_run": total_runs / users, "target_forwards": n_tf / args.steps, "draft_forwards": n_df / args.steps,
                      "draft_ms": 1e3 * stage[0] / args.steps, "target_ms": 1e3 * stage[1] / args.steps, "verify_ms": 1e3 * stage[2] / args.steps},
         "roofline": roofline,
+        "verify_scan": scan,
         "single_user_stream": single,
         "aligned_weight_brackets": aligned,   # same users, shapes and kernels as `value`; only the weights' agreement differs
     }
