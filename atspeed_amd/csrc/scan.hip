@@ -26,17 +26,34 @@ __global__ __launch_bounds__(1024) void lse_rows_kernel(const float* __restrict_
   const float* row = logits + (size_t)blockIdx.x * ld;
   float m = -INFINITY, s = 0.f;
   const int nv4 = vocab >> 2;
-  const float4* row4 = reinterpret_cast<const float4*>(row);
-  for (int i = threadIdx.x; i < nv4; i += 1024) {
-    float4 v = row4[i];
-    float mm = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-    if (mm > m) { s *= expf(m - mm); m = mm; }
-    s += expf(v.x - m) + expf(v.y - m) + expf(v.z - m) + expf(v.w - m);
+  // chunks of 8 independent 16-byte loads per thread (128 KB of a 131 KB row in flight per workgroup), one running-max
+  // rescale per chunk instead of per element; the row is read once and never again: non-temporal loads
+  constexpr int U = 8;
+  for (int base = threadIdx.x; base < nv4; base += 1024 * U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * 1024;
+      if (i < nv4) {
+        v[u].x = __builtin_nontemporal_load(&row[4 * i]);     v[u].y = __builtin_nontemporal_load(&row[4 * i + 1]);
+        v[u].z = __builtin_nontemporal_load(&row[4 * i + 2]); v[u].w = __builtin_nontemporal_load(&row[4 * i + 3]);
+      } else {
+        v[u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      }
+    }
+    float cm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < U; ++u) cm = fmaxf(cm, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+    if (cm > m) { s *= __expf(m - cm); m = cm; }
+    if (m != -INFINITY) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) s += __expf(v[u].x - m) + __expf(v[u].y - m) + __expf(v[u].z - m) + __expf(v[u].w - m);
+    }
   }
   for (int i = (nv4 << 2) + threadIdx.x; i < vocab; i += 1024) {
     float v = row[i];
-    if (v > m) { s *= expf(m - v); m = v; }
-    s += expf(v - m);
+    if (v > m) { s *= __expf(m - v); m = v; }
+    s += __expf(v - m);
   }
   float wm = wave_max_f32(m);
   s = (m == -INFINITY) ? 0.f : s * expf(m - wm);
