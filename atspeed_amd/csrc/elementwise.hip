@@ -84,8 +84,58 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, c
   }
 }
 
+// bf16 rows of up to 8192 elements: 16-byte loads, the row stays in registers between the two passes (read once, written once)
+template <int NC>
+__global__ __launch_bounds__(256) void rmsnorm_bf16_vec_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                               bf16_t* __restrict__ y, int hidden, float eps) {
+  __shared__ float red[4];
+  const int nchunk = hidden >> 3;
+  const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)blockIdx.x * hidden);
+  const uint4* wr = reinterpret_cast<const uint4*>(w);
+  uint4* yr = reinterpret_cast<uint4*>(y + (size_t)blockIdx.x * hidden);
+  uint4 v[NC];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int i = threadIdx.x + c * 256;
+    v[c] = i < nchunk ? xr[i] : make_uint4(0, 0, 0, 0);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v[c]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { float f = bf2f(e[j]); ss += f * f; }
+  }
+  ss = wave_sum_f32(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float rs = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)hidden + eps);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int i = threadIdx.x + c * 256;
+    if (i < nchunk) {
+      const uint4 wv = wr[i];
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&v[c]);
+      const bf16_t* we = reinterpret_cast<const bf16_t*>(&wv);
+      uint4 o;
+      bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) oe[j] = f2bf(bf2f(we[j]) * bf2f(f2bf(bf2f(e[j]) * rs)));   // HF casts the normalised value first
+      yr[i] = o;
+    }
+  }
+}
+
 int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, float eps, int dtype, hipStream_t st) {
   if (rows <= 0) return ATSPEED_OK;
+  const bool vec_ok = dtype == ATSPEED_BF16 && hidden % 8 == 0 && hidden <= 8192 &&
+                      (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0;
+  if (vec_ok) {
+    const bf16_t *xb = (const bf16_t*)x, *wb = (const bf16_t*)w;
+    bf16_t* yb = (bf16_t*)y;
+    if (hidden <= 2048)      rmsnorm_bf16_vec_kernel<1><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps);
+    else if (hidden <= 4096) rmsnorm_bf16_vec_kernel<2><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps);
+    else                     rmsnorm_bf16_vec_kernel<4><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps);
+    ATS_LAUNCH_CHECK();
+    return ATSPEED_OK;
+  }
   if (dtype == ATSPEED_F32)
     rmsnorm_kernel<float><<<rows, 256, 0, st>>>((const float*)x, (const float*)w, (float*)y, hidden, eps);
   else

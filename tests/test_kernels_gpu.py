@@ -117,13 +117,14 @@ def test_gemm_swiglu(lib, m, ffn, k, dtype):
 
 
 # ------------------------------------------------------------------ rmsnorm
+@pytest.mark.parametrize("hidden", [768, 4096, 8192, 11008, 100])       # vectorised bf16 rows up to 8192, scalar beyond / unaligned
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_rmsnorm(lib, dtype):
-    x = _rand((37, 768), 9, 2.0).to(dtype).cuda()
-    w = (1 + _rand((768,), 10, 0.1)).to(dtype).cuda()
+def test_rmsnorm(lib, dtype, hidden):
+    x = _rand((37, hidden), 9, 2.0).to(dtype).cuda()
+    w = (1 + _rand((hidden,), 10, 0.1)).to(dtype).cuda()
     y = torch.empty_like(x)
     code = _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16
-    _lib.check(lib.atspeed_rmsnorm(x.data_ptr(), w.data_ptr(), y.data_ptr(), 37, 768, 1e-6, code, _st()))
+    _lib.check(lib.atspeed_rmsnorm(x.data_ptr(), w.data_ptr(), y.data_ptr(), 37, hidden, 1e-6, code, _st()))
     xf = x.float().cpu()
     ref = w.float().cpu() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))
     np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), atol=1e-5 if dtype == torch.float32 else 4e-2, rtol=0)
