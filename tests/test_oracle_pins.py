@@ -116,3 +116,67 @@ def test_oracle_mask_fns():
     assert sorted(sfn(0, torch.tensor([3, 90, 91]))) == [5, 6]
     assert sfn(0, torch.tensor([3, 90, 91, 5])) == [7]
     assert sfn(0, torch.tensor([3, 90, 91, 9])) == []
+
+
+# ------------------------------------------------------------------ sampling branch (beamSD.py:293-321,332-369)
+def _sample_models(name):
+    import json, os
+    from oracle.llama_ref import RefLlama
+    from tests.golden.cases import CASES, build_case_inputs
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bssd_sample_golden.json")))
+    g = next(x for x in gold if x["name"] == name)
+    case = next(c for c in CASES if c["name"] == name)
+    ci = build_case_inputs(case)
+    return g, case, ci, RefLlama(ci["target_dims"], ci["target_sd"]), RefLlama(ci["draft_dims"], ci["draft_sd"])
+
+
+@pytest.mark.parametrize("name", ["k20_dk40_sigma01_s7", "k5_dk10_indep", "k20_dk40_sigma0", "k10_dk40_sigma01"])
+def test_sampling_oracle_reproduces_the_reference_seed_for_seed(name):
+    """With torch's generator and the reference's call order the restatement returns the real reference's sampled beams,
+    per-round n_matches and scores for every recorded seed (tests/golden/gen_sample_golden.py ran the reference)."""
+    from oracle import beamsd_sample_ref as S
+    g, case, ci, rt, rd = _sample_models(name)
+    P = len(ci["prompt"])
+    for r in g["runs"]:
+        assert "reference_error" not in r
+        torch.manual_seed(r["seed"])
+        o = S.BSSD_sample(rt, rd, ci["prompt"], case["gamma"], case["max_new_tokens"], case["K"], case["DK"], ci["fn"], g["temperature"], S.TorchRng())
+        assert o["beam_sequence"][:, P:].tolist() == r["tokens"], (name, r["seed"])
+        assert [x["n_matches"] for x in o["rounds"]] == r["n_matches"] and o["n_run"] == r["n_run"]
+        np.testing.assert_allclose(o["beam_scores"].numpy(), np.array(r["scores"], dtype=np.float32), atol=1e-3, rtol=0)
+        torch.manual_seed(r["seed"])
+        tg = S.target_generate_sample(rt, ci["prompt"], case["max_new_tokens"], case["K"], ci["fn"], g["temperature"], S.TorchRng())
+        assert tg["beam_sequence"][:, P:].tolist() == r["tg_tokens"]
+        np.testing.assert_allclose(tg["beam_scores"].numpy(), np.array(r["tg_scores"], dtype=np.float32), atol=1e-3, rtol=0)
+
+
+def test_hash_rng_sampling_has_the_reference_law():
+    """The counter-based generator the device uses (Gumbel top-n draws, hashed uniforms / subsets) against torch's generator
+    on the same restatement: accepted steps per verification and the marginal of the best beam's first code agree within
+    sampling error per code (the parity definition of the sampling branch is statistical; this is its pin)."""
+    from oracle import beamsd_sample_ref as S
+    g, case, ci, rt, rd = _sample_models("k10_dk40_sigma01")
+    P, N = len(ci["prompt"]), 120
+    stats = {}
+    for mode in ("torch", "hash"):
+        acc, runs, first = [], [], []
+        for seed in range(N):
+            if mode == "torch":
+                torch.manual_seed(1000 + seed)
+                rng = S.TorchRng()
+            else:
+                rng = S.HashRng(5000 + seed)
+            o = S.BSSD_sample(rt, rd, ci["prompt"], case["gamma"], case["max_new_tokens"], case["K"], case["DK"], ci["fn"], g["temperature"], rng)
+            acc.append(o["total_accept_steps"]); runs.append(o["n_run"])
+            first.append(np.bincount(np.unique(o["beam_sequence"][:, P].numpy()) - 32000, minlength=64) > 0)
+        stats[mode] = (np.array(acc, dtype=np.float64), np.array(runs, dtype=np.float64), np.array(first).mean(0))
+    (a0, r0, h0), (a1, r1, h1) = stats["torch"], stats["hash"]
+    se = np.sqrt(a0.var() / N + a1.var() / N)
+    assert abs(a0.mean() - a1.mean()) < 4 * se + 1e-9, (a0.mean(), a1.mean(), se)
+    se_r = np.sqrt(r0.var() / N + r1.var() / N)
+    assert abs(r0.mean() - r1.mean()) < 4 * se_r + 1e-9
+    # per code: the fraction of runs whose beams contain it as first code (one Bernoulli per run, so runs are independent)
+    pm = (h0 + h1) / 2
+    m = (pm > 0.05) & (pm < 0.95)
+    z = np.abs(h0 - h1)[m] / np.sqrt(pm[m] * (1 - pm[m]) * 2 / N)
+    assert m.sum() >= 5 and z.max() < 4.0, (z.max(), int(m.sum()))
