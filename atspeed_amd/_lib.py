@@ -60,6 +60,7 @@ SIGNATURES = {
     "atspeed_accept": (C.c_int, [_P, _P, _I, _P, _I, _P, _P, _P, _P]),
     "atspeed_decoder_create": (C.c_int, [_P, _P, _I, C.POINTER(_P)]),
     "atspeed_decoder_destroy": (None, [_P]),
+    "atspeed_decoder_set_sampling": (C.c_int, [_P, _I, _F, C.c_uint32]),
     "atspeed_bssd_generate": (C.c_int, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, C.POINTER(GenStats), _P]),
     "atspeed_bssd_generate_batch": (C.c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "atspeed_target_generate": (C.c_int, [_P, _P, _I, _P, _I, _I, _I, _P, _P, C.POINTER(GenStats), _P]),

@@ -16,9 +16,10 @@ reference's per-beam mask calls and `.tolist()` syncs (beamSD.py:62-64,371-372).
 
 Mask functions that can `compile()` (PositionSetConstraint, SuffixTrieConstraint, prefix_allowed_tokens_fn(trie)) run
 as a device automaton; any other callable is served by `hostmask.py` the way the reference does it (one host call per
-beam per step, all arithmetic still in HIP).  Not on this path (raise): sampling (`do_sample`, beamSD.py:293-321,
-332-369 — SURVEY 8a V'), extra `logits_processor` entries (the reference always passes None, inference.py:175-176),
-and no mask at all.
+beam per step, all arithmetic still in HIP).  `generation_config.do_sample` selects the sampling branch
+(beamSD.py:65-75,293-321,332-369) with counter-based draws (`seed=` or torch's generator picks the stream).
+Not on this path (raise): extra `logits_processor` entries (the reference always passes None, inference.py:175-176),
+no mask at all, sampling with a non-compilable mask callable.
 """
 from __future__ import annotations
 
@@ -147,8 +148,27 @@ def _check_models(*models):
     for m in models:
         if not isinstance(m, HipLlama):
             raise TypeError("models must be atspeed_amd.HipLlama (use HipLlama.from_hf(model) for an HF module)")
-        if m.generation_config.do_sample:
-            raise NotImplementedError("sampling-mode verification (beamSD.py:293-321,332-369) is out of scope of this path")
+
+
+def _sampling(model, seed):
+    """(do_sample, temperature, seed) of a call.  The reference samples when `target_model.generation_config.do_sample`
+    is set (beamSD.py:479-481) with its temperature warper; draws there come from torch's global generator, here from a
+    counter-based stream whose 32-bit seed is drawn from that generator (so `torch.manual_seed` makes a call repeatable)
+    unless `seed` is given."""
+    gc = model.generation_config
+    if not getattr(gc, "do_sample", False):
+        return False, 1.0, 0
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    temp = getattr(gc, "temperature", None)
+    return True, 1.0 if temp is None else float(temp), int(seed) & 0xFFFFFFFF
+
+
+def _set_sampling(decs, mode, per_user: bool = True):
+    do, temp, seed = mode
+    lib = _lib.load()
+    for u, d in enumerate(decs):
+        _lib.check(lib.atspeed_decoder_set_sampling(d.handle, 1 if do else 0, temp, (seed + (u if per_user else 0)) & 0xFFFFFFFF))
 
 
 def _prompt_row(inputs) -> torch.Tensor:
@@ -166,8 +186,9 @@ def _result(prompt: torch.Tensor, toks: torch.Tensor, scores: torch.Tensor, k: i
 @Timer()
 @torch.no_grad()
 def BSSD(target_model, draft_model, inputs: Dict, gamma: int, max_new_tokens: int,
-         logits_processor=None, prefix_allowed_tokens_fn=None) -> Dict:
+         logits_processor=None, prefix_allowed_tokens_fn=None, seed=None) -> Dict:
     _check_models(target_model, draft_model)
+    mode = _sampling(target_model, seed)
     if logits_processor is not None and len(logits_processor) != 0:
         raise NotImplementedError("extra logits processors are not on this path (reference passes None)")
     lib = _lib.load()
@@ -178,6 +199,8 @@ def BSSD(target_model, draft_model, inputs: Dict, gamma: int, max_new_tokens: in
     dk = int(draft_model.generation_config.num_beams)                 # beamSD.py:483
     if prefix_allowed_tokens_fn is not None and not hasattr(prefix_allowed_tokens_fn, "compile"):
         # arbitrary Python callable: served like the reference does, one host call per beam per step (hostmask.py)
+        if mode[0]:
+            raise NotImplementedError("sampling needs a compilable constraint (PositionSetConstraint / SuffixTrieConstraint / Trie)")
         from .hostmask import bssd_host_mask
         r = bssd_host_mask(target_model, draft_model, prompt.cpu().numpy().astype(np.int64), int(gamma), int(max_new_tokens),
                            prefix_allowed_tokens_fn)
@@ -190,6 +213,7 @@ def BSSD(target_model, draft_model, inputs: Dict, gamma: int, max_new_tokens: in
     fsm = _compile_constraint(prefix_allowed_tokens_fn, prompt.tolist())
     dfsm = _DeviceFSM.get(fsm, target_model.dims.vocab_size)
     dec = _Decoder.get(target_model, draft_model, P)
+    _set_sampling([dec], mode)
     with torch.cuda.device(dev):
         ids32 = prompt.to(torch.int32).contiguous()
         toks = torch.empty(k, max_new_tokens, dtype=torch.int32, device=dev)
@@ -224,7 +248,7 @@ MAX_USERS_PER_CALL = 64
 
 @torch.no_grad()
 def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_tokens: int,
-               prefix_allowed_tokens_fn=None):
+               prefix_allowed_tokens_fn=None, seed=None):
     """BSSD for several independent users at once (one result dict per user, same keys as BSSD).
 
     The reference decodes users strictly one after another (inference.py:162-176).  Here the users advance in
@@ -233,11 +257,12 @@ def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_token
     weights are streamed once per forward instead of once per user.  Token ids, n_matches and draft candidates
     are identical to calling BSSD() per user (scores agree to fp32 rounding: the GEMM tiling depends on the batch)."""
     _check_models(target_model, draft_model)
+    mode = _sampling(target_model, seed)             # user u of the call draws from stream seed + u
     if len(inputs_list) > MAX_USERS_PER_CALL:            # the library batches up to 64 users per forward
         outs = []
         for i in range(0, len(inputs_list), MAX_USERS_PER_CALL):
             outs += BSSD_batch(target_model, draft_model, inputs_list[i:i + MAX_USERS_PER_CALL], gamma, max_new_tokens,
-                               prefix_allowed_tokens_fn)
+                               prefix_allowed_tokens_fn, seed=(mode[2] + i) if mode[0] else None)
         return outs
     lib = _lib.load()
     dev = target_model.device
@@ -252,6 +277,7 @@ def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_token
         if f.row_ptr is not fsms[0].row_ptr:
             raise ValueError("BSSD_batch needs one shared constraint automaton (only the start node may differ per user)")
     decs = [_Decoder.get(target_model, draft_model, int(p.numel()), lane=i) for i, p in enumerate(prompts)]
+    _set_sampling(decs, mode)
     with torch.cuda.device(dev):
         ids32 = [p.to(torch.int32).contiguous() for p in prompts]
         toks = [torch.empty(k, max_new_tokens, dtype=torch.int32, device=dev) for _ in range(n)]
@@ -283,8 +309,9 @@ def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_token
 @Timer()
 @torch.no_grad()
 def target_generate(model, inputs: Dict, max_new_tokens: int, logits_processor=None,
-                    prefix_allowed_tokens_fn=None) -> Dict:
+                    prefix_allowed_tokens_fn=None, seed=None) -> Dict:
     _check_models(model)
+    mode = _sampling(model, seed)
     if logits_processor is not None and len(logits_processor) != 0:
         raise NotImplementedError("extra logits processors are not on this path (reference passes None)")
     lib = _lib.load()
@@ -293,6 +320,8 @@ def target_generate(model, inputs: Dict, max_new_tokens: int, logits_processor=N
     P = int(prompt.numel())
     k = int(model.generation_config.num_beams)                        # beamSD.py:553
     if prefix_allowed_tokens_fn is not None and not hasattr(prefix_allowed_tokens_fn, "compile"):
+        if mode[0]:
+            raise NotImplementedError("sampling needs a compilable constraint (PositionSetConstraint / SuffixTrieConstraint / Trie)")
         from .hostmask import target_generate_host_mask
         r = target_generate_host_mask(model, prompt.cpu().numpy().astype(np.int64), int(max_new_tokens), prefix_allowed_tokens_fn)
         return {"beam_sequence": torch.from_numpy(r["beam_sequence"]).to(dev), "beam_scores": torch.from_numpy(r["beam_scores"]).to(dev),
@@ -300,6 +329,7 @@ def target_generate(model, inputs: Dict, max_new_tokens: int, logits_processor=N
     fsm = _compile_constraint(prefix_allowed_tokens_fn, prompt.tolist())
     dfsm = _DeviceFSM.get(fsm, model.dims.vocab_size)
     dec = _Decoder.get(model, None, P)
+    _set_sampling([dec], mode)
     with torch.cuda.device(dev):
         ids32 = prompt.to(torch.int32).contiguous()
         toks = torch.empty(k, max_new_tokens, dtype=torch.int32, device=dev)
@@ -313,15 +343,17 @@ def target_generate(model, inputs: Dict, max_new_tokens: int, logits_processor=N
     return out
 
 
-def target_generate_batch(model, inputs_list, max_new_tokens: int, prefix_allowed_tokens_fn=None):
+def target_generate_batch(model, inputs_list, max_new_tokens: int, prefix_allowed_tokens_fn=None, seed=None):
     """`target_generate` for several independent users in lock step (one result dict per user): position g of every
     user's constrained beam search is ONE forward.  This is the loop `code/generate_teacher_data.py:211-244` runs over
     a whole training set with HF `generate`; token ids equal per-user `target_generate` calls."""
     _check_models(model)
+    mode = _sampling(model, seed)
     if len(inputs_list) > MAX_USERS_PER_CALL:
         outs = []
         for i in range(0, len(inputs_list), MAX_USERS_PER_CALL):
-            outs += target_generate_batch(model, inputs_list[i:i + MAX_USERS_PER_CALL], max_new_tokens, prefix_allowed_tokens_fn)
+            outs += target_generate_batch(model, inputs_list[i:i + MAX_USERS_PER_CALL], max_new_tokens, prefix_allowed_tokens_fn,
+                                          seed=(mode[2] + i) if mode[0] else None)
         return outs
     lib = _lib.load()
     dev = model.device
@@ -335,6 +367,7 @@ def target_generate_batch(model, inputs_list, max_new_tokens: int, prefix_allowe
         if f.row_ptr is not fsms[0].row_ptr:
             raise ValueError("target_generate_batch needs one shared constraint automaton (only the start node may differ per user)")
     decs = [_Decoder.get(model, None, int(p.numel()), lane=i) for i, p in enumerate(prompts)]
+    _set_sampling(decs, mode)
     with torch.cuda.device(dev):
         ids32 = [p.to(torch.int32).contiguous() for p in prompts]
         toks = [torch.empty(k, max_new_tokens, dtype=torch.int32, device=dev) for _ in range(n)]

@@ -43,8 +43,22 @@ void atspeed_set_error(const char* fmt, ...);
     if (_s != ATSPEED_OK) return _s; \
   } while (0)
 
+// counter-based hash shared by the synthetic-weight fill and the sampling kernels (= atspeed_amd/synth.py:hash_u32)
+__host__ __device__ inline uint32_t ats_fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__host__ __device__ inline uint32_t ats_hash_u32(uint32_t idx, uint32_t seed) { return ats_fmix32(idx * 0x9E3779B1u + seed); }
+// sub-seed of one random stream: purpose | round << 8 | step << 16 | model tag << 24 (oracle/beamsd_sample_ref.py:HashRng.begin)
+enum { ATS_RNG_STEP = 1, ATS_RNG_ACCEPT = 2, ATS_RNG_PERM = 3, ATS_RNG_RESID = 4, ATS_RNG_BONUS = 5 };
+__host__ __device__ inline uint32_t ats_rng_sub(uint32_t seed, int purpose, int round, int step, int tag) {
+  return ats_hash_u32((uint32_t)(purpose & 0xff) | ((uint32_t)(round & 0xff) << 8) | ((uint32_t)(step & 0xff) << 16) | ((uint32_t)(tag & 0xff) << 24), seed);
+}
+
 // ---------------------------------------------------------------- device helpers
 #if defined(__HIPCC__)
+__device__ __forceinline__ float ats_u01(uint32_t h) { return ((float)(h >> 9) + 0.5f) * 1.1920928955078125e-07f; }   // (k + 1/2) 2^-23, exact
+__device__ __forceinline__ float ats_gumbel(uint32_t h) { return -logf(-logf(ats_u01(h))); }
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
   uint32_t u = __float_as_uint(f);

@@ -3,11 +3,7 @@
 #include "internal.h"
 
 // ---------------------------------------------------------------------------- fill
-__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
-  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-  return h;
-}
-__device__ __forceinline__ uint32_t hash_u32(uint32_t idx, uint32_t seed) { return fmix32(idx * 0x9E3779B1u + seed); }
+__device__ __forceinline__ uint32_t hash_u32(uint32_t idx, uint32_t seed) { return ats_hash_u32(idx, seed); }
 
 template <typename T>
 __global__ void fill_hash_normal_kernel(T* dst, size_t n, uint32_t seed, float scale, float add, uint64_t offset) {

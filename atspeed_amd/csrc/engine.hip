@@ -480,6 +480,11 @@ struct atspeed_decoder {
   Mailbox* mail_host;       // pinned
   int32_t* trace_host;      // pinned: per round [dl][MAXB] draft flat ids
   std::vector<int32_t> trace;   // rounds: {dl, n_matches, nb, flat ids...}
+  // sampling mode (atspeed_decoder_set_sampling): off by default = the greedy path of every BASELINE config
+  bool sample = false; float temperature = 1.f; uint32_t seed = 0;
+  float* tab_score = nullptr;   // [ATSPEED_MAX_GAMMA][ATS_MAX_CAND] the draft's candidate scores per step (allocated on first use)
+  int32_t* tab_off = nullptr;   // [ATSPEED_MAX_GAMMA][MAXB + 1]
+  float* tab_lse = nullptr;     // [ATSPEED_MAX_GAMMA]
   struct Run {
     const atspeed_fsm* fsm; int gamma, max_new, k, dk;
     int32_t* out_tokens; float* out_scores; atspeed_gen_stats* stats_out;
@@ -541,6 +546,7 @@ extern "C" int atspeed_decoder_create(atspeed_llama* target, atspeed_llama* draf
 
 extern "C" void atspeed_decoder_destroy(atspeed_decoder* d) {
   if (!d) return;
+  hipFree(d->tab_score); hipFree(d->tab_off); hipFree(d->tab_lse);
   hipDeviceSynchronize();
   kv_free(&d->tkv);
   if (d->draft) kv_free(&d->dkv);
@@ -548,6 +554,18 @@ extern "C" void atspeed_decoder_destroy(atspeed_decoder* d) {
   hipHostFree(d->mail_host);
   hipHostFree(d->trace_host);
   delete d;
+}
+
+extern "C" int atspeed_decoder_set_sampling(atspeed_decoder* d, int32_t do_sample, float temperature, uint32_t seed) {
+  ATS_REQUIRE(d, ATSPEED_ERR_INVALID, "set_sampling: null decoder");
+  ATS_REQUIRE(!do_sample || (temperature > 0.f && temperature == temperature), ATSPEED_ERR_INVALID, "set_sampling: temperature must be positive");
+  d->sample = do_sample != 0; d->temperature = do_sample ? temperature : 1.f; d->seed = seed;
+  if (d->sample && !d->tab_score) {
+    ATS_HIP(hipMalloc((void**)&d->tab_score, sizeof(float) * ATSPEED_MAX_GAMMA * ATS_MAX_CAND));
+    ATS_HIP(hipMalloc((void**)&d->tab_off, sizeof(int32_t) * ATSPEED_MAX_GAMMA * (MAXB + 1)));
+    ATS_HIP(hipMalloc((void**)&d->tab_lse, sizeof(float) * ATSPEED_MAX_GAMMA));
+  }
+  return ATSPEED_OK;
 }
 
 static TokBuf tb_offset(const TokBuf& t, int row, int W) {
@@ -697,6 +715,10 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
         a.in = tin; a.in_row0 = i == 0 ? r.n0 - r.nb : r.n0 + (i - 1) * r.dk;
         a.out = tin; a.out_row0 = r.n0 + i * r.dk; a.out_slot0 = r.base + r.n0 + i * r.dk; a.vis_words = W;
         a.mail = d->mail_dev;
+        if (d->sample) {
+          a.sample = 1; a.temperature = d->temperature; a.rng_sub = ats_rng_sub(d->seed, ATS_RNG_STEP, r.s.n_run, i, 1);
+          a.tab_score = d->tab_score + (size_t)i * ATS_MAX_CAND; a.tab_off = d->tab_off + (size_t)i * (MAXB + 1); a.tab_lse = d->tab_lse + i;
+        }
         args.push_back(a);
       }
       const BeamStepArgs* dev_args = nullptr;
@@ -735,6 +757,13 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
         va.lse = T->act->lse + t.seg[j].logit_row0; va.fsm = r.fsm->dev;
         va.cur = d->tin[r.cur]; va.n0 = r.n0; va.next = d->tin[r.cur ^ 1]; va.dnext = d->dround; va.vis_words = W;
         va.res = d->round_beams[r.cur ^ 1]; va.mail = d->mail_dev;
+        if (d->sample) {
+          va.sample = 1; va.temperature = d->temperature; va.seed = d->seed; va.round = r.s.n_run;
+          for (int i = 0; i < r.dl; ++i) {
+            va.dtab_score[i] = d->tab_score + (size_t)i * ATS_MAX_CAND; va.dtab_off[i] = d->tab_off + (size_t)i * (MAXB + 1);
+            va.dtab_lse[i] = d->tab_lse + i;
+          }
+        }
         vargs.push_back(va);
       }
       if (!vargs.empty()) {
@@ -752,6 +781,7 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
         a.logits = T->act->logits + (size_t)sg.logit_row0 * T->logits_ld; a.ld = T->logits_ld;
         a.lse = T->act->lse + sg.logit_row0; a.fsm = r.fsm->dev; a.k = r.k;
         a.dst = d->round_beams[r.cur ^ 1]; a.emit = 0; a.mail = d->mail_dev; a.vis_words = W;
+        if (d->sample) { a.sample = 1; a.temperature = d->temperature; a.rng_sub = ats_rng_sub(d->seed, ATS_RNG_STEP, r.s.n_run, 0, 0); }
         fargs.push_back(a);
       }
       if (!fargs.empty()) {
@@ -769,7 +799,7 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
       atspeed_decoder* d = decs[u];
       atspeed_decoder::Run& r = d->run;
       if (r.done) continue;
-      if (r.final_step) ATS_TRY(ats_export_beams(d->round_beams[r.cur], r.k, r.max_new, r.out_tokens, r.out_scores, st));
+      if (r.final_step) ATS_TRY(ats_export_beams(d->round_beams[r.cur], r.k, r.max_new, r.out_tokens, r.out_scores, st, d->sample));
       else
         for (int i = 1; i <= r.dl; ++i)     // trace of the draft's flat ids for parity tests (tiny copies, same stream)
           ATS_HIP(hipMemcpyAsync(d->trace_host + (i - 1) * MAXB, d->blk[i].flat, sizeof(int32_t) * r.dk, hipMemcpyDeviceToHost, st));
@@ -871,10 +901,11 @@ extern "C" int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt
     a.in = tin; a.in_row0 = row0 + n_in - nb;
     a.out = tin; a.out_row0 = row0 + n_in; a.out_slot0 = base + n_in; a.vis_words = W;
     a.mail = d->mail_dev;
+    if (d->sample) { a.sample = 1; a.temperature = d->temperature; a.rng_sub = ats_rng_sub(d->seed, ATS_RNG_STEP, g, 0, 0); }
     ATS_TRY(ats_beam_step(a, st));
     row0 += n_in; base += n_in; n_in = k; nb = k; cur ^= 1;
   }
-  ATS_TRY(ats_export_beams(d->round_beams[cur], k, max_new, out_tokens, out_scores, st));
+  ATS_TRY(ats_export_beams(d->round_beams[cur], k, max_new, out_tokens, out_scores, st, d->sample));
   hipEventRecord(g_ev[1], st);
   ATS_HIP(hipMemcpyAsync(d->mail_host, d->mail_dev, sizeof(Mailbox), hipMemcpyDeviceToHost, st));
   ATS_HIP(hipStreamSynchronize(st));
@@ -933,6 +964,7 @@ extern "C" int atspeed_target_generate_batch(atspeed_decoder** decs, int32_t n, 
       a.in = d->tin[0]; a.in_row0 = s[u].row0 + s[u].n_in - s[u].nb;
       a.out = d->tin[0]; a.out_row0 = s[u].row0 + s[u].n_in; a.out_slot0 = s[u].base + s[u].n_in; a.vis_words = W;
       a.mail = d->mail_dev;
+      if (d->sample) { a.sample = 1; a.temperature = d->temperature; a.rng_sub = ats_rng_sub(d->seed, ATS_RNG_STEP, g, 0, 0); }
       args.push_back(a);
       s[u].row0 += s[u].n_in; s[u].base += s[u].n_in; s[u].n_in = k; s[u].nb = k; s[u].cur ^= 1;
     }
@@ -941,7 +973,7 @@ extern "C" int atspeed_target_generate_batch(atspeed_decoder** decs, int32_t n, 
     ATS_TRY(ats_beam_step_multi(dev_args, n, st));
   }
   for (int u = 0; u < n; ++u) {
-    ATS_TRY(ats_export_beams(decs[u]->round_beams[s[u].cur], k, max_new, out_tokens[u], out_scores[u], st));
+    ATS_TRY(ats_export_beams(decs[u]->round_beams[s[u].cur], k, max_new, out_tokens[u], out_scores[u], st, decs[u]->sample));
     ATS_HIP(hipMemcpyAsync(decs[u]->mail_host, decs[u]->mail_dev, sizeof(Mailbox), hipMemcpyDeviceToHost, st));
   }
   hipEventRecord(g_ev[1], st);

@@ -109,6 +109,10 @@ struct BeamStepArgs {
   TokBuf in;   int in_row0;                   // rows of the src beams (for parent vis/pos)
   TokBuf out;  int out_row0;  int out_slot0;  int vis_words;
   Mailbox* mail;                              // status only
+  // sampling (generation_config.do_sample, beamSD.py:65-75): draw k of the candidates without replacement with probability
+  // softmax(score / temperature); tab_* (optional) keep the draft's whole candidate distribution for the verification
+  int sample;  float temperature;  uint32_t rng_sub;
+  float* tab_score;  int32_t* tab_off;  float* tab_lse;   // [candidates in expand order], [n_src + 1], [1]
 };
 int ats_beam_step(const BeamStepArgs& a, hipStream_t st);
 // one workgroup per user; `dev_args` is a DEVICE array of n argument blocks
@@ -125,6 +129,9 @@ struct VerifyArgs {
   int vis_words;
   BeamSet res;                                // new round beams (k)
   Mailbox* mail;
+  // sampling verification (beamSD.py:293-321,332-369)
+  int sample;  float temperature;  uint32_t seed;  int round;
+  const float* dtab_score[ATSPEED_MAX_GAMMA];  const int32_t* dtab_off[ATSPEED_MAX_GAMMA];  const float* dtab_lse[ATSPEED_MAX_GAMMA];
 };
 int ats_verify_walk(const VerifyArgs& a, hipStream_t st);
 int ats_verify_walk_multi(const VerifyArgs* dev_args, int n, hipStream_t st);
@@ -132,7 +139,8 @@ int ats_verify_walk_multi(const VerifyArgs* dev_args, int n, hipStream_t st);
 int ats_init_prompt(TokBuf tb, const int32_t* prompt, int prompt_len, int vis_words, BeamSet beams, int start_node,
                     int vocab, Mailbox* mail, hipStream_t st);
 // out_tokens[k][max_new] / out_scores[k] from a beam set
-int ats_export_beams(BeamSet b, int k, int max_new, int32_t* out_tokens, float* out_scores, hipStream_t st);
+int ats_export_beams(BeamSet b, int k, int max_new, int32_t* out_tokens, float* out_scores, hipStream_t st, bool sort_desc = false);
+constexpr int ATS_MAX_CAND = 16384;           // candidate capacity of one expand (scan.hip kMaxCand)
 
 int ats_accept(const int32_t* target_flat, const float* target_score, int k, const int32_t* draft_flat, int dk,
                int32_t* hit, float* score_by_hit, int32_t* accept, hipStream_t st);

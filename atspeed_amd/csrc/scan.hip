@@ -135,6 +135,8 @@ struct ExpandShared {
   float bscore[MAXB];
   float lse[MAXB];
   int status;
+  float red_m[kScanWaves], red_s[kScanWaves];   // block reductions of the sampling paths
+  float red_out;
 };
 
 // Expand n_rows parent rows (sh.node/brow/lrow/bscore filled by the caller, first n_rows entries)
@@ -197,6 +199,117 @@ __device__ __forceinline__ Pick decode_pick(unsigned long long key, const FsmDev
   return p;
 }
 
+// ---------------------------------------------------------------------------- sampling helpers (do_sample)
+// Candidates of an expand kept in registers: slot i of thread t is candidate c = t + i * kScanThreads in expand order
+// (rows in order, children of a row's automaton node ascending).  sc = log-softmax / temperature + beam score.
+struct CandRegs { int flat[kCPT]; float sc[kCPT]; };
+
+__device__ void expand_candidates(ExpandShared& sh, int n_rows, const float* __restrict__ logits, int ld,
+                                  const float* __restrict__ lse, const FsmDev& fsm, float temperature, CandRegs& cr) {
+  const int tid = threadIdx.x;
+  if (tid < n_rows) sh.lse[tid] = lse[sh.lrow[tid]];
+  if (tid == 0) {
+    int tot = 0;
+    for (int r = 0; r < n_rows; ++r) {
+      sh.off[r] = tot;
+      int nd = sh.node[r];
+      int deg = fsm.row_ptr[nd + 1] - fsm.row_ptr[nd];
+      bool live = sh.bscore[r] > -INFINITY;
+      if (live && deg == 0) sh.status = ATSPEED_ERR_CONSTRAINT;
+      tot += live ? deg : 0;
+    }
+    sh.off[n_rows] = tot;
+    if (tot > kMaxCand) sh.status = ATSPEED_ERR_CAPACITY;
+  }
+  __syncthreads();
+  const int total = min(sh.off[n_rows], kMaxCand);
+#pragma unroll
+  for (int i = 0; i < kCPT; ++i) {
+    int c = tid + i * kScanThreads;
+    cr.flat[i] = -1; cr.sc[i] = -INFINITY;
+    if (c < total) {
+      int lo = 0, hi = n_rows;
+      while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (sh.off[mid] <= c) lo = mid; else hi = mid; }
+      int r = lo;
+      int tok = fsm.tok[fsm.row_ptr[sh.node[r]] + (c - sh.off[r])];
+      cr.sc[i] = (logits[(size_t)sh.lrow[r] * ld + tok] - sh.lse[r]) / temperature + sh.bscore[r];
+      cr.flat[i] = sh.brow[r] * fsm.vocab + tok;
+    }
+  }
+}
+
+// log sum exp over every thread's kCPT values (block-wide); -inf entries contribute nothing
+__device__ float block_lse(ExpandShared& sh, const float (&v)[kCPT]) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < kCPT; ++i) m = fmaxf(m, v[i]);
+  float s = 0.f;
+  if (m > -INFINITY) {
+#pragma unroll
+    for (int i = 0; i < kCPT; ++i) s += (v[i] > -INFINITY) ? expf(v[i] - m) : 0.f;
+  }
+  float wm = wave_max_f32(m);
+  s = (m > -INFINITY) ? s * expf(m - wm) : 0.f;
+  s = wave_sum_f32(s);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) { sh.red_m[wave] = wm; sh.red_s[wave] = s; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float gm = -INFINITY;
+    for (int w = 0; w < kScanWaves; ++w) gm = fmaxf(gm, sh.red_m[w]);
+    float gs = 0.f;
+    for (int w = 0; w < kScanWaves; ++w) gs += (sh.red_m[w] > -INFINITY) ? sh.red_s[w] * expf(sh.red_m[w] - gm) : 0.f;
+    sh.red_out = gm > -INFINITY ? gm + logf(gs) : -INFINITY;
+  }
+  __syncthreads();
+  return sh.red_out;
+}
+__device__ float block_sum(ExpandShared& sh, float v) {
+  v = wave_sum_f32(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sh.red_s[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { float t = 0.f; for (int w = 0; w < kScanWaves; ++w) t += sh.red_s[w]; sh.red_out = t; }
+  __syncthreads();
+  return sh.red_out;
+}
+
+// n draws without replacement with probability proportional to exp(logw): the n largest logw + Gumbel(hash(flat))
+// (Plackett-Luce, the law of torch.multinomial's sequential draws); result in sh.topk.sel, key 0 = none
+__device__ void sample_topn(ExpandShared& sh, const CandRegs& cr, const float (&logw)[kCPT], int n, uint32_t sub) {
+  unsigned long long keys[kCPT];
+#pragma unroll
+  for (int i = 0; i < kCPT; ++i) {
+    unsigned long long key = 0;
+    if (cr.flat[i] >= 0 && logw[i] > -INFINITY) {
+      float kf = logw[i] + ats_gumbel(ats_hash_u32((uint32_t)cr.flat[i], sub));
+      key = ((unsigned long long)ford(kf) << 32) | (unsigned long long)(~(uint32_t)cr.flat[i]);
+    }
+    keys[i] = key;
+  }
+  block_topk(keys, n, sh.topk);
+}
+
+// a pick by flat id with the TRUE tempered score (sampling keys carry noise); rows describe the expand that produced it
+__device__ Pick pick_of_flat(int flat, const FsmDev& fsm, const ExpandShared& sh, int n_rows, const float* __restrict__ logits,
+                             int ld, float temperature) {
+  Pick p;
+  p.flat = flat;
+  if (flat < 0) { p.score = -INFINITY; p.parent = 0; p.tok = 0; p.node = 0; return p; }
+  p.parent = flat / fsm.vocab;
+  p.tok = flat % fsm.vocab;
+  int r = -1;
+  for (int q = 0; q < n_rows; ++q) if (sh.brow[q] == p.parent) { r = q; break; }
+  if (r < 0) { p.score = -INFINITY; p.node = 0; return p; }
+  p.score = (logits[(size_t)sh.lrow[r] * ld + p.tok] - sh.lse[r]) / temperature + sh.bscore[r];
+  int e = find_edge(fsm, sh.node[r], p.tok);
+  p.node = e >= 0 ? fsm.nxt[e] : 0;
+  if (e < 0) p.score = -INFINITY;
+  return p;
+}
+
 // write a block of k new beams + (optionally) the forward inputs that feed them next
 __device__ void emit_block(const Pick& pk, int j, int k, const BeamSet& src, int gen_len, const BeamSet& dst, bool emit,
                            const TokBuf& in, int in_row0, const TokBuf& out, int out_row0, int out_slot0, int W) {
@@ -249,11 +362,30 @@ __device__ void beam_step_body(const BeamStepArgs& a) {
     sh.bscore[tid] = a.src.score[tid];
   }
   __syncthreads();
-  expand_and_select(sh, a.n_src, a.logits, a.ld, a.lse, a.fsm, a.k);
   Pick pk;
-  if (tid < a.k) {
-    pk = decode_pick(sh.topk.sel[tid], a.fsm, sh.brow, sh.node, a.n_src);
-    parents[tid] = pk.parent;
+  if (a.sample) {                                                        // beamSD.py:65-75
+    CandRegs cr;
+    expand_candidates(sh, a.n_src, a.logits, a.ld, a.lse, a.fsm, a.temperature, cr);
+    if (a.tab_score) {                                                   // the draft's whole distribution, for verify
+      const float L = block_lse(sh, cr.sc);
+      const int total = min(sh.off[a.n_src], kMaxCand);
+#pragma unroll
+      for (int i = 0; i < kCPT; ++i) { int c = tid + i * kScanThreads; if (c < total) a.tab_score[c] = cr.sc[i]; }
+      if (tid <= a.n_src) a.tab_off[tid] = sh.off[tid];
+      if (tid == 0) *a.tab_lse = L;
+    }
+    sample_topn(sh, cr, cr.sc, a.k, a.rng_sub);
+    if (tid < a.k) {
+      unsigned long long key = sh.topk.sel[tid];
+      pk = pick_of_flat(key ? (int)(~(uint32_t)(key & 0xffffffffull)) : -1, a.fsm, sh, a.n_src, a.logits, a.ld, a.temperature);
+      parents[tid] = pk.parent;
+    }
+  } else {
+    expand_and_select(sh, a.n_src, a.logits, a.ld, a.lse, a.fsm, a.k);
+    if (tid < a.k) {
+      pk = decode_pick(sh.topk.sel[tid], a.fsm, sh.brow, sh.node, a.n_src);
+      parents[tid] = pk.parent;
+    }
   }
   __syncthreads();
   emit_block(pk, tid, a.k, a.src, a.gen_len, a.dst, a.emit != 0, a.in, a.in_row0, a.out, a.out_row0, a.out_slot0, a.vis_words);
@@ -270,14 +402,179 @@ __device__ void beam_step_body(const BeamStepArgs& a) {
 // ---------------------------------------------------------------------------- verify
 __device__ void verify_walk_body(const VerifyArgs& a);
 
-__global__ __launch_bounds__(kScanThreads) void verify_walk_kernel(VerifyArgs a) { verify_walk_body(a); }
+__device__ void verify_sample_body(const VerifyArgs& a);
+__global__ __launch_bounds__(kScanThreads) void verify_walk_kernel(VerifyArgs a) {
+  if (a.sample) verify_sample_body(a); else verify_walk_body(a);
+}
 __global__ __launch_bounds__(kScanThreads) void verify_walk_multi_kernel(const VerifyArgs* __restrict__ args) {
   __shared__ VerifyArgs a;
   const int words = sizeof(VerifyArgs) / 4;
   for (int i = threadIdx.x; i < words; i += blockDim.x)
     reinterpret_cast<uint32_t*>(&a)[i] = reinterpret_cast<const uint32_t*>(args + blockIdx.x)[i];
   __syncthreads();
-  verify_walk_body(a);
+  if (a.sample) verify_sample_body(a); else verify_walk_body(a);
+}
+
+// Sampling verification (beamSD.py:293-321 distributions, :332-369 accept / resample, :303-309 bonus draw), one launch for
+// all steps.  Per step i: p = softmax over (hit beams x allowed tokens) of the target's tempered cumulative scores, q the
+// draft's (kept by its step kernel: tab_*); draft candidate j is accepted iff u_j q_j <= p_j; with >= K accepted, K of them
+// (the K smallest hashes) become the next beams in ascending flat-id order and the walk goes on; otherwise the missing
+// beams are drawn from max(p - q, 0) without the accepted ones and the walk stops.  All draws are counter-based
+// (ats_rng_sub), so the CPU restatement (oracle/beamsd_sample_ref.py, HashRng) makes the same decisions.
+__device__ void verify_sample_body(const VerifyArgs& a) {
+  __shared__ ExpandShared sh;
+  __shared__ int t_parent[MAXB], hit[MAXB], d_flat[MAXB], d_acc[MAXB], fin_flat[MAXB];
+  __shared__ uint32_t d_h[MAXB];
+  __shared__ float sbh[MAXB], d_sc[MAXB];
+  const int tid = threadIdx.x;
+  const int k = a.k, dk = a.dk;
+  if (tid == 0) sh.status = 0;
+  int nm = 0, n_rows_last = a.nb;
+  Pick pk;
+  pk.flat = -1; pk.score = -INFINITY; pk.parent = 0; pk.tok = 0; pk.node = 0;
+  for (int i = 0; i <= a.dl; ++i) {
+    const int n_rows = i == 0 ? a.nb : k;
+    n_rows_last = n_rows;
+    __syncthreads();
+    if (tid < n_rows) {
+      int br = i == 0 ? tid : hit[tid];
+      sh.brow[tid] = br;
+      sh.node[tid] = a.blk[i].node[br];
+      sh.lrow[tid] = i == 0 ? tid : a.nb + (i - 1) * dk + br;
+      sh.bscore[tid] = i == 0 ? a.blk[0].score[tid] : sbh[tid];
+    }
+    __syncthreads();
+    CandRegs cr;
+    expand_candidates(sh, n_rows, a.logits, a.ld, a.lse, a.fsm, a.temperature, cr);
+    if (i == a.dl) {                                                     // bonus draw from the target (:303-309)
+      sample_topn(sh, cr, cr.sc, k, ats_rng_sub(a.seed, ATS_RNG_BONUS, a.round, i, 0));
+      if (tid < k) {
+        unsigned long long key = sh.topk.sel[tid];
+        fin_flat[tid] = key ? (int)(~(uint32_t)(key & 0xffffffffull)) : -1;
+      }
+      __syncthreads();
+      break;
+    }
+    const float Lt = block_lse(sh, cr.sc);
+    const float Ld = *a.dtab_lse[i];
+    // ---- accept test of the draft's candidates (:334-339)
+    if (tid < MAXB) { d_flat[tid] = -1; d_acc[tid] = 0; d_sc[tid] = -INFINITY; d_h[tid] = 0; }
+    __syncthreads();
+    int acc = 0;
+    if (tid < dk) {
+      const int fl = a.blk[i + 1].flat[tid];
+      d_flat[tid] = fl;
+      if (fl >= 0) {
+        Pick t = pick_of_flat(fl, a.fsm, sh, n_rows, a.logits, a.ld, a.temperature);
+        const float p = t.score > -INFINITY ? expf(t.score - Lt) : 0.f;
+        const float q = expf(a.blk[i + 1].score[tid] - Ld);
+        const float u = ats_u01(ats_hash_u32((uint32_t)tid, ats_rng_sub(a.seed, ATS_RNG_ACCEPT, a.round, i, 0)));
+        acc = (u * q <= p) ? 1 : 0;
+        d_sc[tid] = t.score;
+        d_h[tid] = ats_hash_u32((uint32_t)tid, ats_rng_sub(a.seed, ATS_RNG_PERM, a.round, i, 0));
+      }
+      d_acc[tid] = acc;
+    }
+    const int n_acc = __syncthreads_count(acc);
+    if (n_acc >= k) {                                                    // :341-350
+      int chosen = 0;
+      if (tid < dk && acc) {
+        int rank = 0;
+        for (int j = 0; j < dk; ++j) rank += (d_acc[j] && (d_h[j] < d_h[tid] || (d_h[j] == d_h[tid] && j < tid))) ? 1 : 0;
+        chosen = rank < k;
+      }
+      __syncthreads();
+      if (tid < dk) d_acc[tid] = chosen;
+      __syncthreads();
+      if (tid < dk && chosen) {
+        int rf = 0;
+        for (int j = 0; j < dk; ++j) rf += (d_acc[j] && d_flat[j] < d_flat[tid]) ? 1 : 0;
+        hit[rf] = tid;                 // position in the draft's block i+1
+        sbh[rf] = d_sc[tid];
+        fin_flat[rf] = d_flat[tid];
+      }
+      __syncthreads();
+      nm += 1;
+      continue;
+    }
+    // ---- rejected: the missing k - n_acc beams from the residual max(p - q, 0) without the accepted ones (:351-369)
+    float logw[kCPT], pr[kCPT];
+    float part = 0.f;
+    const float* dts = a.dtab_score[i];
+    const int* dto = a.dtab_off[i];
+#pragma unroll
+    for (int s2 = 0; s2 < kCPT; ++s2) {
+      logw[s2] = -INFINITY; pr[s2] = 0.f;
+      const int fl = cr.flat[s2];
+      if (fl >= 0 && cr.sc[s2] > -INFINITY) {
+        const int c = tid + s2 * kScanThreads;
+        int lo = 0, hi = n_rows;
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (sh.off[mid] <= c) lo = mid; else hi = mid; }
+        const float q = expf(dts[dto[sh.brow[lo]] + (c - sh.off[lo])] - Ld);   // same node -> same children order in the draft's table
+        const float p = expf(cr.sc[s2] - Lt);
+        bool taken = false;
+        for (int j = 0; j < dk; ++j) taken |= (d_acc[j] && d_flat[j] == fl);
+        if (!taken) {
+          pr[s2] = p;
+          const float rsd = fmaxf(p - q, 0.f);
+          if (rsd > 0.f) { logw[s2] = logf(rsd); part += rsd; }
+        }
+      }
+    }
+    const float tot = block_sum(sh, part);
+    if (tot == 0.f) {
+#pragma unroll
+      for (int s2 = 0; s2 < kCPT; ++s2) logw[s2] = pr[s2] > 0.f ? logf(pr[s2]) : -INFINITY;
+    }
+    sample_topn(sh, cr, logw, k - n_acc, ats_rng_sub(a.seed, ATS_RNG_RESID, a.round, i, 0));
+    // final set = accepted ++ drawn, ascending flat id
+    if (tid < dk && acc) {
+      int r0 = 0;
+      for (int j = 0; j < tid; ++j) r0 += d_acc[j];
+      hit[r0] = d_flat[tid];                                           // scratch: unsorted flats
+    }
+    if (tid < k - n_acc) {
+      unsigned long long key = sh.topk.sel[tid];
+      hit[n_acc + tid] = key ? (int)(~(uint32_t)(key & 0xffffffffull)) : 0x7fffffff;
+    }
+    __syncthreads();
+    if (tid < k) {
+      const int fl = hit[tid];
+      int rf = 0;
+      for (int j = 0; j < k; ++j) rf += (hit[j] < fl || (hit[j] == fl && j < tid)) ? 1 : 0;
+      fin_flat[rf] = fl == 0x7fffffff ? -1 : fl;
+    }
+    __syncthreads();
+    break;
+  }
+  // picks of the final set, in the row space of block nm (sh.* still describe the expand of the last step)
+  if (tid < k) {
+    pk = pick_of_flat(fin_flat[tid], a.fsm, sh, n_rows_last, a.logits, a.ld, a.temperature);
+    t_parent[tid] = pk.parent;
+  }
+  __syncthreads();
+  const int cnt = nm == 0 ? a.nb : dk;
+  const int rowbase = nm == 0 ? a.n0 - a.nb : a.n0 + (nm - 1) * dk;
+  const int base_next = a.cur.slot[rowbase] + cnt;
+  const int W = a.vis_words;
+  emit_block(pk, tid, k, a.blk[nm], a.gen_len0 + nm, a.res, true, a.cur, rowbase, a.next, 0, base_next, W);
+  emit_vis(t_parent, k, a.cur, rowbase, a.next, 0, base_next, W);
+  if (nm == a.dl && a.dl > 0) {
+    for (int j = tid; j < dk; j += blockDim.x) {
+      a.dnext.ids[j] = a.cur.ids[rowbase + j];
+      a.dnext.pos[j] = a.cur.pos[rowbase + j];
+      a.dnext.slot[j] = a.cur.slot[rowbase + j];
+    }
+    for (int idx = tid; idx < dk * W; idx += blockDim.x) a.dnext.vis[idx] = a.cur.vis[(size_t)rowbase * W + idx];
+    emit_block(pk, tid, k, a.blk[nm], a.gen_len0 + nm, a.res, true, a.cur, rowbase, a.dnext, dk, base_next, W);
+    emit_vis(t_parent, k, a.cur, rowbase, a.dnext, dk, base_next, W);
+  }
+  int valid = __syncthreads_count(tid < k && pk.flat >= 0);
+  if (tid == 0) {
+    a.mail->n_matches = nm;
+    a.mail->n_valid = valid;
+    if (sh.status != 0) a.mail->status = sh.status;
+  }
 }
 
 __device__ void verify_walk_body(const VerifyArgs& a) {
@@ -373,11 +670,17 @@ __global__ void init_prompt_kernel(TokBuf tb, const int32_t* __restrict__ prompt
   }
 }
 
-__global__ void export_beams_kernel(BeamSet b, int k, int max_new, int32_t* out_tokens, float* out_scores) {
+__global__ void export_beams_kernel(BeamSet b, int k, int max_new, int32_t* out_tokens, float* out_scores, int sort_desc) {
   int j = threadIdx.x;
   if (j < k) {
-    out_scores[j] = b.score[j];
-    for (int g = 0; g < max_new; ++g) out_tokens[j * max_new + g] = b.seq[j * LMAX + g];
+    int dst = j;
+    if (sort_desc) {                                     // beamSD.py:529-531: stable sort by score, best first
+      const float sj = b.score[j];
+      dst = 0;
+      for (int i = 0; i < k; ++i) { const float si = b.score[i]; dst += (si > sj || (si == sj && i < j)) ? 1 : 0; }
+    }
+    out_scores[dst] = b.score[j];
+    for (int g = 0; g < max_new; ++g) out_tokens[dst * max_new + g] = b.seq[j * LMAX + g];
   }
 }
 
@@ -448,8 +751,8 @@ int ats_init_prompt(TokBuf tb, const int32_t* prompt, int prompt_len, int vis_wo
   return ATSPEED_OK;
 }
 
-int ats_export_beams(BeamSet b, int k, int max_new, int32_t* out_tokens, float* out_scores, hipStream_t st) {
-  export_beams_kernel<<<1, 64, 0, st>>>(b, k, max_new, out_tokens, out_scores);
+int ats_export_beams(BeamSet b, int k, int max_new, int32_t* out_tokens, float* out_scores, hipStream_t st, bool sort_desc) {
+  export_beams_kernel<<<1, 64, 0, st>>>(b, k, max_new, out_tokens, out_scores, sort_desc ? 1 : 0);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }

@@ -169,6 +169,13 @@ int atspeed_decoder_create(atspeed_llama* target, atspeed_llama* draft /* may be
                            int32_t max_prompt, atspeed_decoder** out);
 void atspeed_decoder_destroy(atspeed_decoder* d);
 
+/* Sampling mode of a decoder (generation_config.do_sample / temperature; beamSD.py:65-75 draft and final steps,
+ * :293-321,332-369 verification, :529-531 final sort).  Off by default: every BASELINE config is greedy.  Draws are
+ * counter-based functions of (seed, round, step, candidate), so a call is reproducible and the CPU restatement
+ * (oracle/beamsd_sample_ref.py, HashRng) makes the same decisions; the law is that of the reference's torch.multinomial /
+ * rand / randperm draws (statistical parity).  Applies to the bssd and target_generate calls made with this decoder. */
+int atspeed_decoder_set_sampling(atspeed_decoder* d, int32_t do_sample, float temperature, uint32_t seed);
+
 typedef struct atspeed_gen_stats {
   int32_t n_run;               /* verification rounds (beamSD.py:527)                 */
   int32_t total_accept_steps;  /* sum of n_matches (beamSD.py:528)                    */

@@ -186,9 +186,13 @@ def test_api_errors():
         BSSD(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=None)
     with pytest.raises(TypeError):       # separator absent: the reference's fn returns None -> TypeError in HF
         BSSD(tgt, drf, {"input_ids": torch.tensor([[1, 5, 6, 7]]).cuda()}, 4, 4, prefix_allowed_tokens_fn=ci["fn"])
-    tgt.generation_config.do_sample = True
+    tgt.generation_config.do_sample = True        # sampling needs a compilable constraint (the draws happen on the device)
     with pytest.raises(NotImplementedError):
+        BSSD(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=lambda b, s: ci["fn"](b, s))
+    tgt.generation_config.temperature = 0.0
+    with pytest.raises(atspeed_amd._lib.AtSpeedError):
         BSSD(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=ci["fn"])
+    tgt.generation_config.temperature = 1.0
     tgt.generation_config.do_sample = False
     # position-set mask exhausted (5th generated token after EOS): HF raises ValueError on the empty list
     with pytest.raises((ValueError, KeyError)):
@@ -444,3 +448,79 @@ def test_teacher_data_tensors_match_the_oracle_forward():
             want = ref.forward(inp.ids, inp.pos, inp.slots, inp.vis)[len(p) - 1:]
             cols = slice(32000, None) if got is not tl else slice(None)
             np.testing.assert_allclose(got[:, cols].numpy(), want[:, cols].numpy(), atol=LOGIT_TOL, rtol=0)
+
+
+# ------------------------------------------------------------------ sampling branch
+def _sampling_pair(name, temperature):
+    case = next(c for c in CASES if c["name"] == name)
+    ci = build_case_inputs(case)
+    tgt, drf = _models(ci, case)
+    for m in (tgt, drf):
+        m.generation_config.do_sample = True
+        m.generation_config.temperature = temperature
+    return case, ci, tgt, drf, RefLlama(ci["target_dims"], ci["target_sd"]), RefLlama(ci["draft_dims"], ci["draft_sd"])
+
+
+@pytest.mark.parametrize("name,temperature", [("k10_dk40_sigma01", 1.3), ("k20_dk40_sigma01_s7", 1.0), ("k5_dk10_indep", 1.0),
+                                              ("k20_dk40_sigma0", 0.7), ("k20_dk40_trie", 1.0)])
+def test_sampling_bssd_makes_the_oracles_decisions(name, temperature):
+    """do_sample: the device draws from the same counter-based streams as oracle/beamsd_sample_ref.py (HashRng), whose torch-RNG
+    twin is pinned seed for seed to the real reference.  Same sampled beams and per-round n_matches for every seed whose
+    closest decision margin is above fp32 noise; scores within 1e-3."""
+    from oracle import beamsd_sample_ref as S
+    case, ci, tgt, drf, rt, rd = _sampling_pair(name, temperature)
+    P = len(ci["prompt"])
+    inputs = {"input_ids": torch.from_numpy(ci["prompt"])[None].cuda()}
+    checked = 0
+    acc = []
+    for seed in range(40, 52):
+        rng = S.HashRng(seed)
+        ref = S.BSSD_sample(rt, rd, ci["prompt"], case["gamma"], case["max_new_tokens"], case["K"], case["DK"], ci["fn"], temperature, rng)
+        out = BSSD(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"], seed=seed)
+        acc.append(out["total_accept_steps"])
+        nv = out["n_valid"]                          # fewer finite candidates than beams (strict trie): dead slots sort last
+        same = nv == ref["beam_sequence"].shape[0] and out["beam_sequence"][:nv, P:].cpu().tolist() == ref["beam_sequence"][:, P:].tolist()
+        if rng.min_margin < 1e-4 and not same:
+            continue                                   # a draw decided by less than fp32 rounding: not comparable
+        checked += 1
+        assert same, (name, seed, rng.min_margin)
+        assert out["accept_steps"] == [r["n_matches"] for r in ref["rounds"]] and out["n_run"] == ref["n_run"]
+        np.testing.assert_allclose(out["beam_scores"][:nv].cpu().numpy(), ref["beam_scores"].numpy(), atol=SCORE_TOL, rtol=0)
+        assert (np.diff(out["beam_scores"][:nv].cpu().numpy()) <= 0).all()     # beamSD.py:529-531: sorted best first
+    assert checked >= 10
+    # same seed twice -> same result; another seed -> (almost surely) another
+    a = BSSD(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"], seed=7)
+    b = BSSD(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"], seed=7)
+    assert torch.equal(a["beam_sequence"], b["beam_sequence"])
+
+
+def test_sampling_target_generate_and_batches():
+    from atspeed_amd.beamSD import BSSD_batch, target_generate_batch
+    from oracle import beamsd_sample_ref as S
+    name, temperature = "k10_dk40_sigma01", 1.3
+    case, ci, tgt, drf, rt, rd = _sampling_pair(name, temperature)
+    P = len(ci["prompt"])
+    rng0 = np.random.default_rng(1)
+    prompts = [ci["prompt"]] + [np.concatenate([rng0.integers(3, 31000, size=n), ci["prompt"][-6:]]) for n in (9, 30)]
+    inputs = [{"input_ids": torch.from_numpy(p.astype(np.int64))[None].cuda()} for p in prompts]
+    # plain sampled beam search (beamSD.py:544-595 with do_sample)
+    for seed in (3, 4, 5):
+        rng = S.HashRng(seed)
+        ref = S.target_generate_sample(rt, prompts[0], case["max_new_tokens"], case["K"], ci["fn"], temperature, rng)
+        out = target_generate(tgt, inputs[0], case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"], seed=seed)
+        if rng.min_margin >= 1e-4:
+            assert out["beam_sequence"][:, P:].cpu().tolist() == ref["beam_sequence"][:, P:].tolist()
+    # batches: user u draws from stream seed + u, i.e. equals the single call with that seed
+    outs = BSSD_batch(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"], seed=100)
+    tgs = target_generate_batch(tgt, inputs, case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"], seed=200)
+    for u, (inp, o, t) in enumerate(zip(inputs, outs, tgs)):
+        one = BSSD(tgt, drf, inp, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"], seed=100 + u)
+        assert torch.equal(o["beam_sequence"], one["beam_sequence"]) and o["accept_steps"] == one["accept_steps"]
+        one_t = target_generate(tgt, inp, case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"], seed=200 + u)
+        assert torch.equal(t["beam_sequence"], one_t["beam_sequence"])
+    # greedy again on the same decoders once do_sample is off
+    for m in (tgt, drf):
+        m.generation_config.do_sample = False
+    g = BSSD(tgt, drf, inputs[0], case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"])
+    tg = target_generate(tgt, inputs[0], case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"])
+    assert torch.equal(g["beam_sequence"], tg["beam_sequence"])
