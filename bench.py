@@ -61,6 +61,8 @@ def parse():
                     help="extra brackets (SURVEY.md 8d 'oracle-draft'): same shapes and kernels, draft/target weights aligned through a "
                          "shared bigram table with the layers' residual contributions scaled by each factor of this comma list "
                          "(3e-6: every draft step accepted, 3e-5: about one step per verification); empty string skips the pass")
+    ap.add_argument("--do-sample", action="store_true", help="sampling-mode beam-SD (generation_config.do_sample) instead of the greedy headline")
+    ap.add_argument("--temperature", type=float, default=1.0)
     ap.add_argument("--cpu-baseline-users", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -124,6 +126,11 @@ def main():
     draft = HipLlama.from_synthetic(ddims, args.seed + 1, std=0.02, head_std=0.02, dtype=torch.bfloat16, num_beams=args.draft_beam, **kw)
     if args.target_fp8:
         target.enable_fp8()
+    if args.do_sample:
+        for m in (target, draft):
+            m.generation_config.do_sample = True
+            m.generation_config.temperature = args.temperature
+        torch.manual_seed(args.seed)
     fn = PositionSetConstraint(vocab.allowed_tokens(), synth.RESPONSE_SEP)
 
     n_local = args.warmup + args.steps
@@ -206,6 +213,10 @@ def main():
                                                resid_scale=rs, align_to=draft_a, **kw)
             if args.target_fp8:
                 target_a.enable_fp8()
+            if args.do_sample:
+                for m in (target_a, draft_a):
+                    m.generation_config.do_sample = True
+                    m.generation_config.temperature = args.temperature
 
             def run_aligned(lo, hi):
                 res = []
@@ -313,7 +324,9 @@ def main():
         "single_user_stream": single,
         "aligned_weight_brackets": aligned,   # same users, shapes and kernels as `value`; only the weights' agreement differs
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if args.do_sample:
+        line["decoding"] = f"sampling (temperature {args.temperature})"
+    if world == 1 and not args.no_cpu_baseline and not args.do_sample:
         cb, ref_outs = cpu_baseline(target, draft, prompts[args.warmup:], fn, args)
         line["cpu_baseline"] = cb
         # parity note next to the timing: bf16 engine vs fp32 oracle on identical weights
