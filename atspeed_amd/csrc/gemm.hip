@@ -361,11 +361,14 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // FP8: the operands are e4m3 bytes with per-row scales (W8A8); a 64-byte row then holds 64 k, a lane's 16-byte fragment
 // chunk feeds two v_mfma_f32_16x16x32_fp8_fp8 (low / high 8 bytes: the k order inside a 64-k group is permuted
 // identically on both operands), so a stage carries twice the flops for the same DMA and LDS bytes.
-template <int EPI, int MT2, bool FP8>
+// SPLITK (one user's tokens, M <= 256: every launch is one pass over W and HBM-bound): the grid is tiles x n_split, part z
+// accumulates the k-steps of its share of the 128-k units and stores fp32 partials to slab z of Cv ([z][M][N]); the deep
+// LDS-DMA ring (three k-steps = 72-96 KB per CU in flight, no register staging) is what pulls the weight stream.
+template <int EPI, int MT2, bool FP8, bool SPLITK = false>
 __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const void* __restrict__ X, const void* __restrict__ W,
                                                            const float* __restrict__ sx, const float* __restrict__ sw,
                                                            void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
-                                                           int tiles_n, int tiles_m, int GM) {
+                                                           int tiles_n, int tiles_m, int GM, int n_split = 1) {
   constexpr int BT = 256, RB = 64, ESZ = FP8 ? 1 : 2;
   constexpr int BK = RB / ESZ;                                   // k per stage: 32 (bf16) or 64 (fp8)
   constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
@@ -381,7 +384,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const void* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, g = lane >> 4;
   const int nwg = tiles_n * tiles_m;
-  int bid = blockIdx.x;
+  int bid = blockIdx.x, zpart = 0;
+  if constexpr (SPLITK) { zpart = bid / nwg; bid -= zpart * nwg; }
   {
     const int q = nwg / 8, r = nwg % 8, x = bid % 8;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
@@ -391,7 +395,12 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const void* __restric
   const int tn = rem / band_rows, tm = band * GM + rem % band_rows;
   const int n0 = tn * BT, m0 = tm * XR;
   const int wn = wave >> 1, wm = wave & 1;
-  const int nks = K / BK;                                        // launcher: K % (4 BK) == 0, K >= 8 BK
+  int ks0 = 0, nks = K / BK;                                     // launcher: K % (4 BK) == 0; nks = END of this part's k-steps
+  if constexpr (SPLITK) {
+    const int units = nks >> 2;                                  // launcher: n_split <= units
+    ks0 = 4 * (int)((long long)zpart * units / n_split);
+    nks = 4 * (int)((long long)(zpart + 1) * units / n_split);
+  }
 
   // per-lane DMA source offsets (bytes): piece = 16 rows x 64 B, lane l -> row l>>2, stored position l&3
   auto swz = [](int row) { return (0xD2 >> (((row >> 2) & 3) * 2)) & 3; };   // f = {2,0,1,3} packed in 0b11010010
@@ -478,7 +487,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const void* __restric
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int d = 0; d < NP; ++d) dma_piece(q, q, d);
+    for (int d = 0; d < NP; ++d) dma_piece(q, ks0 + q, d);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP) : "memory");
   asm volatile("s_barrier" ::: "memory");
 #pragma unroll
@@ -487,7 +496,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const void* __restric
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
   asm volatile("s_barrier" ::: "memory");                          // k-step 1 published, stage 0 read by everyone
 
-  int ks = 0;
+  int ks = ks0;
   for (; ks + 4 < nks; ks += 4) {
     ATS_RING_SEGMENT(0, true, true, 2 * NP, ks);
     ATS_RING_SEGMENT(1, true, true, 2 * NP, ks + 1);
@@ -513,7 +522,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const void* __restric
       }
     }
   }
-  big_epilogue<EPI, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
+  if constexpr (SPLITK) big_epilogue<EPI_F32, MT2>(acc, reinterpret_cast<float*>(Cv) + (size_t)zpart * M * N, M, N, N, m0, n0, wn, wm, lq, g);
+  else                  big_epilogue<EPI, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
 }
 
 template <int EPI>
@@ -650,6 +660,59 @@ Plan make_plan(int m, int n, int k) {
 
 struct FusedNorm { const void* w; void* xn; float eps; bool done; };
 
+// second pass of a split-K GEMM: sum the fp32 slabs and apply the epilogue (fused with the next RMSNorm for the residual projections)
+template <typename T, int EPI>
+int reduce_splits(const float* partial, void* c, int m, int n, int ldc, int splits, hipStream_t st, FusedNorm* fn) {
+  if constexpr (EPI == EPI_RESID) {
+    if (fn && n <= 8192) {
+      if (n <= 4096)
+        splitk_resid_rmsnorm_kernel<T, 4><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps);
+      else
+        splitk_resid_rmsnorm_kernel<T, 8><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps);
+      ATS_LAUNCH_CHECK();
+      fn->done = true;
+      return ATSPEED_OK;
+    }
+  }
+  size_t outs = EPI == EPI_SWIGLU ? (size_t)m * (n / 2) : (size_t)m * n;
+  splitk_reduce_kernel<T, EPI><<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(partial, c, m, n, ldc, splits);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+// One user's tokens through the ring kernel: tiles x splits <= 256 workgroups (one per CU: the ring takes 96-128 KB of LDS)
+static int ring_split_count(int m, int n, int k) {
+  static const int on = env_int("ATSPEED_GEMM_RING_SPLIT", 1);
+  static const int min_m = env_int("ATSPEED_GEMM_RING_SPLIT_MIN_M", 33);
+  // measured (tools/yardstick_small.py, cold weights): wins 5-15 % over the LDS-tiled kernel on the wide projections (qkv, gate_up) at
+  // 33-256 tokens, loses on N = 4096 where 16 slabs of partials outweigh the weight stream
+  if (!on || m < min_m || m > 256 || k % 128 != 0 || k < 256 || n < 8192) return 0;
+  const int tiles = (n + 255) / 256, units = k / 128;
+  int s = 256 / tiles;
+  if (s > units) s = units;
+  return s >= 1 ? s : 0;
+}
+template <int EPI>
+int launch_ring_split(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, int lda, int ldc, int splits, float* partial,
+                      hipStream_t st, FusedNorm* fn) {
+  static thread_local bool attr_done = false;
+  if (!attr_done) {
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI_F32, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI_F32, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_done = true;
+  }
+  const int tiles_n = (n + 255) / 256;
+  const float* none = nullptr;
+  if (m > 128)
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 8, false, true>), dim3(tiles_n * splits), dim3(512), 128 * 1024, st, (const void*)a, (const void*)w,
+                       none, none, (void*)partial, m, n, k, lda, n, tiles_n, 1, 1, splits);
+  else
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 4, false, true>), dim3(tiles_n * splits), dim3(512), 96 * 1024, st, (const void*)a, (const void*)w,
+                       none, none, (void*)partial, m, n, k, lda, n, tiles_n, 1, 1, splits);
+  ATS_LAUNCH_CHECK();
+  return reduce_splits<bf16_t, EPI>(partial, c, m, n, ldc, splits, st, fn);
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int EPI>
 int launch_cfg(const T* a, const T* w, void* c, int m, int n, int k, int lda, int ldc, const Plan& p, float* partial,
                hipStream_t st, FusedNorm* fn = nullptr) {
@@ -660,20 +723,7 @@ int launch_cfg(const T* a, const T* w, void* c, int m, int n, int k, int lda, in
     auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI, true>;
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a, w, c, m, n, k, lda, ldc, p.k_per_split, partial);
     ATS_LAUNCH_CHECK();
-    if constexpr (EPI == EPI_RESID) {
-      if (fn && n <= 8192) {
-        if (n <= 4096)
-          splitk_resid_rmsnorm_kernel<T, 4><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, p.splits, fn->eps);
-        else
-          splitk_resid_rmsnorm_kernel<T, 8><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, p.splits, fn->eps);
-        ATS_LAUNCH_CHECK();
-        fn->done = true;
-        return ATSPEED_OK;
-      }
-    }
-    size_t outs = EPI == EPI_SWIGLU ? (size_t)m * (n / 2) : (size_t)m * n;
-    splitk_reduce_kernel<T, EPI><<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(partial, c, m, n, ldc, p.splits);
-    ATS_LAUNCH_CHECK();
+    return reduce_splits<T, EPI>(partial, c, m, n, ldc, p.splits, st, fn);
   } else {
     auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI, false>;
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a, w, c, m, n, k, lda, ldc, p.k_per_split, partial);
@@ -685,6 +735,11 @@ int launch_cfg(const T* a, const T* w, void* c, int m, int n, int k, int lda, in
 template <typename T, int EPI>
 int launch_epi(const T* a, const T* w, void* c, int m, int n, int k, int lda, int ldc, float* partial, size_t ws_bytes,
                hipStream_t st, FusedNorm* fn = nullptr) {
+  if constexpr (sizeof(T) == 2) {
+    const int rs = ring_split_count(m, n, k);
+    if (rs >= 1 && (lda % 8) == 0 && (size_t)rs * m * n * sizeof(float) <= ws_bytes && (EPI != EPI_SWIGLU || n % 32 == 0))
+      return launch_ring_split<EPI>(a, w, c, m, n, k, lda, ldc, rs, partial, st, fn);
+  }
   Plan p = make_plan<T>(m, n, k);
   if (p.bn == 64 && p.bm != 128) p.bn = 128;
   if (p.splits > 1 && (size_t)p.splits * m * n * sizeof(float) > ws_bytes) {   // not enough workspace: no split
@@ -718,7 +773,9 @@ int launch_typed(const void* a, const void* w, void* c, int m, int n, int k, int
 
 size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype) {
   Plan p = dtype == ATSPEED_BF16 ? make_plan<bf16_t>(m, n, k) : make_plan<float>(m, n, k);
-  return p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
+  size_t b = p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
+  if (dtype == ATSPEED_BF16) b = std::max(b, (size_t)ring_split_count(m, n, k) * m * n * sizeof(float));
+  return b;
 }
 
 static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype, int epilogue);
