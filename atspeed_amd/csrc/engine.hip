@@ -60,6 +60,22 @@ int ats_stage(const void* host_obj, size_t bytes, const void** dev_out, hipStrea
   r.used += need;
   return ATSPEED_OK;
 }
+// the same through the pinned ring, but to a device address of the caller's choice
+int ats_stage_to(const void* host_obj, size_t bytes, void* dev_dst, hipStream_t st) {
+  StageRing& r = g_stage;
+  if (!r.host) {
+    ATS_HIP(hipHostMalloc((void**)&r.host, kStageBytes));
+    ATS_HIP(hipMalloc((void**)&r.dev, kStageBytes));
+    r.cap = kStageBytes; r.used = 0;
+  }
+  size_t need = (bytes + 255) / 256 * 256;
+  ATS_REQUIRE(need <= r.cap, ATSPEED_ERR_CAPACITY, "staging: object of %zu bytes too large", bytes);
+  if (r.used + need > r.cap) { ATS_HIP(hipStreamSynchronize(st)); r.used = 0; }
+  memcpy(r.host + r.used, host_obj, bytes);
+  ATS_HIP(hipMemcpyAsync(dev_dst, r.host + r.used, bytes, hipMemcpyHostToDevice, st));
+  r.used += need;
+  return ATSPEED_OK;
+}
 void ats_stage_reset() { g_stage.used = 0; }
 
 // ---------------------------------------------------------------------------- FSM
@@ -149,6 +165,13 @@ struct ActCtx {
   float* lse = nullptr;                          // [cap_rows]
   void* xq = nullptr; float* sx = nullptr;       // fp8 activations [cap_tok][max(hidden, ffn)] + per-token scales
   void* ws = nullptr; size_t ws_bytes = 0;       // split-K slabs
+  // forwards of a recurring shape are replayed as hipGraphs (one launch instead of ~9 per layer: a user's later rounds are
+  // 20-140 tokens and launch-bound); the segment table lives at a fixed device address so that it is data, not a kernel argument
+  SegTable* segtab_dev = nullptr;
+  hipStream_t cap_stream = nullptr;
+  typedef std::tuple<int, int, int, int, int, int> GraphKey;      // tokens, logit rows, segments, query tiles, tile rows, fp8
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  std::map<GraphKey, int> graph_seen;
   // optional per-GEMM hipEvent brackets (bench.py roofline): 0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head
   bool prof_pending = false;
   std::vector<hipEvent_t> prof_ev;               // 2 events per bracket
@@ -223,6 +246,9 @@ static void act_free(ActCtx* cx) {
   hipFree(cx->h); hipFree(cx->xn); hipFree(cx->qkv); hipFree(cx->att); hipFree(cx->act); hipFree(cx->gath);
   hipFree(cx->logits); hipFree(cx->lse); hipFree(cx->ws); hipFree(cx->xq); hipFree(cx->sx);
   for (hipEvent_t e : cx->prof_ev) hipEventDestroy(e);
+  for (auto& g : cx->graphs) hipGraphExecDestroy(g.second);
+  if (cx->cap_stream) hipStreamDestroy(cx->cap_stream);
+  hipFree(cx->segtab_dev);
   delete cx;
 }
 
@@ -247,6 +273,7 @@ static int ensure_act(atspeed_llama* m, int tok, int rows) {
   ATS_HIP(hipMalloc((void**)&cx->sx, T * sizeof(float)));
   cx->ws_bytes = gemm_ws_for(c, cx->cap_tok, cx->cap_rows);
   ATS_HIP(hipMalloc(&cx->ws, cx->ws_bytes));
+  ATS_HIP(hipMalloc((void**)&cx->segtab_dev, sizeof(SegTable)));
   m->act = cx;
   return ATSPEED_OK;
 }
@@ -375,6 +402,8 @@ static int proj_fp8(atspeed_llama* m, const void* x, const void* wq, const float
 
 // One forward over the tokens of every segment (user) of the table.  Logits of each segment's last n_logit rows land
 // in act->logits rows [logit_row0, ..) (or in logits_out), their log-sum-exp in act->lse.
+static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTable* dtab, float* logits_out, hipStream_t st);
+
 static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits_out, hipStream_t st) {
   const atspeed_llama_config& c = m->cfg;
   ActCtx* cx = m->act;
@@ -387,11 +416,46 @@ static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits
                 "forward: segment %d has %d tokens / %d slots (max_slots %d)", i, t.seg[i].n_tok, t.seg[i].n_slots, c.max_slots);
     ATS_REQUIRE(t.seg[i].n_logit >= 0 && t.seg[i].n_logit <= t.seg[i].n_tok, ATSPEED_ERR_INVALID, "forward: bad logit row count");
   }
-  const int H = c.hidden, dt = c.dtype;
   if (m->prof_on) prof_harvest(m);
-  const void* dtab_v = nullptr;
-  ATS_TRY(ats_stage(&t, sizeof(t), &dtab_v, st));
-  const SegTable* dtab = (const SegTable*)dtab_v;
+  // the table travels through the pinned ring to its fixed device address (stream ordered behind the previous forward)
+  ATS_TRY(ats_stage_to(&t, sizeof(t), cx->segtab_dev, st));
+  const SegTable* dtab = cx->segtab_dev;
+  // opt-in (ATSPEED_GRAPHS=1): measured on MI355X, replaying a 100-token forward as one hipGraph does not shorten it (676 vs 679
+  // items/s in the one-user-at-a-time loop) -- the ~10 us between dependent kernels is the GPU's own barrier / cache-flush latency,
+  // not host launch cost, and a graph keeps every node boundary
+  static const int use_graphs = getenv("ATSPEED_GRAPHS") ? atoi(getenv("ATSPEED_GRAPHS")) : 0;
+  static const int graph_max_tok = getenv("ATSPEED_GRAPH_MAX_TOKENS") ? atoi(getenv("ATSPEED_GRAPH_MAX_TOKENS")) : 512;
+  if (use_graphs && !m->prof_on && logits_out == nullptr && T <= graph_max_tok) {
+    const ActCtx::GraphKey key(T, t.total_logit, t.n, t.n_qtiles, t.qtile_rows, m->fp8.empty() ? 0 : 1);
+    auto it = cx->graphs.find(key);
+    if (it == cx->graphs.end() && cx->graphs.size() < 64 && ++cx->graph_seen[key] >= 2) {   // a shape seen twice recurs (K + dl*DK tokens)
+      if (!cx->cap_stream) ATS_HIP(hipStreamCreateWithFlags(&cx->cap_stream, hipStreamNonBlocking));
+      ATS_HIP(hipStreamBeginCapture(cx->cap_stream, hipStreamCaptureModeThreadLocal));
+      const int rc = llama_forward_body(m, t, dtab, nullptr, cx->cap_stream);
+      hipGraph_t g = nullptr;
+      hipError_t e = hipStreamEndCapture(cx->cap_stream, &g);
+      if (rc != ATSPEED_OK) { if (g) hipGraphDestroy(g); return rc; }
+      ATS_HIP(e);
+      hipGraphExec_t ex = nullptr;
+      e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+      hipGraphDestroy(g);
+      ATS_HIP(e);
+      it = cx->graphs.emplace(key, ex).first;
+    }
+    if (it != cx->graphs.end()) {
+      ATS_HIP(hipGraphLaunch(it->second, st));
+      return ATSPEED_OK;
+    }
+  }
+  return llama_forward_body(m, t, dtab, logits_out, st);
+}
+
+// the launches of one forward (also the body of a captured graph: no allocation, no synchronisation, no staging in here)
+static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTable* dtab, float* logits_out, hipStream_t st) {
+  const atspeed_llama_config& c = m->cfg;
+  ActCtx* cx = m->act;
+  const int T = t.total_tok;
+  const int H = c.hidden, dt = c.dtype;
   ATS_TRY(ats_embed_segs(m->embed, t, dtab, cx->h, H, c.vocab_size, dt, st));
   ATS_TRY(ats_rmsnorm(cx->h, m->layers[0].input_norm, cx->xn, T, H, c.rms_eps, dt, st));
   for (int l = 0; l < c.n_layers; ++l) {

@@ -24,6 +24,7 @@ struct SegTable {
 };
 // copy a host object to device memory, stream ordered (pinned staging ring); returns the device address
 int ats_stage(const void* host_obj, size_t bytes, const void** dev_out, hipStream_t st);
+int ats_stage_to(const void* host_obj, size_t bytes, void* dev_dst, hipStream_t st);   // same, to a fixed device address
 void ats_stage_reset();                           // after a stream synchronisation: every staged copy has landed
 
 // ---- fill.hip / elementwise.hip -------------------------------------------------------

@@ -180,14 +180,18 @@ def main():
     single = None
     if rank == 0 and args.streams > 1 and args.single_stream_users > 0:
         n1 = min(args.single_stream_users, args.steps)
-        BSSD(target, draft, dprompts[args.warmup], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
-        target.profile(1)
+        for u in range(args.warmup, args.warmup + min(3, n1)):       # warm-up: recurring forward shapes get their hipGraphs
+            BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for u in range(args.warmup, args.warmup + n1):
             BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
         torch.cuda.synchronize(dev)
         dt1 = time.perf_counter() - t1
+        target.profile(1)                                           # GEMM brackets from a second, untimed pass (profiling bypasses the graphs)
+        for u in range(args.warmup, args.warmup + min(3, n1)):
+            BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
+        torch.cuda.synchronize(dev)
         p1 = target.profile(0)
         k1 = max(p1, key=lambda k: p1[k]["ms"])
         N1, K1 = target.gemm_shape(k1)
