@@ -333,10 +333,12 @@ def main():
     if world == 1 and not args.no_cpu_baseline and not args.do_sample:
         cb, ref_outs = cpu_baseline(target, draft, prompts[args.warmup:], fn, args)
         line["cpu_baseline"] = cb
-        # parity note next to the timing: bf16 engine vs fp32 oracle on identical weights
+        # next to the timing: the bf16 engine's items vs the fp32 oracle's on identical weights (NOT the parity test -- that is fp32
+        # vs fp32 in tests/; random-init logits are nearly flat, so bf16 rounding alone reorders beams)
         P0 = len(prompts[args.warmup])
-        same = outs[0]["beam_sequence"][:, P0:].cpu().tolist() == ref_outs[0]["beam_sequence"][:, P0:].tolist()
-        line["cpu_baseline"]["items_equal_to_gpu_bf16"] = bool(same)
+        gpu_items = {tuple(x) for x in outs[0]["beam_sequence"][:, P0:].cpu().tolist()}
+        ref_items = {tuple(x) for x in ref_outs[0]["beam_sequence"][:, P0:].tolist()}
+        line["cpu_baseline"]["top_k_overlap_with_gpu_bf16"] = len(gpu_items & ref_items) / max(1, len(ref_items))
         line["cpu_baseline"]["gpu_accept_len_same_users"] = float(sum(o["total_accept_steps"] for o in outs[:len(ref_outs)])) / max(
             1, sum(o["n_run"] for o in outs[:len(ref_outs)]))
     else:

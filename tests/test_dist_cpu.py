@@ -83,3 +83,41 @@ def test_two_rank_gloo_all_gather_of_counters():
 def test_all_gather_without_process_group_is_identity():
     c = Counters(2, 5, 1, 10)
     assert all_gather_counters(c) == [c]
+
+
+def _metrics_worker(rank, world, init_file, q):
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        from atspeed_amd.harness import InferenceResult, ItemIndex, reduce_metrics
+        ix = ItemIndex({str(i): [f"<a_{i}>", f"<b_{i % 3}>", f"<c_{i % 5}>", f"<d_{i % 7}>"] for i in range(30)})
+        # rank 0 holds 2 users, rank 1 holds 1: the whole-job metric weights ranks by their user counts
+        if rank == 0:
+            res = InferenceResult(predictions=[[1, 2, 3, 4], [5, 6, 7, 8]], labels=[[2], [9]], rows=[{}] * 2)
+        else:
+            res = InferenceResult(predictions=[[9, 1, 2, 3]], labels=[[9]], rows=[{}])
+        m = reduce_metrics(res, ix, topN=(1, 4))
+        if rank == 0:
+            q.put(m)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_metric_reduction_matches_single_process():
+    from atspeed_amd.harness import InferenceResult, ItemIndex
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    with tempfile.TemporaryDirectory() as d:
+        init = os.path.join(d, "init")
+        procs = [ctx.Process(target=_metrics_worker, args=(r, world, init, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+    got = q.get()
+    ix = ItemIndex({str(i): [f"<a_{i}>", f"<b_{i % 3}>", f"<c_{i % 5}>", f"<d_{i % 7}>"] for i in range(30)})
+    whole = InferenceResult(predictions=[[1, 2, 3, 4], [5, 6, 7, 8], [9, 1, 2, 3]], labels=[[2], [9], [9]], rows=[{}] * 3).metrics(ix, (1, 4))
+    assert got["users"] == 3 and got["topN"] == whole["topN"] == [1, 4]
+    for key in ("precision", "recall", "ndcg", "mrr"):
+        assert got[key] == pytest.approx(whole[key], abs=2e-4)      # per-rank values are rounded to 4 digits before the reduction
