@@ -258,8 +258,10 @@ static int ensure_act(atspeed_llama* m, int tok, int rows) {
   if (m->act) { prof_harvest(m); ATS_HIP(hipDeviceSynchronize()); act_free(m->act); m->act = nullptr; }
   const atspeed_llama_config& c = m->cfg;
   ActCtx* cx = new ActCtx();
-  cx->cap_tok = std::max(tok, c.max_tokens);
-  cx->cap_rows = std::max(rows, c.max_logit_rows);
+  // 25 % headroom: the next batch's token count differs by a few prompt tokens, and growing costs a device synchronisation plus
+  // the re-allocation of every activation buffer (seen as 30-40 ms hiccups inside timed regions)
+  cx->cap_tok = std::max((tok + tok / 4 + 255) / 256 * 256, c.max_tokens);
+  cx->cap_rows = std::max((rows + rows / 4 + 63) / 64 * 64, c.max_logit_rows);
   size_t T = cx->cap_tok, H = c.hidden, e = m->esz;
   ATS_HIP(hipMalloc(&cx->h, T * H * e));
   ATS_HIP(hipMalloc(&cx->xn, T * H * e));

@@ -806,13 +806,14 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
 
 // h += a * w^T, then xn = rmsnorm(h) * norm_w  (split-K path fuses the reduce, the residual and the norm)
 static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype, int epilogue) {
-  // 256x256 tiles pay off when they fill the 256 CUs evenly (measured, tools/sweep_big.sh): >= ~85 % of the last
-  // wave of workgroups busy; otherwise the 128-wide LDS-tiled kernel (with split-K) is faster
+  // the 256-wide ring kernel vs the 128-wide LDS-tiled kernel (with split-K): the ring kernel wins once its tile grid keeps
+  // a fair share of the 256 CUs busy (measured, tools/gemm_ab.py with ATSPEED_GEMM_BIG_MIN_FILL)
   static const int big_min_m = env_int("ATSPEED_GEMM_BIG_MIN_M", 512);
+  static const int min_fill = env_int("ATSPEED_GEMM_BIG_MIN_FILL", 60);   // crossover measured at ~50-60 % (o_proj, down, qkv, gate_up at 512-1920 tokens)
   if (dtype != ATSPEED_BF16 || m < big_min_m || k % 128 != 0 || (lda % 8) != 0) return false;
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
   const int tn = (n + 255) / 256;
-  return big_fill_pct(tn * ((m + 255) / 256)) >= 80 || big_fill_pct(tn * ((m + 127) / 128)) >= 80;
+  return big_fill_pct(tn * ((m + 255) / 256)) >= min_fill || big_fill_pct(tn * ((m + 127) / 128)) >= min_fill;
 }
 
 int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int k, int lda, int ldh, int dtype,
@@ -838,7 +839,7 @@ bool ats_gemm_fp8_applies(int m, int n, int k, int ldc, int epilogue) {
   if (m < 512 || k % 256 != 0) return false;
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
   const int tn = (n + 255) / 256;
-  return big_fill_pct(tn * ((m + 255) / 256)) >= 80 || big_fill_pct(tn * ((m + 127) / 128)) >= 80;
+  return big_fill_pct(tn * ((m + 255) / 256)) >= 60 || big_fill_pct(tn * ((m + 127) / 128)) >= 60;
 }
 
 int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int m, int n, int k, int ldc,
