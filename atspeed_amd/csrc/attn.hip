@@ -101,6 +101,11 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q,
   }
 }
 
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+
 // ---------------------------------------------------------------------------- MFMA kernel (bf16)
 // blockIdx.x walks the 64-row query tiles of all segments (tile -> segment through the table's qtile arrays)
 template <int DH, int NW>   // NW waves per workgroup = 16*NW query rows per tile
@@ -109,11 +114,11 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
                                                              bf16_t* __restrict__ out, int ldo,
                                                              int n_heads, float scale) {
   constexpr int KCH = DH / 8;                 // 16-byte chunks per K row
-  constexpr int VT_LD = 68;                   // padded row (elements) of the transposed V tile
+  constexpr int VROW = DH * 2 + 32;           // V tile row stride in bytes: 8 rows x 32 B of a transposed read cover all 64 banks
   constexpr int DT = DH / 16;                 // output d-tiles
   constexpr int KS = DH / 32;                 // k-steps of the QK product
   __shared__ __attribute__((aligned(16))) unsigned char ks_lds[64 * DH * 2];
-  __shared__ __attribute__((aligned(16))) bf16_t vt_lds[DH * VT_LD];
+  __shared__ __attribute__((aligned(16))) unsigned char vs_lds[64 * VROW];   // V tile row-major; consumed column-wise by ds_read_b64_tr_b16
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y;
@@ -139,26 +144,38 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
   float m_run = -INFINITY, l_run = 0.f;
 
   const int n_tiles = (n_slots + 63) >> 6;
+  // K/V of tile kt+1 travel to registers while tile kt is being multiplied (one tile of global-load latency hidden)
+  constexpr int NLD = (64 * KCH + 64 * NW - 1) / (64 * NW);
+  uint4 kreg[NLD], vreg[NLD];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int qi = tid + i * (64 * NW);
+      const int r = qi / KCH, c = qi % KCH;
+      const int key = kt * 64 + r;
+      kreg[i] = make_uint4(0, 0, 0, 0); vreg[i] = make_uint4(0, 0, 0, 0);
+      if (qi < 64 * KCH && key < n_slots) {
+        const size_t off = (size_t)key * hidden + h * DH + c * 8;
+        kreg[i] = *reinterpret_cast<const uint4*>(kc + off);
+        vreg[i] = *reinterpret_cast<const uint4*>(vc + off);
+      }
+    }
+  };
+  load_tile(0);
   for (int kt = 0; kt < n_tiles; ++kt) {
     __syncthreads();                                   // previous tile fully consumed
-    // ---- stage K (swizzled rows) and V^T
+    // ---- stage K (swizzled rows) and V (row-major, padded rows)
 #pragma unroll
-    for (int i = 0; i < (64 * KCH) / (64 * NW); ++i) {
-      int qi = tid + i * (64 * NW);
-      int r = qi / KCH, c = qi % KCH;
-      int key = kt * 64 + r;
-      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-      if (key < n_slots) {
-        size_t off = (size_t)key * hidden + h * DH + c * 8;
-        kv = *reinterpret_cast<const uint4*>(kc + off);
-        vv = *reinterpret_cast<const uint4*>(vc + off);
+    for (int i = 0; i < NLD; ++i) {
+      const int qi = tid + i * (64 * NW);
+      const int r = qi / KCH, c = qi % KCH;
+      if (qi < 64 * KCH) {
+        *reinterpret_cast<uint4*>(ks_lds + (r * KCH + (c ^ (r & 7))) * 16) = kreg[i];
+        *reinterpret_cast<uint4*>(vs_lds + r * VROW + c * 16) = vreg[i];
       }
-      *reinterpret_cast<uint4*>(ks_lds + (r * KCH + (c ^ (r & 7))) * 16) = kv;
-      const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) vt_lds[(c * 8 + e) * VT_LD + r] = ve[e];
     }
     __syncthreads();
+    if (kt + 1 < n_tiles) load_tile(kt + 1);
     uint64_t word = qok ? vis_row[kt] : 0ull;
     if (kt == n_tiles - 1 && (n_slots & 63)) word &= (~0ull) >> (64 - (n_slots & 63));
     if (__ballot(word != 0ull) == 0ull) continue;      // this wave's 16 rows see nothing here (wave-uniform)
@@ -205,17 +222,27 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
     for (int d = 0; d < DT; ++d) {
       o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha;
     }
-    // ---- O^T += V^T . P^T  (k-slot j<4 -> key tile 2kk, j>=4 -> key tile 2kk+1, both 4g + (j&3))
+    // ---- O^T += V^T . P^T  (k-slot j<4 -> key block 2kk, j>=4 -> key block 2kk+1, both keys 4g + (j&3))
+    // the A operand (V^T) comes straight out of the row-major V tile: per 16-lane group a transposed read takes the 4 keys
+    // 16*blk + 4g .. +3 x 16 columns of d-tile d; lane 4q+p addresses key q, columns 4p..4p+3, lane lq receives column lq
+    const unsigned vaddr = lds_off(vs_lds) + (4 * g + (lq >> 2)) * VROW + (lq & 3) * 8;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x2_t va[DT], vb[DT];
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
-        const bf16_t* vrow = vt_lds + (d * 16 + lq) * VT_LD + g * 4;
-        uint2 va = *reinterpret_cast<const uint2*>(vrow + (2 * kk) * 16);
-        uint2 vb = *reinterpret_cast<const uint2*>(vrow + (2 * kk + 1) * 16);
-        uint4 vv = make_uint4(va.x, va.y, vb.x, vb.y);
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(va[d]) : "v"(vaddr), "i"((2 * kk) * 16 * VROW + d * 32));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vb[d]) : "v"(vaddr), "i"((2 * kk + 1) * 16 * VROW + d * 32));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        // the compiler cannot see that the registers are filled asynchronously: tie every use to a point behind the wait
+        asm volatile("" : "+v"(va[d]), "+v"(vb[d]));
+        u32x4_t vv = {va[d][0], va[d][1], vb[d][0], vb[d][1]};
         o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), __builtin_bit_cast(bf16x8_t, pf[kk]), o[d], 0, 0, 0);
       }
+    }
   }
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
@@ -243,8 +270,13 @@ int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const Seg
   float scale = 1.0f / sqrtf((float)head_dim);
   if (dtype == ATSPEED_BF16 && (head_dim == 64 || head_dim == 128) && (ldq % 8) == 0 && (ldo % 4) == 0) {
     dim3 mgrid(t.n_qtiles, n_heads);
-    ATS_REQUIRE(t.qtile_rows == 64 || t.qtile_rows == 128, ATSPEED_ERR_INVALID, "attention: query tile of %d rows", t.qtile_rows);
-    if (t.qtile_rows == 128) {
+    ATS_REQUIRE(t.qtile_rows == 64 || t.qtile_rows == 128 || t.qtile_rows == 256, ATSPEED_ERR_INVALID, "attention: query tile of %d rows", t.qtile_rows);
+    if (t.qtile_rows == 256) {
+      if (head_dim == 128)
+        tree_attn_mfma_kernel<128, 16><<<mgrid, 1024, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+      else
+        tree_attn_mfma_kernel<64, 16><<<mgrid, 1024, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+    } else if (t.qtile_rows == 128) {
       if (head_dim == 128)
         tree_attn_mfma_kernel<128, 8><<<mgrid, 512, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
       else
@@ -277,7 +309,7 @@ int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* v
   t.seg[0].row0 = 0; t.seg[0].n_tok = n_tokens; t.seg[0].n_slots = n_slots;
   ATS_REQUIRE(n_slots <= vis_words * 64, ATSPEED_ERR_CAPACITY, "attention: %d slots exceed the visibility bitset (%d words)", n_slots, vis_words);
   ATS_REQUIRE((n_tokens + 63) / 64 <= 255, ATSPEED_ERR_CAPACITY, "attention: too many query rows");
-  t.n_qtiles = 0; t.qtile_rows = n_tokens > 96 ? 128 : 64;
+  t.n_qtiles = 0; t.qtile_rows = n_tokens > 160 ? 256 : (n_tokens > 96 ? 128 : 64);
   for (int j = 0; j * t.qtile_rows < n_tokens; ++j) { t.qtile_seg[t.n_qtiles] = 0; t.qtile_idx[t.n_qtiles++] = (unsigned char)j; }
   const void* dt = nullptr;
   ATS_TRY(ats_stage(&t, sizeof(t), &dt, st));

@@ -271,7 +271,7 @@ def test_accept_equals_reference_logic(lib, k, dk, kind):
 
 # ------------------------------------------------------------------ attention
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("T", [23, 150])            # 150 rows take the 8-wave / 128-row-tile kernel
+@pytest.mark.parametrize("T", [23, 150, 230])       # 150 rows take the 8-wave (128-row tile) kernel, 230 the 16-wave (256-row) one
 @pytest.mark.parametrize("heads,dh", [(4, 32), (12, 64), (32, 128)])
 def test_tree_attention(lib, dtype, heads, dh, T):
     from atspeed_amd.model import vis_bits_from_bool
