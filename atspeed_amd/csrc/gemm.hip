@@ -257,10 +257,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, void* __
 }
 
 
-// Epilogue of the 256-wide kernels: wave (wn, wm) holds 4 x MT2 accumulator tiles, n = n0 + wn*64 + i*16 + g*4 + r,
+// Epilogue of the 256-wide kernels: wave (wn, wm) holds NA x MT2 accumulator tiles, n = n0 + wn*NA*16 + i*16 + g*4 + r,
 // m = m0 + wm*MT2*16 + j*16 + lq.
-template <int EPI, int MT2>
-__device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[4][MT2], void* __restrict__ Cv, int M, int N, int ldc, int m0, int n0,
+template <int EPI, int NA, int MT2>
+__device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[NA][MT2], void* __restrict__ Cv, int M, int N, int ldc, int m0, int n0,
                                              int wn, int wm, int lq, int g) {
   const bool vec = (ldc & 3) == 0;
 #pragma unroll
@@ -270,8 +270,8 @@ __device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[4][MT2], void* __res
     if constexpr (EPI == EPI_SWIGLU) {
       bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
 #pragma unroll
-      for (int i = 0; i < 4; i += 2) {
-        const int gn = n0 + wn * 64 + i * 16;
+      for (int i = 0; i < NA; i += 2) {
+        const int gn = n0 + wn * (NA * 16) + i * 16;
         if (gn >= N) continue;
         ushort4 o;
         bf16_t* op = reinterpret_cast<bf16_t*>(&o);
@@ -284,8 +284,8 @@ __device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[4][MT2], void* __res
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gn = n0 + wn * 64 + i * 16 + g * 4;
+      for (int i = 0; i < NA; ++i) {
+        const int gn = n0 + wn * (NA * 16) + i * 16 + g * 4;
         if (gn >= N) continue;
         if constexpr (EPI == EPI_F32) {
           float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
@@ -354,6 +354,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // Result on MI355X: MFMA pipe 74 % busy at ~1.55 GHz (the chip lowers its clock under this load), 1.15-1.25 PF on the
 // Llama-7B projections at 2-7 k tokens; hipBLASLt's stream-K 256x256x64 kernel reaches 1.05-1.39 PF on the same shapes.
 #define ATS_MFMA_BF16(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
+#define ATS_MFMA_BF16_A(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
 #define ATS_MFMA_FP8(c, a, b) asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
 #define ATS_DMA16(voff, sbase, m0v) \
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory")
@@ -364,19 +365,23 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // SPLITK (one user's tokens, M <= 256: every launch is one pass over W and HBM-bound): the grid is tiles x n_split, part z
 // accumulates the k-steps of its share of the 128-k units and stores fp32 partials to slab z of Cv ([z][M][N]); the deep
 // LDS-DMA ring (three k-steps = 72-96 KB per CU in flight, no register staging) is what pulls the weight stream.
-template <int EPI, int MT2, bool FP8, bool SPLITK = false>
-__global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const void* __restrict__ X, const void* __restrict__ W,
+// NA = 16-row weight tiles per wave: 4 -> 8 waves (4 x 2) of 64 x (MT2*16); 8 -> 4 waves (2 x 2) of 128 x 128 with the 256
+// accumulator registers in AGPRs: one wave per SIMD and a third fewer LDS fragment bytes per flop (the kernel is power-limited).
+template <int EPI, int MT2, bool FP8, bool SPLITK = false, int NA = 4>
+__global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const void* __restrict__ X, const void* __restrict__ W,
                                                            const float* __restrict__ sx, const float* __restrict__ sw,
                                                            void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
                                                            int tiles_n, int tiles_m, int GM, int n_split = 1) {
   constexpr int BT = 256, RB = 64, ESZ = FP8 ? 1 : 2;
   constexpr int BK = RB / ESZ;                                   // k per stage: 32 (bf16) or 64 (fp8)
   constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
-  constexpr int XP = XR / 128;                                   // X DMA pieces (16 rows each) per wave per k-step
-  constexpr int NP = 2 + XP;                                     // DMA pieces per wave per k-step
+  constexpr int NWV = (BT / (NA * 16)) * 2;                      // waves per workgroup: 8 or 4
+  constexpr int WP = 16 / NWV;                                   // W DMA pieces (16 rows each) per wave per k-step
+  constexpr int XP = XR / (16 * NWV);                            // X DMA pieces per wave per k-step
+  constexpr int NP = WP + XP;                                    // DMA pieces per wave per k-step
   constexpr int STAGE = (BT + XR) * RB;                          // 32 or 24 KB
-  constexpr int NR = 4 + MT2;                                    // fragment reads per wave per k-step
-  constexpr int NMF = 4 * MT2;                                   // MFMAs per wave per k-step
+  constexpr int NR = NA + MT2;                                   // fragment reads per wave per k-step
+  constexpr int NMF = NA * MT2;                                  // MFMAs per wave per k-step
   constexpr int RG = (NMF * 3 / 4) / NR;                         // one read every RG MFMAs, from the segment's start
   constexpr int DG = (NMF - NR * RG) / NP;                       // then one DMA piece every DG MFMAs
   static_assert(RG >= 1 && DG >= 1, "segment too short for its reads and DMA pieces");
@@ -404,14 +409,14 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const void* __restric
 
   // per-lane DMA source offsets (bytes): piece = 16 rows x 64 B, lane l -> row l>>2, stored position l&3
   auto swz = [](int row) { return (0xD2 >> (((row >> 2) & 3) * 2)) & 3; };   // f = {2,0,1,3} packed in 0b11010010
-  unsigned woff[2], xoff[XP];
-  int m0w[2], m0x[XP];
+  unsigned woff[WP], xoff[XP];
+  int m0w[WP], m0x[XP];
   const unsigned lbase = lds_addr(smem);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = (wave * 2 + j) * 16 + (lane >> 2);
+  for (int j = 0; j < WP; ++j) {
+    const int row = (wave * WP + j) * 16 + (lane >> 2);
     woff[j] = (unsigned)min(n0 + row, N - 1) * (unsigned)(K * ESZ) + (((lane & 3) ^ swz(row)) * 16);
-    m0w[j] = __builtin_amdgcn_readfirstlane((int)lbase + (wave * 2 + j) * 1024);
+    m0w[j] = __builtin_amdgcn_readfirstlane((int)lbase + (wave * WP + j) * 1024);
   }
 #pragma unroll
   for (int j = 0; j < XP; ++j) {
@@ -423,46 +428,52 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const void* __restric
   // fragment addresses: lane (lq, g) reads chunk g of row lq of each 16-row tile
   const unsigned lp = lq * RB + ((g ^ swz(lq)) * 16);
   unsigned aA[2], aB[2];                                          // stages {0,1} and {2,3}
-  aA[0] = lbase + (wn * 64) * RB + lp;
+  aA[0] = lbase + (wn * NA * 16) * RB + lp;
   aB[0] = lbase + BT * RB + (wm * MT2 * 16) * RB + lp;
   aA[1] = aA[0] + 2 * STAGE;
   aB[1] = aB[0] + 2 * STAGE;
 
-  f32x4_t acc[4][MT2];
+  f32x4_t acc[NA][MT2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NA; ++i)
 #pragma unroll
     for (int j = 0; j < MT2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  u32x4_t fa[2][4], fb[2][MT2];
+  u32x4_t fa[2][NA], fb[2][MT2];
 
   auto dma_piece = [&](int q, int ks, int d) {                    // piece d of k-step ks into stage q (q, d compile-time after unrolling)
-    if (d < 2) ATS_DMA16(woff[d], wb + (unsigned long long)ks * RB, m0w[d] + q * STAGE);
-    else       ATS_DMA16(xoff[(d - 2) % XP], xb + (unsigned long long)ks * RB, m0x[(d - 2) % XP] + q * STAGE);
+    if (d < WP) ATS_DMA16(woff[d % WP], wb + (unsigned long long)ks * RB, m0w[d % WP] + q * STAGE);
+    else        ATS_DMA16(xoff[(d - WP) % XP], xb + (unsigned long long)ks * RB, m0x[(d - WP) % XP] + q * STAGE);
   };
   auto read_one = [&](int q, int buf, int r) {                    // fragment read r of stage q into register buffer buf
     const unsigned a = aA[q >> 1], b = aB[q >> 1];
     const int so = (q & 1) * STAGE;
-    switch (r) {
-      case 0: ATS_DS_READ_B128(fa[buf][0], a, so); break;
-      case 1: ATS_DS_READ_B128(fa[buf][1], a, so + 1024); break;
-      case 2: ATS_DS_READ_B128(fa[buf][2], a, so + 2048); break;
-      case 3: ATS_DS_READ_B128(fa[buf][3], a, so + 3072); break;
-      case 4: ATS_DS_READ_B128(fb[buf][0], b, so); break;
-      case 5: ATS_DS_READ_B128(fb[buf][1], b, so + 1024); break;
-      case 6: ATS_DS_READ_B128(fb[buf][2], b, so + 2048); break;
-      case 7: ATS_DS_READ_B128(fb[buf][3], b, so + 3072); break;
-      case 8: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][4], b, so + 4096); break;
-      case 9: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][5], b, so + 5120); break;
-      case 10: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][6], b, so + 6144); break;
-      case 11: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][7], b, so + 7168); break;
-      default: break;
+#define ATS_RD(dst, base, t) case t: ATS_DS_READ_B128(dst, base, so + (t) * 1024); break;
+    if (r < NA) {
+      switch (r) {
+        ATS_RD(fa[buf][0], a, 0) ATS_RD(fa[buf][1], a, 1) ATS_RD(fa[buf][2], a, 2) ATS_RD(fa[buf][3], a, 3)
+        case 4: if constexpr (NA == 8) ATS_DS_READ_B128(fa[buf][NA - 4], a, so + 4096); break;
+        case 5: if constexpr (NA == 8) ATS_DS_READ_B128(fa[buf][NA - 3], a, so + 5120); break;
+        case 6: if constexpr (NA == 8) ATS_DS_READ_B128(fa[buf][NA - 2], a, so + 6144); break;
+        case 7: if constexpr (NA == 8) ATS_DS_READ_B128(fa[buf][NA - 1], a, so + 7168); break;
+        default: break;
+      }
+    } else {
+      switch (r - NA) {
+        ATS_RD(fb[buf][0], b, 0) ATS_RD(fb[buf][1], b, 1) ATS_RD(fb[buf][2], b, 2) ATS_RD(fb[buf][3], b, 3)
+        case 4: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][MT2 - 4], b, so + 4096); break;
+        case 5: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][MT2 - 3], b, so + 5120); break;
+        case 6: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][MT2 - 2], b, so + 6144); break;
+        case 7: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][MT2 - 1], b, so + 7168); break;
+        default: break;
+      }
     }
+#undef ATS_RD
   };
   // one k-step: MFMAs of stage Q from register buffer Q&1, reads of stage Q+1 into the other buffer, DMA of k-step
   // ks+4 into stage Q; VM = vmcnt to wait for before the closing barrier (-1: no wait, no barrier)
 #define ATS_RING_SEGMENT(Q, DMA, RD, VM, ks)                                                            \
   {                                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < MT2; ++j) {      \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) _Pragma("unroll") for (int j = 0; j < MT2; ++j) {     \
       const int idx = i * MT2 + j;                                                                       \
       if (RD && idx % RG == 0 && idx / RG < NR) read_one(((Q) + 1) & 3, ((Q) + 1) & 1, idx / RG);       \
       if (DMA && idx >= NR * RG && (idx - NR * RG) % DG == 0 && (idx - NR * RG) / DG < NP)              \
@@ -472,6 +483,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const void* __restric
                      __builtin_shufflevector(fb[(Q) & 1][j], fb[(Q) & 1][j], 0, 1));                     \
         ATS_MFMA_FP8(acc[i][j], __builtin_shufflevector(fa[(Q) & 1][i], fa[(Q) & 1][i], 2, 3),           \
                      __builtin_shufflevector(fb[(Q) & 1][j], fb[(Q) & 1][j], 2, 3));                     \
+      } else if constexpr (NA == 8) {                                                                    \
+        ATS_MFMA_BF16_A(acc[i][j], fa[(Q) & 1][i], fb[(Q) & 1][j]);                                      \
       } else {                                                                                           \
         ATS_MFMA_BF16(acc[i][j], fa[(Q) & 1][i], fb[(Q) & 1][j]);                                        \
       }                                                                                                  \
@@ -515,15 +528,15 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const void* __restric
     for (int j = 0; j < MT2; ++j) {
       const float fx = sx[min(m0 + wm * (MT2 * 16) + j * 16 + lq, M - 1)];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gn = n0 + wn * 64 + i * 16 + g * 4;
+      for (int i = 0; i < NA; ++i) {
+        const int gn = n0 + wn * (NA * 16) + i * 16 + g * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] *= fx * sw[min(gn + r, N - 1)];
       }
     }
   }
-  if constexpr (SPLITK) big_epilogue<EPI_F32, MT2>(acc, reinterpret_cast<float*>(Cv) + (size_t)zpart * M * N, M, N, N, m0, n0, wn, wm, lq, g);
-  else                  big_epilogue<EPI, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
+  if constexpr (SPLITK) big_epilogue<EPI_F32, NA, MT2>(acc, reinterpret_cast<float*>(Cv) + (size_t)zpart * M * N, M, N, N, m0, n0, wn, wm, lq, g);
+  else                  big_epilogue<EPI, NA, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
 }
 
 template <int EPI>
@@ -540,6 +553,14 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
   const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
   const bool use256 = force_mt ? force_mt == 8 : big_use_256_rows(t256, t128);
   const float* none = nullptr;
+  static const int four_waves = env_int("ATSPEED_GEMM_4WAVE", 0);
+  if (use256 && four_waves) {
+    static thread_local bool a4 = false;
+    if (!a4) { ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); a4 = true; }
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false, false, 8>), dim3(t256), dim3(256), 128 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1);
+    ATS_LAUNCH_CHECK();
+    return ATSPEED_OK;
+  }
   if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
   else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
   ATS_LAUNCH_CHECK();

@@ -71,7 +71,9 @@ def _gemm(lib, a, w, epi, dtype, resid=None, n_out=None):
 
 SHAPES = [(900, 1000, 512), (1024, 2304, 768), (1543, 300, 1024), (1, 128, 128), (5, 200, 96), (16, 384, 352), (20, 4096, 768), (40, 2304, 768), (61, 768, 3072),
           (100, 512, 4096), (228, 1024, 1024), (228, 4096, 4096), (130, 32256, 128), (121, 32859, 768),
-          (257, 640, 1376)]
+          (257, 640, 1376),
+          # one user's wide projections: ring kernel in split-K mode (33-256 tokens, N >= 8192, K % 128 == 0)
+          (40, 8192, 512), (100, 12288, 1024), (129, 8448, 256), (228, 12288, 640), (256, 9000, 384)]
 
 
 @pytest.mark.parametrize("m,n,k", SHAPES)
@@ -89,7 +91,7 @@ def test_gemm_store_and_f32(lib, m, n, k, dtype):
     np.testing.assert_allclose(c.double().cpu().numpy(), ref.numpy(), atol=tol2, rtol=0)
 
 
-@pytest.mark.parametrize("m,n,k", [(7, 256, 128), (40, 768, 768), (228, 4096, 11008), (228, 4096, 4096), (1100, 768, 1024), (2000, 500, 256)])
+@pytest.mark.parametrize("m,n,k", [(7, 256, 128), (40, 768, 768), (228, 4096, 11008), (228, 4096, 4096), (1100, 768, 1024), (2000, 500, 256), (100, 8192, 512), (6400, 4096, 512)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_residual(lib, m, n, k, dtype):
     a = _rand((m, k), 3).to(dtype).cuda()
