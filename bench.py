@@ -297,7 +297,7 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         bound, peak, unit = "hbm", HBM_PEAK_GBS, "GB/s"
     epi = {"qkv": 0, "o_proj": 2, "gate_up": 3, "down": 2, "lm_head": 1}[kind]
-    kname = (f"gemm_ring_kernel<{epi}, 8, {'true' if args.target_fp8 else 'false'}> [{kind}] N={N} K={K} avg_M={avg_m:.0f} (launches of >= 1024 tokens)"
+    kname = (f"gemm_ring_kernel<{epi}, 8, {'true' if args.target_fp8 else 'false'}, false, 4> [{kind}] N={N} K={K} avg_M={avg_m:.0f} (launches of >= 1024 tokens)"
              if one_kernel else f"projection GEMM [{kind}] N={N} K={K} avg_M={avg_m:.0f} (all launches)")
     roofline = dict(bound=bound, kernel=kname,
                     achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
