@@ -61,6 +61,9 @@ def parse():
                     help="extra brackets (SURVEY.md 8d 'oracle-draft'): same shapes and kernels, draft/target weights aligned through a "
                          "shared bigram table with the layers' residual contributions scaled by each factor of this comma list "
                          "(3e-6: every draft step accepted, 3e-5: about one step per verification); empty string skips the pass")
+    ap.add_argument("--dataset", choices=("beauty", "games"), default="beauty", help="vocabulary / prompt-length shape (games = BASELINE config 3)")
+    ap.add_argument("--mask", choices=("position", "trie"), default="position",
+                    help="position = the per-position allowed sets inference.py installs; trie = strict item trie on the generated suffix")
     ap.add_argument("--do-sample", action="store_true", help="sampling-mode beam-SD (generation_config.do_sample) instead of the greedy headline")
     ap.add_argument("--temperature", type=float, default=1.0)
     ap.add_argument("--cpu-baseline-users", type=int, default=1)
@@ -117,7 +120,7 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
-    vocab = synth.BEAUTY
+    vocab = synth.BEAUTY if args.dataset == "beauty" else synth.GAMES
     V = vocab.vocab_size
     tdims = synth.llama_7b(V, args.target_layers)
     ddims = synth.llama_68m(V)
@@ -131,11 +134,15 @@ def main():
             m.generation_config.do_sample = True
             m.generation_config.temperature = args.temperature
         torch.manual_seed(args.seed)
-    fn = PositionSetConstraint(vocab.allowed_tokens(), synth.RESPONSE_SEP)
+    if args.mask == "trie":
+        from atspeed_amd.generation_trie import SuffixTrieConstraint, Trie
+        fn = SuffixTrieConstraint(Trie([[1] + [int(t) for t in it] + [2] for it in synth.synthetic_items(vocab)]), synth.RESPONSE_SEP, 1)
+    else:
+        fn = PositionSetConstraint(vocab.allowed_tokens(), synth.RESPONSE_SEP)
 
     n_local = args.warmup + args.steps
     first = rank * n_local                                   # contiguous user shard per rank
-    plens = synth.prompt_lengths(world * n_local, args.seed)
+    plens = synth.prompt_lengths(world * n_local, args.seed, mean_hist=7.33 if args.dataset == "beauty" else 5.98)
     prompts = [synth.synthetic_prompt(int(plens[first + u]), synth.tensor_seed(args.seed, f"user{first + u}")) for u in range(n_local)]
     dprompts = [{"input_ids": torch.from_numpy(p)[None].to(dev)} for p in prompts]   # resident in HBM before timing
 
@@ -315,8 +322,9 @@ def main():
         "value": value, "unit": "items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp8-e4m3 (W8A8 target projections, bf16 elsewhere)" if args.target_fp8 else "bf16", "data": "synthetic (hash-PRNG weights, Beauty-shaped vocabulary and prompts)",
-        "config": {"workload": f"Beauty V={V}, Llama-68M draft / Llama-7B({args.target_layers}L) target, K={args.beam}, DK={args.draft_beam}, "
-                               f"gamma={args.gamma}, L={args.new_tokens}, {args.streams} user(s) per lock-step batch per GPU, position-set mask",
+        "config": {"workload": f"{args.dataset.capitalize()} V={V}, Llama-68M draft / Llama-7B({args.target_layers}L) target, K={args.beam}, DK={args.draft_beam}, "
+                               f"gamma={args.gamma}, L={args.new_tokens}, {args.streams} user(s) per lock-step batch per GPU, "
+                               f"{'position-set mask' if args.mask == 'position' else 'strict item trie'}",
                    "users_per_gpu": args.steps, "streams": args.streams, "mean_prompt_len": float(np.mean([len(p) for p in prompts[args.warmup:]])),
                    "parallelism": f"user-shard x{world}"},
         "mean_accept_len": mean_accept,
