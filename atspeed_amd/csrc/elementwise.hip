@@ -80,15 +80,18 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, c
   }
 }
 
-// bf16 rows of up to 8192 elements: 16-byte loads, the row stays in registers between the two passes (read once, written once)
-template <int NC>
+// bf16 rows of up to 8192 elements: 16-byte loads, the row stays in registers between the two passes (read once, written once).
+// QUANT: also emit the row as OCP e4m3 with its scale (= what quant_rows_fp8_kernel makes of the bf16 output, bit for bit), so the
+// W8A8 projection that consumes the norm needs no quantisation pass of its own; y may then be null.
+template <int NC, bool QUANT>
 __global__ __launch_bounds__(256) void rmsnorm_bf16_vec_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                               bf16_t* __restrict__ y, int hidden, float eps) {
-  __shared__ float red[4];
+                                                               bf16_t* __restrict__ y, int hidden, float eps,
+                                                               unsigned char* __restrict__ q, float* __restrict__ scale) {
+  __shared__ float red[4], red2[4];
   const int nchunk = hidden >> 3;
   const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)blockIdx.x * hidden);
   const uint4* wr = reinterpret_cast<const uint4*>(w);
-  uint4* yr = reinterpret_cast<uint4*>(y + (size_t)blockIdx.x * hidden);
+  uint4* yr = y ? reinterpret_cast<uint4*>(y + (size_t)blockIdx.x * hidden) : nullptr;
   uint4 v[NC];
   float ss = 0.f;
 #pragma unroll
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bf16_vec_kernel(const bf16_t* __r
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
   __syncthreads();
   const float rs = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)hidden + eps);
+  float amax = 0.f;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int i = threadIdx.x + c * 256;
@@ -113,10 +117,55 @@ __global__ __launch_bounds__(256) void rmsnorm_bf16_vec_kernel(const bf16_t* __r
       uint4 o;
       bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) oe[j] = f2bf(bf2f(we[j]) * bf2f(f2bf(bf2f(e[j]) * rs)));   // HF casts the normalised value first
-      yr[i] = o;
+      for (int j = 0; j < 8; ++j) {
+        oe[j] = f2bf(bf2f(we[j]) * bf2f(f2bf(bf2f(e[j]) * rs)));   // HF casts the normalised value first
+        if constexpr (QUANT) amax = fmaxf(amax, fabsf(bf2f(oe[j])));
+      }
+      if (yr) yr[i] = o;
+      v[c] = o;
     }
   }
+  if constexpr (QUANT) {
+    amax = wave_max_f32(amax);
+    if ((threadIdx.x & 63) == 0) red2[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red2[0], red2[1]), fmaxf(red2[2], red2[3]));
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (threadIdx.x == 0) scale[blockIdx.x] = sc;
+    unsigned char* qr = q + (size_t)blockIdx.x * hidden;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int i = threadIdx.x + c * 256;
+      if (i < nchunk) {
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v[c]);
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(bf2f(e[j]) * inv, -448.f), 448.f);
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+        *reinterpret_cast<uint2*>(qr + i * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+      }
+    }
+  }
+}
+
+// RMSNorm whose consumer is a W8A8 projection: y (bf16, optional) and the e4m3 row + scale in one pass
+int ats_rmsnorm_quant_fp8(const void* x, const void* w, void* y, void* q, float* scale, int rows, int hidden, float eps, hipStream_t st) {
+  if (rows <= 0) return ATSPEED_OK;
+  ATS_REQUIRE(hidden % 8 == 0 && hidden <= 8192 && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)q) & 15) == 0,
+              ATSPEED_ERR_INVALID, "rmsnorm_quant: hidden %d unsupported", hidden);
+  const bf16_t *xb = (const bf16_t*)x, *wb = (const bf16_t*)w;
+  bf16_t* yb = (bf16_t*)y;
+  unsigned char* qb = (unsigned char*)q;
+  if (hidden <= 2048)      rmsnorm_bf16_vec_kernel<1, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale);
+  else if (hidden <= 4096) rmsnorm_bf16_vec_kernel<2, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale);
+  else                     rmsnorm_bf16_vec_kernel<4, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
 }
 
 int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, float eps, int dtype, hipStream_t st) {
@@ -126,9 +175,9 @@ int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, flo
   if (vec_ok) {
     const bf16_t *xb = (const bf16_t*)x, *wb = (const bf16_t*)w;
     bf16_t* yb = (bf16_t*)y;
-    if (hidden <= 2048)      rmsnorm_bf16_vec_kernel<1><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps);
-    else if (hidden <= 4096) rmsnorm_bf16_vec_kernel<2><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps);
-    else                     rmsnorm_bf16_vec_kernel<4><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps);
+    if (hidden <= 2048)      rmsnorm_bf16_vec_kernel<1, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr);
+    else if (hidden <= 4096) rmsnorm_bf16_vec_kernel<2, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr);
+    else                     rmsnorm_bf16_vec_kernel<4, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr);
     ATS_LAUNCH_CHECK();
     return ATSPEED_OK;
   }
@@ -138,6 +187,12 @@ int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, flo
     rmsnorm_kernel<bf16_t><<<rows, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, hidden, eps);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
+}
+
+extern "C" int atspeed_rmsnorm_quant_fp8(const void* x, const void* w, void* y, void* q, float* scale, int32_t rows, int32_t hidden,
+                                         float eps, void* stream) {
+  ATS_REQUIRE(x && w && q && scale && hidden > 0, ATSPEED_ERR_INVALID, "rmsnorm_quant_fp8: bad arguments");
+  return ats_rmsnorm_quant_fp8(x, w, y, q, scale, rows, hidden, eps, (hipStream_t)stream);
 }
 
 extern "C" int atspeed_rmsnorm(const void* x, const void* w, void* y, int32_t rows, int32_t hidden, float eps,

@@ -395,10 +395,11 @@ extern "C" int atspeed_llama_enable_fp8(atspeed_llama* m, void* stream) {
 }
 
 // fp8 projection when enabled and the shape is on the batched path: quantise the activations per token, then W8A8 GEMM
+// x == nullptr: cx->xq / cx->sx already hold the quantised activations (written by the fused RMSNorm)
 static int proj_fp8(atspeed_llama* m, const void* x, const void* wq, const float* sw, void* out, int M, int N, int K, int ldc,
                     int epi, hipStream_t st) {
   ActCtx* cx = m->act;
-  ATS_TRY(ats_quant_rows_fp8(x, M, K, K, cx->xq, cx->sx, st));
+  if (x) ATS_TRY(ats_quant_rows_fp8(x, M, K, K, cx->xq, cx->sx, st));
   return ats_gemm_fp8(cx->xq, cx->sx, wq, sw, out, M, N, K, ldc, epi, st);
 }
 
@@ -459,7 +460,12 @@ static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTabl
   const int T = t.total_tok;
   const int H = c.hidden, dt = c.dtype;
   ATS_TRY(ats_embed_segs(m->embed, t, dtab, cx->h, H, c.vocab_size, dt, st));
-  ATS_TRY(ats_rmsnorm(cx->h, m->layers[0].input_norm, cx->xn, T, H, c.rms_eps, dt, st));
+  // fp8 projections fed by an RMSNorm take their e4m3 rows + scales straight from the norm kernel (no quantisation pass, no bf16 xn)
+  const bool f8_qkv = !m->fp8.empty() && H <= 8192 && ats_gemm_fp8_applies(T, 3 * H, H, 3 * H, EPI_STORE);
+  const bool f8_gu = !m->fp8.empty() && H <= 8192 && ats_gemm_fp8_applies(T, 2 * c.ffn, H, c.ffn, EPI_SWIGLU);
+  bool xq_ready = false;
+  if (f8_qkv) { ATS_TRY(ats_rmsnorm_quant_fp8(cx->h, m->layers[0].input_norm, nullptr, cx->xq, cx->sx, T, H, c.rms_eps, st)); xq_ready = true; }
+  else ATS_TRY(ats_rmsnorm(cx->h, m->layers[0].input_norm, cx->xn, T, H, c.rms_eps, dt, st));
   for (int l = 0; l < c.n_layers; ++l) {
     const atspeed_llama_layer_weights& w = m->layers[l];
     const size_t loff = (size_t)l * m->layer_kv_bytes;
@@ -467,7 +473,7 @@ static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTabl
     const bool f8 = !m->fp8.empty();
     { ProfBracket pb(m, 0, T, st);
       if (f8 && ats_gemm_fp8_applies(T, 3 * H, H, 3 * H, EPI_STORE)) {
-        ATS_TRY(proj_fp8(m, cx->xn, m->fp8[l].wqkv, m->fp8[l].sqkv, cx->qkv, T, 3 * H, H, 3 * H, EPI_STORE, st));
+        ATS_TRY(proj_fp8(m, xq_ready ? nullptr : cx->xn, m->fp8[l].wqkv, m->fp8[l].sqkv, cx->qkv, T, 3 * H, H, 3 * H, EPI_STORE, st));
       } else {
         ATS_TRY(ats_gemm(cx->xn, w.wqkv, cx->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, cx->ws, cx->ws_bytes, st));
       } }
@@ -476,23 +482,30 @@ static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTabl
     { ProfBracket pb(m, 1, T, st);     // h += att Wo^T ; xn = rmsnorm(h) * post_norm
       if (f8 && ats_gemm_fp8_applies(T, H, H, H, EPI_RESID)) {
         ATS_TRY(proj_fp8(m, cx->att, m->fp8[l].wo, m->fp8[l].so, cx->h, T, H, H, H, EPI_RESID, st));
-        ATS_TRY(ats_rmsnorm(cx->h, w.post_norm, cx->xn, T, H, c.rms_eps, dt, st));
+        if (f8_gu) { ATS_TRY(ats_rmsnorm_quant_fp8(cx->h, w.post_norm, nullptr, cx->xq, cx->sx, T, H, c.rms_eps, st)); xq_ready = true; }
+        else { ATS_TRY(ats_rmsnorm(cx->h, w.post_norm, cx->xn, T, H, c.rms_eps, dt, st)); xq_ready = false; }
       } else {
         ATS_TRY(ats_gemm_resid_norm(cx->att, w.wo, cx->h, T, H, H, H, H, dt, w.post_norm, cx->xn, c.rms_eps, cx->ws, cx->ws_bytes, st));
+        xq_ready = false;
       } }
     { ProfBracket pb(m, 2, T, st);
       if (f8 && ats_gemm_fp8_applies(T, 2 * c.ffn, H, c.ffn, EPI_SWIGLU)) {
-        ATS_TRY(proj_fp8(m, cx->xn, m->fp8[l].wgu, m->fp8[l].sgu, cx->act, T, 2 * c.ffn, H, c.ffn, EPI_SWIGLU, st));
+        ATS_TRY(proj_fp8(m, xq_ready ? nullptr : cx->xn, m->fp8[l].wgu, m->fp8[l].sgu, cx->act, T, 2 * c.ffn, H, c.ffn, EPI_SWIGLU, st));
       } else {
         ATS_TRY(ats_gemm(cx->xn, w.wgu, cx->act, T, 2 * c.ffn, H, H, c.ffn, dt, EPI_SWIGLU, cx->ws, cx->ws_bytes, st));
       } }
     { ProfBracket pb(m, 3, T, st);     // h += act Wd^T ; xn = rmsnorm(h) * next layer's input_norm
       if (f8 && ats_gemm_fp8_applies(T, H, c.ffn, H, EPI_RESID)) {
         ATS_TRY(proj_fp8(m, cx->act, m->fp8[l].wd, m->fp8[l].sd, cx->h, T, H, c.ffn, H, EPI_RESID, st));
-        if (l + 1 < c.n_layers) ATS_TRY(ats_rmsnorm(cx->h, m->layers[l + 1].input_norm, cx->xn, T, H, c.rms_eps, dt, st));
+        xq_ready = false;
+        if (l + 1 < c.n_layers) {
+          if (f8_qkv) { ATS_TRY(ats_rmsnorm_quant_fp8(cx->h, m->layers[l + 1].input_norm, nullptr, cx->xq, cx->sx, T, H, c.rms_eps, st)); xq_ready = true; }
+          else ATS_TRY(ats_rmsnorm(cx->h, m->layers[l + 1].input_norm, cx->xn, T, H, c.rms_eps, dt, st));
+        }
       } else if (l + 1 < c.n_layers) {
         ATS_TRY(ats_gemm_resid_norm(cx->act, w.wd, cx->h, T, H, c.ffn, c.ffn, H, dt, m->layers[l + 1].input_norm, cx->xn, c.rms_eps,
                                     cx->ws, cx->ws_bytes, st));
+        xq_ready = false;
       } else {
         ATS_TRY(ats_gemm(cx->act, w.wd, cx->h, T, H, c.ffn, c.ffn, H, dt, EPI_RESID, cx->ws, cx->ws_bytes, st));
       } }

@@ -53,6 +53,8 @@ int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int
 // fp8 (e4m3, per-row scales) variants of the batched projections; returns ATSPEED_ERR_INVALID if the shape does not
 // qualify (ats_gemm_fp8_applies)
 int ats_quant_rows_fp8(const void* x, int rows, int cols, int ld, void* q, float* scale, hipStream_t st);
+// RMSNorm fused with the per-token quantisation of its output (bf16, hidden <= 8192); y may be null
+int ats_rmsnorm_quant_fp8(const void* x, const void* w, void* y, void* q, float* scale, int rows, int hidden, float eps, hipStream_t st);
 bool ats_gemm_fp8_applies(int m, int n, int k, int ldc, int epilogue);
 int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int m, int n, int k, int ldc,
                  int epilogue, hipStream_t st);

@@ -231,6 +231,10 @@ int atspeed_gemm_fp8(const void* xq_dev, const float* sx_dev, const void* wq_dev
                      int32_t n, int32_t k, int32_t ldc, int32_t epilogue, void* stream);
 int atspeed_rmsnorm(const void* x_dev, const void* w_dev, void* y_dev, int32_t rows, int32_t hidden,
                     float eps, int32_t dtype, void* stream);
+/* bf16 RMSNorm fused with the per-token e4m3 quantisation of its output (what the fp8 forward runs in front of the qkv and
+ * gate_up projections); y_dev may be NULL; q / scale equal atspeed_quant_rows_fp8 of the bf16 norm output bit for bit */
+int atspeed_rmsnorm_quant_fp8(const void* x_dev, const void* w_dev, void* y_dev, void* q_dev, float* scale_dev, int32_t rows,
+                              int32_t hidden, float eps, void* stream);
 /* tree attention over a slot-addressed KV cache ([max_slots][hidden] per K and V) */
 int atspeed_tree_attention(const void* q_dev, int32_t ldq, const void* kcache_dev, const void* vcache_dev,
                            const uint64_t* vis_bits_dev, int32_t vis_words, void* out_dev, int32_t n_tokens,

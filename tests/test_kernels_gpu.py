@@ -328,6 +328,25 @@ def test_quant_rows_fp8(lib):
     assert (ref_codes == q.cpu()).float().mean() > 0.999          # same rounding as torch's e4m3 conversion
 
 
+@pytest.mark.parametrize("hidden", [768, 4096, 8192])
+def test_rmsnorm_quant_fp8_equals_norm_then_quant(lib, hidden):
+    rows = 37
+    x = _rand((rows, hidden), 41, 2.0).to(torch.bfloat16).cuda()
+    w = (1 + _rand((hidden,), 42, 0.1)).to(torch.bfloat16).cuda()
+    y = torch.empty_like(x); y2 = torch.empty_like(x)
+    q = torch.empty(rows, hidden, dtype=torch.uint8, device="cuda"); q2 = torch.empty_like(q)
+    sc = torch.empty(rows, dtype=torch.float32, device="cuda"); sc2 = torch.empty_like(sc)
+    _lib.check(lib.atspeed_rmsnorm(x.data_ptr(), w.data_ptr(), y.data_ptr(), rows, hidden, 1e-6, _lib.ATSPEED_BF16, _st()))
+    _lib.check(lib.atspeed_quant_rows_fp8(y.data_ptr(), rows, hidden, q.data_ptr(), sc.data_ptr(), _st()))
+    _lib.check(lib.atspeed_rmsnorm_quant_fp8(x.data_ptr(), w.data_ptr(), y2.data_ptr(), q2.data_ptr(), sc2.data_ptr(), rows, hidden, 1e-6, _st()))
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16)) and torch.equal(q, q2) and torch.equal(sc, sc2)
+    q3 = torch.empty_like(q); sc3 = torch.empty_like(sc)                      # y = NULL: only the quantised row
+    _lib.check(lib.atspeed_rmsnorm_quant_fp8(x.data_ptr(), w.data_ptr(), None, q3.data_ptr(), sc3.data_ptr(), rows, hidden, 1e-6, _st()))
+    torch.cuda.synchronize()
+    assert torch.equal(q, q3) and torch.equal(sc, sc3)
+
+
 @pytest.mark.parametrize("m,n,k,epi", [(1024, 2304, 768, 0), (640, 12288, 512, 0), (1300, 1024, 1280, 2), (900, 2752, 512, 3), (1543, 1000, 256, 1)])
 def test_gemm_fp8(lib, m, n, k, epi):
     x = _rand((m, k), 51, 1.5).to(torch.bfloat16).cuda()
