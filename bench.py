@@ -7,14 +7,16 @@
 Metric (BASELINE.json): recommended items/sec + mean accepted length, Llama-68M draft /
 Llama-7B target, K=20 beams, DK=40 draft beams, gamma=4, L=4 code tokens, Beauty vocabulary
 (V=32859), bf16, synthetic hash-PRNG weights and prompts (no tokenizer/checkpoints offline).
-A "step" is one user's complete BSSD() call (draft steps + packed target verification +
-verify rounds) with the prompt already resident in HBM; `value` = users * K / wall time.
-Users are independent, so N GPUs shard the user list (weak scaling: --steps users per GPU)
+A "step" is one pass of the hot path over one batch of inputs: a lock-step batch of `--streams`
+users (default 64), each running its complete BSSD() (draft steps + packed target verification +
+verify rounds), prompts already resident in HBM; `value` = users * K beams / wall time.
+Users are independent, so N GPUs shard the user list (weak scaling: --steps batches per GPU)
 and exchange only one all-gather of counters at the end.
 
 Extra objects on the JSON line:
-  roofline     — the dominant kernel family (target-forward projection GEMM with the largest total
-                 time), algorithmic bytes / launch over hipEvent-measured launch time vs 8 TB/s HBM.
+  roofline     — the dominant kernel (the target forward's gate_up projection GEMM), hipEvent-bracketed on its
+                 launch stream: algorithmic flops / launch time vs the 2.5 PF dense bf16 MFMA peak when users are
+                 batched (HBM bytes vs 8 TB/s with --streams 1); verify_scan: the verify step's scan vs 8 TB/s.
   cpu_baseline — the oracle (oracle/beamsd_ref.py, torch-CPU fp32) timed on the host cores on a
                  bounded sample of the same workload with the same weights (rank 0, N=1 only).
 """
@@ -46,8 +48,8 @@ MFMA_PEAK_TFLOPS = 2500.0    # same guide: ~2.5 PF dense bf16
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128, help="users per GPU in the timed region")
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4, help="timed steps per GPU; a step = one lock-step batch of --streams users")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed steps (batches) before the timed region")
     ap.add_argument("--target-layers", type=int, default=32, help="32 = Llama-7B (the metric's config)")
     ap.add_argument("--beam", type=int, default=20)
     ap.add_argument("--draft-beam", type=int, default=40)
@@ -140,7 +142,10 @@ def main():
     else:
         fn = PositionSetConstraint(vocab.allowed_tokens(), synth.RESPONSE_SEP)
 
-    n_local = args.warmup + args.steps
+    # a STEP is one lock-step batch: `--streams` users decoded together (one pass of the hot path over one batch of inputs)
+    ups = max(1, args.streams)
+    n_warm, n_timed = args.warmup * ups, args.steps * ups
+    n_local = n_warm + n_timed
     first = rank * n_local                                   # contiguous user shard per rank
     plens = synth.prompt_lengths(world * n_local, args.seed, mean_hist=7.33 if args.dataset == "beauty" else 5.98)
     prompts = [synth.synthetic_prompt(int(plens[first + u]), synth.tensor_seed(args.seed, f"user{first + u}")) for u in range(n_local)]
@@ -158,7 +163,7 @@ def main():
                               prefix_allowed_tokens_fn=fn)
         return res
 
-    run_users(0, args.warmup)
+    run_users(0, n_warm)
     if args.streams > 1:                         # create every decoder / grow the batch buffers outside the timed region
         BSSD_batch(target, draft, dprompts[:args.streams], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
     target.profile(1)
@@ -170,7 +175,7 @@ def main():
     stage = np.zeros(3)
     n_tf = n_df = 0
     outs = []
-    for o in run_users(args.warmup, n_local):
+    for o in run_users(n_warm, n_local):
         n_run += o["n_run"]; acc += o["total_accept_steps"]
         stage += (o["draft_time_cost"], o["target_time_cost"], o["verify_time_cost"])
         n_tf += o["n_target_forwards"]; n_df += o["n_draft_forwards"]
@@ -186,17 +191,17 @@ def main():
     # Here every projection is one pass over the weights (M ~ 20-230 tokens): HBM-bound.
     single = None
     if rank == 0 and args.streams > 1 and args.single_stream_users > 0:
-        n1 = min(args.single_stream_users, args.steps)
-        for u in range(args.warmup, args.warmup + min(3, n1)):       # warm-up: recurring forward shapes get their hipGraphs
+        n1 = min(args.single_stream_users, n_timed)
+        for u in range(n_warm, n_warm + min(3, n1)):       # warm-up: recurring forward shapes get their hipGraphs
             BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
-        for u in range(args.warmup, args.warmup + n1):
+        for u in range(n_warm, n_warm + n1):
             BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
         torch.cuda.synchronize(dev)
         dt1 = time.perf_counter() - t1
         target.profile(1)                                           # GEMM brackets from a second, untimed pass (profiling bypasses the graphs)
-        for u in range(args.warmup, args.warmup + min(3, n1)):
+        for u in range(n_warm, n_warm + min(3, n1)):
             BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
         torch.cuda.synchronize(dev)
         p1 = target.profile(0)
@@ -234,16 +239,16 @@ def main():
                 for g in range(lo, hi, grp):
                     res += BSSD_batch(target_a, draft_a, dprompts[g:min(hi, g + grp)], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
                 return res
-            run_aligned(0, min(n_local, max(args.warmup, grp)))
+            run_aligned(0, min(n_local, max(n_warm, grp)))
             torch.cuda.synchronize(dev)
             ta = time.perf_counter()
-            ro = run_aligned(args.warmup, n_local)
+            ro = run_aligned(n_warm, n_local)
             torch.cuda.synchronize(dev)
             dta = time.perf_counter() - ta
-            aligned.append(dict(resid_scale=rs, items_per_s=args.steps * args.beam / dta, ms_per_user=1e3 * dta / args.steps,
+            aligned.append(dict(resid_scale=rs, items_per_s=n_timed * args.beam / dta, ms_per_user=1e3 * dta / n_timed,
                                 mean_accept_len=sum(o["total_accept_steps"] for o in ro) / max(1, sum(o["n_run"] for o in ro)),
-                                n_run_per_user=sum(o["n_run"] for o in ro) / args.steps,
-                                target_forwards_per_user=sum(o["n_target_forwards"] for o in ro) / args.steps))
+                                n_run_per_user=sum(o["n_run"] for o in ro) / n_timed,
+                                target_forwards_per_user=sum(o["n_target_forwards"] for o in ro) / n_timed))
             del target_a, draft_a, run_aligned
 
     # ---- the verify step's scan (full-vocabulary log-sum-exp over the packed logit rows of one lock-step round, the HBM-bound
@@ -271,7 +276,7 @@ def main():
                     achieved=rows * V * 4 / (us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=rows * V * 4 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
         del lg, lse
 
-    per_rank = all_gather_counters(Counters(args.steps, n_run, acc, int(elapsed * 1e9)), dev)   # the path's single collective
+    per_rank = all_gather_counters(Counters(n_timed, n_run, acc, int(elapsed * 1e9)), dev)   # the path's single collective
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -325,12 +330,13 @@ def main():
         "config": {"workload": f"{args.dataset.capitalize()} V={V}, Llama-68M draft / Llama-7B({args.target_layers}L) target, K={args.beam}, DK={args.draft_beam}, "
                                f"gamma={args.gamma}, L={args.new_tokens}, {args.streams} user(s) per lock-step batch per GPU, "
                                f"{'position-set mask' if args.mask == 'position' else 'strict item trie'}",
-                   "users_per_gpu": args.steps, "streams": args.streams, "mean_prompt_len": float(np.mean([len(p) for p in prompts[args.warmup:]])),
+                   "users_per_step": ups, "users_per_gpu": n_timed, "streams": args.streams,
+                   "mean_prompt_len": float(np.mean([len(p) for p in prompts[n_warm:]])),
                    "parallelism": f"user-shard x{world}"},
         "mean_accept_len": mean_accept,
         "accept_note": "unrelated random draft/target weights accept ~0 draft steps: worst-case bracket (3 verify rounds + 1 final step = 4 target forwards per user)",
-        "per_user": {"n_run": total_runs / users, "target_forwards": n_tf / args.steps, "draft_forwards": n_df / args.steps,
-                     "draft_ms": 1e3 * stage[0] / args.steps, "target_ms": 1e3 * stage[1] / args.steps, "verify_ms": 1e3 * stage[2] / args.steps},
+        "per_user": {"n_run": total_runs / users, "target_forwards": n_tf / n_timed, "draft_forwards": n_df / n_timed,
+                     "draft_ms": 1e3 * stage[0] / n_timed, "target_ms": 1e3 * stage[1] / n_timed, "verify_ms": 1e3 * stage[2] / n_timed},
         "roofline": roofline,
         "verify_scan": scan,
         "single_user_stream": single,
@@ -339,11 +345,11 @@ def main():
     if args.do_sample:
         line["decoding"] = f"sampling (temperature {args.temperature})"
     if world == 1 and not args.no_cpu_baseline and not args.do_sample:
-        cb, ref_outs = cpu_baseline(target, draft, prompts[args.warmup:], fn, args)
+        cb, ref_outs = cpu_baseline(target, draft, prompts[n_warm:], fn, args)
         line["cpu_baseline"] = cb
         # next to the timing: the bf16 engine's items vs the fp32 oracle's on identical weights (NOT the parity test -- that is fp32
         # vs fp32 in tests/; random-init logits are nearly flat, so bf16 rounding alone reorders beams)
-        P0 = len(prompts[args.warmup])
+        P0 = len(prompts[n_warm])
         gpu_items = {tuple(x) for x in outs[0]["beam_sequence"][:, P0:].cpu().tolist()}
         ref_items = {tuple(x) for x in ref_outs[0]["beam_sequence"][:, P0:].tolist()}
         line["cpu_baseline"]["top_k_overlap_with_gpu_bf16"] = len(gpu_items & ref_items) / max(1, len(ref_items))

@@ -2,7 +2,7 @@
 # A/B of an env switch on the single-user-stream pass of bench.py.  usage: tools/ab_single_stream.sh ENVVAR v1 v2 ...
 var=$1; shift
 for v in "$@"; do
-  env $var=$v python bench.py --no-cpu-baseline --steps 64 --aligned-resid-scale "" --single-stream-users 12 2>/dev/null > gpurun_out/ab_$v.json
+  env $var=$v python bench.py --no-cpu-baseline --steps 1 --aligned-resid-scale "" --single-stream-users 12 2>/dev/null > gpurun_out/ab_$v.json
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_$v.json")); s=d["single_user_stream"]

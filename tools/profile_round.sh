@@ -4,6 +4,6 @@ mkdir -p gpurun_out/final
 python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final/stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --aligned-resid-scale '' --single-stream-users 0 > $GRAFT_REPO_ROOT/gpurun_out/final/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 128 --warmup 0 --no-cpu-baseline --aligned-resid-scale '' --single-stream-users 0 > $GRAFT_REPO_ROOT/gpurun_out/final/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 128 --warmup 0 --no-cpu-baseline --aligned-resid-scale '' --single-stream-users 0 > $GRAFT_REPO_ROOT/gpurun_out/final/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --no-cpu-baseline --aligned-resid-scale '' --single-stream-users 0 > $GRAFT_REPO_ROOT/gpurun_out/final/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --no-cpu-baseline --aligned-resid-scale '' --single-stream-users 0 > $GRAFT_REPO_ROOT/gpurun_out/final/pmc_write.log 2>&1
 ls -R $GRAFT_REPO_ROOT/gpurun_out/final | head -30
