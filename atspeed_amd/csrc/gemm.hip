@@ -489,12 +489,22 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
         ATS_MFMA_BF16(acc[i][j], fa[(Q) & 1][i], fb[(Q) & 1][j]);                                        \
       }                                                                                                  \
     }                                                                                                    \
+    ATS_STAMP(0);                                                                                        \
     if (RD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
+    ATS_STAMP(1);                                                                                        \
     if ((VM) >= 0) {                                                                                     \
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VM) < 0 ? 0 : (VM)) : "memory");                         \
+      ATS_STAMP(2);                                                                                      \
       asm volatile("s_barrier" ::: "memory");                                                            \
+      ATS_STAMP(3);                                                                                      \
     }                                                                                                    \
   }
+#ifdef ATS_RING_STAMPS   // tuning build only: cycles a wave spends in the MFMA/issue part, the lgkmcnt wait, the vmcnt wait and the barrier
+  unsigned long long st_t[4] = {0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+#define ATS_STAMP(i) { unsigned long long _n = __builtin_readcyclecounter(); st_t[i] += _n - st_last; st_last = _n; }
+#else
+#define ATS_STAMP(i)
+#endif
 
   // prologue: k-steps 0..3 into stages 0..3; fragments of k-step 0
 #pragma unroll
@@ -521,6 +531,13 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   ATS_RING_SEGMENT(2, false, true, -1, ks + 2);
   ATS_RING_SEGMENT(3, false, false, -1, ks + 3);
 #undef ATS_RING_SEGMENT
+#ifdef ATS_RING_STAMPS
+  if (lane == 0 && sx == nullptr && sw != nullptr) {               // tuning build: sw carries the stamp buffer [workgroup][wave][4]
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(sw)) + ((size_t)blockIdx.x * NWV + wave) * 4;
+    dbg[0] = st_t[0]; dbg[1] = st_t[1]; dbg[2] = st_t[2]; dbg[3] = st_t[3];
+  }
+#endif
+#undef ATS_STAMP
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");               // MFMA results -> VALU reads (the compiler cannot see the asm MFMAs)
 
   if constexpr (FP8) {                                             // per-row scales: acc[i][j][r] *= sx[m] * sw[n]
@@ -553,6 +570,12 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
   const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
   const bool use256 = force_mt ? force_mt == 8 : big_use_256_rows(t256, t128);
   const float* none = nullptr;
+#ifdef ATS_RING_STAMPS
+  static const char* stamp_env = getenv("ATSPEED_STAMP_PTR");      // tuning build: device buffer for the in-kernel cycle stamps
+  const float* stamps = stamp_env ? (const float*)(uintptr_t)strtoull(stamp_env, nullptr, 16) : nullptr;
+#else
+  const float* stamps = nullptr;
+#endif
   static const int four_waves = env_int("ATSPEED_GEMM_4WAVE", 0);
   if (use256 && four_waves) {
     static thread_local bool a4 = false;
@@ -561,7 +584,7 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
     ATS_LAUNCH_CHECK();
     return ATSPEED_OK;
   }
-  if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
+  if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, none, stamps, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
   else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
