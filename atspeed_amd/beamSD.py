@@ -136,6 +136,16 @@ class _Decoder:
         return d
 
 
+def release_decoders(*models) -> int:
+    """Free the cached per-user decoders (KV arenas: ~270 MB each at Llama-7B dims, 512 slots) of the given models, or all of
+    them when called without arguments; returns how many were freed.  They are re-created on demand."""
+    ids = {id(m) for m in models}
+    keys = [k for k, d in _Decoder._cache.items() if not ids or id(d.models[0]) in ids or (d.models[1] is not None and id(d.models[1]) in ids)]
+    for k in keys:
+        del _Decoder._cache[k]
+    return len(keys)
+
+
 def _compile_constraint(fn, prompt):
     if fn is None:
         raise NotImplementedError(
@@ -243,7 +253,7 @@ def BSSD(target_model, draft_model, inputs: Dict, gamma: int, max_new_tokens: in
 
 
 beam_sd_generate = BSSD
-MAX_USERS_PER_CALL = 64
+MAX_USERS_PER_CALL = 256
 
 
 @torch.no_grad()
@@ -258,7 +268,7 @@ def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_token
     are identical to calling BSSD() per user (scores agree to fp32 rounding: the GEMM tiling depends on the batch)."""
     _check_models(target_model, draft_model)
     mode = _sampling(target_model, seed)             # user u of the call draws from stream seed + u
-    if len(inputs_list) > MAX_USERS_PER_CALL:            # the library batches up to 64 users per forward
+    if len(inputs_list) > MAX_USERS_PER_CALL:            # the library batches up to 256 users per forward
         outs = []
         for i in range(0, len(inputs_list), MAX_USERS_PER_CALL):
             outs += BSSD_batch(target_model, draft_model, inputs_list[i:i + MAX_USERS_PER_CALL], gamma, max_new_tokens,

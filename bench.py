@@ -8,7 +8,7 @@ Metric (BASELINE.json): recommended items/sec + mean accepted length, Llama-68M 
 Llama-7B target, K=20 beams, DK=40 draft beams, gamma=4, L=4 code tokens, Beauty vocabulary
 (V=32859), bf16, synthetic hash-PRNG weights and prompts (no tokenizer/checkpoints offline).
 A "step" is one pass of the hot path over one batch of inputs: a lock-step batch of `--streams`
-users (default 64), each running its complete BSSD() (draft steps + packed target verification +
+users (default 256), each running its complete BSSD() (draft steps + packed target verification +
 verify rounds), prompts already resident in HBM; `value` = users * K beams / wall time.
 Users are independent, so N GPUs shard the user list (weak scaling: --steps batches per GPU)
 and exchange only one all-gather of counters at the end.
@@ -36,7 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from atspeed_amd import synth                      # noqa: E402
-from atspeed_amd.beamSD import BSSD, BSSD_batch    # noqa: E402
+from atspeed_amd.beamSD import BSSD, BSSD_batch, release_decoders    # noqa: E402
 from atspeed_amd.dist import Counters, aggregate, all_gather_counters   # noqa: E402
 from atspeed_amd.generation_trie import PositionSetConstraint   # noqa: E402
 from atspeed_amd.model import HipLlama             # noqa: E402
@@ -48,7 +48,7 @@ MFMA_PEAK_TFLOPS = 2500.0    # same guide: ~2.5 PF dense bf16
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4, help="timed steps per GPU; a step = one lock-step batch of --streams users")
+    ap.add_argument("--steps", type=int, default=2, help="timed steps per GPU; a step = one lock-step batch of --streams users")
     ap.add_argument("--warmup", type=int, default=1, help="untimed steps (batches) before the timed region")
     ap.add_argument("--target-layers", type=int, default=32, help="32 = Llama-7B (the metric's config)")
     ap.add_argument("--beam", type=int, default=20)
@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--gamma", type=int, default=4)
     ap.add_argument("--new-tokens", type=int, default=4)
     ap.add_argument("--seed", type=int, default=2025)
-    ap.add_argument("--streams", type=int, default=64, help="users decoded in lock step per GPU (one batched forward per draft step / verification); 1 = the reference's one-user-at-a-time loop")
+    ap.add_argument("--streams", type=int, default=256, help="users decoded in lock step per GPU (one batched forward per draft step / verification); 1 = the reference's one-user-at-a-time loop")
     ap.add_argument("--target-fp8", action="store_true", help="BASELINE config 5: fp8 (e4m3 W8A8) target projections in the batched forwards")
     ap.add_argument("--single-stream-users", type=int, default=6, help="extra untimed-for-value pass: users decoded one at a time (the reference's loop)")
     ap.add_argument("--aligned-resid-scale", type=str, default="3e-6,3e-5",
@@ -220,6 +220,7 @@ def main():
     aligned = None
     scales = [float(x) for x in args.aligned_resid_scale.split(",") if x.strip()]
     if rank == 0 and scales:
+        release_decoders(target, draft)                # the main pass's per-user KV arenas: room for the second model pair
         aligned = []
         grp = max(1, args.streams)
         for rs in scales:
@@ -249,6 +250,7 @@ def main():
                                 mean_accept_len=sum(o["total_accept_steps"] for o in ro) / max(1, sum(o["n_run"] for o in ro)),
                                 n_run_per_user=sum(o["n_run"] for o in ro) / n_timed,
                                 target_forwards_per_user=sum(o["n_target_forwards"] for o in ro) / n_timed))
+            release_decoders(target_a, draft_a)
             del target_a, draft_a, run_aligned
 
     # ---- the verify step's scan (full-vocabulary log-sum-exp over the packed logit rows of one lock-step round, the HBM-bound
