@@ -5,7 +5,7 @@
 // ---- segment table: one forward over the tokens of several users ----------------------
 // Each user (decoder) contributes a contiguous run of rows; its KV cache, visibility bitsets, positions
 // and slots stay private.  The host builds the table, stages it to device memory (ats_stage) and kernels read it
-// through a pointer (64 users x 72 B does not fit the 4 KB kernel-argument block).
+// through a pointer (256 users x 72 B do not fit the 4 KB kernel-argument block).
 constexpr int ATS_MAX_SEGS = 256;           // users per lock-step batch (qtile_seg is a byte: <= 256)
 constexpr int ATS_MAX_QTILES = ATS_MAX_SEGS * 8;
 struct Seg {

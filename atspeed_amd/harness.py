@@ -254,7 +254,7 @@ class InferenceResult:
 
 
 def run_inference(target, draft, data: SeqRecTestData, gamma: int = 4, max_new_tokens: int = 4, L: int = 0, R: Optional[int] = None,
-                  users_per_batch: int = 32, prefix_allowed_tokens_fn=None, tokenizer=None, baseline: bool = False,
+                  users_per_batch: int = 128, prefix_allowed_tokens_fn=None, tokenizer=None, baseline: bool = False,
                   device=None) -> InferenceResult:
     """Users [L, R) of the test set through beam-SD (inference.py:123-124,162-187), `users_per_batch` at a time in lock step.
     `baseline=True` also runs `target_generate` per user and records its time and the speed-up columns."""

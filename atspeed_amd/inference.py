@@ -36,7 +36,7 @@ def parse(argv=None):
     ap.add_argument("--draft_beam_size", type=int, default=40)
     ap.add_argument("--L", type=int, default=0)
     ap.add_argument("--R", type=int, default=None)
-    ap.add_argument("--users_per_batch", type=int, default=32, help="users decoded in lock step (1 = the reference's loop)")
+    ap.add_argument("--users_per_batch", type=int, default=128, help="users decoded in lock step (1 = the reference's loop)")
     ap.add_argument("--strict_trie", action="store_true", help="strict item trie instead of the position-set mask")
     ap.add_argument("--target_ckpt", type=str, default=None)
     ap.add_argument("--draft_ckpt", type=str, default=None)
