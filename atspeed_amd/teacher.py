@@ -18,33 +18,34 @@ import numpy as np
 import torch
 
 from .beamSD import target_generate_batch
-from .model import HipLlama, vis_bits_from_bool
+from .model import HipLlama
 
 
 def _branch_inputs(prompt: np.ndarray, branches: Sequence[Sequence[int]], max_slots: int):
     """Packed inputs: prompt rows, then every branch's tokens EXCEPT its last (the logits of a row predict the next token;
-    the prompt's last row predicts every branch's first token).  Returns ids, pos, slots, vis bitset and, per branch, the
-    packed rows whose logits predict its tokens."""
+    the prompt's last row predicts every branch's first token).  Returns ids, pos, slots, the visibility bitset (built
+    directly as 64-bit words: row r of the prompt sees slots [0, r], a branch row sees the prompt and its own prefix) and, per
+    branch, the packed rows whose logits predict its tokens."""
     P = len(prompt)
-    ids, pos, rows = list(int(t) for t in prompt), list(range(P)), []
-    vis = [np.tril(np.ones((P, P), dtype=bool))]
-    n_extra = sum(len(b) - 1 for b in branches)
-    T = P + n_extra
-    full = np.zeros((T, T), dtype=bool)
-    full[:P, :P] = vis[0]
+    W = max_slots // 64
+    ids, pos, rows, masks = [int(t) for t in prompt], list(range(P)), [], [(1 << (r + 1)) - 1 for r in range(P)]
+    full_prompt = (1 << P) - 1
     r = P
     for b in branches:
-        br_rows = [P - 1]
-        first = r
+        br_rows, own = [P - 1], 0
         for j, tok in enumerate(b[:-1]):
             ids.append(int(tok)); pos.append(P + j)
-            full[r, :P] = True
-            full[r, first: r + 1] = True
+            own |= 1 << r
+            masks.append(full_prompt | own)
             br_rows.append(r)
             r += 1
         rows.append(br_rows)
+    T = r
+    if T > max_slots:
+        raise ValueError(f"score_branches: {T} packed tokens exceed max_slots {max_slots}")
+    bits = np.frombuffer(b"".join(m.to_bytes(W * 8, "little") for m in masks), dtype=np.uint64).reshape(T, W)
     i32 = lambda x: torch.tensor(x, dtype=torch.int32)
-    return i32(ids), i32(pos), torch.arange(T, dtype=torch.int32), vis_bits_from_bool(torch.from_numpy(full), max_slots), rows, T
+    return i32(ids), i32(pos), torch.arange(T, dtype=torch.int32), torch.from_numpy(bits.view(np.int64).copy()), rows, T
 
 
 @torch.no_grad()
