@@ -48,6 +48,7 @@ SIGNATURES = {
     "atspeed_llama_create": (C.c_int, [C.POINTER(LlamaConfig), _P, _P, _P, C.POINTER(LlamaLayerWeights), C.POINTER(_P)]),
     "atspeed_llama_destroy": (None, [_P]),
     "atspeed_llama_forward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "atspeed_llama_forward_batch": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "atspeed_llama_logits": (_P, [_P]),
     "atspeed_llama_enable_fp8": (C.c_int, [_P, _P]),
     "atspeed_quant_rows_fp8": (C.c_int, [_P, _I, _I, _P, _P, _P]),

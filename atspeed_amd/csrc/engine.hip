@@ -189,6 +189,7 @@ struct atspeed_llama {
   struct Fp8Layer { void *wqkv, *wo, *wgu, *wd; float *sqkv, *so, *sgu, *sd; };
   std::vector<Fp8Layer> fp8;
   KvCache kv0;                                   // cache of the plain atspeed_llama_forward API
+  std::vector<KvCache> kv_pool;                  // one more cache per segment of atspeed_llama_forward_batch (grown on demand)
   ActCtx* act;                                   // grown on demand (ensure_act)
   bool prof_on = false;
   double prof_ms[5] = {0, 0, 0, 0, 0};
@@ -335,6 +336,7 @@ extern "C" int atspeed_llama_create(const atspeed_llama_config* cfg, const void*
 extern "C" void atspeed_llama_destroy(atspeed_llama* m) {
   if (!m) return;
   kv_free(&m->kv0);
+  for (KvCache& kv : m->kv_pool) kv_free(&kv);
   act_free(m->act);
   for (auto& f : m->fp8) { hipFree(f.wqkv); hipFree(f.wo); hipFree(f.wgu); hipFree(f.wd); hipFree(f.sqkv); hipFree(f.so); hipFree(f.sgu); hipFree(f.sd); }
   hipFree(m->cos_tab); hipFree(m->sin_tab);
@@ -536,6 +538,40 @@ extern "C" int atspeed_llama_forward(atspeed_llama* m, const int32_t* ids, const
   s.row0 = 0; s.n_tok = n_tokens; s.n_slots = n_slots_visible; s.logit_row0 = 0; s.n_logit = n_logit_rows;
   t.n_qtiles = 0; t.qtile_rows = n_tokens > 96 ? 128 : 64;
   for (int j = 0; j * t.qtile_rows < n_tokens; ++j) { t.qtile_seg[t.n_qtiles] = 0; t.qtile_idx[t.n_qtiles++] = (unsigned char)j; }
+  return llama_forward_segs(m, t, logits_out, (hipStream_t)stream);
+}
+
+static int seg_finish(SegTable& t);
+
+// n independent forwards as ONE batched forward (segment table): sequence i has its own token / position / slot / visibility
+// arrays and a KV arena of its own from the model's pool; logits of its last n_logit[i] rows follow each other in logits_out.
+// What the teacher-data job needs to score the label and the K beams of many samples at once (generate_teacher_data.py:225-232).
+extern "C" int atspeed_llama_forward_batch(atspeed_llama* m, int32_t n, const int32_t* const* ids, const int32_t* const* pos,
+                                           const int32_t* const* slots, const uint64_t* const* vis, const int32_t* n_tokens,
+                                           const int32_t* n_slots_visible, const int32_t* n_logit_rows, float* logits_out,
+                                           void* stream) {
+  ATS_REQUIRE(m && ids && pos && slots && vis && n_tokens && n_slots_visible && n_logit_rows && logits_out, ATSPEED_ERR_INVALID,
+              "forward_batch: null argument");
+  ATS_REQUIRE(n >= 1 && n <= ATS_MAX_SEGS, ATSPEED_ERR_CAPACITY, "forward_batch: %d sequences per call (max %d)", n, ATS_MAX_SEGS);
+  while ((int)m->kv_pool.size() < n) {
+    KvCache kv;
+    ATS_TRY(kv_create(m, &kv));
+    m->kv_pool.push_back(kv);
+  }
+  SegTable t{};
+  int tot = 0, rows = 0;
+  for (int i = 0; i < n; ++i) {
+    ATS_REQUIRE(ids[i] && pos[i] && slots[i] && vis[i], ATSPEED_ERR_INVALID, "forward_batch: null array for sequence %d", i);
+    ATS_REQUIRE(n_tokens[i] >= 1 && n_tokens[i] <= m->cfg.max_tokens, ATSPEED_ERR_CAPACITY, "forward_batch: %d tokens exceed max_tokens %d",
+                n_tokens[i], m->cfg.max_tokens);
+    ATS_REQUIRE(n_logit_rows[i] >= 0 && n_logit_rows[i] <= n_tokens[i], ATSPEED_ERR_INVALID, "forward_batch: bad logit row count");
+    Seg& sg = t.seg[t.n++];
+    sg.ids = ids[i]; sg.pos = pos[i]; sg.slot = slots[i]; sg.vis = vis[i]; sg.kc = m->kv_pool[i].k; sg.vc = m->kv_pool[i].v;
+    sg.n_tok = n_tokens[i]; sg.n_slots = n_slots_visible[i]; sg.n_logit = n_logit_rows[i];
+    tot += n_tokens[i]; rows += n_logit_rows[i];
+  }
+  ATS_TRY(seg_finish(t));
+  ATS_TRY(ensure_act(m, tot, rows));
   return llama_forward_segs(m, t, logits_out, (hipStream_t)stream);
 }
 

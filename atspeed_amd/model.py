@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 from types import SimpleNamespace
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch
@@ -235,6 +235,38 @@ class HipLlama:
                                                  vis_bits.data_ptr(), T, n_slots, n_logit_rows, raw.data_ptr(),
                                                  _lib.stream_ptr(self._device)))
         return raw.view(n_logit_rows, self.logits_ld)[:, : self.dims.vocab_size]
+
+    def forward_raw_batch(self, seqs, return_all: bool = False):
+        """Several independent sequences in ONE forward.  `seqs`: list of (ids, pos, slots, vis_bits, n_slots, n_logit_rows) with CPU
+        tensors shaped as in `forward_raw`.  Returns one fp32 [n_logit_rows, vocab] view per sequence (views of one buffer), or with
+        `return_all` the buffer itself, [sum of n_logit_rows, vocab], sequences one after the other."""
+        lib = _lib.load()
+        n = len(seqs)
+        W = self.max_slots // 64
+        for ids, pos, slots, vis, _, _ in seqs:
+            assert ids.dtype == pos.dtype == slots.dtype == torch.int32 and vis.dtype == torch.int64
+            assert vis.shape == (ids.numel(), W)
+        nt = np.array([s[0].numel() for s in seqs], dtype=np.int32)
+        ns = np.array([s[4] for s in seqs], dtype=np.int32)
+        nl = np.array([s[5] for s in seqs], dtype=np.int32)
+        off = np.concatenate([[0], np.cumsum(nt)]).astype(np.int64)
+        with torch.cuda.device(self._device):
+            # one upload for all sequences: [ids | pos | slots] as int32 and the bitsets as int64
+            ips = torch.cat([torch.cat([s[k] for s in seqs]) for k in range(3)]).to(self._device, non_blocking=True)
+            vis = torch.cat([s[3] for s in seqs]).to(self._device, non_blocking=True)
+            tot = int(off[-1])
+            ptrs = lambda base, stride: (C.c_void_p * n)(*[base + int(o) * stride for o in off[:-1]])
+            a_ids, a_pos, a_slot = (ptrs(ips.data_ptr() + k * tot * 4, 4) for k in range(3))
+            a_vis = ptrs(vis.data_ptr(), W * 8)
+            rows = int(nl.sum())
+            raw = torch.empty(rows * self.logits_ld, dtype=torch.float32, device=self._device)
+            _lib.check(lib.atspeed_llama_forward_batch(self._handle, n, a_ids, a_pos, a_slot, a_vis, nt.ctypes.data, ns.ctypes.data,
+                                                       nl.ctypes.data, raw.data_ptr(), _lib.stream_ptr(self._device)))
+        out = raw.view(rows, self.logits_ld)[:, : self.dims.vocab_size]
+        if return_all:
+            return out
+        r0 = np.concatenate([[0], np.cumsum(nl)])
+        return [out[int(r0[i]): int(r0[i + 1])] for i in range(n)]
 
 
 def vis_bits_from_bool(vis: torch.Tensor, max_slots: int) -> torch.Tensor:

@@ -6,9 +6,9 @@ For every training sample the reference stores three things from the teacher (th
   2. `teacher_output_logits`  — the teacher's logits along each of those K sequences, item-token columns only (`32000:`).
 
 The reference gets 1 from HF `generate` one sample at a time and 2 by repeating the prompt K times.  Here 1 is
-`target_generate_batch` (users in lock step) and 0 + 2 are ONE packed forward per sample under a tree mask: the prompt
-once, then the label tokens and the K beams as branches that each see the prompt and their own prefix — the same
-visibility-bitset attention the verification forward of beam-SD uses.
+`target_generate_batch` (users in lock step) and 0 + 2 are ONE packed forward per chunk of samples under a tree mask: per sample
+the prompt once, then the label tokens and the K beams as branches that each see the prompt and their own prefix — the same
+visibility-bitset attention the verification forward of beam-SD uses, with one segment (and KV arena) per sample.
 """
 from __future__ import annotations
 
@@ -48,20 +48,44 @@ def _branch_inputs(prompt: np.ndarray, branches: Sequence[Sequence[int]], max_sl
     return i32(ids), i32(pos), torch.arange(T, dtype=torch.int32), torch.from_numpy(bits.view(np.int64).copy()), rows, T
 
 
+def _check_capacity(model: HipLlama, T: int) -> None:
+    if T > model.max_tokens or T > model.max_slots:
+        raise ValueError(f"score_branches: {T} packed tokens exceed the model's capacity")
+
+
 @torch.no_grad()
 def score_branches(model: HipLlama, prompt: np.ndarray, branches: Sequence[Sequence[int]]) -> List[torch.Tensor]:
     """fp32 logits [len(branch), vocab] for each branch (row j predicts branch[j]) from ONE forward."""
-    ids, pos, slots, vis, rows, T = _branch_inputs(prompt, branches, model.max_slots)
-    if T > model.max_tokens or T > model.max_slots or T > model.max_logit_rows:
-        raise ValueError(f"score_branches: {T} packed tokens exceed the model's capacity")
+    return score_branches_batch(model, [prompt], [branches])[0]
+
+
+def _score_rows(model: HipLlama, prompts, branches):
+    """One forward for all samples.  Returns the logits of every scored row, [rows, vocab], and per sample / branch the indices
+    into it (row j of a branch predicts its token j)."""
+    seqs, index, base = [], [], 0
+    for prompt, brs in zip(prompts, branches):
+        ids, pos, slots, vis, rows, T = _branch_inputs(np.asarray(prompt), brs, model.max_slots)
+        _check_capacity(model, T)
+        first = len(prompt) - 1                       # only rows from the prompt's last one on reach the lm_head
+        seqs.append((ids, pos, slots, vis, T, T - first))
+        index.append([[base + r - first for r in br] for br in rows])
+        base += T - first
+    return model.forward_raw_batch(seqs, return_all=True), index
+
+
+@torch.no_grad()
+def score_branches_batch(model: HipLlama, prompts: Sequence[np.ndarray], branches: Sequence[Sequence[Sequence[int]]]) -> List[List[torch.Tensor]]:
+    """`score_branches` for many samples in ONE forward (`HipLlama.forward_raw_batch`: every sample is a segment with a KV arena of
+    its own)."""
+    logits, index = _score_rows(model, prompts, branches)
     dev = model.device
-    logits = model.forward_raw(ids.to(dev), pos.to(dev), slots.to(dev), vis.to(dev), T, T)
-    return [logits[torch.tensor(r, device=dev)] for r in rows]
+    return [[logits[torch.tensor(r, device=dev)] for r in rows] for rows in index]
 
 
 @torch.no_grad()
 def generate_teacher_data(model: HipLlama, prompts: Sequence[np.ndarray], labels: Sequence[Sequence[int]], strict_trie_fn,
-                          beam_size: int = 20, max_new_token: int = 5, users_per_batch: int = 32, item_col0: int = 32000) -> Dict[str, List]:
+                          beam_size: int = 20, max_new_token: int = 5, users_per_batch: int = 32, item_col0: int = 32000,
+                          score_batch: int = 32) -> Dict[str, List]:
     """The three teacher tensors per sample, as the reference stores them (lists over samples):
     `teacher_logits` [L, V], `teacher_output` [K, L] (int64), `teacher_output_logits` [K, L, V - item_col0]."""
     old = model.generation_config.num_beams
@@ -73,12 +97,19 @@ def generate_teacher_data(model: HipLlama, prompts: Sequence[np.ndarray], labels
             chunk = prompts[lo: lo + users_per_batch]
             gens = target_generate_batch(model, [{"input_ids": torch.from_numpy(np.asarray(p, dtype=np.int64))[None].to(dev)} for p in chunk],
                                          max_new_token, prefix_allowed_tokens_fn=strict_trie_fn)
-            for p, lab, g in zip(chunk, labels[lo: lo + users_per_batch], gens):
-                beams = g["beam_sequence"][:, len(p):]                                   # [K, L]
-                sc = score_branches(model, np.asarray(p), [list(lab)] + beams.cpu().tolist())
-                out["teacher_logits"].append(sc[0].cpu())
-                out["teacher_output"].append(beams.cpu())
-                out["teacher_output_logits"].append(torch.stack(sc[1:])[:, :, item_col0:].cpu())
+            beams = [g["beam_sequence"][:, len(p):].cpu() for p, g in zip(chunk, gens)]      # [K, L] each
+            for s0 in range(0, len(chunk), score_batch):
+                sl = slice(s0, s0 + score_batch)
+                logits, index = _score_rows(model, chunk[sl], [[list(lab)] + b.tolist() for lab, b in
+                                                               zip(labels[lo: lo + users_per_batch][sl], beams[sl])])
+                # two gathers and two downloads per chunk: [n, L, V] for the labels, [n, K, L, V - item_col0] for the beams
+                idx = torch.tensor(index, device=dev)                                          # [n, 1 + K, L]
+                lab_logits = logits[idx[:, 0]].cpu()
+                beam_logits = logits[:, item_col0:][idx[:, 1:]].cpu()
+                for i, b in enumerate(beams[sl]):
+                    out["teacher_logits"].append(lab_logits[i])
+                    out["teacher_output"].append(b)
+                    out["teacher_output_logits"].append(beam_logits[i])
         return out
     finally:
         model.generation_config.num_beams = old

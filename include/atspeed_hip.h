@@ -116,6 +116,13 @@ void atspeed_llama_destroy(atspeed_llama* m);
 int atspeed_llama_forward(atspeed_llama* m, const int32_t* ids_dev, const int32_t* pos_dev,
                           const int32_t* slots_dev, const uint64_t* vis_bits_dev, int32_t n_tokens,
                           int32_t n_slots_visible, int32_t n_logit_rows, float* logits_out_dev, void* stream);
+/* n independent sequences as ONE forward (generate_teacher_data.py:225-232 scores the label and the K beams of every sample;
+ * the reference runs one sample at a time).  Host arrays of n device pointers / counts; sequence i gets KV arena i of a pool the
+ * handle owns (grown on demand), so slot numbers are private to a sequence.  The logits of the last n_logit_rows[i] rows of
+ * sequence 0, 1, ... follow each other in logits_out_dev (row stride atspeed_llama_logits_ld()).  n <= 256. */
+int atspeed_llama_forward_batch(atspeed_llama* m, int32_t n, const int32_t* const* ids_dev, const int32_t* const* pos_dev,
+                                const int32_t* const* slots_dev, const uint64_t* const* vis_bits_dev, const int32_t* n_tokens,
+                                const int32_t* n_slots_visible, const int32_t* n_logit_rows, float* logits_out_dev, void* stream);
 float* atspeed_llama_logits(atspeed_llama* m);
 /* hipEvent brackets around the forward's five GEMM kinds (0 qkv, 1 o_proj, 2 gate_up+SwiGLU, 3 down,
  * 4 lm_head), recorded on the launch stream.  Returns the sums since the last reset in ms_out[5] /

@@ -448,6 +448,12 @@ def test_teacher_data_tensors_match_the_oracle_forward():
             want = ref.forward(inp.ids, inp.pos, inp.slots, inp.vis)[len(p) - 1:]
             cols = slice(32000, None) if got is not tl else slice(None)
             np.testing.assert_allclose(got[:, cols].numpy(), want[:, cols].numpy(), atol=LOGIT_TOL, rtol=0)
+    # samples scored one per forward give what the batched forward (one segment and KV arena per sample) gave
+    one = generate_teacher_data(m, prompts, labels, data.strict_trie_fn(), beam_size=10, max_new_token=5, users_per_batch=3, score_batch=1)
+    for k in ("teacher_logits", "teacher_output_logits"):
+        for a, b in zip(out[k], one[k]):
+            np.testing.assert_allclose(a.numpy(), b.numpy(), atol=LOGIT_TOL, rtol=0)
+    assert all(torch.equal(a, b) for a, b in zip(out["teacher_output"], one["teacher_output"]))
 
 
 # ------------------------------------------------------------------ sampling branch

@@ -26,3 +26,22 @@ for upb in (64, 128):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"{n} samples, {upb} per lock-step batch: {dt:.2f} s  {n / dt:.1f} samples/s  (teacher_output {tuple(out['teacher_output'][0].shape)}, logits {tuple(out['teacher_output_logits'][0].shape)})", flush=True)
+
+# where the time goes (synchronised brackets around the three stages; slower than the pipelined run above)
+import atspeed_amd.teacher as TT
+acc = {"search": 0.0, "pack+forward": 0.0}
+def timed(name, fn):
+    def w(*a, **k):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        r = fn(*a, **k)
+        torch.cuda.synchronize(); acc[name] += time.perf_counter() - t
+        return r
+    return w
+TT.target_generate_batch = timed("search", TT.target_generate_batch)
+TT._score_rows = timed("pack+forward", TT._score_rows)
+t0 = time.perf_counter()
+generate_teacher_data(m, prompts, labels, fn, beam_size=20, max_new_token=5, users_per_batch=128)
+torch.cuda.synchronize()
+tot = time.perf_counter() - t0
+print(f"breakdown over {n} samples: total {tot:.2f} s; " + "; ".join(f"{k} {v:.2f} s" for k, v in acc.items()) +
+      f"; gathers + downloads {tot - sum(acc.values()):.2f} s", flush=True)
