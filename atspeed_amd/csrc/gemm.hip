@@ -221,37 +221,74 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const T* __restrict__ A,
   }
 }
 
-// sum the split-K slabs and apply the epilogue; one thread per output element (pair for SwiGLU)
-template <typename T, int EPI>
+// V consecutive floats of every slab, summed in slab order.  The loads of four slabs are issued before their adds: with a runtime
+// slab count the plain loop waited out one memory round trip per slab (8 slabs = 8 x ~2 us; seen as 19 us reduce kernels behind
+// 15 us GEMMs in the one-user trace).
+template <int V>
+__device__ __forceinline__ void sum_slabs(const float* __restrict__ p, size_t slab_stride, int splits, float (&acc)[V]) {
+  typedef float vf __attribute__((ext_vector_type(V)));
+#pragma unroll
+  for (int i = 0; i < V; ++i) acc[i] = 0.f;
+  int z = 0;
+  for (; z + 4 <= splits; z += 4) {
+    vf q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const vf*>(p + (size_t)(z + u) * slab_stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc[i] += q[u][i];
+    }
+  }
+  for (; z < splits; ++z) {
+    vf q = *reinterpret_cast<const vf*>(p + (size_t)z * slab_stride);
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] += q[i];
+  }
+}
+
+// sum the split-K slabs and apply the epilogue; one thread per V consecutive output elements (pairs for SwiGLU).
+// V = 4 needs N % 4 == 0 and ldc % 4 == 0 (N % 32 == 0 holds for SwiGLU).
+template <typename T, int EPI, int V>
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, void* __restrict__ Cv, int M, int N, int ldc,
                                      int splits) {
   const size_t mn = (size_t)M * N;
   if constexpr (EPI == EPI_SWIGLU) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over M * N/2 outputs
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;   // over M * N/2 outputs
     size_t tot = (size_t)M * (N / 2);
     if (i >= tot) return;
     int m = (int)(i / (N / 2)), o = (int)(i % (N / 2));
     int grp = o >> 4, c = o & 15;
     size_t gi = (size_t)m * N + grp * 32 + c, ui = gi + 16;
-    float g = 0.f, u = 0.f;
-    for (int z = 0; z < splits; ++z) { g += partial[z * mn + gi]; u += partial[z * mn + ui]; }
-    if constexpr (sizeof(T) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
-    float s = g / (1.f + __expf(-g));
-    Elt<T>::store(reinterpret_cast<T*>(Cv) + (size_t)m * ldc + o, s * u);
+    float g[V], u[V];
+    sum_slabs<V>(partial + gi, mn, splits, g);
+    sum_slabs<V>(partial + ui, mn, splits, u);
+    T* out = reinterpret_cast<T*>(Cv) + (size_t)m * ldc + o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float gj = g[j], uj = u[j];
+      if constexpr (sizeof(T) == 2) { gj = bf2f(f2bf(gj)); uj = bf2f(f2bf(uj)); }
+      float sj = gj / (1.f + __expf(-gj));
+      Elt<T>::store(out + j, sj * uj);
+    }
   } else {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (i >= mn) return;
     int m = (int)(i / N), n = (int)(i % N);
-    float v = 0.f;
-    for (int z = 0; z < splits; ++z) v += partial[z * mn + i];
-    if constexpr (EPI == EPI_F32) {
-      reinterpret_cast<float*>(Cv)[(size_t)m * ldc + n] = v;
-    } else if constexpr (EPI == EPI_RESID) {
-      T* C = reinterpret_cast<T*>(Cv);
-      if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
-      Elt<T>::store(C + (size_t)m * ldc + n, Elt<T>::load(C + (size_t)m * ldc + n) + v);
-    } else {
-      Elt<T>::store(reinterpret_cast<T*>(Cv) + (size_t)m * ldc + n, v);
+    float v[V];
+    sum_slabs<V>(partial + i, mn, splits, v);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      if constexpr (EPI == EPI_F32) {
+        reinterpret_cast<float*>(Cv)[(size_t)m * ldc + n + j] = v[j];
+      } else if constexpr (EPI == EPI_RESID) {
+        T* C = reinterpret_cast<T*>(Cv);
+        float x = v[j];
+        if constexpr (sizeof(T) == 2) x = bf2f(f2bf(x));
+        Elt<T>::store(C + (size_t)m * ldc + n + j, Elt<T>::load(C + (size_t)m * ldc + n + j) + x);
+      } else {
+        Elt<T>::store(reinterpret_cast<T*>(Cv) + (size_t)m * ldc + n + j, v[j]);
+      }
     }
   }
 }
@@ -386,6 +423,9 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   constexpr int DG = (NMF - NR * RG) / NP;                       // then one DMA piece every DG MFMAs
   static_assert(RG >= 1 && DG >= 1, "segment too short for its reads and DMA pieces");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef ATS_RING_STAMPS
+  const unsigned long long st_entry = __builtin_readcyclecounter();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, g = lane >> 4;
   const int nwg = tiles_n * tiles_m;
@@ -519,6 +559,9 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
   asm volatile("s_barrier" ::: "memory");                          // k-step 1 published, stage 0 read by everyone
 
+#ifdef ATS_RING_STAMPS
+  const unsigned long long st_loop0 = st_last = __builtin_readcyclecounter();
+#endif
   int ks = ks0;
   for (; ks + 4 < nks; ks += 4) {
     ATS_RING_SEGMENT(0, true, true, 2 * NP, ks);
@@ -532,10 +575,7 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   ATS_RING_SEGMENT(3, false, false, -1, ks + 3);
 #undef ATS_RING_SEGMENT
 #ifdef ATS_RING_STAMPS
-  if (lane == 0 && sx == nullptr && sw != nullptr) {               // tuning build: sw carries the stamp buffer [workgroup][wave][4]
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(sw)) + ((size_t)blockIdx.x * NWV + wave) * 4;
-    dbg[0] = st_t[0]; dbg[1] = st_t[1]; dbg[2] = st_t[2]; dbg[3] = st_t[3];
-  }
+  const unsigned long long st_loop1 = __builtin_readcyclecounter();
 #endif
 #undef ATS_STAMP
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");               // MFMA results -> VALU reads (the compiler cannot see the asm MFMAs)
@@ -554,6 +594,16 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   }
   if constexpr (SPLITK) big_epilogue<EPI_F32, NA, MT2>(acc, reinterpret_cast<float*>(Cv) + (size_t)zpart * M * N, M, N, N, m0, n0, wn, wm, lq, g);
   else                  big_epilogue<EPI, NA, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
+#ifdef ATS_RING_STAMPS
+  // tuning build: sw carries the stamp buffer [workgroup][wave][8] = loop cycles in {issue, lgkmcnt wait, vmcnt wait, barrier}, then
+  // the absolute counter at kernel entry, loop start, loop end and after the epilogue's stores have been acknowledged
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && (FP8 ? false : sw != nullptr)) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(sw)) + ((size_t)blockIdx.x * NWV + wave) * 8;
+    dbg[0] = st_t[0]; dbg[1] = st_t[1]; dbg[2] = st_t[2]; dbg[3] = st_t[3];
+    dbg[4] = st_entry; dbg[5] = st_loop0; dbg[6] = st_loop1; dbg[7] = __builtin_readcyclecounter();
+  }
+#endif
 }
 
 template <int EPI>
@@ -595,10 +645,11 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
 //   xn[m][:] = w * (h[m][:] * rsqrt(mean(h^2) + eps))   (the NEXT op's input norm)
 // Saves one launch and one read of h per projection; numerics identical to the unfused pair
 // (statistics are taken from the stored, dtype-rounded h).
-template <typename T, int NPT>
+template <typename T, int NPT, int V>
 __global__ __launch_bounds__(1024) void splitk_resid_rmsnorm_kernel(const float* __restrict__ partial, T* __restrict__ h,
                                                                     const T* __restrict__ norm_w, T* __restrict__ xn, int M, int N,
                                                                     int ldh, int splits, float eps) {
+  // thread t owns columns (t + i*1024) * V .. + V-1, i < NPT / V   (V = 4: 16-byte slab loads; needs N % 4 == 0)
   __shared__ float red[16];
   const int m = blockIdx.x;
   const size_t mn = (size_t)M * N;
@@ -606,25 +657,27 @@ __global__ __launch_bounds__(1024) void splitk_resid_rmsnorm_kernel(const float*
   float ss = 0.f;
   const float* prow = partial + (size_t)m * N;
 #pragma unroll
-  for (int i = 0; i < NPT; ++i) vals[i] = 0.f;
-  for (int z = 0; z < splits; ++z) {              // NPT independent loads in flight per slab
+  for (int i = 0; i < NPT / V; ++i) {
+    const int n = (threadIdx.x + i * 1024) * V;
+    float acc[V];
+    if (n < N) sum_slabs<V>(prow + n, mn, splits, acc);
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-      int n = threadIdx.x + i * 1024;
-      if (n < N) vals[i] += prow[z * mn + n];
-    }
+    for (int j = 0; j < V; ++j) vals[i * V + j] = n < N ? acc[j] : 0.f;
   }
 #pragma unroll
-  for (int i = 0; i < NPT; ++i) {
-    int n = threadIdx.x + i * 1024;
+  for (int i = 0; i < NPT / V; ++i) {
+    const int n = (threadIdx.x + i * 1024) * V;
     if (n < N) {
-      float v = vals[i];
-      if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
-      v = Elt<T>::load(h + (size_t)m * ldh + n) + v;
-      Elt<T>::store(h + (size_t)m * ldh + n, v);
-      if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
-      ss += v * v;
-      vals[i] = v;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float v = vals[i * V + j];
+        if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
+        v = Elt<T>::load(h + (size_t)m * ldh + n + j) + v;
+        Elt<T>::store(h + (size_t)m * ldh + n + j, v);
+        if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
+        ss += v * v;
+        vals[i * V + j] = v;
+      }
     }
   }
   ss = wave_sum_f32(ss);
@@ -635,12 +688,15 @@ __global__ __launch_bounds__(1024) void splitk_resid_rmsnorm_kernel(const float*
   for (int w = 0; w < 16; ++w) tot += red[w];
   const float rs = rsqrtf(tot / (float)N + eps);
 #pragma unroll
-  for (int i = 0; i < NPT; ++i) {
-    int n = threadIdx.x + i * 1024;
+  for (int i = 0; i < NPT / V; ++i) {
+    const int n = (threadIdx.x + i * 1024) * V;
     if (n < N) {
-      float v = vals[i] * rs;
-      if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
-      Elt<T>::store(xn + (size_t)m * N + n, Elt<T>::load(norm_w + n) * v);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float v = vals[i * V + j] * rs;
+        if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
+        Elt<T>::store(xn + (size_t)m * N + n + j, Elt<T>::load(norm_w + n + j) * v);
+      }
     }
   }
 }
@@ -707,31 +763,38 @@ struct FusedNorm { const void* w; void* xn; float eps; bool done; };
 // second pass of a split-K GEMM: sum the fp32 slabs and apply the epilogue (fused with the next RMSNorm for the residual projections)
 template <typename T, int EPI>
 int reduce_splits(const float* partial, void* c, int m, int n, int ldc, int splits, hipStream_t st, FusedNorm* fn) {
+  const bool v4 = (n % 4) == 0 && (ldc % 4) == 0 && ((uintptr_t)partial & 15) == 0;
   if constexpr (EPI == EPI_RESID) {
     if (fn && n <= 8192) {
-      if (n <= 4096)
-        splitk_resid_rmsnorm_kernel<T, 4><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps);
-      else
-        splitk_resid_rmsnorm_kernel<T, 8><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps);
+      if (n <= 4096) {
+        if (v4) splitk_resid_rmsnorm_kernel<T, 4, 4><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps);
+        else    splitk_resid_rmsnorm_kernel<T, 4, 1><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps);
+      } else {
+        if (v4) splitk_resid_rmsnorm_kernel<T, 8, 4><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps);
+        else    splitk_resid_rmsnorm_kernel<T, 8, 1><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps);
+      }
       ATS_LAUNCH_CHECK();
       fn->done = true;
       return ATSPEED_OK;
     }
   }
   size_t outs = EPI == EPI_SWIGLU ? (size_t)m * (n / 2) : (size_t)m * n;
-  splitk_reduce_kernel<T, EPI><<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(partial, c, m, n, ldc, splits);
+  if (v4) splitk_reduce_kernel<T, EPI, 4><<<(unsigned)((outs / 4 + 255) / 256), 256, 0, st>>>(partial, c, m, n, ldc, splits);
+  else    splitk_reduce_kernel<T, EPI, 1><<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(partial, c, m, n, ldc, splits);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
 
-// One user's tokens through the ring kernel: tiles x splits <= 256 workgroups (one per CU: the ring takes 96-128 KB of LDS)
+// One user's tokens through the ring kernel: tiles x splits <= 256 workgroups (one per CU: the ring takes 96-128 KB of LDS).
+// 257-512 tokens (the first verification of a long prompt) take two 256-row token tiles per weight tile.
 static int ring_split_count(int m, int n, int k) {
   static const int on = env_int("ATSPEED_GEMM_RING_SPLIT", 1);
   static const int min_m = env_int("ATSPEED_GEMM_RING_SPLIT_MIN_M", 33);
+  static const int max_m = env_int("ATSPEED_GEMM_RING_SPLIT_MAX_M", 512);
   // measured (tools/yardstick_small.py, cold weights): wins 5-15 % over the LDS-tiled kernel on the wide projections (qkv, gate_up) at
   // 33-256 tokens, loses on N = 4096 where 16 slabs of partials outweigh the weight stream
-  if (!on || m < min_m || m > 256 || k % 128 != 0 || k < 256 || n < 8192) return 0;
-  const int tiles = (n + 255) / 256, units = k / 128;
+  if (!on || m < min_m || m > max_m || k % 128 != 0 || k < 256 || n < 8192) return 0;
+  const int tiles = ((n + 255) / 256) * ((m + 255) / 256), units = k / 128;
   int s = 256 / tiles;
   if (s > units) s = units;
   return s >= 1 ? s : 0;
@@ -747,12 +810,19 @@ int launch_ring_split(const bf16_t* a, const bf16_t* w, void* c, int m, int n, i
   }
   const int tiles_n = (n + 255) / 256;
   const float* none = nullptr;
+#ifdef ATS_RING_STAMPS
+  static const char* stamp_env = getenv("ATSPEED_STAMP_PTR");
+  const float* stamps = stamp_env ? (const float*)(uintptr_t)strtoull(stamp_env, nullptr, 16) : nullptr;
+#else
+  const float* stamps = nullptr;
+#endif
+  const int tiles_m = (m + 255) / 256;
   if (m > 128)
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 8, false, true>), dim3(tiles_n * splits), dim3(512), 128 * 1024, st, (const void*)a, (const void*)w,
-                       none, none, (void*)partial, m, n, k, lda, n, tiles_n, 1, 1, splits);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 8, false, true>), dim3(tiles_n * tiles_m * splits), dim3(512), 128 * 1024, st, (const void*)a, (const void*)w,
+                       none, stamps, (void*)partial, m, n, k, lda, n, tiles_n, tiles_m, 1, splits);
   else
     hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 4, false, true>), dim3(tiles_n * splits), dim3(512), 96 * 1024, st, (const void*)a, (const void*)w,
-                       none, none, (void*)partial, m, n, k, lda, n, tiles_n, 1, 1, splits);
+                       none, stamps, (void*)partial, m, n, k, lda, n, tiles_n, 1, 1, splits);
   ATS_LAUNCH_CHECK();
   return reduce_splits<bf16_t, EPI>(partial, c, m, n, ldc, splits, st, fn);
 }
@@ -852,7 +922,8 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
 static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype, int epilogue) {
   // the 256-wide ring kernel vs the 128-wide LDS-tiled kernel (with split-K): the ring kernel wins once its tile grid keeps
   // a fair share of the 256 CUs busy (measured, tools/gemm_ab.py with ATSPEED_GEMM_BIG_MIN_FILL)
-  static const int big_min_m = env_int("ATSPEED_GEMM_BIG_MIN_M", 512);
+  // from 257 tokens (two token tiles): measured against the split-K mode at 300-500 tokens, gate_up 115-138 -> 96-108 us, qkv 80 -> 75 us
+  static const int big_min_m = env_int("ATSPEED_GEMM_BIG_MIN_M", 257);
   static const int min_fill = env_int("ATSPEED_GEMM_BIG_MIN_FILL", 60);   // crossover measured at ~50-60 % (o_proj, down, qkv, gate_up at 512-1920 tokens)
   if (dtype != ATSPEED_BF16 || m < big_min_m || k % 128 != 0 || (lda % 8) != 0) return false;
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;

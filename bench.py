@@ -211,7 +211,7 @@ def main():
         b1 = N1 * K1 * 2 + m1 * K1 * 2 + m1 * (N1 // 2 if k1 == "gate_up" else N1) * (4 if k1 == "lm_head" else 2)
         us1 = 1e3 * p1[k1]["ms"] / max(1, p1[k1]["count"])
         single = dict(users=n1, items_per_s=n1 * args.beam / dt1, ms_per_user=1e3 * dt1 / n1,
-                      roofline=dict(bound="hbm", kernel=f"gemm_kernel<bf16>[{k1}] N={N1} K={K1} avg_M={m1:.0f}",
+                      roofline=dict(bound="hbm", kernel=f"small-M projection [{k1}] N={N1} K={K1} avg_M={m1:.0f} (split-K ring GEMM + slab reduce)",
                                     achieved=b1 / (us1 * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                     frac=b1 / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, avg_launch_us=us1))
 
@@ -278,6 +278,22 @@ def main():
                     achieved=rows * V * 4 / (us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=rows * V * 4 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
         del lg, lse
 
+    # ---- measured peaks of THIS box: register-only bf16 MFMA loop on random operands, read-only HBM stream over 2 GiB
+    measured = None
+    if rank == 0:
+        import ctypes as C
+        from atspeed_amd import _lib
+        lib, tf, gbs = _lib.load(), C.c_double(), C.c_double()
+        buf = torch.empty(2 << 30, dtype=torch.uint8, device=dev).fill_(1)
+        scratch = torch.empty(4 << 20, dtype=torch.uint8, device=dev)
+        _lib.check(lib.atspeed_probe_mfma_bf16(4000, scratch.data_ptr(), scratch.numel(), _lib.stream_ptr(dev), C.byref(tf)))
+        _lib.check(lib.atspeed_probe_hbm_read(buf.data_ptr(), buf.numel(), 8, scratch.data_ptr(), _lib.stream_ptr(dev), C.byref(gbs)))
+        measured = dict(mfma_bf16_tflops=tf.value, hbm_read_gbs=gbs.value,
+                        how="atspeed_probe_mfma_bf16 (16x16x32, random operands, 8 waves/CU) and atspeed_probe_hbm_read (2 GiB, 8 passes)")
+        del buf, scratch
+        if scan is not None:
+            scan["peak_measured"], scan["frac_of_measured"] = gbs.value, scan["achieved"] / gbs.value
+
     per_rank = all_gather_counters(Counters(n_timed, n_run, acc, int(elapsed * 1e9)), dev)   # the path's single collective
     if rank != 0:
         if world > 1:
@@ -315,6 +331,8 @@ def main():
              if one_kernel else f"projection GEMM [{kind}] N={N} K={K} avg_M={avg_m:.0f} (all launches)")
     roofline = dict(bound=bound, kernel=kname,
                     achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
+                    peak_measured=(measured["mfma_bf16_tflops"] if bound == "mfma" else measured["hbm_read_gbs"]) if measured else None,
+                    frac_of_measured=(achieved / (measured["mfma_bf16_tflops"] if bound == "mfma" else measured["hbm_read_gbs"])) if measured else None,
                     traffic=traffic_from_profiles(kind), avg_launch_us=avg_ms * 1e3, launches=pk["count"],
                     algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=alg_flops,
                     arithmetic_intensity=intensity,
@@ -340,6 +358,7 @@ def main():
         "per_user": {"n_run": total_runs / users, "target_forwards": n_tf / n_timed, "draft_forwards": n_df / n_timed,
                      "draft_ms": 1e3 * stage[0] / n_timed, "target_ms": 1e3 * stage[1] / n_timed, "verify_ms": 1e3 * stage[2] / n_timed},
         "roofline": roofline,
+        "measured_peaks": measured,
         "verify_scan": scan,
         "single_user_stream": single,
         "aligned_weight_brackets": aligned,   # same users, shapes and kernels as `value`; only the weights' agreement differs

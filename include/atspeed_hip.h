@@ -133,6 +133,12 @@ int atspeed_llama_profile(atspeed_llama* m, int32_t enable, double* ms_out, int6
  * atspeed_llama_profile call that resets them.  bench.py's roofline uses these so that its average launch time is
  * that of one kernel (gemm_ring_kernel<EPI, 8, false>) and can be checked against the rocprofv3 kernel summary. */
 int atspeed_llama_profile_big(atspeed_llama* m, double* ms_out, int64_t* count_out, int64_t* rows_out);
+/* Measured peaks for the roofline report (nominal peaks are re-measured on the box).  No reference counterpart.
+ * atspeed_probe_mfma_bf16: register-only loop of v_mfma_f32_16x16x32_bf16 on random operands, `iters` trips of 32 MFMAs per wave,
+ * 8 waves x 1024 workgroups; scratch_dev >= 2 MiB.  atspeed_probe_hbm_read: `reps` read-only passes over buf_dev (use a buffer far
+ * larger than the 256 MB Infinity Cache); scratch_dev >= 4 bytes.  Both time themselves with HIP events on `stream` and synchronise. */
+int atspeed_probe_mfma_bf16(int32_t iters, void* scratch_dev, size_t scratch_bytes, void* stream, double* tflops_out);
+int atspeed_probe_hbm_read(const void* buf_dev, size_t bytes, int32_t reps, void* scratch_dev, void* stream, double* gbs_out);
 int32_t atspeed_llama_logits_ld(const atspeed_llama* m);
 /* BASELINE config 5 (fp8 target verification): build OCP-e4m3 copies of the layer projections (per-output-row scales,
  * library-owned) from the bf16 weights.  From then on the batched forwards (M >= 512 tokens, shapes that fill the chip)

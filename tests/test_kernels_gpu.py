@@ -73,7 +73,9 @@ SHAPES = [(900, 1000, 512), (1024, 2304, 768), (1543, 300, 1024), (1, 128, 128),
           (100, 512, 4096), (228, 1024, 1024), (228, 4096, 4096), (130, 32256, 128), (121, 32859, 768),
           (257, 640, 1376),
           # one user's wide projections: ring kernel in split-K mode (33-256 tokens, N >= 8192, K % 128 == 0)
-          (40, 8192, 512), (100, 12288, 1024), (129, 8448, 256), (228, 12288, 640), (256, 9000, 384)]
+          (40, 8192, 512), (100, 12288, 1024), (129, 8448, 256), (228, 12288, 640), (256, 9000, 384),
+          # 257-512 tokens: two 256-row token tiles per weight tile in the same mode
+          (300, 12288, 640), (400, 8448, 256), (512, 9000, 384)]
 
 
 @pytest.mark.parametrize("m,n,k", SHAPES)
@@ -103,7 +105,7 @@ def test_gemm_residual(lib, m, n, k, dtype):
     np.testing.assert_allclose(c.double().cpu().numpy(), ref.numpy(), atol=tol, rtol=0)
 
 
-@pytest.mark.parametrize("m,ffn,k", [(3, 32, 64), (40, 352, 128), (228, 11008, 4096), (20, 3072, 768), (1300, 1376, 512), (800, 496, 256)])
+@pytest.mark.parametrize("m,ffn,k", [(3, 32, 64), (40, 352, 128), (228, 11008, 4096), (20, 3072, 768), (1300, 1376, 512), (800, 496, 256), (300, 4224, 256)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_swiglu(lib, m, ffn, k, dtype):
     from atspeed_amd.model import _interleave_gate_up
@@ -376,3 +378,17 @@ def test_gemm_fp8(lib, m, n, k, epi):
     scale = float(ref.abs().max())
     tol = 2e-5 * scale * np.sqrt(k) if epi == _lib.EPI_F32 else 2e-2 * scale
     np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=tol, rtol=0)
+
+
+def test_measured_peak_probes_are_plausible(lib):
+    """bench.py's measured peaks: the probes run, synchronise and return numbers between a loose floor and the
+    nominal peaks of /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF dense bf16, 8 TB/s)."""
+    tf, gbs = C.c_double(), C.c_double()
+    scratch = torch.empty(4 << 20, dtype=torch.uint8, device="cuda")
+    buf = torch.ones(1 << 30, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.atspeed_probe_mfma_bf16(2000, scratch.data_ptr(), scratch.numel(), _lib.stream_ptr(), C.byref(tf)))
+    _lib.check(lib.atspeed_probe_hbm_read(buf.data_ptr(), buf.numel(), 4, scratch.data_ptr(), _lib.stream_ptr(), C.byref(gbs)))
+    assert 800.0 < tf.value < 2600.0, tf.value
+    assert 2000.0 < gbs.value < 8200.0, gbs.value
+    with pytest.raises(_lib.AtSpeedError):
+        _lib.check(lib.atspeed_probe_mfma_bf16(10, scratch.data_ptr(), 1024, _lib.stream_ptr(), C.byref(tf)))
