@@ -121,13 +121,21 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
   __shared__ __attribute__((aligned(16))) unsigned char vs_lds[64 * VROW];   // V tile row-major; consumed column-wise by ds_read_b64_tr_b16
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, lq = lane & 15;
-  const int h = blockIdx.y;
+  // 1-D grid over (head, query tile).  Workgroup L runs on XCD L % 8: give every XCD a contiguous range of work items, heads
+  // outermost, so that the query tiles of one (user, head) -- which read the same K/V rows -- run back to back behind one L2
+  const int n_qt = tab->n_qtiles;
+  int wi;
+  {
+    const int total = gridDim.x, q8 = total >> 3, r8 = total & 7, x = blockIdx.x & 7;
+    wi = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (blockIdx.x >> 3);
+  }
+  const int h = wi / n_qt, qt = wi - h * n_qt;
   const int hidden = n_heads * DH;
-  const Seg& sg = tab->seg[tab->qtile_seg[blockIdx.x]];
+  const Seg& sg = tab->seg[tab->qtile_seg[qt]];
   const bf16_t* kc = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(sg.kc) + layer_off);
   const bf16_t* vc = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(sg.vc) + layer_off);
   const int n_slots = sg.n_slots;
-  const int lrow = tab->qtile_idx[blockIdx.x] * (16 * NW) + wave * 16 + lq;  // row inside the segment
+  const int lrow = tab->qtile_idx[qt] * (16 * NW) + wave * 16 + lq;  // row inside the segment
   const bool qok = lrow < sg.n_tok;
   const int qrow = sg.row0 + lrow;                                           // row in the batched buffers
   const uint64_t* vis_row = sg.vis + (size_t)lrow * vis_words;
@@ -269,7 +277,7 @@ int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const Seg
     ATS_REQUIRE(t.seg[i].n_slots <= vis_words * 64, ATSPEED_ERR_CAPACITY, "attention: %d slots exceed the visibility bitset", t.seg[i].n_slots);
   float scale = 1.0f / sqrtf((float)head_dim);
   if (dtype == ATSPEED_BF16 && (head_dim == 64 || head_dim == 128) && (ldq % 8) == 0 && (ldo % 4) == 0) {
-    dim3 mgrid(t.n_qtiles, n_heads);
+    dim3 mgrid(t.n_qtiles * n_heads);
     ATS_REQUIRE(t.qtile_rows == 64 || t.qtile_rows == 128 || t.qtile_rows == 256, ATSPEED_ERR_INVALID, "attention: query tile of %d rows", t.qtile_rows);
     if (t.qtile_rows == 256) {
       if (head_dim == 128)

@@ -793,10 +793,13 @@ static int ring_split_count(int m, int n, int k) {
   static const int max_m = env_int("ATSPEED_GEMM_RING_SPLIT_MAX_M", 512);
   // measured (tools/yardstick_small.py, cold weights): wins 5-15 % over the LDS-tiled kernel on the wide projections (qkv, gate_up) at
   // 33-256 tokens, loses on N = 4096 where 16 slabs of partials outweigh the weight stream
-  if (!on || m < min_m || m > max_m || k % 128 != 0 || k < 256 || n < 8192) return 0;
+  static const int min_n = env_int("ATSPEED_GEMM_RING_SPLIT_MIN_N", 8192);
+  static const int max_s = env_int("ATSPEED_GEMM_RING_SPLIT_MAX_SPLITS", 256);
+  if (!on || m < min_m || m > max_m || k % 128 != 0 || k < 256 || n < min_n) return 0;
   const int tiles = ((n + 255) / 256) * ((m + 255) / 256), units = k / 128;
   int s = 256 / tiles;
   if (s > units) s = units;
+  if (s > max_s) s = max_s;
   return s >= 1 ? s : 0;
 }
 template <int EPI>
