@@ -73,6 +73,7 @@ SIGNATURES = {
     "atspeed_rmsnorm": (C.c_int, [_P, _P, _P, _I, _I, _F, _I, _P]),
     "atspeed_rmsnorm_quant_fp8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "atspeed_tree_attention": (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "atspeed_tree_attention_tiled": (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -14,6 +14,7 @@
 //    B operand of O^T = V^T.P^T (k-slots permuted identically on the V^T operand).
 //  * tree_attn_kernel (fp32 parity mode / odd head dims): one wave per (token, head), scalar.
 #include "internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -266,10 +267,189 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
   }
 }
 
+
+// ---------------------------------------------------------------------------- MFMA kernel, 32 query rows per wave (bf16)
+// Same algorithm on v_mfma_f32_32x32x16_bf16: a wave owns 32 query rows, so one pass over the K / V tile in LDS feeds twice the
+// MFMA work of the 16-row form (which is bound by exactly those LDS reads: every wave re-reads the whole 32 KB tile).
+//   S^T block = K[32 keys] . Q^T[32 queries]: lane (lc = lane & 31, hi = lane >> 5) holds query lc and, in accumulator register i,
+//   key 8*(i/4) + 4*hi + (i%4) of the block -> a query's statistics live in the lane pair (lc, lc + 32).
+//   O^T += V^T . P^T in 16-key steps: the lane's 8 exponentiated registers of a step ARE its B operand (k-slot j <-> key
+//   16t + 8*(j/4) + 4*hi + (j%4)); the A operand takes the same keys out of the row-major V tile with two transposed reads.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// K / V tiles travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers) into a double buffer, tile kt+1 while
+// tile kt is multiplied; ONE barrier per tile.  A DMA instruction fills 64 consecutive 16-byte LDS positions, so the K swizzle and
+// the V row padding are applied on the source side: lane i of instruction j fetches whatever belongs at position 64 j + i.
+#define ATS_ATTN_DMA16(voff, sbase, m0v) \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory")
+
+template <int DH, int NW>   // NW waves per workgroup = 32*NW query rows per tile
+__global__ __launch_bounds__(64 * NW, 2) void tree_attn32_kernel(const bf16_t* __restrict__ q, int ldq, const SegTable* __restrict__ tab,
+                                                                 size_t layer_off, int vis_words, bf16_t* __restrict__ out, int ldo,
+                                                                 int n_heads, float scale) {
+  constexpr int KCH = DH / 8;                 // 16-byte chunks per K row
+  constexpr int VROW = DH * 2 + 32;           // V tile row stride in bytes
+  constexpr int VCH = VROW / 16;              // 16-byte positions per V row (the last two are padding)
+  constexpr int DB = DH / 32;                 // 32-row blocks of O^T
+  constexpr int KS = DH / 16;                 // k-steps of the QK product
+  constexpr int KBYTES = 64 * DH * 2, TILE = KBYTES + 64 * VROW;
+  constexpr int NI = KCH + VCH;               // DMA instructions per tile (K: KCH, V: VCH), dealt round-robin to the waves
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][K tile | V tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 31, hi = lane >> 5;
+  const int n_qt = tab->n_qtiles;
+  int wi;
+  {
+    const int total = gridDim.x, q8 = total >> 3, r8 = total & 7, x = blockIdx.x & 7;
+    wi = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (blockIdx.x >> 3);
+  }
+  const int h = wi / n_qt, qt = wi - h * n_qt;
+  const int hidden = n_heads * DH;
+  const Seg& sg = tab->seg[tab->qtile_seg[qt]];
+  const unsigned long long kbase = (unsigned long long)sg.kc + layer_off + (size_t)h * DH * 2;
+  const unsigned long long vbase = (unsigned long long)sg.vc + layer_off + (size_t)h * DH * 2;
+  const int n_slots = sg.n_slots;
+  const int lrow = tab->qtile_idx[qt] * (32 * NW) + wave * 32 + lc;
+  const bool qok = lrow < sg.n_tok;
+  const int qrow = sg.row0 + lrow;
+  const uint64_t* vis_row = sg.vis + (size_t)lrow * vis_words;
+  const int lds0 = __builtin_amdgcn_readfirstlane((int)lds_off(smem));
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  // rows past n_slots (last tile) are fetched from the last valid row: finite values, masked out by the visibility word
+  auto dma_tile = [&](int kt, int buf) {
+#pragma unroll
+    for (int j0 = 0; j0 < NI; j0 += NW) {
+      const int j = j0 + wave_u;                       // wave-uniform (SGPR): the DMA's M0 and branch are scalar
+      if (j < KCH) {
+        const int P = j * 64 + lane, r = P / KCH, cs = P % KCH;
+        const int key = min(kt * 64 + r, n_slots - 1);
+        const unsigned voff = (unsigned)key * (unsigned)(hidden * 2) + ((cs ^ (r & (KCH - 1))) * 16);
+        ATS_ATTN_DMA16(voff, kbase, lds0 + buf * TILE + j * 1024);
+      } else if (j < NI) {
+        const int P = (j - KCH) * 64 + lane, r = P / VCH, c = P % VCH;
+        const int key = min(kt * 64 + r, n_slots - 1);
+        const unsigned voff = (unsigned)key * (unsigned)(hidden * 2) + (c < KCH ? c * 16 : 0);
+        ATS_ATTN_DMA16(voff, vbase, lds0 + buf * TILE + KBYTES + (j - KCH) * 1024);
+      }
+    }
+  };
+
+  const int n_tiles = (n_slots + 63) >> 6;
+  if (n_tiles > 0) dma_tile(0, 0);
+  s16x8_t qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (qok) qf[ks] = *reinterpret_cast<const s16x8_t*>(q + (size_t)qrow * ldq + h * DH + ks * 16 + hi * 8);
+    else qf[ks] = s16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  f32x16_t o[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+  const float sl2 = scale * 1.4426950408889634f;        // scores carried in the log2 domain
+  float m_run = -INFINITY, l_run = 0.f;
+
+  auto kpos = [](int r, int c) { return (r * KCH + (c ^ (r & (KCH - 1)))) * 16; };
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt have landed
+    __syncthreads();                                   // everyone's have, and the other buffer is fully consumed
+    if (kt + 1 < n_tiles) dma_tile(kt + 1, (kt + 1) & 1);
+    const unsigned char* ks_lds = smem + (kt & 1) * TILE;
+    const unsigned char* vs_lds = ks_lds + KBYTES;
+    uint64_t word = qok ? vis_row[kt] : 0ull;
+    if (kt == n_tiles - 1 && (n_slots & 63)) word &= (~0ull) >> (64 - (n_slots & 63));
+    if (__ballot(word != 0ull) == 0ull) continue;      // this wave's 32 rows see nothing here (wave-uniform)
+
+    // V^T fragments: 16-lane group gg = lane >> 4 takes d-columns 16*(gg & 1) .. +15 of the block and the 4 keys 4*hi .. +3 (second
+    // read: +8); inside the group lane 4q + p addresses key q, columns 4p .. 4p+3 and receives column (lane & 15)
+    const unsigned vaddr = lds_off(vs_lds) + (4 * hi + ((lane & 15) >> 2)) * VROW + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+    // the 64-key tile is consumed as two 32-key blocks, each one online-softmax step (16 score registers live instead of 32)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const unsigned wb = (unsigned)(word >> (32 * b));
+      if (__ballot(wb != 0u) == 0ull) continue;        // wave-uniform
+      f32x16_t sc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        s16x8_t kf = *reinterpret_cast<const s16x8_t*>(ks_lds + kpos(b * 32 + lc, ks * 2 + hi));
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ks]), sc, 0, 0, 0);
+      }
+      // softmax in the log2 domain (one v_exp_f32 per score); the VALU work per score is what bounds this kernel, not the MFMAs:
+      // masks from a pre-shifted word with compile-time bit positions, hardware bf16 packing, rescale of O only when a maximum moved
+      const unsigned wsh = wb >> (4 * hi);
+      float mt = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float x = (wsh & (1u << (8 * (i >> 2) + (i & 3)))) ? sc[i] * sl2 : -INFINITY;
+        sc[i] = x;
+        mt = fmaxf(mt, x);
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run, mt);
+      const float m_sub = (m_new == -INFINITY) ? 0.f : m_new;          // nothing visible yet: exp2(-inf - 0) = 0
+      float psum = 0.f;
+      u32x4_t pf[2];
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(sc[i] - m_sub), p1 = __builtin_amdgcn_exp2f(sc[i + 1] - m_sub);
+        psum += p0 + p1;
+        unsigned pk;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(p0), "v"(p1));
+        pf[i >> 3][(i & 7) >> 1] = pk;
+      }
+      if (__ballot(m_new != m_run) != 0ull) {          // wave-uniform: some query's maximum moved
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+      }
+      l_run += psum;
+      m_run = m_new;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * b + tt;
+        u32x2_t va[DB], vb[DB];
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(va[d]) : "v"(vaddr), "i"(t * 16 * VROW + d * 64));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vb[d]) : "v"(vaddr), "i"((t * 16 + 8) * VROW + d * 64));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          asm volatile("" : "+v"(va[d]), "+v"(vb[d]));   // registers are filled asynchronously: uses stay behind the wait
+          u32x4_t vv = {va[d][0], va[d][1], vb[d][0], vb[d][1]};
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), __builtin_bit_cast(bf16x8_t, pf[tt]), o[d], 0, 0, 0);
+        }
+      }
+    }
+  }
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (qok) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    bf16_t* orow = out + (size_t)qrow * ldo + h * DH;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        ushort4 pk;
+        pk.x = f2bf(o[d][i4 * 4 + 0] * inv); pk.y = f2bf(o[d][i4 * 4 + 1] * inv);
+        pk.z = f2bf(o[d][i4 * 4 + 2] * inv); pk.w = f2bf(o[d][i4 * 4 + 3] * inv);
+        *reinterpret_cast<ushort4*>(orow + d * 32 + 8 * i4 + 4 * hi) = pk;
+      }
+  }
+}
+
 }  // namespace
 
 int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const SegTable* dt, size_t layer_off_bytes, int vis_words,
-                            void* out, int ldo, int n_heads, int head_dim, int dtype, hipStream_t st) {
+                            void* out, int ldo, int n_heads, int head_dim, int dtype, hipStream_t st, int rows_per_wave) {
   if (t.total_tok <= 0) return ATSPEED_OK;
   ATS_REQUIRE(head_dim % 8 == 0 && head_dim <= 256, ATSPEED_ERR_INVALID, "attention: head_dim %d unsupported", head_dim);
   ATS_REQUIRE(vis_words * 64 <= kMaxSlots, ATSPEED_ERR_CAPACITY, "attention: visibility bitset too wide (%d words)", vis_words);
@@ -279,6 +459,27 @@ int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const Seg
   if (dtype == ATSPEED_BF16 && (head_dim == 64 || head_dim == 128) && (ldq % 8) == 0 && (ldo % 4) == 0) {
     dim3 mgrid(t.n_qtiles * n_heads);
     ATS_REQUIRE(t.qtile_rows == 64 || t.qtile_rows == 128 || t.qtile_rows == 256, ATSPEED_ERR_INVALID, "attention: query tile of %d rows", t.qtile_rows);
+    static const int rows32 = getenv("ATSPEED_ATTN32") ? atoi(getenv("ATSPEED_ATTN32")) : 1;
+    // small grids (one user: 32-64 workgroups) are latency-bound per workgroup and keep the 16-rows-per-wave kernel (twice the waves per tile)
+    static const int rows32_min_wgs = getenv("ATSPEED_ATTN32_MIN_WGS") ? atoi(getenv("ATSPEED_ATTN32_MIN_WGS")) : 512;
+    if (rows_per_wave == 32 || (rows_per_wave == 0 && rows32 && t.n_qtiles * n_heads >= rows32_min_wgs)) {
+#define ATS_ATTN32(DHV, NWV)                                                                                                   \
+  {                                                                                                                            \
+    constexpr int lds_bytes = 2 * (64 * DHV * 2 + 64 * (DHV * 2 + 32));                                                        \
+    static thread_local bool attr_done = false;                                                                                \
+    if (!attr_done) {                                                                                                          \
+      ATS_HIP(hipFuncSetAttribute((const void*)tree_attn32_kernel<DHV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+      attr_done = true;                                                                                                        \
+    }                                                                                                                          \
+    tree_attn32_kernel<DHV, NWV><<<mgrid, 64 * NWV, lds_bytes, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words,    \
+                                                                     (bf16_t*)out, ldo, n_heads, scale);                       \
+  }
+      if (head_dim == 128) { if (t.qtile_rows == 256) ATS_ATTN32(128, 8) else if (t.qtile_rows == 128) ATS_ATTN32(128, 4) else ATS_ATTN32(128, 2) }
+      else                 { if (t.qtile_rows == 256) ATS_ATTN32(64, 8)  else if (t.qtile_rows == 128) ATS_ATTN32(64, 4)  else ATS_ATTN32(64, 2) }
+#undef ATS_ATTN32
+      ATS_LAUNCH_CHECK();
+      return ATSPEED_OK;
+    }
     if (t.qtile_rows == 256) {
       if (head_dim == 128)
         tree_attn_mfma_kernel<128, 16><<<mgrid, 1024, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
@@ -310,18 +511,21 @@ int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const Seg
 
 int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* vcache, const uint64_t* vis,
                        int vis_words, void* out, int ldo, int n_tokens, int n_slots, int n_heads, int head_dim,
-                       int dtype, hipStream_t st) {
+                       int dtype, hipStream_t st, int qtile_rows, int rows_per_wave) {
   SegTable t{};
   t.n = 1; t.total_tok = n_tokens; t.total_logit = 0;
   t.seg[0].vis = vis; t.seg[0].kc = const_cast<void*>(kcache); t.seg[0].vc = const_cast<void*>(vcache);
   t.seg[0].row0 = 0; t.seg[0].n_tok = n_tokens; t.seg[0].n_slots = n_slots;
   ATS_REQUIRE(n_slots <= vis_words * 64, ATSPEED_ERR_CAPACITY, "attention: %d slots exceed the visibility bitset (%d words)", n_slots, vis_words);
-  ATS_REQUIRE((n_tokens + 63) / 64 <= 255, ATSPEED_ERR_CAPACITY, "attention: too many query rows");
-  t.n_qtiles = 0; t.qtile_rows = n_tokens > 160 ? 256 : (n_tokens > 96 ? 128 : 64);
+  ATS_REQUIRE(qtile_rows == 0 || qtile_rows == 64 || qtile_rows == 128 || qtile_rows == 256, ATSPEED_ERR_INVALID, "attention: query tile of %d rows", qtile_rows);
+  ATS_REQUIRE(rows_per_wave == 0 || rows_per_wave == 16 || rows_per_wave == 32, ATSPEED_ERR_INVALID, "attention: %d rows per wave", rows_per_wave);
+  t.n_qtiles = 0; t.qtile_rows = qtile_rows ? qtile_rows : (n_tokens > 160 ? 256 : (n_tokens > 96 ? 128 : 64));
+  ATS_REQUIRE((n_tokens + t.qtile_rows - 1) / t.qtile_rows <= ATS_MAX_QTILES && (n_tokens + t.qtile_rows - 1) / t.qtile_rows <= 255, ATSPEED_ERR_CAPACITY,
+              "attention: too many query rows");
   for (int j = 0; j * t.qtile_rows < n_tokens; ++j) { t.qtile_seg[t.n_qtiles] = 0; t.qtile_idx[t.n_qtiles++] = (unsigned char)j; }
   const void* dt = nullptr;
   ATS_TRY(ats_stage(&t, sizeof(t), &dt, st));
-  return ats_tree_attention_segs(q, ldq, t, (const SegTable*)dt, 0, vis_words, out, ldo, n_heads, head_dim, dtype, st);
+  return ats_tree_attention_segs(q, ldq, t, (const SegTable*)dt, 0, vis_words, out, ldo, n_heads, head_dim, dtype, st, rows_per_wave);
 }
 
 extern "C" int atspeed_tree_attention(const void* q, int32_t ldq, const void* kcache, const void* vcache,
@@ -329,5 +533,14 @@ extern "C" int atspeed_tree_attention(const void* q, int32_t ldq, const void* kc
                                       int32_t n_slots, int32_t n_heads, int32_t head_dim, int32_t dtype, void* stream) {
   ATS_REQUIRE(q && kcache && vcache && vis && out, ATSPEED_ERR_INVALID, "attention: null argument");
   return ats_tree_attention(q, ldq, kcache, vcache, vis, vis_words, out, n_heads * head_dim, n_tokens, n_slots, n_heads,
-                            head_dim, dtype, (hipStream_t)stream);
+                            head_dim, dtype, (hipStream_t)stream, 0, 0);
+}
+
+extern "C" int atspeed_tree_attention_tiled(const void* q, int32_t ldq, const void* kcache, const void* vcache,
+                                            const uint64_t* vis, int32_t vis_words, void* out, int32_t n_tokens,
+                                            int32_t n_slots, int32_t n_heads, int32_t head_dim, int32_t dtype, int32_t qtile_rows,
+                                            int32_t rows_per_wave, void* stream) {
+  ATS_REQUIRE(q && kcache && vcache && vis && out, ATSPEED_ERR_INVALID, "attention: null argument");
+  return ats_tree_attention(q, ldq, kcache, vcache, vis, vis_words, out, n_heads * head_dim, n_tokens, n_slots, n_heads,
+                            head_dim, dtype, (hipStream_t)stream, qtile_rows, rows_per_wave);
 }

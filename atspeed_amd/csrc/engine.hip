@@ -741,6 +741,11 @@ static int seg_finish(SegTable& t) {
   // 128-row tiles (8 waves) halve the K/V re-reads of long segments; 256-row tiles (16 waves, kept in attn.hip) measured slower:
   // 393 vs ~210 us per launch at 64 users x 220 tokens
   t.qtile_rows = (2 * long_segs >= t.n) ? 128 : 64;
+  // lock-step batches (thousands of workgroups) run the 32-rows-per-wave kernel: its 4-wave 128-row tile also wins on short segments
+  // (the idle waves still carry a quarter of the tile's DMA): 249 vs 286 us at 256 users
+  if (t.n >= 16) t.qtile_rows = 128;
+  static const int force_rows = getenv("ATSPEED_ATTN_QTILE") ? atoi(getenv("ATSPEED_ATTN_QTILE")) : 0;      // tuning: 64 / 128 / 256
+  if (force_rows == 64 || force_rows == 128 || force_rows == 256) t.qtile_rows = force_rows;
   for (int i = 0; i < t.n; ++i) {
     t.seg[i].row0 = t.total_tok; t.total_tok += t.seg[i].n_tok;
     t.seg[i].logit_row0 = t.total_logit; t.total_logit += t.seg[i].n_logit;

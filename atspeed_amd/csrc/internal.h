@@ -62,10 +62,10 @@ int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* s
 // ---- attn.hip -------------------------------------------------------------------------
 int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* vcache, const uint64_t* vis,
                        int vis_words, void* out, int ldo, int n_tokens, int n_slots, int n_heads, int head_dim,
-                       int dtype, hipStream_t st);
+                       int dtype, hipStream_t st, int qtile_rows = 0, int rows_per_wave = 0);
 
 int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const SegTable* dt, size_t layer_off_bytes, int vis_words,
-                            void* out, int ldo, int n_heads, int head_dim, int dtype, hipStream_t st);
+                            void* out, int ldo, int n_heads, int head_dim, int dtype, hipStream_t st, int rows_per_wave = 0);
 
 // ---- scan.hip -------------------------------------------------------------------------
 struct FsmDev {

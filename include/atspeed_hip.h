@@ -252,6 +252,13 @@ int atspeed_rmsnorm_quant_fp8(const void* x_dev, const void* w_dev, void* y_dev,
 int atspeed_tree_attention(const void* q_dev, int32_t ldq, const void* kcache_dev, const void* vcache_dev,
                            const uint64_t* vis_bits_dev, int32_t vis_words, void* out_dev, int32_t n_tokens,
                            int32_t n_slots, int32_t n_heads, int32_t head_dim, int32_t dtype, void* stream);
+/* the same with the tiling chosen by the caller (parity tests reach every kernel form): qtile_rows 0 (auto) / 64 / 128 / 256 query rows
+ * per workgroup; rows_per_wave 0 (auto) / 16 (v_mfma 16x16x32, register-staged tiles: small grids) / 32 (v_mfma 32x32x16, LDS-DMA
+ * double buffer: the lock-step batches).  bf16 with head_dim 64 / 128 only; other inputs take the scalar kernel whatever is asked. */
+int atspeed_tree_attention_tiled(const void* q_dev, int32_t ldq, const void* kcache_dev, const void* vcache_dev,
+                                 const uint64_t* vis_bits_dev, int32_t vis_words, void* out_dev, int32_t n_tokens,
+                                 int32_t n_slots, int32_t n_heads, int32_t head_dim, int32_t dtype, int32_t qtile_rows,
+                                 int32_t rows_per_wave, void* stream);
 
 #ifdef __cplusplus
 }

@@ -304,6 +304,49 @@ def test_tree_attention(lib, dtype, heads, dh, T):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=2e-5 if dtype == torch.float32 else 3e-2, rtol=0)
 
 
+@pytest.mark.parametrize("rows_per_wave", [16, 32])
+@pytest.mark.parametrize("qtile", [64, 128, 256])
+@pytest.mark.parametrize("heads,dh,T,S", [(12, 64, 200, 330), (32, 128, 300, 470), (8, 128, 37, 64), (4, 64, 129, 1)])
+def test_tree_attention_every_tiling(lib, heads, dh, T, S, qtile, rows_per_wave):
+    """Both MFMA kernels (16 rows per wave, register-staged tiles; 32 rows per wave, LDS-DMA double buffer) at every query-tile
+    height: ragged last tiles (T, S not multiples of 64), a single-slot cache, rows that see one far slot, rows that see nothing
+    in whole 64-slot tiles."""
+    from atspeed_amd.model import vis_bits_from_bool
+    max_slots = 512
+    H = heads * dh
+    q = _rand((T, 3 * H), 41).to(torch.bfloat16).cuda()
+    kc = _rand((max_slots, H), 42).to(torch.bfloat16).cuda()
+    vc = _rand((max_slots, H), 43).to(torch.bfloat16).cuda()
+    g = torch.Generator().manual_seed(9)
+    vis = torch.rand(T, S, generator=g) < 0.25
+    vis[:, 0] = True
+    if S > 100:
+        vis[5] = False; vis[5, S - 1] = True        # one visible slot, in the last (ragged) tile
+        vis[7, 64:] = False                         # nothing beyond the first tile
+        vis[T - 1, : S - 3] = False; vis[T - 1, S - 3:] = True
+    bits = vis_bits_from_bool(vis, max_slots).cuda()
+    out = torch.full((T, H), 7.0, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.atspeed_tree_attention_tiled(q.data_ptr(), 3 * H, kc.data_ptr(), vc.data_ptr(), bits.data_ptr(), max_slots // 64,
+                                                out.data_ptr(), T, S, heads, dh, _lib.ATSPEED_BF16, qtile, rows_per_wave, _st()))
+    torch.cuda.synchronize()
+    qf = q.float().cpu()[:, :H].view(T, heads, dh)
+    kf = kc.float().cpu()[:S].view(S, heads, dh)
+    vf = vc.float().cpu()[:S].view(S, heads, dh)
+    sc = torch.einsum("thd,shd->hts", qf, kf) / np.sqrt(dh)
+    sc = sc.masked_fill(~vis[None], float("-inf"))
+    ref = torch.einsum("hts,shd->thd", torch.softmax(sc, -1), vf).reshape(T, H)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=3e-2, rtol=0)
+
+
+def test_tree_attention_tiled_rejects_bad_tiling(lib):
+    z = torch.zeros(64, 3 * 64, dtype=torch.bfloat16, device="cuda")
+    bits = torch.zeros(64, 1, dtype=torch.int64, device="cuda")
+    for qtile, rpw in ((100, 0), (64, 8)):
+        with pytest.raises(_lib.AtSpeedError):
+            _lib.check(lib.atspeed_tree_attention_tiled(z.data_ptr(), 192, z.data_ptr(), z.data_ptr(), bits.data_ptr(), 1, z.data_ptr(), 64, 64, 1, 64,
+                                                        _lib.ATSPEED_BF16, qtile, rpw, _st()))
+
+
 # ------------------------------------------------------------------ fp8 (BASELINE config 5)
 def _fp8_to_float(q_u8: torch.Tensor) -> torch.Tensor:
     return q_u8.cpu().view(torch.float8_e4m3fn).to(torch.float32)
