@@ -14,11 +14,20 @@
 //    B operand of O^T = V^T.P^T (k-slots permuted identically on the V^T operand).
 //  * tree_attn_kernel (fp32 parity mode / odd head dims): one wave per (token, head), scalar.
 #include "internal.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
 
 constexpr int kMaxSlots = 2048;
+// Integer round-to-nearest-even (finite inputs) for the probabilities of the 16-rows-per-wave kernel.  With the hardware conversion
+// (common.h f2bf) hipcc's packing of the eight values into the MFMA operand gives wrong rows >= 64 in the <64, 16> instantiation
+// (1024 threads, 128-VGPR cap; every other form passes): kept on the form all instantiations are tested with.
+__device__ __forceinline__ bf16_t f2bf_int(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q, int ldq, const SegTable* __restrict__ tab, size_t layer_off,
@@ -105,6 +114,19 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q,
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned lds_off(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+
+// Two pairs of transposed V reads AND their wait in ONE asm statement: the outputs are filled asynchronously, so anything the compiler
+// may put between a read and the wait (a copy, or a spill store when registers are tight: the 16-wave form is capped at 128 VGPRs)
+// would see stale registers.  Early-clobber outputs: they must not share a register with the address.
+template <int OA0, int OB0, int OA1, int OB1>
+__device__ __forceinline__ void tr_read_2pairs(u32x2_t& a0, u32x2_t& b0, u32x2_t& a1, u32x2_t& b1, unsigned addr) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %4 offset:%5\n\tds_read_b64_tr_b16 %1, %4 offset:%6\n\t"
+      "ds_read_b64_tr_b16 %2, %4 offset:%7\n\tds_read_b64_tr_b16 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1)
+      : "v"(addr), "i"(OA0), "i"(OB0), "i"(OA1), "i"(OB1)
+      : "memory");
 }
 
 // ---------------------------------------------------------------------------- MFMA kernel (bf16)
@@ -223,7 +245,7 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
       for (int r = 0; r < 4; ++r) {
         float p = (s[c][r] == -INFINITY) ? 0.f : __expf(s[c][r] - m_new);
         psum += p;
-        pf[c >> 1][(c & 1) * 4 + r] = (short)f2bf(p);
+        pf[c >> 1][(c & 1) * 4 + r] = (short)f2bf_int(p);   // see f2bf_int
       }
     l_run = l_run * alpha + psum;
     m_run = m_new;
@@ -237,20 +259,18 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
     const unsigned vaddr = lds_off(vs_lds) + (4 * g + (lq >> 2)) * VROW + (lq & 3) * 8;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      u32x2_t va[DT], vb[DT];
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(va[d]) : "v"(vaddr), "i"((2 * kk) * 16 * VROW + d * 32));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vb[d]) : "v"(vaddr), "i"((2 * kk + 1) * 16 * VROW + d * 32));
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        // the compiler cannot see that the registers are filled asynchronously: tie every use to a point behind the wait
-        asm volatile("" : "+v"(va[d]), "+v"(vb[d]));
-        u32x4_t vv = {va[d][0], va[d][1], vb[d][0], vb[d][1]};
-        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), __builtin_bit_cast(bf16x8_t, pf[kk]), o[d], 0, 0, 0);
-      }
+      // two d-tiles per statement
+      auto pv_pair = [&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        u32x2_t a0, b0, a1, b1;
+        if (kk == 0) tr_read_2pairs<0 * 16 * VROW + d * 32, 1 * 16 * VROW + d * 32, 0 * 16 * VROW + (d + 1) * 32, 1 * 16 * VROW + (d + 1) * 32>(a0, b0, a1, b1, vaddr);
+        else         tr_read_2pairs<2 * 16 * VROW + d * 32, 3 * 16 * VROW + d * 32, 2 * 16 * VROW + (d + 1) * 32, 3 * 16 * VROW + (d + 1) * 32>(a0, b0, a1, b1, vaddr);
+        u32x4_t v0 = {a0[0], a0[1], b0[0], b0[1]}, v1 = {a1[0], a1[1], b1[0], b1[1]};
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, v0), __builtin_bit_cast(bf16x8_t, pf[kk]), o[d], 0, 0, 0);
+        o[d + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, v1), __builtin_bit_cast(bf16x8_t, pf[kk]), o[d + 1], 0, 0, 0);
+      };
+      pv_pair(std::integral_constant<int, 0>{}); pv_pair(std::integral_constant<int, 2>{});
+      if constexpr (DT == 8) { pv_pair(std::integral_constant<int, 4>{}); pv_pair(std::integral_constant<int, 6>{}); }
     }
   }
   l_run += __shfl_xor(l_run, 16, 64);
@@ -414,19 +434,19 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn32_kernel(const bf16_t* _
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int t = 2 * b + tt;
-        u32x2_t va[DB], vb[DB];
-#pragma unroll
-        for (int d = 0; d < DB; ++d) {
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(va[d]) : "v"(vaddr), "i"(t * 16 * VROW + d * 64));
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vb[d]) : "v"(vaddr), "i"((t * 16 + 8) * VROW + d * 64));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int d = 0; d < DB; ++d) {
-          asm volatile("" : "+v"(va[d]), "+v"(vb[d]));   // registers are filled asynchronously: uses stay behind the wait
-          u32x4_t vv = {va[d][0], va[d][1], vb[d][0], vb[d][1]};
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), __builtin_bit_cast(bf16x8_t, pf[tt]), o[d], 0, 0, 0);
-        }
+        auto pv_pair = [&](auto dc) {
+          constexpr int d = decltype(dc)::value;
+          u32x2_t a0, b0, a1, b1;
+          if (t == 0)      tr_read_2pairs<0 * 16 * VROW + d * 64, (0 * 16 + 8) * VROW + d * 64, 0 * 16 * VROW + (d + 1) * 64, (0 * 16 + 8) * VROW + (d + 1) * 64>(a0, b0, a1, b1, vaddr);
+          else if (t == 1) tr_read_2pairs<1 * 16 * VROW + d * 64, (1 * 16 + 8) * VROW + d * 64, 1 * 16 * VROW + (d + 1) * 64, (1 * 16 + 8) * VROW + (d + 1) * 64>(a0, b0, a1, b1, vaddr);
+          else if (t == 2) tr_read_2pairs<2 * 16 * VROW + d * 64, (2 * 16 + 8) * VROW + d * 64, 2 * 16 * VROW + (d + 1) * 64, (2 * 16 + 8) * VROW + (d + 1) * 64>(a0, b0, a1, b1, vaddr);
+          else             tr_read_2pairs<3 * 16 * VROW + d * 64, (3 * 16 + 8) * VROW + d * 64, 3 * 16 * VROW + (d + 1) * 64, (3 * 16 + 8) * VROW + (d + 1) * 64>(a0, b0, a1, b1, vaddr);
+          u32x4_t v0 = {a0[0], a0[1], b0[0], b0[1]}, v1 = {a1[0], a1[1], b1[0], b1[1]};
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, v0), __builtin_bit_cast(bf16x8_t, pf[tt]), o[d], 0, 0, 0);
+          o[d + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, v1), __builtin_bit_cast(bf16x8_t, pf[tt]), o[d + 1], 0, 0, 0);
+        };
+        pv_pair(std::integral_constant<int, 0>{});
+        if constexpr (DB == 4) pv_pair(std::integral_constant<int, 2>{});
       }
     }
   }

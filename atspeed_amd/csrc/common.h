@@ -60,12 +60,18 @@ __host__ __device__ inline uint32_t ats_rng_sub(uint32_t seed, int purpose, int 
 __device__ __forceinline__ float ats_u01(uint32_t h) { return ((float)(h >> 9) + 0.5f) * 1.1920928955078125e-07f; }   // (k + 1/2) 2^-23, exact
 __device__ __forceinline__ float ats_gumbel(uint32_t h) { return -logf(-logf(ats_u01(h))); }
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;   // NaN stays NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                               // round to nearest even
-  return (bf16_t)(u >> 16);
+// round to nearest even in hardware (v_cvt_pk_bf16_f32 on gfx950: the compiler pairs neighbouring conversions); the six-instruction
+// integer form this replaces was a sixth of the ring GEMM's epilogue and most of the attention softmax's VALU work
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+// two values -> one packed register (low half = lo); and the two values back as floats (a bf16 is the high half of its fp32)
+typedef __attribute__((ext_vector_type(2))) float ats_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 ats_bf16x2_t;
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
+  ats_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ats_bf16x2_t));
 }
+__device__ __forceinline__ float bf_lo(uint32_t pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t pk) { return __uint_as_float(pk & 0xffff0000u); }
 
 template <typename T> struct Elt;
 template <> struct Elt<float> {

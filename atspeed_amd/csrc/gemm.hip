@@ -300,6 +300,35 @@ template <int EPI, int NA, int MT2>
 __device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[NA][MT2], void* __restrict__ Cv, int M, int N, int ldc, int m0, int n0,
                                              int wn, int wm, int lq, int g) {
   const bool vec = (ldc & 3) == 0;
+  if constexpr (EPI == EPI_RESID) {
+    // read-modify-write of h: the loads of a row group must not wait behind the previous group's stores (same pointer: the compiler
+    // keeps them in order, one memory round trip per 8 bytes -- 30 k cycles per tile), so all of a wave's residuals are fetched first
+    if (vec && n0 + wn * (NA * 16) + NA * 16 <= N) {              // whole 64-column span inside N (else the element-wise path below)
+      bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
+      uint2 rs[NA][MT2];
+#pragma unroll
+      for (int j = 0; j < MT2; ++j) {
+        const int gm = min(m0 + wm * (MT2 * 16) + j * 16 + lq, M - 1);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+          rs[i][j] = *reinterpret_cast<const uint2*>(Cb + (size_t)gm * ldc + n0 + wn * (NA * 16) + i * 16 + g * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < MT2; ++j) {
+        const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const uint32_t p0 = f2bf_pk(acc[i][j][0], acc[i][j][1]), p1 = f2bf_pk(acc[i][j][2], acc[i][j][3]);
+          uint2 o;
+          o.x = f2bf_pk(bf_lo(rs[i][j].x) + bf_lo(p0), bf_hi(rs[i][j].x) + bf_hi(p0));
+          o.y = f2bf_pk(bf_lo(rs[i][j].y) + bf_lo(p1), bf_hi(rs[i][j].y) + bf_hi(p1));
+          *reinterpret_cast<uint2*>(Cb + (size_t)gm * ldc + n0 + wn * (NA * 16) + i * 16 + g * 4) = o;
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < MT2; ++j) {
     const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
@@ -310,14 +339,16 @@ __device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[NA][MT2], void* __re
       for (int i = 0; i < NA; i += 2) {
         const int gn = n0 + wn * (NA * 16) + i * 16;
         if (gn >= N) continue;
-        ushort4 o;
-        bf16_t* op = reinterpret_cast<bf16_t*>(&o);
+        // gate and up rounded to bf16 first (the reference's two projections are bf16 tensors), packed conversions throughout
+        uint2 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float gt = bf2f(f2bf(acc[i][j][r])), up = bf2f(f2bf(acc[i + 1][j][r]));
-          op[r] = f2bf(gt / (1.f + __expf(-gt)) * up);
+        for (int r = 0; r < 4; r += 2) {
+          const uint32_t gp = f2bf_pk(acc[i][j][r], acc[i][j][r + 1]), upk = f2bf_pk(acc[i + 1][j][r], acc[i + 1][j][r + 1]);
+          const float g0 = bf_lo(gp), g1 = bf_hi(gp);
+          const uint32_t res = f2bf_pk(g0 / (1.f + __expf(-g0)) * bf_lo(upk), g1 / (1.f + __expf(-g1)) * bf_hi(upk));
+          if (r == 0) o.x = res; else o.y = res;
         }
-        *reinterpret_cast<ushort4*>(C + (size_t)gm * ldc + (gn >> 1) + g * 4) = o;
+        *reinterpret_cast<uint2*>(C + (size_t)gm * ldc + (gn >> 1) + g * 4) = o;
       }
     } else {
 #pragma unroll
@@ -333,18 +364,16 @@ __device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[NA][MT2], void* __re
         } else {
           bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
           if (gn + 3 < N && vec) {
-            ushort4 o;
-            bf16_t* op = reinterpret_cast<bf16_t*>(&o);
+            uint2 o;
+            const uint32_t p0 = f2bf_pk(acc[i][j][0], acc[i][j][1]), p1 = f2bf_pk(acc[i][j][2], acc[i][j][3]);
             if constexpr (EPI == EPI_RESID) {
-              ushort4 rs = *reinterpret_cast<const ushort4*>(C);
-              const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) op[r] = f2bf(bf2f(rp[r]) + bf2f(f2bf(acc[i][j][r])));
+              const uint2 rs = *reinterpret_cast<const uint2*>(C);
+              o.x = f2bf_pk(bf_lo(rs.x) + bf_lo(p0), bf_hi(rs.x) + bf_hi(p0));
+              o.y = f2bf_pk(bf_lo(rs.y) + bf_lo(p1), bf_hi(rs.y) + bf_hi(p1));
             } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) op[r] = f2bf(acc[i][j][r]);
+              o.x = p0; o.y = p1;
             }
-            *reinterpret_cast<ushort4*>(C) = o;
+            *reinterpret_cast<uint2*>(C) = o;
           } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
