@@ -75,7 +75,9 @@ SHAPES = [(900, 1000, 512), (1024, 2304, 768), (1543, 300, 1024), (1, 128, 128),
           # one user's wide projections: ring kernel in split-K mode (33-256 tokens, N >= 8192, K % 128 == 0)
           (40, 8192, 512), (100, 12288, 1024), (129, 8448, 256), (228, 12288, 640), (256, 9000, 384),
           # 257-512 tokens: two 256-row token tiles per weight tile in the same mode
-          (300, 12288, 640), (400, 8448, 256), (512, 9000, 384)]
+          (300, 12288, 640), (400, 8448, 256), (512, 9000, 384),
+          # more than two tiles per CU, ragged last tiles
+          (4200, 8192, 256), (2100, 16700, 128), (8300, 4100, 384)]
 
 
 @pytest.mark.parametrize("m,n,k", SHAPES)
@@ -93,7 +95,7 @@ def test_gemm_store_and_f32(lib, m, n, k, dtype):
     np.testing.assert_allclose(c.double().cpu().numpy(), ref.numpy(), atol=tol2, rtol=0)
 
 
-@pytest.mark.parametrize("m,n,k", [(7, 256, 128), (40, 768, 768), (228, 4096, 11008), (228, 4096, 4096), (1100, 768, 1024), (2000, 500, 256), (100, 8192, 512), (6400, 4096, 512)])
+@pytest.mark.parametrize("m,n,k", [(7, 256, 128), (40, 768, 768), (228, 4096, 11008), (228, 4096, 4096), (1100, 768, 1024), (2000, 500, 256), (100, 8192, 512), (6400, 4096, 512), (8300, 4096, 512), (4500, 8192, 256)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_residual(lib, m, n, k, dtype):
     a = _rand((m, k), 3).to(dtype).cuda()
@@ -105,7 +107,7 @@ def test_gemm_residual(lib, m, n, k, dtype):
     np.testing.assert_allclose(c.double().cpu().numpy(), ref.numpy(), atol=tol, rtol=0)
 
 
-@pytest.mark.parametrize("m,ffn,k", [(3, 32, 64), (40, 352, 128), (228, 11008, 4096), (20, 3072, 768), (1300, 1376, 512), (800, 496, 256), (300, 4224, 256)])
+@pytest.mark.parametrize("m,ffn,k", [(3, 32, 64), (40, 352, 128), (228, 11008, 4096), (20, 3072, 768), (1300, 1376, 512), (800, 496, 256), (300, 4224, 256), (4200, 4224, 256)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_swiglu(lib, m, ffn, k, dtype):
     from atspeed_amd.model import _interleave_gate_up
@@ -392,7 +394,8 @@ def test_rmsnorm_quant_fp8_equals_norm_then_quant(lib, hidden):
     assert torch.equal(q, q3) and torch.equal(sc, sc3)
 
 
-@pytest.mark.parametrize("m,n,k,epi", [(1024, 2304, 768, 0), (640, 12288, 512, 0), (1300, 1024, 1280, 2), (900, 2752, 512, 3), (1543, 1000, 256, 1)])
+@pytest.mark.parametrize("m,n,k,epi", [(1024, 2304, 768, 0), (640, 12288, 512, 0), (1300, 1024, 1280, 2), (900, 2752, 512, 3), (1543, 1000, 256, 1),
+                                      (4200, 8192, 256, 0), (8300, 4096, 512, 2), (4200, 8448, 256, 3)])      # more than two tiles per CU
 def test_gemm_fp8(lib, m, n, k, epi):
     x = _rand((m, k), 51, 1.5).to(torch.bfloat16).cuda()
     w = _rand((n, k), 52, 0.05).to(torch.bfloat16).cuda()
