@@ -41,6 +41,35 @@ def test_forward_fp32_logits_match_oracle_with_tree_mask():
     np.testing.assert_allclose(l1.cpu().numpy(), l_ref1.numpy(), atol=LOGIT_TOL, rtol=0)
 
 
+@pytest.mark.parametrize("heads,n_seq", [(12, 48), (6, 96)])       # head_dim 64 and 128; >= 512 attention workgroups: the lock-step kernels
+def test_batched_forward_equals_per_sequence_forwards_bf16(heads, n_seq):
+    """`forward_raw_batch` (one segment and KV arena per sequence: the engine's lock-step form, 128-row query tiles, 32-rows-per-wave
+    attention with LDS-DMA, ring GEMMs over all rows) against the same sequences one per forward (small-grid kernels): bf16 logits agree
+    to bf16 noise, and both are tree forwards (a hidden prompt slot, ragged lengths)."""
+    V = 32000 + 256
+    dims = synth.LlamaDims(V, 768, 2, heads, 1536)
+    m = HipLlama.from_synthetic(dims, 77, dtype=torch.bfloat16, max_slots=256, max_tokens=256, max_logit_rows=256, device=torch.device("cuda", 0))
+    g = torch.Generator().manual_seed(3)
+    seqs = []
+    for i in range(n_seq):
+        T = int(torch.randint(9, 70, (1,), generator=g))
+        ids = torch.randint(3, V, (T,), generator=g).to(torch.int32)
+        vis = torch.tril(torch.ones(T, T, dtype=torch.bool))
+        if T > 12:
+            vis[8:, 3] = False                                     # a hidden slot: not plain causal attention
+        seqs.append((ids, torch.arange(T, dtype=torch.int32), torch.arange(T, dtype=torch.int32), vis_bits_from_bool(vis, 256), T, 4))
+    outs = m.forward_raw_batch(seqs)
+    torch.cuda.synchronize()
+    for i in (0, 1, n_seq // 2, n_seq - 1):
+        ids, pos, slots, bits, T, nl = seqs[i]
+        one = m.forward_raw(ids.cuda(), pos.cuda(), slots.cuda(), bits.cuda(), T, nl)
+        a, b = outs[i].float().cpu().numpy(), one.float().cpu().numpy()
+        assert a.shape == b.shape == (4, V)
+        scale = float(np.abs(b).max())
+        np.testing.assert_allclose(a, b, atol=0.03 * scale, rtol=0)
+        assert float(np.abs(a - b).mean()) < 0.004 * scale
+
+
 def _models(ci, case, dtype=torch.float32):
     kw = dict(max_slots=512, max_tokens=512, max_logit_rows=448)
     t = HipLlama.from_state_dict(ci["target_dims"], ci["target_sd"], dtype, num_beams=case["K"], **kw)
