@@ -20,15 +20,6 @@
 namespace {
 
 constexpr int kMaxSlots = 2048;
-// Integer round-to-nearest-even (finite inputs) for the probabilities of the 16-rows-per-wave kernel.  With the hardware conversion
-// (common.h f2bf) hipcc's packing of the eight values into the MFMA operand gives wrong rows >= 64 in the <64, 16> instantiation
-// (1024 threads, 128-VGPR cap; every other form passes): kept on the form all instantiations are tested with.
-__device__ __forceinline__ bf16_t f2bf_int(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q, int ldq, const SegTable* __restrict__ tab, size_t layer_off,
                                                         int vis_words, T* __restrict__ out, int ldo,
@@ -238,14 +229,17 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
     const float m_new = fmaxf(m_run, mt);
     const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
     float psum = 0.f;
-    s16x8_t pf[2];
+    u32x4_t pf[2];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float p = (s[c][r] == -INFINITY) ? 0.f : __expf(s[c][r] - m_new);
-        psum += p;
-        pf[c >> 1][(c & 1) * 4 + r] = (short)f2bf_int(p);   // see f2bf_int
+      for (int r = 0; r < 4; r += 2) {
+        const float p0 = (s[c][r] == -INFINITY) ? 0.f : __expf(s[c][r] - m_new);
+        const float p1 = (s[c][r + 1] == -INFINITY) ? 0.f : __expf(s[c][r + 1] - m_new);
+        psum += p0 + p1;
+        // packed explicitly: element-wise (short)f2bf(p) into the 8-vector was miscompiled in the <64, 16> instantiation (1024 threads,
+        // 128-VGPR cap: wrong rows >= 64) once f2bf became the hardware conversion
+        pf[c >> 1][(c & 1) * 2 + (r >> 1)] = f2bf_pk(p0, p1);
       }
     l_run = l_run * alpha + psum;
     m_run = m_new;
