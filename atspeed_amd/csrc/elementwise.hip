@@ -344,6 +344,87 @@ __global__ void rope_kv_segs_vec_kernel(bf16_t* __restrict__ qkv, const SegTable
   *reinterpret_cast<uint4*>(vc + d1) = *reinterpret_cast<const uint4*>(r + 2 * hidden + d1);
 }
 
+// The same on the qkv projection's split-K slabs (one user's forward): sums the fp32 slabs in slab order, rounds to bf16 exactly as the
+// separate reduce pass stored them, rotates, writes q to the qkv buffer and k / v straight to the caches.
+__global__ void rope_kv_segs_slab_kernel(const float* __restrict__ slabs, int splits, bf16_t* __restrict__ qkv, const SegTable* __restrict__ t,
+                                         const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, size_t layer_off, int n_heads,
+                                         int head_dim, int max_pos) {
+  // a thread owns 8 consecutive (i, i + dh/2) pairs of ONE of q / k / v (part): 4 float4 loads per slab, four slabs' loads in flight
+  const int half = head_dim >> 1, groups = half >> 3;
+  const int hidden = n_heads * head_dim;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t->total_tok * 3 * n_heads * groups) return;
+  const int gi = i % groups;
+  const int h = (i / groups) % n_heads;
+  const int part = (i / (groups * n_heads)) % 3;
+  const int row = i / (groups * n_heads * 3);
+  const Seg& sg = t->seg[seg_of_row(t, row)];
+  const int lt = row - sg.row0;
+  const int d0 = h * head_dim + gi * 8, d1 = d0 + half;
+  const size_t slab = (size_t)t->total_tok * 3 * hidden;
+  const float* p0 = slabs + (size_t)row * 3 * hidden + part * hidden + d0;
+  const float* p1 = p0 + half;
+  float lo[8], hi[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lo[e] = hi[e] = 0.f;
+  auto add = [](float (&acc)[8], const float4& a, const float4& b) {
+    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+  };
+  int z = 0;
+  for (; z + 4 <= splits; z += 4) {
+    float4 v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t o = (size_t)(z + u) * slab;
+      v[u][0] = *reinterpret_cast<const float4*>(p0 + o); v[u][1] = *reinterpret_cast<const float4*>(p0 + o + 4);
+      v[u][2] = *reinterpret_cast<const float4*>(p1 + o); v[u][3] = *reinterpret_cast<const float4*>(p1 + o + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { add(lo, v[u][0], v[u][1]); add(hi, v[u][2], v[u][3]); }
+  }
+  for (; z < splits; ++z) {
+    const size_t o = (size_t)z * slab;
+    const float4 a = *reinterpret_cast<const float4*>(p0 + o), b = *reinterpret_cast<const float4*>(p0 + o + 4);
+    const float4 c = *reinterpret_cast<const float4*>(p1 + o), d = *reinterpret_cast<const float4*>(p1 + o + 4);
+    add(lo, a, b); add(hi, c, d);
+  }
+  uint4 o0, o1;
+  uint32_t *w0 = (uint32_t*)&o0, *w1 = (uint32_t*)&o1;
+  if (part == 2) {                                   // v: the projection's bf16 output as it is
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) { w0[e >> 1] = f2bf_pk(lo[e], lo[e + 1]); w1[e >> 1] = f2bf_pk(hi[e], hi[e + 1]); }
+  } else {
+    int ps = sg.pos[lt];
+    ps = ps < 0 ? 0 : (ps >= max_pos ? max_pos - 1 : ps);
+    const float* cp = cos_tab + (size_t)ps * half + gi * 8;
+    const float* sp = sin_tab + (size_t)ps * half + gi * 8;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      // the projection's bf16 outputs first (what the reduce pass stored), then the rotation on those
+      const uint32_t x0 = f2bf_pk(lo[e], lo[e + 1]), x1 = f2bf_pk(hi[e], hi[e + 1]);
+      const float ca = cp[e], sa = sp[e], cb = cp[e + 1], sb = sp[e + 1];
+      w0[e >> 1] = f2bf_pk(bf_lo(x0) * ca - bf_lo(x1) * sa, bf_hi(x0) * cb - bf_hi(x1) * sb);
+      w1[e >> 1] = f2bf_pk(bf_lo(x1) * ca + bf_lo(x0) * sa, bf_hi(x1) * cb + bf_hi(x0) * sb);
+    }
+  }
+  bf16_t* dst;
+  if (part == 0) dst = qkv + (size_t)row * 3 * hidden;
+  else dst = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(part == 1 ? sg.kc : sg.vc) + layer_off) + (size_t)sg.slot[lt] * hidden;
+  *reinterpret_cast<uint4*>(dst + d0) = o0;
+  *reinterpret_cast<uint4*>(dst + d1) = o1;
+}
+
+int ats_rope_kv_segs_slabs(const float* qkv_slabs, int splits, void* qkv, const SegTable& t, const SegTable* dt, const float* cos_tab,
+                           const float* sin_tab, size_t layer_off_bytes, int n_heads, int head_dim, int max_pos, hipStream_t st) {
+  ATS_REQUIRE(head_dim % 16 == 0 && splits >= 1 && qkv_slabs, ATSPEED_ERR_INVALID, "rope: slab input needs head_dim %% 16 == 0");
+  const int totalv = t.total_tok * 3 * n_heads * (head_dim / 16);
+  if (totalv <= 0) return ATSPEED_OK;
+  rope_kv_segs_slab_kernel<<<(totalv + 255) / 256, 256, 0, st>>>(qkv_slabs, splits, (bf16_t*)qkv, dt, cos_tab, sin_tab, layer_off_bytes, n_heads,
+                                                                 head_dim, max_pos);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
 int ats_rope_kv_segs(void* qkv, const SegTable& t, const SegTable* dt, const float* cos_tab, const float* sin_tab, size_t layer_off_bytes,
                      int n_heads, int head_dim, int max_pos, int dtype, hipStream_t st) {
   if (dtype == ATSPEED_BF16 && head_dim % 16 == 0) {

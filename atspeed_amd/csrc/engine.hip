@@ -473,13 +473,20 @@ static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTabl
     const size_t loff = (size_t)l * m->layer_kv_bytes;
     // cx->xn holds rmsnorm(h) * input_norm here (from the embed above or the previous layer's fused down_proj epilogue)
     const bool f8 = !m->fp8.empty();
+    static const bool fuse_qkv_reduce = !(getenv("ATSPEED_FUSE_QKV_REDUCE") && atoi(getenv("ATSPEED_FUSE_QKV_REDUCE")) == 0);
+    int qkv_splits = 0;
     { ProfBracket pb(m, 0, T, st);
       if (f8 && ats_gemm_fp8_applies(T, 3 * H, H, 3 * H, EPI_STORE)) {
         ATS_TRY(proj_fp8(m, xq_ready ? nullptr : cx->xn, m->fp8[l].wqkv, m->fp8[l].sqkv, cx->qkv, T, 3 * H, H, 3 * H, EPI_STORE, st));
       } else {
-        ATS_TRY(ats_gemm(cx->xn, w.wqkv, cx->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, cx->ws, cx->ws_bytes, st));
+        // one user's forward: the projection leaves fp32 split-K slabs and RoPE sums them itself (one launch less per layer)
+        if (fuse_qkv_reduce && m->head_dim % 16 == 0) ATS_TRY(ats_gemm_partials(cx->xn, w.wqkv, T, 3 * H, H, H, dt, cx->ws, cx->ws_bytes, st, &qkv_splits));
+        if (qkv_splits == 0) ATS_TRY(ats_gemm(cx->xn, w.wqkv, cx->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, cx->ws, cx->ws_bytes, st));
       } }
-    ATS_TRY(ats_rope_kv_segs(cx->qkv, t, dtab, m->cos_tab, m->sin_tab, loff, c.n_heads, m->head_dim, c.max_slots, dt, st));
+    if (qkv_splits > 0)
+      ATS_TRY(ats_rope_kv_segs_slabs((const float*)cx->ws, qkv_splits, cx->qkv, t, dtab, m->cos_tab, m->sin_tab, loff, c.n_heads, m->head_dim, c.max_slots, st));
+    else
+      ATS_TRY(ats_rope_kv_segs(cx->qkv, t, dtab, m->cos_tab, m->sin_tab, loff, c.n_heads, m->head_dim, c.max_slots, dt, st));
     ATS_TRY(ats_tree_attention_segs(cx->qkv, 3 * H, t, dtab, loff, m->vis_words, cx->att, H, c.n_heads, m->head_dim, dt, st));
     { ProfBracket pb(m, 1, T, st);     // h += att Wo^T ; xn = rmsnorm(h) * post_norm
       if (f8 && ats_gemm_fp8_applies(T, H, H, H, EPI_RESID)) {

@@ -856,6 +856,7 @@ int launch_ring_split(const bf16_t* a, const bf16_t* w, void* c, int m, int n, i
     hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 4, false, true>), dim3(tiles_n * splits), dim3(512), 96 * 1024, st, (const void*)a, (const void*)w,
                        none, stamps, (void*)partial, m, n, k, lda, n, tiles_n, 1, 1, splits);
   ATS_LAUNCH_CHECK();
+  if (c == nullptr) return ATSPEED_OK;          // partials only: the caller's next kernel sums the slabs itself (ats_gemm_partials)
   return reduce_splits<bf16_t, EPI>(partial, c, m, n, ldc, splits, st, fn);
 }
 
@@ -925,6 +926,23 @@ size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype) {
 }
 
 static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype, int epilogue);
+
+// One user's wide bf16 projection as fp32 split-K slabs [splits][m][n] in the workspace, WITHOUT the reduce pass: the consumer sums the
+// slabs while it reads them (RoPE + KV scatter after the qkv projection: one launch less per layer).  *splits_out = 0 when this shape does
+// not take the split-K ring path (the caller then runs the ordinary ats_gemm).
+int ats_gemm_partials(const void* a, const void* w, int m, int n, int k, int lda, int dtype, void* workspace, size_t workspace_bytes,
+                      hipStream_t st, int* splits_out) {
+  *splits_out = 0;
+  if (dtype != ATSPEED_BF16 || m <= 0 || big_kernel_applies(m, n, k, lda, n, dtype, EPI_STORE)) return ATSPEED_OK;
+  const int rs = ring_split_count(m, n, k);
+  if (rs < 1 || (lda % 8) != 0 || (n % 4) != 0 || ((uintptr_t)workspace & 15) != 0 || (size_t)rs * m * n * sizeof(float) > workspace_bytes) return ATSPEED_OK;
+  ATS_REQUIRE(a && w && workspace, ATSPEED_ERR_INVALID, "gemm: null operand");
+  ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "gemm: operands must be 16-byte aligned");
+  ATS_TRY(launch_ring_split<EPI_STORE>((const bf16_t*)a, (const bf16_t*)w, nullptr, m, n, k, lda, n, rs, (float*)workspace, st, nullptr));
+  *splits_out = rs;
+  return ATSPEED_OK;
+}
+
 int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int dtype, int epilogue,
              void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (m <= 0 || n <= 0) return ATSPEED_OK;

@@ -30,6 +30,9 @@ void ats_stage_reset();                           // after a stream synchronisat
 // ---- fill.hip / elementwise.hip -------------------------------------------------------
 // `t` = host copy (sizes), `dt` = the staged device copy the kernels read
 int ats_embed_segs(const void* table, const SegTable& t, const SegTable* dt, void* out, int hidden, int vocab, int dtype, hipStream_t st);
+// qkv_slabs != nullptr: the projection's fp32 split-K slabs [splits][total_tok][3 * hidden]; q is written (rotated) to qkv, k / v only to the caches
+int ats_rope_kv_segs_slabs(const float* qkv_slabs, int splits, void* qkv, const SegTable& t, const SegTable* dt, const float* cos_tab,
+                           const float* sin_tab, size_t layer_off_bytes, int n_heads, int head_dim, int max_pos, hipStream_t st);
 int ats_rope_kv_segs(void* qkv, const SegTable& t, const SegTable* dt, const float* cos_tab, const float* sin_tab, size_t layer_off_bytes,
                      int n_heads, int head_dim, int max_pos, int dtype, hipStream_t st);
 int ats_gather_logit_rows(const void* h, const SegTable& t, const SegTable* dt, void* out, int hidden, int dtype, hipStream_t st);
@@ -58,6 +61,9 @@ int ats_rmsnorm_quant_fp8(const void* x, const void* w, void* y, void* q, float*
 bool ats_gemm_fp8_applies(int m, int n, int k, int ldc, int epilogue);
 int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int m, int n, int k, int ldc,
                  int epilogue, hipStream_t st);
+
+int ats_gemm_partials(const void* a, const void* w, int m, int n, int k, int lda, int dtype, void* workspace, size_t workspace_bytes,
+                      hipStream_t st, int* splits_out);
 
 // ---- attn.hip -------------------------------------------------------------------------
 int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* vcache, const uint64_t* vis,

@@ -41,18 +41,20 @@ def test_forward_fp32_logits_match_oracle_with_tree_mask():
     np.testing.assert_allclose(l1.cpu().numpy(), l_ref1.numpy(), atol=LOGIT_TOL, rtol=0)
 
 
-@pytest.mark.parametrize("heads,n_seq", [(12, 48), (6, 96)])       # head_dim 64 and 128; >= 512 attention workgroups: the lock-step kernels
-def test_batched_forward_equals_per_sequence_forwards_bf16(heads, n_seq):
+# head_dim 64 and 128 with >= 512 attention workgroups (the lock-step kernels); hidden 3072: the one-sequence forwards take the split-K
+# ring GEMM for qkv (N = 9216) with the slab-summing RoPE, the batched one the plain ring GEMM + reduce-free RoPE
+@pytest.mark.parametrize("hidden,heads,n_seq", [(768, 12, 48), (768, 6, 96), (3072, 24, 24)])
+def test_batched_forward_equals_per_sequence_forwards_bf16(hidden, heads, n_seq):
     """`forward_raw_batch` (one segment and KV arena per sequence: the engine's lock-step form, 128-row query tiles, 32-rows-per-wave
     attention with LDS-DMA, ring GEMMs over all rows) against the same sequences one per forward (small-grid kernels): bf16 logits agree
     to bf16 noise, and both are tree forwards (a hidden prompt slot, ragged lengths)."""
     V = 32000 + 256
-    dims = synth.LlamaDims(V, 768, 2, heads, 1536)
+    dims = synth.LlamaDims(V, hidden, 2, heads, 1536)
     m = HipLlama.from_synthetic(dims, 77, dtype=torch.bfloat16, max_slots=256, max_tokens=256, max_logit_rows=256, device=torch.device("cuda", 0))
     g = torch.Generator().manual_seed(3)
     seqs = []
     for i in range(n_seq):
-        T = int(torch.randint(9, 70, (1,), generator=g))
+        T = 64 if i < 2 else int(torch.randint(9, 70, (1,), generator=g))      # 33+ tokens: the split-K mode of one-sequence forwards
         ids = torch.randint(3, V, (T,), generator=g).to(torch.int32)
         vis = torch.tril(torch.ones(T, T, dtype=torch.bool))
         if T > 12:
