@@ -45,19 +45,26 @@ __global__ __launch_bounds__(512, 1) void probe_mfma_kernel(float* __restrict__ 
   out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
 }
 
-// every thread: 8 independent non-temporal 16-byte loads per trip (the verify scan's access shape), grid-stride over the buffer
+// every thread: 8 independent non-temporal 16-byte loads per trip (the verify scan's access shape).  CONTIG = false: grid-stride over the
+// whole buffer; true: every workgroup streams its own contiguous span (how the scan walks a logit row: better DRAM page locality)
+template <bool CONTIG>
 __global__ __launch_bounds__(256) void probe_read_kernel(const probe_u32x4_t* __restrict__ p, size_t n_vec, unsigned* __restrict__ sink) {
-  const size_t stride = (size_t)gridDim.x * 256;
   probe_u32x4_t x = {0, 0, 0, 0};
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 7 * stride < n_vec; i += 8 * stride) {
+  size_t i, end, stride;
+  if constexpr (CONTIG) {
+    const size_t span = (n_vec + gridDim.x - 1) / gridDim.x;
+    i = (size_t)blockIdx.x * span + threadIdx.x; end = min((size_t)(blockIdx.x + 1) * span, n_vec); stride = 256;
+  } else {
+    i = (size_t)blockIdx.x * 256 + threadIdx.x; end = n_vec; stride = (size_t)gridDim.x * 256;
+  }
+  for (; i + 7 * stride < end; i += 8 * stride) {
     probe_u32x4_t v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + i + u * stride);
 #pragma unroll
     for (int u = 0; u < 8; ++u) x ^= v[u];
   }
-  for (; i < n_vec; i += stride) x ^= __builtin_nontemporal_load(p + i);
+  for (; i < end; i += stride) x ^= __builtin_nontemporal_load(p + i);
   if ((x[0] ^ x[1] ^ x[2] ^ x[3]) == 0x9e3779b1u) sink[0] = 1;     // keeps the loads alive
 }
 
@@ -96,18 +103,23 @@ extern "C" int atspeed_probe_hbm_read(const void* buf_dev, size_t bytes, int32_t
   ATS_HIP(hipEventCreate(&ev.e0)); ATS_HIP(hipEventCreate(&ev.e1));
   const size_t n_vec = bytes / 16;
   double best = 0.0;
-  for (int per_cu : {4, 8, 16, 32}) {                      // resident workgroups per CU: the best grid is the measured peak
-    const int blocks = 256 * per_cu;
-    probe_read_kernel<<<blocks, 256, 0, st>>>((const probe_u32x4_t*)buf_dev, n_vec, (unsigned*)scratch_dev);
-    ATS_HIP(hipEventRecord(ev.e0, st));
-    for (int r = 0; r < reps; ++r) probe_read_kernel<<<blocks, 256, 0, st>>>((const probe_u32x4_t*)buf_dev, n_vec, (unsigned*)scratch_dev);
-    ATS_HIP(hipEventRecord(ev.e1, st));
-    ATS_LAUNCH_CHECK();
-    ATS_HIP(hipEventSynchronize(ev.e1));
-    float ms = 0.f;
-    ATS_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
-    best = std::max(best, (double)n_vec * 16 * reps / (ms * 1e-3) / 1e9);
-  }
+  for (int variant = 0; variant < 2; ++variant)
+    for (int per_cu : {4, 8, 16, 32, 64}) {                // resident workgroups per CU; the best (shape, grid) is the measured peak
+      const int blocks = 256 * per_cu;
+      auto launch = [&]() {
+        if (variant) probe_read_kernel<true><<<blocks, 256, 0, st>>>((const probe_u32x4_t*)buf_dev, n_vec, (unsigned*)scratch_dev);
+        else         probe_read_kernel<false><<<blocks, 256, 0, st>>>((const probe_u32x4_t*)buf_dev, n_vec, (unsigned*)scratch_dev);
+      };
+      launch();
+      ATS_HIP(hipEventRecord(ev.e0, st));
+      for (int r = 0; r < reps; ++r) launch();
+      ATS_HIP(hipEventRecord(ev.e1, st));
+      ATS_LAUNCH_CHECK();
+      ATS_HIP(hipEventSynchronize(ev.e1));
+      float ms = 0.f;
+      ATS_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+      best = std::max(best, (double)n_vec * 16 * reps / (ms * 1e-3) / 1e9);
+    }
   *gbs_out = best;
   return ATSPEED_OK;
 }

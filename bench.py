@@ -289,7 +289,7 @@ def main():
         _lib.check(lib.atspeed_probe_mfma_bf16(4000, scratch.data_ptr(), scratch.numel(), _lib.stream_ptr(dev), C.byref(tf)))
         _lib.check(lib.atspeed_probe_hbm_read(buf.data_ptr(), buf.numel(), 8, scratch.data_ptr(), _lib.stream_ptr(dev), C.byref(gbs)))
         measured = dict(mfma_bf16_tflops=tf.value, hbm_read_gbs=gbs.value,
-                        how="atspeed_probe_mfma_bf16 (16x16x32, random operands, 8 waves/CU) and atspeed_probe_hbm_read (2 GiB, 8 passes)")
+                        how="atspeed_probe_mfma_bf16 (16x16x32, random operands, 8 waves/CU) and atspeed_probe_hbm_read (2 GiB, 8 passes, best of 2 access shapes x 5 grids)")
         del buf, scratch
         if scan is not None:
             scan["peak_measured"], scan["frac_of_measured"] = gbs.value, scan["achieved"] / gbs.value
