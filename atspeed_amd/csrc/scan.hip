@@ -7,6 +7,7 @@
 // "highest score first, lowest flat id on ties" — the tie-break this build defines
 // (torch.topk leaves it unspecified).  Key 0 = no candidate.
 #include "internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -19,38 +20,49 @@ constexpr int LMAX = ATSPEED_MAX_NEW_TOKENS;
 constexpr uint32_t kOrdNegInf = 0x007fffffu;           // ford(-inf)
 
 // ---------------------------------------------------------------------------- LSE
-// one workgroup per row, float4 streaming reads, online (max, sum) per lane
-__global__ __launch_bounds__(1024) void lse_rows_kernel(const float* __restrict__ logits, int vocab, int ld,
-                                                        float* __restrict__ lse) {
-  __shared__ float smax[16], ssum[16];
+// one workgroup per row, 16-byte non-temporal streaming reads (the row is read once and never again), online (max, sum) per lane.
+// Chunks of 8 independent loads per thread, double-buffered: chunk c+1 is in flight while chunk c is exponentiated (with one chunk per
+// 1024-thread workgroup the loads and the exponentials of a row alternated and only other workgroups overlapped them: 6.5 TB/s; the
+// read-only stream peak measured by atspeed_probe_hbm_read is 7.05 TB/s).  One running-max rescale per chunk instead of per element.
+template <int NT>
+__global__ __launch_bounds__(NT) void lse_rows_kernel(const float* __restrict__ logits, int vocab, int ld, float* __restrict__ lse) {
+  constexpr int U = 8, NWV = NT / 64;
+  __shared__ float smax[NWV], ssum[NWV];
   const float* row = logits + (size_t)blockIdx.x * ld;
+  const f32x4_t* row4 = reinterpret_cast<const f32x4_t*>(row);
   float m = -INFINITY, s = 0.f;
   const int nv4 = vocab >> 2;
-  // chunks of 8 independent 16-byte loads per thread (128 KB of a 131 KB row in flight per workgroup), one running-max
-  // rescale per chunk instead of per element; the row is read once and never again: non-temporal loads
-  constexpr int U = 8;
-  for (int base = threadIdx.x; base < nv4; base += 1024 * U) {
-    float4 v[U];
+  const int n_full = nv4 / (NT * U);                      // chunks in which every thread has all U loads
+  auto load = [&](int c, f32x4_t (&v)[U]) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = base + u * 1024;
-      if (i < nv4) {
-        v[u].x = __builtin_nontemporal_load(&row[4 * i]);     v[u].y = __builtin_nontemporal_load(&row[4 * i + 1]);
-        v[u].z = __builtin_nontemporal_load(&row[4 * i + 2]); v[u].w = __builtin_nontemporal_load(&row[4 * i + 3]);
-      } else {
-        v[u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-      }
-    }
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(row4 + (size_t)c * NT * U + u * NT + threadIdx.x);
+  };
+  auto consume = [&](const f32x4_t (&v)[U]) {
     float cm = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < U; ++u) cm = fmaxf(cm, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+    for (int u = 0; u < U; ++u) cm = fmaxf(cm, fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3])));
     if (cm > m) { s *= __expf(m - cm); m = cm; }
     if (m != -INFINITY) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) s += __expf(v[u].x - m) + __expf(v[u].y - m) + __expf(v[u].z - m) + __expf(v[u].w - m);
+      for (int u = 0; u < U; ++u) s += __expf(v[u][0] - m) + __expf(v[u][1] - m) + __expf(v[u][2] - m) + __expf(v[u][3] - m);
     }
+  };
+  f32x4_t a[U], b[U];
+  if (n_full > 0) load(0, a);
+  for (int c = 0; c < n_full; c += 2) {
+    if (c + 1 < n_full) load(c + 1, b);
+    consume(a);
+    if (c + 1 >= n_full) break;
+    if (c + 2 < n_full) load(c + 2, a);
+    consume(b);
   }
-  for (int i = (nv4 << 2) + threadIdx.x; i < vocab; i += 1024) {
+  for (int i = n_full * NT * U + threadIdx.x; i < nv4; i += NT) {           // the last partial chunk: at most U - 1 loads per thread
+    const f32x4_t v = __builtin_nontemporal_load(row4 + i);
+    const float cm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    if (cm > m) { s *= __expf(m - cm); m = cm; }
+    if (m != -INFINITY) s += __expf(v[0] - m) + __expf(v[1] - m) + __expf(v[2] - m) + __expf(v[3] - m);
+  }
+  for (int i = (nv4 << 2) + threadIdx.x; i < vocab; i += NT) {
     float v = row[i];
     if (v > m) { s *= __expf(m - v); m = v; }
     s += __expf(v - m);
@@ -63,9 +75,9 @@ __global__ __launch_bounds__(1024) void lse_rows_kernel(const float* __restrict_
   __syncthreads();
   if (threadIdx.x == 0) {
     float gm = smax[0];
-    for (int w = 1; w < 16; ++w) gm = fmaxf(gm, smax[w]);
+    for (int w = 1; w < NWV; ++w) gm = fmaxf(gm, smax[w]);
     float gs = 0.f;
-    for (int w = 0; w < 16; ++w) gs += (smax[w] == -INFINITY) ? 0.f : ssum[w] * expf(smax[w] - gm);
+    for (int w = 0; w < NWV; ++w) gs += (smax[w] == -INFINITY) ? 0.f : ssum[w] * expf(smax[w] - gm);
     lse[blockIdx.x] = gm + logf(gs);
   }
 }
@@ -709,7 +721,13 @@ __global__ void accept_kernel(const int32_t* __restrict__ tflat, const float* __
 int ats_lse_rows(const float* logits, int n_rows, int vocab, int ld, float* lse, hipStream_t st) {
   if (n_rows <= 0) return ATSPEED_OK;
   ATS_REQUIRE((ld & 3) == 0 && ((uintptr_t)logits & 15) == 0, ATSPEED_ERR_INVALID, "lse: rows must be 16-byte aligned (ld %d)", ld);
-  lse_rows_kernel<<<n_rows, 1024, 0, st>>>(logits, vocab, ld, lse);
+  // measured (tools/lse_bench.py, 30976 rows of 32859): 1024 threads 6.2 TB/s, 512: 6.5, 256 (four double-buffered chunks per row, eight
+  // workgroups per CU): 6.9 TB/s = 98 % of the measured read peak; a single user's 121 rows are launch-bound (6.0 us with 512 threads, 6.6 with 256)
+  static const int force_nt = getenv("ATSPEED_LSE_THREADS") ? atoi(getenv("ATSPEED_LSE_THREADS")) : 0;
+  const int nt = force_nt ? force_nt : (n_rows >= 1024 ? 256 : 512);
+  if (nt == 256)       lse_rows_kernel<256><<<n_rows, 256, 0, st>>>(logits, vocab, ld, lse);
+  else if (nt == 1024) lse_rows_kernel<1024><<<n_rows, 1024, 0, st>>>(logits, vocab, ld, lse);
+  else                 lse_rows_kernel<512><<<n_rows, 512, 0, st>>>(logits, vocab, ld, lse);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }

@@ -6,7 +6,7 @@ import torch
 from atspeed_amd import _lib
 lib = _lib.load(); st = _lib.stream_ptr()
 V, ld = 32859, 32896
-for rows in (121, 3872, 7744):
+for rows in (121, 3872, 7744, 30976):
     lg = torch.randn(rows, ld, dtype=torch.float32, device="cuda"); out = torch.empty(rows, dtype=torch.float32, device="cuda")
     f = lambda: _lib.check(lib.atspeed_lse_rows(lg.data_ptr(), rows, V, ld, out.data_ptr(), st))
     for _ in range(3): f()
