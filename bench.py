@@ -190,7 +190,7 @@ def main():
     # ---- the reference's own regime, for the record (not part of `value`): a few users strictly one at a time.
     # Here every projection is one pass over the weights (M ~ 20-230 tokens): HBM-bound.
     single = None
-    if rank == 0 and args.streams > 1 and args.single_stream_users > 0:
+    if world == 1 and args.streams > 1 and args.single_stream_users > 0:      # auxiliary passes belong to the N=1 line only
         n1 = min(args.single_stream_users, n_timed)
         for u in range(n_warm, n_warm + min(3, n1)):       # warm-up: recurring forward shapes get their hipGraphs
             BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
@@ -219,7 +219,7 @@ def main():
     # the target's (the natural bracket above accepts ~0 steps because the random weights are unrelated).
     aligned = None
     scales = [float(x) for x in args.aligned_resid_scale.split(",") if x.strip()]
-    if rank == 0 and scales:
+    if world == 1 and scales:
         release_decoders(target, draft)                # the main pass's per-user KV arenas: room for the second model pair
         aligned = []
         grp = max(1, args.streams)
