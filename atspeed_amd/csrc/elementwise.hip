@@ -329,14 +329,15 @@ __global__ void rope_kv_segs_vec_kernel(bf16_t* __restrict__ qkv, const SegTable
   uint4 q0v = *reinterpret_cast<const uint4*>(r + d0), q1v = *reinterpret_cast<const uint4*>(r + d1);
   uint4 k0v = *reinterpret_cast<const uint4*>(r + hidden + d0), k1v = *reinterpret_cast<const uint4*>(r + hidden + d1);
   uint4 qo0, qo1, ko0, ko1;
-  const bf16_t *q0 = (const bf16_t*)&q0v, *q1 = (const bf16_t*)&q1v, *k0 = (const bf16_t*)&k0v, *k1 = (const bf16_t*)&k1v;
-  bf16_t *a0 = (bf16_t*)&qo0, *a1 = (bf16_t*)&qo1, *b0 = (bf16_t*)&ko0, *b1 = (bf16_t*)&ko1;
+  const uint32_t *q0 = (const uint32_t*)&q0v, *q1 = (const uint32_t*)&q1v, *k0 = (const uint32_t*)&k0v, *k1 = (const uint32_t*)&k1v;
+  uint32_t *a0 = (uint32_t*)&qo0, *a1 = (uint32_t*)&qo1, *b0 = (uint32_t*)&ko0, *b1 = (uint32_t*)&ko1;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float c = cp[e], s = sp[e];
-    const float x0 = bf2f(q0[e]), x1 = bf2f(q1[e]), y0 = bf2f(k0[e]), y1 = bf2f(k1[e]);
-    a0[e] = f2bf(x0 * c - x1 * s); a1[e] = f2bf(x1 * c + x0 * s);
-    b0[e] = f2bf(y0 * c - y1 * s); b1[e] = f2bf(y1 * c + y0 * s);
+  for (int e = 0; e < 4; ++e) {                                   // two elements per packed register
+    const float ca = cp[2 * e], sa = sp[2 * e], cb = cp[2 * e + 1], sb = sp[2 * e + 1];
+    a0[e] = f2bf_pk(bf_lo(q0[e]) * ca - bf_lo(q1[e]) * sa, bf_hi(q0[e]) * cb - bf_hi(q1[e]) * sb);
+    a1[e] = f2bf_pk(bf_lo(q1[e]) * ca + bf_lo(q0[e]) * sa, bf_hi(q1[e]) * cb + bf_hi(q0[e]) * sb);
+    b0[e] = f2bf_pk(bf_lo(k0[e]) * ca - bf_lo(k1[e]) * sa, bf_hi(k0[e]) * cb - bf_hi(k1[e]) * sb);
+    b1[e] = f2bf_pk(bf_lo(k1[e]) * ca + bf_lo(k0[e]) * sa, bf_hi(k1[e]) * cb + bf_hi(k0[e]) * sb);
   }
   *reinterpret_cast<uint4*>(r + d0) = qo0; *reinterpret_cast<uint4*>(r + d1) = qo1;
   *reinterpret_cast<uint4*>(kc + d0) = ko0; *reinterpret_cast<uint4*>(kc + d1) = ko1;
