@@ -188,6 +188,26 @@ def _prompt_row(inputs) -> torch.Tensor:
     return ids
 
 
+def _batch_buffers(prompts, k: int, max_new_tokens: int, dev):
+    """One allocation / conversion for a whole lock-step batch instead of three small kernels per user: the prompts as ONE int32 buffer,
+    the K x L token block and the K scores of every user as slices of two tensors."""
+    lens = [int(p.numel()) for p in prompts]
+    flat = torch.cat([p.reshape(-1) for p in prompts]).to(torch.int32)          # two kernels for the whole batch
+    starts = [0]
+    for n_tok in lens[:-1]:
+        starts.append(starts[-1] + n_tok)
+    ids32 = [flat[s0: s0 + n_tok] for s0, n_tok in zip(starts, lens)]
+    toks = torch.empty(len(prompts), k, max_new_tokens, dtype=torch.int32, device=dev)
+    scores = torch.empty(len(prompts), k, dtype=torch.float32, device=dev)
+    return ids32, toks, scores, flat
+
+
+def _batch_results(prompts, toks: torch.Tensor, scores: torch.Tensor, k: int):
+    toks64 = toks.to(torch.int64)                     # one conversion for all users; a user's rows are then one cat of two views
+    return [{"beam_sequence": torch.cat((p.to(torch.int64)[None, :].expand(k, -1), toks64[i]), dim=1), "beam_scores": scores[i]}
+            for i, p in enumerate(prompts)]
+
+
 def _result(prompt: torch.Tensor, toks: torch.Tensor, scores: torch.Tensor, k: int) -> Dict:
     seq = torch.cat((prompt.to(torch.int64)[None, :].repeat(k, 1), toks.to(torch.int64)), dim=1)
     return {"beam_sequence": seq, "beam_scores": scores}
@@ -289,9 +309,7 @@ def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_token
     decs = [_Decoder.get(target_model, draft_model, int(p.numel()), lane=i) for i, p in enumerate(prompts)]
     _set_sampling(decs, mode)
     with torch.cuda.device(dev):
-        ids32 = [p.to(torch.int32).contiguous() for p in prompts]
-        toks = [torch.empty(k, max_new_tokens, dtype=torch.int32, device=dev) for _ in range(n)]
-        scores = [torch.empty(k, dtype=torch.float32, device=dev) for _ in range(n)]
+        ids32, toks, scores, _keep = _batch_buffers(prompts, k, max_new_tokens, dev)
         stats = (_lib.GenStats * n)()
         arr_p = (C.c_void_p * n)
         _lib.check(lib.atspeed_bssd_generate_batch(
@@ -301,9 +319,10 @@ def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_token
             arr_p(*[t.data_ptr() for t in scores]), stats, _lib.stream_ptr(dev)))
     wall = time.time() - t0
     outs = []
+    results = _batch_results(prompts, toks, scores, k)
     for i in range(n):
         st = stats[i]
-        out = _result(prompts[i], toks[i], scores[i], k)
+        out = results[i]
         n_run, total = int(st.n_run), int(st.total_accept_steps)
         out.update({"n_run": n_run, "total_accept_steps": total, "total_accept_tokens": total * k,
                     "ave_accept_tokens": total * k / n_run if n_run else 0.0,
@@ -379,9 +398,7 @@ def target_generate_batch(model, inputs_list, max_new_tokens: int, prefix_allowe
     decs = [_Decoder.get(model, None, int(p.numel()), lane=i) for i, p in enumerate(prompts)]
     _set_sampling(decs, mode)
     with torch.cuda.device(dev):
-        ids32 = [p.to(torch.int32).contiguous() for p in prompts]
-        toks = [torch.empty(k, max_new_tokens, dtype=torch.int32, device=dev) for _ in range(n)]
-        scores = [torch.empty(k, dtype=torch.float32, device=dev) for _ in range(n)]
+        ids32, toks, scores, _keep = _batch_buffers(prompts, k, max_new_tokens, dev)
         stats = (_lib.GenStats * n)()
         arr_p = (C.c_void_p * n)
         _lib.check(lib.atspeed_target_generate_batch(
@@ -391,8 +408,9 @@ def target_generate_batch(model, inputs_list, max_new_tokens: int, prefix_allowe
             _lib.stream_ptr(dev)))
     wall = time.time() - t0
     outs = []
+    results = _batch_results(prompts, toks, scores, k)
     for i in range(n):
-        out = _result(prompts[i], toks[i], scores[i], k)
+        out = results[i]
         out.update({"n_valid": int(stats[i].n_valid), "device_time_cost": stats[i].total_ms * 1e-3, "time_cost": wall / n})
         outs.append(out)
     return outs
