@@ -13,7 +13,7 @@ kw = dict(max_slots=512, max_tokens=512, max_logit_rows=384, device=dev)
 t = HipLlama.from_synthetic(synth.llama_7b(V, 32), 2025, dtype=torch.bfloat16, num_beams=20, **kw)
 d = HipLlama.from_synthetic(synth.llama_68m(V), 2026, dtype=torch.bfloat16, num_beams=40, **kw)
 fn = PositionSetConstraint(synth.BEAUTY.allowed_tokens(), synth.RESPONSE_SEP)
-n = 64
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 plens = synth.prompt_lengths(n, 2025)
 prompts = [{"input_ids": torch.from_numpy(synth.synthetic_prompt(int(plens[u]), synth.tensor_seed(2025, f"user{u}")))[None].to(dev)} for u in range(n)]
 BSSD_batch(t, d, prompts, 4, 4, prefix_allowed_tokens_fn=fn)
