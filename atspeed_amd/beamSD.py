@@ -154,6 +154,18 @@ def _compile_constraint(fn, prompt):
     return fn.compile(prompt)
 
 
+def _prompt_lists(prompts):
+    """Token lists of all prompts with ONE device-to-host copy (a `.tolist()` per user is a synchronising copy each)."""
+    if len(prompts) == 1:
+        return [prompts[0].tolist()]
+    flat = torch.cat([p.reshape(-1) for p in prompts]).tolist()
+    out, s0 = [], 0
+    for p in prompts:
+        out.append(flat[s0: s0 + p.numel()])
+        s0 += p.numel()
+    return out
+
+
 def _check_models(*models):
     for m in models:
         if not isinstance(m, HipLlama):
@@ -301,7 +313,7 @@ def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_token
     dk = int(draft_model.generation_config.num_beams)
     t0 = time.time()
     prompts = [_prompt_row(inp).to(dev) for inp in inputs_list]
-    fsms = [_compile_constraint(prefix_allowed_tokens_fn, p.tolist()) for p in prompts]
+    fsms = [_compile_constraint(prefix_allowed_tokens_fn, ids) for ids in _prompt_lists(prompts)]
     dfsm = _DeviceFSM.get(fsms[0], target_model.dims.vocab_size)
     for f in fsms[1:]:
         if f.row_ptr is not fsms[0].row_ptr:
@@ -390,7 +402,7 @@ def target_generate_batch(model, inputs_list, max_new_tokens: int, prefix_allowe
     k = int(model.generation_config.num_beams)
     t0 = time.time()
     prompts = [_prompt_row(inp).to(dev) for inp in inputs_list]
-    fsms = [_compile_constraint(prefix_allowed_tokens_fn, p.tolist()) for p in prompts]
+    fsms = [_compile_constraint(prefix_allowed_tokens_fn, ids) for ids in _prompt_lists(prompts)]
     dfsm = _DeviceFSM.get(fsms[0], model.dims.vocab_size)
     for f in fsms[1:]:
         if f.row_ptr is not fsms[0].row_ptr:
