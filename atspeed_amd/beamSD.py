@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import ctypes as C
 import time
+import weakref
 from typing import Dict, Optional
 
 import numpy as np
@@ -105,7 +106,11 @@ class _DeviceFSM:
 
 
 class _Decoder:
+    """One user stream (private KV arenas + beam state) of a (target, draft) pair.  The cache refers to its models WEAKLY and
+    drops a model's decoders when the model is collected, so `del model` really frees the weights and the ~0.27 GB of KV
+    arenas per lane (a `--run_beam_sizes` sweep would otherwise keep every beam size's models resident)."""
     _cache: Dict[tuple, "_Decoder"] = {}
+    _watched: set = set()
 
     def __init__(self, target: HipLlama, draft: Optional[HipLlama], max_prompt: int):
         lib = _lib.load()
@@ -114,7 +119,11 @@ class _Decoder:
             _lib.check(lib.atspeed_decoder_create(target._handle, draft._handle if draft is not None else None,
                                                   max_prompt, C.byref(h)))
         self.handle, self.max_prompt = h, max_prompt
-        self.models = (target, draft)
+        self.models = (weakref.ref(target), weakref.ref(draft) if draft is not None else None)
+        for m in (target, draft):
+            if m is not None and id(m) not in _Decoder._watched:
+                _Decoder._watched.add(id(m))
+                weakref.finalize(m, _evict_model, id(m))
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -125,22 +134,32 @@ class _Decoder:
                 pass
             self.handle = None
 
+    def serves(self, target, draft) -> bool:
+        return self.models[0]() is target and (self.models[1]() if self.models[1] is not None else None) is draft
+
     @classmethod
     def get(cls, target: HipLlama, draft: Optional[HipLlama], prompt_len: int, lane: int = 0) -> "_Decoder":
         """One decoder (= one user stream: private KV + activations) per (model pair, lane)."""
-        key = (id(target), id(draft), lane)
+        key = (id(target), id(draft) if draft is not None else None, lane)
         d = cls._cache.get(key)
-        if d is None or d.max_prompt < prompt_len or d.models[0] is not target or d.models[1] is not draft:
+        if d is None or d.max_prompt < prompt_len or not d.serves(target, draft):
             d = cls(target, draft, max(prompt_len, min(target.max_tokens, 512)))
             cls._cache[key] = d
         return d
+
+
+def _evict_model(model_id: int) -> None:
+    """weakref.finalize callback: the model with this id() is gone, so are the decoders that used it."""
+    _Decoder._watched.discard(model_id)
+    for k in [k for k in _Decoder._cache if model_id in k[:2]]:
+        del _Decoder._cache[k]
 
 
 def release_decoders(*models) -> int:
     """Free the cached per-user decoders (KV arenas: ~270 MB each at Llama-7B dims, 512 slots) of the given models, or all of
     them when called without arguments; returns how many were freed.  They are re-created on demand."""
     ids = {id(m) for m in models}
-    keys = [k for k, d in _Decoder._cache.items() if not ids or id(d.models[0]) in ids or (d.models[1] is not None and id(d.models[1]) in ids)]
+    keys = [k for k in _Decoder._cache if not ids or k[0] in ids or k[1] in ids]
     for k in keys:
         del _Decoder._cache[k]
     return len(keys)
@@ -432,7 +451,7 @@ def last_trace(target_model, draft_model):
     """Per-round trace of the last BSSD call on this model pair (parity tests):
     list of dict(draft_len, n_matches, n_beams, draft_ids=[draft_len][dk])."""
     lib = _lib.load()
-    dec = _Decoder._cache[(id(target_model), id(draft_model), 0)]
+    dec = _Decoder._cache[(id(target_model), id(draft_model) if draft_model is not None else None, 0)]
     n = lib.atspeed_decoder_trace(dec.handle, None, 0)
     buf = (C.c_int32 * max(n, 1))()
     lib.atspeed_decoder_trace(dec.handle, buf, n)

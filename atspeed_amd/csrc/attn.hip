@@ -480,7 +480,8 @@ int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const Seg
 #define ATS_ATTN32(DHV, NWV)                                                                                                   \
   {                                                                                                                            \
     constexpr int lds_bytes = 2 * (64 * DHV * 2 + 64 * (DHV * 2 + 32));                                                        \
-    static thread_local bool attr_done = false;                                                                                \
+    static thread_local AtsPerDeviceFlag attr_flag;                                                                            \
+    bool& attr_done = attr_flag.cur();                                                                                         \
     if (!attr_done) {                                                                                                          \
       ATS_HIP(hipFuncSetAttribute((const void*)tree_attn32_kernel<DHV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
       attr_done = true;                                                                                                        \

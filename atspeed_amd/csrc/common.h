@@ -43,6 +43,19 @@ void atspeed_set_error(const char* fmt, ...);
     if (_s != ATSPEED_OK) return _s; \
   } while (0)
 
+// per-(thread, device) state: one process may drive several GPUs from one thread, so staging buffers, events and the
+// "function attribute set" flags are kept per HIP device, selected by the device current at the call
+constexpr int ATS_MAX_DEVICES = 16;
+inline int ats_cur_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= ATS_MAX_DEVICES) d = 0;
+  return d;
+}
+struct AtsPerDeviceFlag {
+  bool done[ATS_MAX_DEVICES] = {};
+  bool& cur() { return done[ats_cur_device()]; }
+};
+
 // counter-based hash shared by the synthetic-weight fill and the sampling kernels (= atspeed_amd/synth.py:hash_u32)
 __host__ __device__ inline uint32_t ats_fmix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;

@@ -40,12 +40,12 @@ struct StageRing {
   char *host = nullptr, *dev = nullptr;
   size_t cap = 0, used = 0;
 };
-thread_local StageRing g_stage;
+thread_local StageRing g_stage_dev[ATS_MAX_DEVICES];      // one ring per device (ats_cur_device)
 constexpr size_t kStageBytes = 8u << 20;
 }  // namespace
 
 int ats_stage(const void* host_obj, size_t bytes, const void** dev_out, hipStream_t st) {
-  StageRing& r = g_stage;
+  StageRing& r = g_stage_dev[ats_cur_device()];
   if (!r.host) {
     ATS_HIP(hipHostMalloc((void**)&r.host, kStageBytes));
     ATS_HIP(hipMalloc((void**)&r.dev, kStageBytes));
@@ -62,7 +62,7 @@ int ats_stage(const void* host_obj, size_t bytes, const void** dev_out, hipStrea
 }
 // the same through the pinned ring, but to a device address of the caller's choice
 int ats_stage_to(const void* host_obj, size_t bytes, void* dev_dst, hipStream_t st) {
-  StageRing& r = g_stage;
+  StageRing& r = g_stage_dev[ats_cur_device()];
   if (!r.host) {
     ATS_HIP(hipHostMalloc((void**)&r.host, kStageBytes));
     ATS_HIP(hipMalloc((void**)&r.dev, kStageBytes));
@@ -76,7 +76,7 @@ int ats_stage_to(const void* host_obj, size_t bytes, void* dev_dst, hipStream_t 
   r.used += need;
   return ATSPEED_OK;
 }
-void ats_stage_reset() { g_stage.used = 0; }
+void ats_stage_reset() { g_stage_dev[ats_cur_device()].used = 0; }
 
 // ---------------------------------------------------------------------------- FSM
 extern "C" int atspeed_fsm_create(const int32_t* row_ptr, const int32_t* tok, const int32_t* nxt, int32_t n_nodes,
@@ -724,8 +724,14 @@ static int mailbox_status(atspeed_decoder* d) {
 }
 
 // ---- a group of users decoded in lock step ----------------------------------------------------------------------
-static thread_local hipEvent_t g_ev[8];
-static thread_local bool g_ev_init = false;
+struct StageEvents { hipEvent_t ev[8]; bool init = false; };
+static thread_local StageEvents g_ev_dev[ATS_MAX_DEVICES];    // stage-time events, per device
+static int stage_events(hipEvent_t** out) {
+  StageEvents& s = g_ev_dev[ats_cur_device()];
+  if (!s.init) { for (auto& e : s.ev) ATS_HIP(hipEventCreate(&e)); s.init = true; }
+  *out = s.ev;
+  return ATSPEED_OK;
+}
 
 template <typename A>
 static int stage_args(const std::vector<A>& v, const A** dev_out, hipStream_t st) {
@@ -787,7 +793,8 @@ static int bssd_begin(atspeed_decoder* d, const int32_t* prompt, int P, const at
 static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
   atspeed_llama *T = decs[0]->target, *D = decs[0]->draft;
   const int W = decs[0]->W;
-  if (!g_ev_init) { for (auto& e : g_ev) ATS_HIP(hipEventCreate(&e)); g_ev_init = true; }
+  hipEvent_t* g_ev = nullptr;
+  ATS_TRY(stage_events(&g_ev));
   // capacity for the largest possible batched forward of this group
   int cap_t = 0, cap_r = 0, cap_d = 0;
   for (int u = 0; u < n; ++u) {
@@ -843,7 +850,7 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
         a.src = i == 0 ? d->round_beams[r.cur] : d->blk[i]; a.n_src = t.seg[j].n_logit; a.gen_len = r.gen + i;
         a.logits = D->act->logits + (size_t)t.seg[j].logit_row0 * D->logits_ld; a.ld = D->logits_ld;
         a.lse = D->act->lse + t.seg[j].logit_row0; a.fsm = r.fsm->dev; a.k = r.dk;
-        a.dst = d->blk[i + 1]; a.emit = 1;
+        a.dst = d->blk[i + 1]; a.emit = 1; a.filter_ids = 1;
         a.in = tin; a.in_row0 = i == 0 ? r.n0 - r.nb : r.n0 + (i - 1) * r.dk;
         a.out = tin; a.out_row0 = r.n0 + i * r.dk; a.out_slot0 = r.base + r.n0 + i * r.dk; a.vis_words = W;
         a.mail = d->mail_dev;
@@ -912,7 +919,7 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
         a.src = d->round_beams[r.cur]; a.n_src = r.nb; a.gen_len = r.gen;
         a.logits = T->act->logits + (size_t)sg.logit_row0 * T->logits_ld; a.ld = T->logits_ld;
         a.lse = T->act->lse + sg.logit_row0; a.fsm = r.fsm->dev; a.k = r.k;
-        a.dst = d->round_beams[r.cur ^ 1]; a.emit = 0; a.mail = d->mail_dev; a.vis_words = W;
+        a.dst = d->round_beams[r.cur ^ 1]; a.emit = 0; a.filter_ids = 1; a.mail = d->mail_dev; a.vis_words = W;
         if (d->sample) { a.sample = 1; a.temperature = d->temperature; a.rng_sub = ats_rng_sub(d->seed, ATS_RNG_STEP, r.s.n_run, 0, 0); }
         fargs.push_back(a);
       }
@@ -1015,7 +1022,8 @@ extern "C" int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt
   ATS_REQUIRE(P + max_new * k <= T->cfg.max_slots, ATSPEED_ERR_CAPACITY, "target_generate: KV slots exhausted");
   ATS_REQUIRE(P + max_new * k <= d->tok_cap, ATSPEED_ERR_CAPACITY, "target_generate: token buffer too small");
   ATS_TRY(ensure_act(T, std::max(P, k), MAXB));
-  if (!g_ev_init) { for (auto& e : g_ev) ATS_HIP(hipEventCreate(&e)); g_ev_init = true; }
+  hipEvent_t* g_ev = nullptr;
+  ATS_TRY(stage_events(&g_ev));
   TokBuf& tin = d->tin[0];
   ATS_TRY(ats_init_prompt(tin, prompt, P, W, d->round_beams[0], start_node, T->cfg.vocab_size, d->mail_dev, st));
   hipEventRecord(g_ev[0], st);
@@ -1030,7 +1038,7 @@ extern "C" int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt
     BeamStepArgs a{};
     a.src = d->round_beams[cur]; a.n_src = nb; a.gen_len = g;
     a.logits = T->act->logits; a.ld = T->logits_ld; a.lse = T->act->lse; a.fsm = fsm->dev; a.k = k;
-    a.dst = d->round_beams[cur ^ 1]; a.emit = 1;
+    a.dst = d->round_beams[cur ^ 1]; a.emit = 1; a.filter_ids = 1;
     a.in = tin; a.in_row0 = row0 + n_in - nb;
     a.out = tin; a.out_row0 = row0 + n_in; a.out_slot0 = base + n_in; a.vis_words = W;
     a.mail = d->mail_dev;
@@ -1071,7 +1079,8 @@ extern "C" int atspeed_target_generate_batch(atspeed_decoder** decs, int32_t n, 
     cap_t += std::max(prompt_lens[u], k);
   }
   ATS_TRY(ensure_act(T, cap_t, n * MAXB));
-  if (!g_ev_init) { for (auto& e : g_ev) ATS_HIP(hipEventCreate(&e)); g_ev_init = true; }
+  hipEvent_t* g_ev = nullptr;
+  ATS_TRY(stage_events(&g_ev));
   for (int u = 0; u < n; ++u)
     ATS_TRY(ats_init_prompt(decs[u]->tin[0], prompts[u], prompt_lens[u], W, decs[u]->round_beams[0], start_nodes[u], T->cfg.vocab_size,
                             decs[u]->mail_dev, st));
@@ -1092,7 +1101,7 @@ extern "C" int atspeed_target_generate_batch(atspeed_decoder** decs, int32_t n, 
       a.src = d->round_beams[s[u].cur]; a.n_src = s[u].nb; a.gen_len = g;
       a.logits = T->act->logits + (size_t)t.seg[u].logit_row0 * T->logits_ld; a.ld = T->logits_ld;
       a.lse = T->act->lse + t.seg[u].logit_row0; a.fsm = fsm->dev; a.k = k;
-      a.dst = d->round_beams[s[u].cur ^ 1]; a.emit = 1;
+      a.dst = d->round_beams[s[u].cur ^ 1]; a.emit = 1; a.filter_ids = 1;
       a.in = d->tin[0]; a.in_row0 = s[u].row0 + s[u].n_in - s[u].nb;
       a.out = d->tin[0]; a.out_row0 = s[u].row0 + s[u].n_in; a.out_slot0 = s[u].base + s[u].n_in; a.vis_words = W;
       a.mail = d->mail_dev;

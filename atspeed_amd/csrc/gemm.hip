@@ -640,7 +640,8 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
   static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
   static const int force_mt = env_int("ATSPEED_GEMM_FORCE_MT", 0);     // tuning: 8 / 4 = always 256- / 128-row token tiles
   const int tiles_n = (n + 255) / 256;
-  static thread_local bool attr_done = false;
+  static thread_local AtsPerDeviceFlag attr_flag;
+  bool& attr_done = attr_flag.cur();
   if (!attr_done) {
     ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -657,7 +658,8 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
 #endif
   static const int four_waves = env_int("ATSPEED_GEMM_4WAVE", 0);
   if (use256 && four_waves) {
-    static thread_local bool a4 = false;
+    static thread_local AtsPerDeviceFlag a4_flag;
+    bool& a4 = a4_flag.cur();
     if (!a4) { ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); a4 = true; }
     hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false, false, 8>), dim3(t256), dim3(256), 128 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1);
     ATS_LAUNCH_CHECK();
@@ -735,7 +737,8 @@ int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char*
                    int ldc, hipStream_t st) {
   static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
   const int tiles_n = (n + 255) / 256;
-  static thread_local bool attr_done = false;
+  static thread_local AtsPerDeviceFlag attr_flag;
+  bool& attr_done = attr_flag.cur();
   if (!attr_done) {
     ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -834,7 +837,8 @@ static int ring_split_count(int m, int n, int k) {
 template <int EPI>
 int launch_ring_split(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, int lda, int ldc, int splits, float* partial,
                       hipStream_t st, FusedNorm* fn) {
-  static thread_local bool attr_done = false;
+  static thread_local AtsPerDeviceFlag attr_flag;
+  bool& attr_done = attr_flag.cur();
   if (!attr_done) {
     ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI_F32, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI_F32, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));

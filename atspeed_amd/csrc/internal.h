@@ -115,6 +115,7 @@ struct BeamStepArgs {
   int k;
   BeamSet dst;
   int emit;                                   // write next-step inputs?
+  int filter_ids;                             // one_step_beam_search's post-top-k id filter (beamSD.py:80-86); off for verify-style expands
   TokBuf in;   int in_row0;                   // rows of the src beams (for parent vis/pos)
   TokBuf out;  int out_row0;  int out_slot0;  int vis_words;
   Mailbox* mail;                              // status only

@@ -400,7 +400,26 @@ __device__ void beam_step_body(const BeamStepArgs& a) {
     }
   }
   __syncthreads();
-  emit_block(pk, tid, a.k, a.src, a.gen_len, a.dst, a.emit != 0, a.in, a.in_row0, a.out, a.out_row0, a.out_slot0, a.vis_words);
+  int slot = tid;
+  if (a.filter_ids) {
+    // beamSD.py:80-86: picks whose token is neither an item code (>= 32000) nor EOS (2) are dropped AFTER the top-k, so the
+    // beam set shrinks instead of lower-ranked candidates moving up; the survivors keep their order (stable compaction),
+    // the freed slots hold "no beam" (flat = -1) at the end of the block
+    __shared__ int keep[MAXB];
+    const bool ok = tid < a.k && pk.flat >= 0 && (pk.tok >= 32000 || pk.tok == 2);
+    if (tid < MAXB) keep[tid] = ok ? 1 : 0;
+    __syncthreads();
+    if (tid < a.k) {
+      int before = 0, total = 0;
+      for (int j = 0; j < a.k; ++j) { total += keep[j]; before += (j < tid) ? keep[j] : 0; }
+      slot = ok ? before : total + (tid - before);
+      if (!ok) { pk.score = -INFINITY; pk.parent = 0; pk.tok = 0; pk.node = 0; pk.flat = -1; }
+    }
+    __syncthreads();
+    if (tid < a.k) parents[slot] = pk.parent;
+    __syncthreads();
+  }
+  emit_block(pk, slot, a.k, a.src, a.gen_len, a.dst, a.emit != 0, a.in, a.in_row0, a.out, a.out_row0, a.out_slot0, a.vis_words);
   if (a.emit) emit_vis(parents, a.k, a.in, a.in_row0, a.out, a.out_row0, a.out_slot0, a.vis_words);
   if (a.mail) {
     int valid = __syncthreads_count(tid < a.k && pk.flat >= 0);

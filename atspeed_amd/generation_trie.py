@@ -110,26 +110,30 @@ class Trie:
 
     # -- device form ------------------------------------------------------------
     def flatten(self, root_prefix: Sequence[int] = ()) -> "ConstraintFSM":
-        """CSR automaton of the subtree below `root_prefix` (breadth-first node ids,
-        children sorted by token id).  Chained tries (`append`) are not flattened."""
+        """CSR automaton of the subtree below `root_prefix` (breadth-first node ids, children sorted by token id), built by
+        the native `atspeed_trie_flatten` (include/atspeed_hip.h: the C-ABI counterpart of `Trie.__init__` / `_add_to_trie`,
+        reference `code/generation_trie.py:8-14,40-44`).  Chained tries (`append`) are not flattened."""
         if self.append_trie is not None:
             raise NotImplementedError("flatten() of a chained Trie (append) is not supported")
+        import ctypes as C
+        from . import _lib
         root, _ = self._descend([int(t) for t in root_prefix])
-        if root is None:
-            root = {}
-        nodes = [root]
-        row_ptr = [0]
-        tok: List[int] = []
-        nxt: List[int] = []
-        i = 0
-        while i < len(nodes):
-            for t in sorted(nodes[i]):
-                tok.append(int(t))
-                nxt.append(len(nodes))
-                nodes.append(nodes[i][t])
-            row_ptr.append(len(tok))
-            i += 1
-        return ConstraintFSM(np.asarray(row_ptr, np.int32), np.asarray(tok, np.int32), np.asarray(nxt, np.int32), 0)
+        # root-to-leaf sequences of the subtree carry every node (a sequence that is a prefix of another adds none)
+        seqs = [s for s in Trie.load_from_dict(root)] if root else []
+        offsets = np.zeros(len(seqs) + 1, np.int32)
+        if seqs:
+            offsets[1:] = np.cumsum([len(s) for s in seqs])
+        tokens = np.asarray([t for s in seqs for t in s], np.int32) if seqs else np.zeros(1, np.int32)
+        lib = _lib.load()
+        n_nodes, n_edges = C.c_int32(), C.c_int32()
+        _lib.check(lib.atspeed_trie_flatten(tokens.ctypes.data, offsets.ctypes.data, len(seqs), None, None, None,
+                                            C.byref(n_nodes), C.byref(n_edges)))
+        row_ptr = np.zeros(n_nodes.value + 1, np.int32)
+        tok = np.zeros(max(n_edges.value, 1), np.int32)
+        nxt = np.zeros(max(n_edges.value, 1), np.int32)
+        _lib.check(lib.atspeed_trie_flatten(tokens.ctypes.data, offsets.ctypes.data, len(seqs), row_ptr.ctypes.data, tok.ctypes.data,
+                                            nxt.ctypes.data, C.byref(n_nodes), C.byref(n_edges)))
+        return ConstraintFSM(row_ptr, tok[: n_edges.value], nxt[: n_edges.value], 0)
 
 
 @dataclass

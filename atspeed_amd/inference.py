@@ -15,6 +15,7 @@ prompts are laid out as code-token ids (`harness.CodeTokenEncoder`).
 from __future__ import annotations
 
 import argparse
+import ast
 import json
 import os
 import sys
@@ -69,6 +70,7 @@ def load_models(args, vocab_size: int, beam: int, dev):
 
 def main(argv=None):
     args = parse(argv)
+    from .beamSD import release_decoders
     from .dist import Counters, aggregate, all_gather_counters, shard_range
     from .harness import SeqRecTestData, reduce_metrics, run_inference
 
@@ -93,7 +95,7 @@ def main(argv=None):
     lo, hi = shard_range(stop_r - args.L, rank, world)
     fn = data.strict_trie_fn() if args.strict_trie else data.get_prefix_allowed_tokens_fn()
     summary = []
-    for beam in eval(args.run_beam_sizes):                      # the reference evals this flag too (inference.py:144)
+    for beam in ast.literal_eval(args.run_beam_sizes):          # the reference eval()s this flag (inference.py:151); a literal list is all it needs
         tgt, drf = load_models(args, data.index.vocab_size, beam, dev)
         res = run_inference(tgt, drf, data, args.gamma, 4, args.L + lo, args.L + hi, args.users_per_batch, fn, tok, args.baseline, dev)
         c = res.counters()
@@ -111,7 +113,8 @@ def main(argv=None):
             with open(os.path.join(args.output_dir, args.dataset, name), "w") as f:
                 json.dump(row, f, indent=1)
             print(json.dumps(row))
-        del tgt, drf
+        release_decoders(tgt, drf)        # per-lane KV arenas of this beam size (the cache only holds weak references to the models)
+        del tgt, drf, res
     if world > 1:
         torch.distributed.destroy_process_group()
     return summary

@@ -28,6 +28,11 @@ from .llama_ref import RefLlama
 LLAMA_VOCAB = 32000   # beamSD.py:81
 EOS_ID = 2            # beamSD.py:81
 
+# Decision margins (test aid): when a list is installed here, every top-k appends the smallest gap between neighbours
+# among its k + 1 best finite scores.  A comparison with an engine that sums in another order (or in bf16) is only
+# meaningful where this margin is above that engine's rounding noise.
+MARGINS: Optional[List[float]] = None
+
 
 @dataclass
 class StepInputs:
@@ -77,6 +82,11 @@ def expand_and_prune(logits: torch.Tensor, beam_scores: torch.Tensor, beam_seq: 
             logp = constrain(beam_seq, logp, fn)
     flat = (logp + beam_scores.to(torch.float32)[:, None]).reshape(-1)            # :69-70
     scores, idx = topk_desc_stable(flat, beam_size)                               # :76
+    if MARGINS is not None:
+        top = topk_desc_stable(flat, beam_size + 1)[0]
+        top = top[torch.isfinite(top)]
+        if len(top) > 1:
+            MARGINS.append(float((top[:-1] - top[1:]).min()))
     parents, toks = idx // V, idx % V                                             # :77-78
     if fn is not None and drop_disallowed:                                        # :80-86 (one_step only)
         keep = (toks >= LLAMA_VOCAB) | (toks == EOS_ID)

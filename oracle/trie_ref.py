@@ -118,3 +118,24 @@ def ref_suffix_trie_fn(trie: RefTrie, sep: Sequence[int], bos: int = 1):
             raise NameError("sentence_")   # reference: unbound local when "Response:" is absent
         return trie.get(key)
     return fn
+
+
+def ref_flatten(trie_dict: Dict, root_prefix: Sequence[int] = ()):
+    """Plain-Python flattening of a nested-dict trie into the CSR automaton (breadth-first node ids, children ascending by
+    token id): the comparator for the native `atspeed_trie_flatten`.  Returns (row_ptr, tok, nxt) lists."""
+    root = trie_dict
+    for t in root_prefix:
+        root = root.get(t)
+        if root is None:
+            root = {}
+            break
+    nodes, row_ptr, tok, nxt = [root], [0], [], []
+    i = 0
+    while i < len(nodes):
+        for t in sorted(nodes[i]):
+            tok.append(int(t))
+            nxt.append(len(nodes))
+            nodes.append(nodes[i][t])
+        row_ptr.append(len(tok))
+        i += 1
+    return row_ptr, tok, nxt

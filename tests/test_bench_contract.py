@@ -1,46 +1,84 @@
-"""The committed bench line (profiles/r01_final_bench.json = the last `python bench.py` of the round on an MI355X) carries every field of
-the driver's contract, with consistent arithmetic.  CPU-only: guards the JSON shape, not the numbers."""
-import json
-import os
+"""Host logic of bench.py that decides what the driver's JSON line says (CPU only, no GPU call): how the rank count is resolved
+(`--gpus N` must give N ranks or fail loudly), the torchrun command it starts, the provenance of `roofline.traffic`, and the
+oracle-side scoring behind `cpu_baseline.bf16_vs_fp32_disagreements`."""
+import argparse
+import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+import pytest
+import torch
 
-
-def _line():
-    with open(os.path.join(ROOT, "profiles", "r01_final_bench.json")) as f:
-        return json.load(f)
-
-
-def test_contract_fields_present():
-    d = _line()
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline"):
-        assert k in d, k
-    assert d["unit"] == "items/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["dtype"] == "bf16" and "synthetic" in d["data"]
-    assert "workload" in d["config"] and "model" not in d["config"]
-    assert d["n_gpus"] == 1 and d["steps"] >= 1
+import bench
+from atspeed_amd import synth
+from atspeed_amd.generation_trie import PositionSetConstraint
+from oracle import beamsd_ref as R
+from oracle.llama_ref import RefLlama
 
 
-def test_value_is_users_times_beams_over_time():
-    d = _line()
-    users = d["config"]["users_per_step"] * d["steps"]
-    items = users * 20                                    # K = 20 beams per user (BASELINE.json)
-    assert abs(d["value"] - items / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"] + 1e-3
+def _args(gpus):
+    return argparse.Namespace(gpus=gpus)
 
 
-def test_roofline_and_cpu_baseline_objects():
-    d = _line()
-    r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["peak"] == (2500.0 if r["bound"] == "mfma" else 8000.0)       # nominal peaks of /opt/skills/guides/MI355X_MICROARCH.md
-    assert r["traffic"] is None or r["traffic"] > 0
-    c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in c, k
-    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
-    s = d["verify_scan"]
-    assert s["bound"] == "hbm" and abs(s["frac"] - s["achieved"] / s["peak"]) < 1e-9
+def test_rank_count_comes_from_gpus_flag():
+    assert bench.resolve_world(_args(1), env={}) == ("run", 0, 0, 1)
+    assert bench.resolve_world(_args(8), env={}) == ("spawn", 8)                       # plain `python bench.py --gpus 8`: start 8 ranks
+    assert bench.resolve_world(_args(4), env={"WORLD_SIZE": "4", "RANK": "3", "LOCAL_RANK": "3"}) == ("run", 3, 3, 4)
+    assert bench.resolve_world(_args(1), env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}) == ("run", 0, 0, 1)
+    for gpus, world in ((8, 1), (1, 2), (2, 4)):                                        # a line must never claim another n_gpus than it ran
+        with pytest.raises(SystemExit) as e:
+            bench.resolve_world(_args(gpus), env={"WORLD_SIZE": str(world), "RANK": "0"})
+        assert "--gpus" in str(e.value) and "WORLD_SIZE" in str(e.value)
+
+
+def test_launcher_command_is_the_drivers_torchrun_line():
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "3", "--warmup", "1"], port=29611)
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29611"
+    i = cmd.index(bench.os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]             # the children see the same flags (incl. --gpus)
+
+
+def test_traffic_carries_its_provenance():
+    v, src = bench.traffic_from_profiles("gate_up")
+    assert v is not None and v > 0 and "profiles/pmc_traffic.json" in src and "not measured in this run" in src
+    assert bench.traffic_from_profiles("no_such_kernel") == (None, None)
+
+
+def test_oracle_scores_of_reproduces_the_oracles_own_beam_scores():
+    """The packed tree forward that scores arbitrary sequences must give, for the oracle's own final beams, the oracle's beam scores."""
+    V = synth.TINY.vocab_size
+    dims = synth.LlamaDims(V, 64, 2, 4, 128)
+    sd = synth.synthetic_state_dict(dims, 5, std=0.08, head_std=0.3)
+    m = RefLlama(dims, sd)
+    fn = PositionSetConstraint(synth.TINY.allowed_tokens(), synth.RESPONSE_SEP)
+    prompt = synth.synthetic_prompt(20, 9)
+    ref = R.target_generate(m, prompt, 4, 6, fn)
+    seqs = ref["beam_sequence"][:, len(prompt):].tolist()
+    got = bench.oracle_scores_of(m, prompt, seqs)
+    np.testing.assert_allclose(got, ref["beam_scores"].numpy(), atol=2e-5, rtol=0)
+
+
+def test_disagreement_report_scores_both_items_with_the_oracle():
+    V = synth.TINY.vocab_size
+    dims = synth.LlamaDims(V, 64, 2, 4, 128)
+    m = RefLlama(dims, synth.synthetic_state_dict(dims, 5, std=0.08, head_std=0.3))
+    fn = PositionSetConstraint(synth.TINY.allowed_tokens(), synth.RESPONSE_SEP)
+    prompt = synth.synthetic_prompt(20, 9)
+    P = len(prompt)
+    ref = R.target_generate(m, prompt, 4, 6, fn)
+    same = {"beam_sequence": ref["beam_sequence"].clone(), "beam_scores": ref["beam_scores"].clone()}
+    rep = bench.disagreement_report(same, ref, P, m, prompt)
+    assert rep["top_k_overlap"] == 1.0 and rep["ranks_that_differ"] == []
+    # an "engine" that swapped ranks 2 and 3 and replaced the last item by a worse one
+    seq = ref["beam_sequence"].clone()
+    seq[[2, 3]] = seq[[3, 2]]
+    seq[5, P + 3] = seq[5, P + 3] + 1 if int(seq[5, P + 3]) + 1 < V else seq[5, P + 3] - 1
+    other = {"beam_sequence": seq, "beam_scores": ref["beam_scores"].clone()}
+    rep = bench.disagreement_report(other, ref, P, m, prompt)
+    assert rep["ranks_that_differ"] == [2, 3, 5] and rep["top_k_overlap"] == pytest.approx(5 / 6)
+    rows = {r["rank"]: r for r in rep["per_rank"]}
+    sc = ref["beam_scores"].tolist()
+    assert rows[2]["gap"] == pytest.approx(sc[2] - sc[3], abs=2e-5) and rows[3]["gap"] == pytest.approx(sc[3] - sc[2], abs=2e-5)
+    assert rows[5]["oracle_score_of_oracle_item"] == pytest.approx(sc[5])
+    assert rep["max_gap"] >= abs(rows[2]["gap"])

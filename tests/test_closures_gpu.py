@@ -1,0 +1,184 @@
+"""GPU closures of SURVEY.md section 8 rows that had no hardware test: M1 (`prefix_allowed_tokens_fn(trie)` keyed on the whole
+sentence, generation_trie.py:92-98), the post-top-k id filter of one_step_beam_search (beamSD.py:80-86) on the device path,
+config 3 at its stated batch (Games, strict trie, 256 users in lock step), the RCCL collective, and the decoder cache's
+lifetime across a beam-size sweep (inference.py:151)."""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import atspeed_amd
+from atspeed_amd import synth
+from atspeed_amd.beamSD import BSSD, BSSD_batch, _Decoder, last_trace, release_decoders, target_generate
+from atspeed_amd.generation_trie import SuffixTrieConstraint, Trie, prefix_allowed_tokens_fn
+from atspeed_amd.model import HipLlama
+from oracle import beamsd_ref as R
+from oracle.llama_ref import RefLlama
+from oracle.trie_ref import RefTrie, ref_whole_sentence_fn
+from tests.golden.cases import CASES, build_case_inputs
+
+SCORE_TOL = 1e-3
+
+
+def _models(ci, K, DK, dtype=torch.float32):
+    kw = dict(max_slots=512, max_tokens=512, max_logit_rows=448)
+    t = HipLlama.from_state_dict(ci["target_dims"], ci["target_sd"], dtype, num_beams=K, **kw)
+    d = HipLlama.from_state_dict(ci["draft_dims"], ci["draft_sd"], dtype, num_beams=DK, **kw)
+    return t, d
+
+
+def _same_as_oracle(out, ref, P):
+    nv = out["n_valid"]
+    assert nv == ref["beam_sequence"].shape[0]
+    assert out["beam_sequence"][:nv, P:].cpu().tolist() == ref["beam_sequence"][:, P:].tolist()
+    np.testing.assert_allclose(out["beam_scores"][:nv].cpu().numpy(), ref["beam_scores"].numpy(), atol=SCORE_TOL, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["k20_dk40_sigma01_s7", "k5_dk10_indep"])
+def test_whole_sentence_trie_fn_through_the_hip_path(name):
+    """M1: the callable `prefix_allowed_tokens_fn(trie)` looks the ENTIRE sentence (prompt included) up in the trie, so the
+    trie holds prompt ++ item codes ++ eos.  Compiled to the device automaton (start node = the prompt's node) it must make
+    the oracle's decisions (oracle: the same lookups on the host, `ref_whole_sentence_fn`)."""
+    case = next(c for c in CASES if c["name"] == name)
+    ci = build_case_inputs(case)
+    prompt = [int(t) for t in ci["prompt"]]
+    seqs = [prompt + [int(t) for t in it] + [2] for it in ci["items"]]
+    fn = prefix_allowed_tokens_fn(Trie(seqs))
+    ref_fn = ref_whole_sentence_fn(RefTrie(seqs))
+    tgt, drf = _models(ci, case["K"], case["DK"])
+    P = len(prompt)
+    inputs = {"input_ids": torch.from_numpy(ci["prompt"])[None].cuda()}
+    rt, rd = RefLlama(ci["target_dims"], ci["target_sd"]), RefLlama(ci["draft_dims"], ci["draft_sd"])
+    ref = R.BSSD(rt, rd, ci["prompt"], case["gamma"], case["max_new_tokens"], case["K"], case["DK"], ref_fn)
+    out = BSSD(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=fn)
+    _same_as_oracle(out, ref, P)
+    assert (out["n_run"], out["accept_steps"]) == (ref["n_run"], [r["n_matches"] for r in ref["rounds"]])
+    for r, g in zip(last_trace(tgt, drf), ref["rounds"]):
+        for ids, gids in zip(r["draft_ids"], g["draft_ids"]):
+            assert [x for x in ids if x >= 0] == gids
+    tg = target_generate(tgt, inputs, case["max_new_tokens"], prefix_allowed_tokens_fn=fn)
+    _same_as_oracle(tg, R.target_generate(rt, ci["prompt"], case["max_new_tokens"], case["K"], ref_fn), P)
+    items = {tuple(int(t) for t in it) for it in ci["items"]}
+    assert all(tuple(g) in items for g in out["beam_sequence"][: out["n_valid"], P:].cpu().tolist())
+    # a prompt the trie does not contain: the reference's fn returns [] and HF raises ValueError
+    with pytest.raises(ValueError):
+        BSSD(tgt, drf, {"input_ids": torch.tensor([prompt[:-1] + [77]]).cuda()}, 4, 4, prefix_allowed_tokens_fn=fn)
+
+
+def test_post_topk_id_filter_on_device_host_and_oracle_paths():
+    """beamSD.py:80-86 drops picks whose token is < 32000 and != 2 AFTER the top-k (the beam set shrinks, lower-ranked candidates
+    do not move up).  A trie that allows such a token makes the filter bite: the compiled device path, the host-callable path
+    (hostmask.py) and the oracle must agree, in plain beam search and inside BSSD's draft steps."""
+    case = next(c for c in CASES if c["name"] == "k5_dk10_indep")
+    ci = build_case_inputs(case)
+    prompt = [int(t) for t in ci["prompt"]]
+    firsts = sorted({int(it[0]) for it in ci["items"]})[:9]
+    items = [next(it for it in ci["items"] if int(it[0]) == f) for f in firsts]
+    seqs = [prompt + [int(t) for t in it] + [2] for it in items]
+    seqs += [prompt + [7, int(items[0][1]), int(items[0][2]), int(items[0][3]), 2],          # token 7: allowed by the trie, dropped by the filter
+             prompt + [int(items[1][0]), 11, int(items[1][2]), int(items[1][3]), 2]]
+    fn = prefix_allowed_tokens_fn(Trie(seqs))
+    ref_fn = ref_whole_sentence_fn(RefTrie(seqs))
+    closure = lambda b, s: fn(b, s)                                       # no .compile(): served by hostmask.py
+    P = len(prompt)
+    inputs = {"input_ids": torch.from_numpy(ci["prompt"])[None].cuda()}
+    rt, rd = RefLlama(ci["target_dims"], ci["target_sd"]), RefLlama(ci["draft_dims"], ci["draft_sd"])
+    bit = 0
+    for K, DK in ((5, 10), (8, 11)):
+        tgt, drf = _models(ci, K, DK)
+        ref_tg = R.target_generate(rt, ci["prompt"], 4, K, ref_fn)
+        bit += ref_tg["beam_sequence"].shape[0] < K
+        for f in (fn, closure):
+            tg = target_generate(tgt, inputs, 4, prefix_allowed_tokens_fn=f)
+            nv = tg["n_valid"]
+            assert nv == ref_tg["beam_sequence"].shape[0]
+            assert tg["beam_sequence"][:nv, P:].cpu().tolist() == ref_tg["beam_sequence"][:, P:].tolist()
+            np.testing.assert_allclose(tg["beam_scores"][:nv].cpu().numpy(), ref_tg["beam_scores"].numpy(), atol=SCORE_TOL, rtol=0)
+            gen = tg["beam_sequence"][:nv, P:].cpu()
+            assert bool(((gen >= 32000) | (gen == 2)).all())              # nothing the filter drops survives a one_step search
+        ref = R.BSSD(rt, rd, ci["prompt"], 4, 4, K, DK, ref_fn)
+        bit += any(n < DK for r in ref["rounds"] for n in r["step_len"][1:])
+        out = BSSD(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=fn)
+        _same_as_oracle(out, ref, P)
+        assert out["accept_steps"] == [r["n_matches"] for r in ref["rounds"]]
+        for r, g in zip(last_trace(tgt, drf), ref["rounds"]):
+            for ids, gids in zip(r["draft_ids"], g["draft_ids"]):
+                assert [x for x in ids if x >= 0] == gids
+    assert bit >= 1, "the filter never dropped a pick: the case does not exercise beamSD.py:80-86"
+
+
+def test_games_strict_trie_256_users_in_lock_step():
+    """BASELINE config 3 at its stated batch: Games vocabulary (V = 33014), strict item trie, 256 users per lock-step batch
+    (ATS_MAX_SEGS, the query-tile table and the per-user argument staging at their limits), small fp32 models so that four users
+    can be checked against the oracle bit for bit."""
+    vocab = synth.GAMES
+    V = vocab.vocab_size
+    tdims, ddims = synth.LlamaDims(V, 256, 2, 4, 704), synth.LlamaDims(V, 128, 2, 2, 352)
+    tsd = synth.synthetic_state_dict(tdims, 21, std=0.05, head_std=0.3)
+    dsd = synth.synthetic_state_dict(ddims, 22, std=0.05, head_std=0.3)
+    kw = dict(max_slots=512, max_tokens=512, max_logit_rows=448)
+    tgt = HipLlama.from_state_dict(tdims, tsd, torch.float32, num_beams=20, **kw)
+    drf = HipLlama.from_state_dict(ddims, dsd, torch.float32, num_beams=40, **kw)
+    items = synth.synthetic_items(vocab)
+    item_set = {tuple(int(t) for t in it) for it in items}
+    fn = SuffixTrieConstraint(Trie([[1] + [int(t) for t in it] + [2] for it in items]), synth.RESPONSE_SEP, 1)
+    n_users = 256
+    plens = synth.prompt_lengths(n_users, 2025, mean_hist=5.98)           # Games history shape
+    prompts = [synth.synthetic_prompt(int(plens[u]), 7000 + u) for u in range(n_users)]
+    inputs = [{"input_ids": torch.from_numpy(p)[None].cuda()} for p in prompts]
+    bat = BSSD_batch(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=fn)
+    assert len(bat) == n_users
+    rt, rd = RefLlama(tdims, tsd), RefLlama(ddims, dsd)
+    for u in (0, 85, 170, 255):
+        ref = R.BSSD(rt, rd, prompts[u], 4, 4, 20, 40, fn)
+        P = len(prompts[u])
+        nv = bat[u]["n_valid"]
+        assert bat[u]["beam_sequence"][:nv, P:].cpu().tolist() == ref["beam_sequence"][:, P:].tolist()[:nv]
+        np.testing.assert_allclose(bat[u]["beam_scores"][:nv].cpu().numpy(), ref["beam_scores"].numpy()[:nv], atol=SCORE_TOL, rtol=0)
+        assert (bat[u]["n_run"], bat[u]["accept_steps"]) == (ref["n_run"], [r["n_matches"] for r in ref["rounds"]])
+    for u in range(n_users):
+        P = len(prompts[u])
+        toks = bat[u]["beam_sequence"][: bat[u]["n_valid"], P:].cpu().tolist()
+        assert bat[u]["n_valid"] >= 1 and all(tuple(t) in item_set for t in toks)
+        assert len({tuple(t) for t in toks}) == len(toks)
+    release_decoders(tgt, drf)
+
+
+def test_rccl_all_gather_of_counters_one_rank():
+    """The path's single collective on the device backend (`nccl` = RCCL on ROCm), world size 1 on the one GPU of this box."""
+    import torch.distributed as dist
+    from atspeed_amd.dist import Counters, aggregate, all_gather_counters
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29653", rank=0, world_size=1)
+    try:
+        got = all_gather_counters(Counters(256, 768, 19, 1_250_000_000), torch.device("cuda", 0))
+        assert [(c.n_users, c.n_run, c.accept_steps, c.elapsed_ns) for c in got] == [(256, 768, 19, 1_250_000_000)]
+        agg = aggregate(got, 20)
+        assert agg["items_per_s"] == pytest.approx(256 * 20 / 1.25) and agg["mean_accept_len"] == pytest.approx(19 / 768)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_decoder_cache_does_not_keep_models_alive():
+    """a `--run_beam_sizes` sweep must not accumulate weights + KV arenas.  The decoder cache refers to models weakly
+    and evicts their decoders when a model is collected."""
+    case = CASES[0]
+    ci = build_case_inputs(case)
+    inputs = {"input_ids": torch.from_numpy(ci["prompt"])[None].cuda()}
+    release_decoders()
+    gc.collect(); torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    n0 = len(_Decoder._cache)
+    for beam in (1, 5, 10, 20):                                            # the reference's style of sweep (inference.py:151)
+        tgt, drf = _models(ci, beam, 40)
+        BSSD_batch(tgt, drf, [inputs] * 3, 4, 4, prefix_allowed_tokens_fn=ci["fn"])
+        assert len(_Decoder._cache) == n0 + 3
+        del tgt, drf
+        gc.collect()
+        assert len(_Decoder._cache) == n0, "decoders of a collected model stayed in the cache"
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20, "device memory grew across the sweep"

@@ -7,7 +7,7 @@ import torch
 from atspeed_amd import synth
 from atspeed_amd.generation_trie import (PositionSetConstraint, SuffixTrieConstraint, Trie,
                                          WholeSentenceTrieConstraint, prefix_allowed_tokens_fn)
-from oracle.trie_ref import RefTrie, ref_position_set_fn, ref_suffix_trie_fn
+from oracle.trie_ref import RefTrie, ref_flatten, ref_position_set_fn, ref_suffix_trie_fn
 from tests.golden.cases import TRIE_CASES
 
 
@@ -98,3 +98,36 @@ def test_whole_sentence_constraint_compile():
     assert c.compile([1, 5]).allowed(c.compile([1, 5]).start).tolist() == [7, 8]
     with pytest.raises(ValueError):
         c.compile([1, 4])
+
+
+def _same_csr(fsm, ref):
+    return fsm.row_ptr.tolist() == ref[0] and fsm.tok.tolist() == ref[1] and fsm.nxt.tolist() == ref[2]
+
+
+def test_native_trie_flatten_equals_python_flattening():
+    """`Trie.flatten` runs the C-ABI `atspeed_trie_flatten` (host code: works without a GPU); the comparator is the plain-Python
+    breadth-first flattening in the oracle.  Empty tries, duplicate and prefix sequences, a root prefix that is absent."""
+    cases = [[], [[5]], [[1, 2, 3], [1, 2, 3], [1, 2], [4], [1, 5, 6, 7]],
+             [[1] + [int(x) for x in r] + [2] for r in synth.synthetic_items(synth.GAMES)]]
+    for seqs in cases:
+        t = Trie(seqs)
+        for pre in ((), (1,), (1, 2), (9, 9)):
+            assert _same_csr(t.flatten(pre), ref_flatten(RefTrie(seqs).trie_dict, pre)), (len(seqs), pre)
+    with pytest.raises(NotImplementedError):
+        t = Trie([[1, 2]]); t.append(Trie([[3]]), 1); t.flatten()
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/data"), reason="reference data files are only in the build container")
+def test_native_trie_flatten_on_the_real_item_tries():
+    """The strict tries of the real Beauty / Games indices (12 023 / 17 289 distinct code tuples, keyed bos + codes + eos as
+    inference.py:130 builds them): native CSR == Python flattening; node counts per depth as SURVEY.md 8a row T records."""
+    from atspeed_amd.harness import ItemIndex
+    for name, depth_nodes in (("beauty", [91, 6539, 11172, 12023]), ("games", [248, 11317, 16628, 17289])):
+        tr = ItemIndex.load("/root/reference/data", name).trie()
+        fsm = tr.flatten([1])
+        assert _same_csr(fsm, ref_flatten(tr.trie_dict, [1]))
+        level, counts = [0], []
+        for _ in range(4):
+            level = [int(n) for p in level for n in fsm.nxt[fsm.row_ptr[p]: fsm.row_ptr[p + 1]]]
+            counts.append(len(level))
+        assert counts == depth_nodes
