@@ -146,7 +146,9 @@ class SeqRecTestData:
         his = [self.index.item_string(i) for i in u.history]
         if self.add_prefix:
             his = [str(k + 1) + ". " + s for k, s in enumerate(his)]
-        return SFT_PROMPT.format(INSTRUCTION.format(self.his_sep.join(his)))
+        # the reference's llama branch joins with a literal ", " whatever --his_sep says (data.py:246); `his_sep` is kept as a
+        # constructor argument for flag compatibility only (pinned by tests/golden/harness_golden.json, variant nolimit_sep)
+        return SFT_PROMPT.format(INSTRUCTION.format(", ".join(his)))
 
     def get_all_items(self) -> set:
         return self.index.all_items()

@@ -1,6 +1,9 @@
 """Harness either side of the hot path: item index, test-set construction, prompt encoding and the
-ranking metrics, on CPU.  Facts about the real Beauty / Games files are checked when the reference tree is present
-(this container); the formulas are pinned against scikit-learn and hand-computed values."""
+ranking metrics, on CPU.  Pinned to the REFERENCE: tests/golden/harness_golden.json holds the outputs of the reference's own
+`computeTopNAccuracy` (utils.py:215-271), `SeqRecDataset(mode="test")` (data.py:112-278) and
+`BaseDataset.get_prefix_allowed_tokens_fn` (data.py:84-104), produced by tests/golden/gen_harness_golden.py importing them.
+Facts about the real Beauty / Games files are checked when the data files are present (this container); scikit-learn and
+hand-computed values stay as independent cross-checks of the formulas."""
 import json
 import math
 import os
@@ -14,6 +17,100 @@ from atspeed_amd.harness import (CodeTokenEncoder, InferenceResult, ItemIndex, S
 
 REF_DATA = "/root/reference/data"
 has_ref = os.path.isdir(REF_DATA)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(ROOT, "tests", "golden", "harness_golden.json")) as f:
+        return json.load(f)
+
+
+def _digest(strings):
+    import hashlib
+    h = hashlib.sha256()
+    for s in strings:
+        h.update(s.encode("utf-8"))
+        h.update(b"\x00")
+    return h.hexdigest()
+
+
+def test_metrics_equal_the_references_function(gold):
+    g = gold["metrics"]
+    p, r, n, m = computeTopNAccuracy(g["truth"], g["pred"], g["topN"])
+    assert (p, r, n, m) == (g["precision"], g["recall"], g["ndcg"], g["mrr"])          # rounded to 4 digits on both sides: exact
+    s = g["strings_first40"]
+    truth = [[f"i{x}" for x in t] for t in g["truth"][:40]]
+    pred = [[f"i{x}" for x in q] for q in g["pred"][:40]]
+    assert computeTopNAccuracy(truth, pred, s["topN"]) == (s["precision"], s["recall"], s["ndcg"], s["mrr"])
+
+
+def _int_keys(d):
+    return {int(k): v for k, v in d.items()}
+
+
+@pytest.mark.parametrize("variant", ["default", "his5_prefix", "nolimit_sep"])
+def test_test_split_equals_the_references_seqrecdataset(gold, variant):
+    """Same users in the same order, same label strings, same prompt TEXT as `SeqRecDataset(args, mode="test")` built from the same
+    index / train / valid / test dicts (the fixture carries the inputs)."""
+    g = gold["synthetic"]
+    v = g["variants"][variant]
+    ix = ItemIndex(g["index"])
+    d = SeqRecTestData(ix, _int_keys(g["train"]), _int_keys(g["valid"]), _int_keys(g["test"]), **v["kw"])
+    sp = v["split"]
+    assert len(d) == sp["n_users"]
+    assert [len(u.history) for u in d.users] == sp["history_len"]
+    for i, u in enumerate(d.users):
+        ref = sp["users"][str(i)]
+        assert [ix.item_string(x) for x in u.labels] == ref["labels"]
+        assert d.text(u) == ref["text"]
+    assert _digest(d.text(u) for u in d.users) == sp["prompts_digest"]
+    assert _digest("|".join(ix.item_string(x) for x in u.labels) for u in d.users) == sp["labels_digest"]
+
+
+def test_position_set_mask_equals_the_references_closure(gold):
+    """`get_prefix_allowed_tokens_fn` (data.py:84-104) driven by a stub tokenizer with the ids the extended tokenizer assigns:
+    allowed-token dict, new-token order and the closure's answers (incl. None without a separator, last separator wins)."""
+    g = gold["synthetic"]
+    m = g["mask"]
+    ix = ItemIndex(g["index"])
+    assert len(ix.new_tokens) == m["n_new_tokens"] and _digest(ix.new_tokens) == m["new_tokens_digest"]
+    assert len(ix.all_items()) == m["all_items"]
+    assert {str(i): v for i, v in ix.allowed_tokens().items()} == m["allowed_tokens"]
+    d = SeqRecTestData(ix, _int_keys(g["train"]), _int_keys(g["valid"]), _int_keys(g["test"]))
+    fn = d.get_prefix_allowed_tokens_fn()
+    import torch
+    for sentence, want in m["fn"]:
+        got = fn(0, torch.tensor(sentence))
+        assert (None if got is None else sorted(got)) == want
+        if want is not None:                                                # and the compiled automaton allows the same set there
+            fsm = fn.compile(sentence)
+            assert fsm.allowed(fsm.start).tolist() == want
+
+
+@pytest.mark.skipif(not has_ref, reason="reference data files are only in the build container")
+@pytest.mark.parametrize("name", ["beauty", "games"])
+def test_real_splits_equal_the_references(gold, name):
+    g = gold["real"][name]
+    d = SeqRecTestData.load(REF_DATA, name)
+    ix = d.index
+    sp = g["split"]
+    assert len(d) == sp["n_users"]
+    assert _digest(d.text(u) for u in d.users) == sp["prompts_digest"]
+    assert _digest("|".join(ix.item_string(x) for x in u.labels) for u in d.users) == sp["labels_digest"]
+    for i, ref in sp["users"].items():
+        u = d.users[int(i)]
+        assert d.text(u) == ref["text"] and [ix.item_string(x) for x in u.labels] == ref["labels"]
+    m = g["mask"]
+    assert len(ix.new_tokens) == m["n_new_tokens"] and _digest(ix.new_tokens) == m["new_tokens_digest"] and len(ix.all_items()) == m["all_items"]
+    al = ix.allowed_tokens()
+    assert {str(i): [v[0], v[-1] + 1, len(v)] for i, v in al.items()} == m["allowed_ranges"]
+    assert _digest(json.dumps(al[i]) for i in sorted(al, key=str)) == m["allowed_digest"]
+    fn = d.get_prefix_allowed_tokens_fn()
+    import torch
+    for sentence, want in m["fn"]:
+        got = sorted(fn(0, torch.tensor(sentence)))
+        assert (got if len(got) < 8 else [got[0], got[-1] + 1, len(got)]) == want
 
 
 def tiny_index():
