@@ -199,6 +199,8 @@ struct atspeed_llama {
   double prof_big_ms[5] = {0, 0, 0, 0, 0};
   long prof_big_cnt[5] = {0, 0, 0, 0, 0};
   long prof_big_rows[5] = {0, 0, 0, 0, 0};
+  // how often each layer projection (0 qkv, 1 o_proj, 2 gate_up, 3 down) ran as an fp8 / as a bf16 (fp32) GEMM (atspeed_llama_fp8_counters)
+  long fp8_cnt[4] = {0, 0, 0, 0}, other_cnt[4] = {0, 0, 0, 0};
 };
 constexpr int ATS_PROF_BIG_ROWS = 1024;
 
@@ -368,6 +370,16 @@ extern "C" int atspeed_llama_profile_big(atspeed_llama* m, double* ms_out, int64
   return ATSPEED_OK;
 }
 
+extern "C" int atspeed_llama_fp8_counters(atspeed_llama* m, int64_t* fp8_out, int64_t* other_out, int32_t reset) {
+  ATS_REQUIRE(m, ATSPEED_ERR_INVALID, "fp8_counters: null model");
+  for (int i = 0; i < 4; ++i) {
+    if (fp8_out) fp8_out[i] = m->fp8_cnt[i];
+    if (other_out) other_out[i] = m->other_cnt[i];
+    if (reset) { m->fp8_cnt[i] = 0; m->other_cnt[i] = 0; }
+  }
+  return ATSPEED_OK;
+}
+
 extern "C" float* atspeed_llama_logits(atspeed_llama* m) { return m && m->act ? m->act->logits : nullptr; }
 extern "C" int32_t atspeed_llama_logits_ld(const atspeed_llama* m) { return m ? m->logits_ld : 0; }
 
@@ -477,8 +489,10 @@ static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTabl
     int qkv_splits = 0;
     { ProfBracket pb(m, 0, T, st);
       if (f8 && ats_gemm_fp8_applies(T, 3 * H, H, 3 * H, EPI_STORE)) {
+        m->fp8_cnt[0]++;
         ATS_TRY(proj_fp8(m, xq_ready ? nullptr : cx->xn, m->fp8[l].wqkv, m->fp8[l].sqkv, cx->qkv, T, 3 * H, H, 3 * H, EPI_STORE, st));
       } else {
+        m->other_cnt[0]++;
         // one user's forward: the projection leaves fp32 split-K slabs and RoPE sums them itself (one launch less per layer)
         if (fuse_qkv_reduce && m->head_dim % 16 == 0) ATS_TRY(ats_gemm_partials(cx->xn, w.wqkv, T, 3 * H, H, H, dt, cx->ws, cx->ws_bytes, st, &qkv_splits));
         if (qkv_splits == 0) ATS_TRY(ats_gemm(cx->xn, w.wqkv, cx->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, cx->ws, cx->ws_bytes, st));
@@ -490,20 +504,26 @@ static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTabl
     ATS_TRY(ats_tree_attention_segs(cx->qkv, 3 * H, t, dtab, loff, m->vis_words, cx->att, H, c.n_heads, m->head_dim, dt, st));
     { ProfBracket pb(m, 1, T, st);     // h += att Wo^T ; xn = rmsnorm(h) * post_norm
       if (f8 && ats_gemm_fp8_applies(T, H, H, H, EPI_RESID)) {
+        m->fp8_cnt[1]++;
         ATS_TRY(proj_fp8(m, cx->att, m->fp8[l].wo, m->fp8[l].so, cx->h, T, H, H, H, EPI_RESID, st));
         if (f8_gu) { ATS_TRY(ats_rmsnorm_quant_fp8(cx->h, w.post_norm, nullptr, cx->xq, cx->sx, T, H, c.rms_eps, st)); xq_ready = true; }
         else { ATS_TRY(ats_rmsnorm(cx->h, w.post_norm, cx->xn, T, H, c.rms_eps, dt, st)); xq_ready = false; }
       } else {
+        m->other_cnt[1]++;
         ATS_TRY(ats_gemm_resid_norm(cx->att, w.wo, cx->h, T, H, H, H, H, dt, w.post_norm, cx->xn, c.rms_eps, cx->ws, cx->ws_bytes, st));
         xq_ready = false;
       } }
     { ProfBracket pb(m, 2, T, st);
       if (f8 && ats_gemm_fp8_applies(T, 2 * c.ffn, H, c.ffn, EPI_SWIGLU)) {
+        m->fp8_cnt[2]++;
         ATS_TRY(proj_fp8(m, xq_ready ? nullptr : cx->xn, m->fp8[l].wgu, m->fp8[l].sgu, cx->act, T, 2 * c.ffn, H, c.ffn, EPI_SWIGLU, st));
       } else {
+        m->other_cnt[2]++;
         ATS_TRY(ats_gemm(cx->xn, w.wgu, cx->act, T, 2 * c.ffn, H, H, c.ffn, dt, EPI_SWIGLU, cx->ws, cx->ws_bytes, st));
       } }
     { ProfBracket pb(m, 3, T, st);     // h += act Wd^T ; xn = rmsnorm(h) * next layer's input_norm
+      m->fp8_cnt[3] += (f8 && ats_gemm_fp8_applies(T, H, c.ffn, H, EPI_RESID)) ? 1 : 0;
+      m->other_cnt[3] += (f8 && ats_gemm_fp8_applies(T, H, c.ffn, H, EPI_RESID)) ? 0 : 1;
       if (f8 && ats_gemm_fp8_applies(T, H, c.ffn, H, EPI_RESID)) {
         ATS_TRY(proj_fp8(m, cx->act, m->fp8[l].wd, m->fp8[l].sd, cx->h, T, H, c.ffn, H, EPI_RESID, st));
         xq_ready = false;

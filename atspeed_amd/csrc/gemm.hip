@@ -635,6 +635,274 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
 #endif
 }
 
+// =====================================================================================
+// The same ring on the block-scaled fp8 MFMA (BASELINE config 5): v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 operands and unit
+// block scales (E8M0 0x7f) issues 2x the flops per cycle of the bf16 / non-scaled fp8 forms (tools/probe/mx_probe.hip on MI355X:
+// 4.6 PF register-only against 2.4 PF for v_mfma_f32_16x16x32_fp8_fp8; lane map checked there with exact integer data: lane l
+// holds row l&31 and the 32 bytes k = 32*(l>>5) .. +31; C/D as the bf16 32x32 forms).  The per-row / per-token fp32 scales of
+// the W8A8 scheme are applied to the accumulators as before, so the numerics equal the non-scaled kernel's (exact products,
+// fp32 accumulation; only the summation order inside a 64-k group differs).
+// Same LDS image, DMA pieces and four-stage ring as gemm_ring_kernel<.., FP8 = true> (a stage = 64 k of e4m3 in 64-byte rows);
+// what changes is the consumer: a wave's 64 x (MT2*16) tile is 2 x MT2/2 tiles of 32x32, a lane's operand for one 32x32x64
+// MFMA is the two 16-byte chunks 2h, 2h+1 of its row (two ds_read_b128 into the halves of an 8-register tuple), and a k-step
+// is 8 (4) MFMAs of 64 cycles with the 12 (8) fragment reads of the next k-step and the 4 (3) DMA pieces of k-step s+4 spread
+// evenly between them.  Register budget as before: 128 accumulators + 96 fragment registers (double buffered).
+typedef unsigned int u32x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+#define ATS_MFMA_MX(c, a, b, s) \
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(a), "v"(b), "v"(s))
+
+// accumulator tile (it, jt) of a wave: m = m0w + jt*32 + (lane&31); registers 4q..4q+3 hold n = n0w + it*32 + 8q + 4(lane>>5) + r
+template <int EPI, int TA, int TB>
+__device__ __forceinline__ void mx_epilogue(f32x16_t (&acc)[TA][TB], void* __restrict__ Cv, int M, int N, int ldc, int m0w, int n0w, int lane) {
+  const int r32 = lane & 31, h = lane >> 5;
+  const bool vec = (ldc & 3) == 0;
+  if constexpr (EPI == EPI_RESID) {
+    if (vec && n0w + TA * 32 <= N) {       // residuals of the whole wave tile fetched before the first store (see big_epilogue)
+      bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
+      uint2 rs[TA][TB][4];
+#pragma unroll
+      for (int jt = 0; jt < TB; ++jt) {
+        const int gm = min(m0w + jt * 32 + r32, M - 1);
+#pragma unroll
+        for (int it = 0; it < TA; ++it)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rs[it][jt][q] = *reinterpret_cast<const uint2*>(Cb + (size_t)gm * ldc + n0w + it * 32 + 8 * q + 4 * h);
+      }
+#pragma unroll
+      for (int jt = 0; jt < TB; ++jt) {
+        const int gm = m0w + jt * 32 + r32;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int it = 0; it < TA; ++it)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t p0 = f2bf_pk(acc[it][jt][4 * q], acc[it][jt][4 * q + 1]), p1 = f2bf_pk(acc[it][jt][4 * q + 2], acc[it][jt][4 * q + 3]);
+            uint2 o;
+            o.x = f2bf_pk(bf_lo(rs[it][jt][q].x) + bf_lo(p0), bf_hi(rs[it][jt][q].x) + bf_hi(p0));
+            o.y = f2bf_pk(bf_lo(rs[it][jt][q].y) + bf_lo(p1), bf_hi(rs[it][jt][q].y) + bf_hi(p1));
+            *reinterpret_cast<uint2*>(Cb + (size_t)gm * ldc + n0w + it * 32 + 8 * q + 4 * h) = o;
+          }
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int jt = 0; jt < TB; ++jt) {
+    const int gm = m0w + jt * 32 + r32;
+    if (gm >= M) continue;
+#pragma unroll
+    for (int it = 0; it < TA; ++it) {
+      if constexpr (EPI == EPI_SWIGLU) {
+        // rows 0-15 of the 32-row weight tile are a gate group (q = 0, 1), rows 16-31 its up group (q = 2, 3): the pair sits in one lane
+        bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
+        const int gn0 = n0w + it * 32;
+        if (gn0 >= N) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          uint2 o;
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const uint32_t gp = f2bf_pk(acc[it][jt][4 * q + r], acc[it][jt][4 * q + r + 1]);
+            const uint32_t upk = f2bf_pk(acc[it][jt][4 * (q + 2) + r], acc[it][jt][4 * (q + 2) + r + 1]);
+            const float g0 = bf_lo(gp), g1 = bf_hi(gp);
+            const uint32_t res = f2bf_pk(g0 / (1.f + __expf(-g0)) * bf_lo(upk), g1 / (1.f + __expf(-g1)) * bf_hi(upk));
+            if (r == 0) o.x = res; else o.y = res;
+          }
+          *reinterpret_cast<uint2*>(C + (size_t)gm * ldc + (gn0 >> 1) + 8 * q + 4 * h) = o;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gn = n0w + it * 32 + 8 * q + 4 * h;
+          if (gn >= N) continue;
+          const float v0 = acc[it][jt][4 * q], v1 = acc[it][jt][4 * q + 1], v2 = acc[it][jt][4 * q + 2], v3 = acc[it][jt][4 * q + 3];
+          if constexpr (EPI == EPI_F32) {
+            float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
+            if (gn + 3 < N && vec) *reinterpret_cast<float4*>(C) = make_float4(v0, v1, v2, v3);
+            else { const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = vv[r]; }
+          } else {
+            bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
+            if (gn + 3 < N && vec) {
+              uint2 o;
+              const uint32_t p0 = f2bf_pk(v0, v1), p1 = f2bf_pk(v2, v3);
+              if constexpr (EPI == EPI_RESID) {
+                const uint2 rs = *reinterpret_cast<const uint2*>(C);
+                o.x = f2bf_pk(bf_lo(rs.x) + bf_lo(p0), bf_hi(rs.x) + bf_hi(p0));
+                o.y = f2bf_pk(bf_lo(rs.y) + bf_lo(p1), bf_hi(rs.y) + bf_hi(p1));
+              } else { o.x = p0; o.y = p1; }
+              *reinterpret_cast<uint2*>(C) = o;
+            } else {
+              const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (gn + r < N) {
+                  float v = vv[r];
+                  if constexpr (EPI == EPI_RESID) v = bf2f(C[r]) + bf2f(f2bf(v));
+                  C[r] = f2bf(v);
+                }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, int MT2>
+__global__ __launch_bounds__(512, 1) void gemm_ring_mx_kernel(const void* __restrict__ X, const void* __restrict__ W, const float* __restrict__ sx,
+                                                              const float* __restrict__ sw, void* __restrict__ Cv, int M, int N, int K, int ldc,
+                                                              int tiles_n, int tiles_m, int GM) {
+  constexpr int BT = 256, RB = 64;                                // 64-byte LDS rows = 64 k of e4m3 per stage
+  constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
+  constexpr int WP = 2, XP = XR / 128, NP = WP + XP;             // DMA pieces (16 rows x 64 B) per wave per k-step
+  constexpr int STAGE = (BT + XR) * RB;
+  constexpr int TA = 2, TB = MT2 / 2;                            // 32x32 tiles per wave: weight rows x token rows
+  constexpr int NR = 2 * (TA + TB);                              // ds_read_b128 per wave per k-step
+  constexpr int NMF = TA * TB;                                   // MFMAs per wave per k-step
+  constexpr int NIT = NR + NP;                                   // reads + DMA pieces placed between the MFMAs of a k-step
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int nwg = tiles_n * tiles_m;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;             // XCD-contiguous runs of tiles (see gemm_ring_kernel)
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+  }
+  const int band = bid / (GM * tiles_n), rem = bid % (GM * tiles_n);
+  const int band_rows = min(GM, tiles_m - band * GM);
+  const int tn = rem / band_rows, tm = band * GM + rem % band_rows;
+  const int n0 = tn * BT, m0 = tm * XR;
+  const int wn = wave >> 1, wm = wave & 1;
+  const int nks = K / 64;                                         // launcher: K % 256 == 0
+
+  auto swz = [](int row) { return (0xD2 >> (((row >> 2) & 3) * 2)) & 3; };   // f = {2,0,1,3}
+  unsigned woff[WP], xoff[XP];
+  int m0w_[WP], m0x_[XP];
+  const unsigned lbase = lds_addr(smem);
+#pragma unroll
+  for (int j = 0; j < WP; ++j) {
+    const int row = (wave * WP + j) * 16 + (lane >> 2);
+    woff[j] = (unsigned)min(n0 + row, N - 1) * (unsigned)K + (((lane & 3) ^ swz(row)) * 16);
+    m0w_[j] = __builtin_amdgcn_readfirstlane((int)lbase + (wave * WP + j) * 1024);
+  }
+#pragma unroll
+  for (int j = 0; j < XP; ++j) {
+    const int row = (wave * XP + j) * 16 + (lane >> 2);
+    xoff[j] = (unsigned)min(m0 + row, M - 1) * (unsigned)K + (((lane & 3) ^ swz(row)) * 16);
+    m0x_[j] = __builtin_amdgcn_readfirstlane((int)lbase + BT * RB + (wave * XP + j) * 1024);
+  }
+  const unsigned long long wb = (unsigned long long)W, xb = (unsigned long long)X;
+  // fragment addresses: lane (r32, h) reads chunks 2h and 2h+1 of row r32 of each 32-row tile
+  const unsigned lp_lo = r32 * RB + (((2 * h) ^ swz(r32)) * 16), lp_hi = r32 * RB + (((2 * h + 1) ^ swz(r32)) * 16);
+  unsigned aAl[2], aAh[2], aBl[2], aBh[2];                        // stages {0,1} and {2,3}
+  aAl[0] = lbase + (wn * TA * 32) * RB + lp_lo;  aAh[0] = lbase + (wn * TA * 32) * RB + lp_hi;
+  aBl[0] = lbase + BT * RB + (wm * TB * 32) * RB + lp_lo;  aBh[0] = lbase + BT * RB + (wm * TB * 32) * RB + lp_hi;
+  aAl[1] = aAl[0] + 2 * STAGE; aAh[1] = aAh[0] + 2 * STAGE; aBl[1] = aBl[0] + 2 * STAGE; aBh[1] = aBh[0] + 2 * STAGE;
+
+  f32x16_t acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  u32x4_t fal[2][TA], fah[2][TA], fbl[2][TB], fbh[2][TB];
+  const unsigned unit_scale = 0x7f7f7f7fu;                        // E8M0 1.0 for every 32-k block of both operands
+
+  auto dma_piece = [&](int q, int ks, int d) {
+    if (d < WP) ATS_DMA16(woff[d % WP], wb + (unsigned long long)ks * RB, m0w_[d % WP] + q * STAGE);
+    else        ATS_DMA16(xoff[(d - WP) % XP], xb + (unsigned long long)ks * RB, m0x_[(d - WP) % XP] + q * STAGE);
+  };
+  auto read_one = [&](int q, int buf, int r) {                    // read r of stage q into register buffer buf (all compile-time after unrolling)
+    const unsigned al = aAl[q >> 1], ah = aAh[q >> 1], bl = aBl[q >> 1], bh = aBh[q >> 1];
+    const int so = (q & 1) * STAGE;
+    switch (r) {
+      case 0: ATS_DS_READ_B128(fal[buf][0], al, so); break;
+      case 1: ATS_DS_READ_B128(fah[buf][0], ah, so); break;
+      case 2: ATS_DS_READ_B128(fal[buf][1], al, so + 2048); break;
+      case 3: ATS_DS_READ_B128(fah[buf][1], ah, so + 2048); break;
+      case 4: ATS_DS_READ_B128(fbl[buf][0], bl, so); break;
+      case 5: ATS_DS_READ_B128(fbh[buf][0], bh, so); break;
+      case 6: ATS_DS_READ_B128(fbl[buf][1], bl, so + 2048); break;
+      case 7: ATS_DS_READ_B128(fbh[buf][1], bh, so + 2048); break;
+      case 8:  if constexpr (TB == 4) ATS_DS_READ_B128(fbl[buf][TB - 2], bl, so + 4096); break;
+      case 9:  if constexpr (TB == 4) ATS_DS_READ_B128(fbh[buf][TB - 2], bh, so + 4096); break;
+      case 10: if constexpr (TB == 4) ATS_DS_READ_B128(fbl[buf][TB - 1], bl, so + 6144); break;
+      case 11: if constexpr (TB == 4) ATS_DS_READ_B128(fbh[buf][TB - 1], bh, so + 6144); break;
+      default: break;
+    }
+  };
+#define ATS_CAT8(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
+  // one k-step: MFMAs of stage Q from register buffer Q&1; item t (reads of stage Q+1, then the DMA pieces of k-step ks+4 into
+  // stage Q) is issued in front of MFMA t*NMF/NIT; VM = vmcnt to wait for before the closing barrier (-1: no wait, no barrier)
+#define ATS_MX_SEGMENT(Q, DMA, RD, VM, ks)                                                               \
+  {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < TA; ++i) _Pragma("unroll") for (int j = 0; j < TB; ++j) {      \
+      const int idx = i * TB + j;                                                                        \
+      _Pragma("unroll") for (int t = 0; t < NIT; ++t) {                                                  \
+        if (t * NMF / NIT == idx) {                                                                      \
+          if (t < NR) { if (RD) read_one(((Q) + 1) & 3, ((Q) + 1) & 1, t); }                             \
+          else if (DMA) dma_piece((Q), (ks) + 4, t - NR);                                                \
+        }                                                                                                \
+      }                                                                                                  \
+      ATS_MFMA_MX(acc[i][j], ATS_CAT8(fal[(Q) & 1][i], fah[(Q) & 1][i]), ATS_CAT8(fbl[(Q) & 1][j], fbh[(Q) & 1][j]), unit_scale); \
+    }                                                                                                    \
+    if (RD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
+    if ((VM) >= 0) {                                                                                     \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VM) < 0 ? 0 : (VM)) : "memory");                         \
+      asm volatile("s_barrier" ::: "memory");                                                            \
+    }                                                                                                    \
+  }
+
+  // prologue: k-steps 0..3 into stages 0..3; fragments of k-step 0
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int d = 0; d < NP; ++d) dma_piece(q, q, d);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP) : "memory");
+  asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+  for (int r = 0; r < NR; ++r) read_one(0, 0, r);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+  asm volatile("s_barrier" ::: "memory");
+
+  int ks = 0;
+  for (; ks + 4 < nks; ks += 4) {
+    ATS_MX_SEGMENT(0, true, true, 2 * NP, ks);
+    ATS_MX_SEGMENT(1, true, true, 2 * NP, ks + 1);
+    ATS_MX_SEGMENT(2, true, true, 2 * NP, ks + 2);
+    ATS_MX_SEGMENT(3, true, true, 2 * NP, ks + 3);
+  }
+  ATS_MX_SEGMENT(0, false, true, NP, ks);
+  ATS_MX_SEGMENT(1, false, true, 0, ks + 1);
+  ATS_MX_SEGMENT(2, false, true, -1, ks + 2);
+  ATS_MX_SEGMENT(3, false, false, -1, ks + 3);
+#undef ATS_MX_SEGMENT
+#undef ATS_CAT8
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // 16-pass MFMA results -> VALU reads (the compiler cannot see the asm MFMAs)
+
+  // per-row scales of the W8A8 scheme: acc *= sx[m] * sw[n]
+  const int m0w = m0 + wm * (TB * 32), n0w = n0 + wn * (TA * 32);
+#pragma unroll
+  for (int jt = 0; jt < TB; ++jt) {
+    const float fx = sx[min(m0w + jt * 32 + r32, M - 1)];
+#pragma unroll
+    for (int it = 0; it < TA; ++it)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int gn = n0w + it * 32 + 8 * q + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[it][jt][4 * q + r] *= fx * sw[min(gn + r, N - 1)];
+      }
+  }
+  mx_epilogue<EPI, TA, TB>(acc, Cv, M, N, ldc, m0w, n0w, lane);
+}
+
 template <int EPI>
 int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st) {
   static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
@@ -745,6 +1013,23 @@ int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char*
     attr_done = true;
   }
   const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
+  // block-scaled MFMA form (2x the flops per cycle); ATSPEED_FP8_MX=0 keeps the non-scaled v_mfma_f32_16x16x32_fp8_fp8 kernel for A/B runs
+  static const int use_mx = env_int("ATSPEED_FP8_MX", 1);
+  if (use_mx) {
+    static thread_local AtsPerDeviceFlag mx_flag;
+    bool& mx_done = mx_flag.cur();
+    if (!mx_done) {
+      ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_mx_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_mx_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      mx_done = true;
+    }
+    if (big_use_256_rows(t256, t128))
+      hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 255) / 256, gm);
+    else
+      hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 127) / 128, gm);
+    ATS_LAUNCH_CHECK();
+    return ATSPEED_OK;
+  }
   if (big_use_256_rows(t256, t128))
     hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, true>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 255) / 256, gm);
   else

@@ -176,6 +176,13 @@ class HipLlama:
         self.fp8 = True
         return self
 
+    def fp8_counters(self, reset: bool = False) -> Dict[str, Dict[str, int]]:
+        """Launches of each layer projection that ran as fp8 / as bf16 GEMMs since the last reset (atspeed_llama_fp8_counters)."""
+        f8 = (C.c_int64 * 4)()
+        other = (C.c_int64 * 4)()
+        _lib.check(_lib.load().atspeed_llama_fp8_counters(self._handle, f8, other, 1 if reset else 0))
+        return {k: dict(fp8=int(f8[i]), other=int(other[i])) for i, k in enumerate(self.GEMM_KINDS[:4])}
+
     # ---- measurement hooks --------------------------------------------------------------
     GEMM_KINDS = ("qkv", "o_proj", "gate_up", "down", "lm_head")
 

@@ -146,6 +146,10 @@ int32_t atspeed_llama_logits_ld(const atspeed_llama* m);
  * forwards, the lm_head, norms, attention and the KV cache stay bf16.  No reference counterpart (its target is int8
  * weights via bitsandbytes, inference.py:88). */
 int atspeed_llama_enable_fp8(atspeed_llama* m, void* stream);
+/* how many launches of each layer projection (0 qkv, 1 o_proj, 2 gate_up, 3 down; one per layer per forward) ran as an fp8 GEMM
+ * (fp8_out[4]) and how many as a bf16 / fp32 GEMM (other_out[4]) since the last reset: lets a test or a bench state that config 5
+ * really ran its projections in fp8 rather than fell back by shape.  Either output may be NULL.  No reference counterpart. */
+int atspeed_llama_fp8_counters(atspeed_llama* m, int64_t* fp8_out, int64_t* other_out, int32_t reset);
 
 /* ------------------------------------------------------------------ scan kernels
  * log-softmax normaliser over the FULL vocabulary, before masking (beamSD.py:58,285):

@@ -23,6 +23,16 @@ exactly 0 to the fp32 softmax either way.
 Pinned by tests/test_oracle_pins.py against the installed HF `LlamaForCausalLM`
 (eager, fp32) and, end to end, by the golden fixtures generated from the imported
 reference (tests/golden/gen_golden.py).
+
+`w8a8=True` restates BASELINE config 5 (fp8 target verification): the four layer
+projections (q/k/v, o, gate/up, down) run on OCP e4m3 operands -- weights quantised per
+output row, activations per token, scale = max|row| / 448, q = e4m3(x / scale) with
+torch's float8_e4m3fn rounding -- with fp32 accumulation and the two scales applied to
+the sum; embedding, norms, attention, KV cache and lm_head stay as above.  It stands where
+the reference loads its target with `load_in_8bit=True` (bitsandbytes LLM.int8,
+`code/inference.py:88`): that arithmetic is third-party, unpinned and absent offline, so
+this mode defines the build's own 8-bit scheme and is pinned only to itself ("parity
+unpinned" against the reference for config 5).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this.
 """
 from __future__ import annotations
@@ -56,13 +66,33 @@ def _t(x) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
 
 
+E4M3_MAX = 448.0
+
+
+def quant_rows_e4m3(x: torch.Tensor):
+    """Per-row e4m3 quantisation: (dequantised codes as fp32, scale[rows]); an all-zero row gets scale 1."""
+    amax = x.abs().amax(-1)
+    scale = torch.where(amax > 0, amax / E4M3_MAX, torch.ones_like(amax))
+    q = (x / scale[..., None]).clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).to(torch.float32)
+    return q, scale
+
+
 class RefLlama:
     """Slot-addressed fp32 Llama; `state_dict` uses HF parameter names."""
 
-    def __init__(self, dims, state_dict: Dict[str, object], max_slots: int = 1024):
+    PROJ = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")
+
+    def __init__(self, dims, state_dict: Dict[str, object], max_slots: int = 1024, w8a8: bool = False):
         self.d = RefDims(dims.vocab_size, dims.hidden, dims.n_layers, dims.n_heads, dims.ffn,
                          dims.rope_theta, dims.rms_eps)
         self.w = {k: _t(v) for k, v in state_dict.items()}
+        self.w8a8 = w8a8
+        self.wq: Dict[str, tuple] = {}
+        if w8a8:
+            for l in range(self.d.n_layers):
+                for pj in self.PROJ:
+                    name = f"model.layers.{l}.{pj}.weight"
+                    self.wq[name] = quant_rows_e4m3(self.w[name])
         d = self.d
         self.kcache = torch.zeros(d.n_layers, max_slots, d.n_heads, d.head_dim)
         self.vcache = torch.zeros(d.n_layers, max_slots, d.n_heads, d.head_dim)
@@ -71,6 +101,14 @@ class RefLlama:
         self.inv_freq = 1.0 / (d.rope_theta ** (torch.arange(0, half, dtype=torch.float32) * 2.0 / d.head_dim))
 
     # -- pieces -----------------------------------------------------------------
+    def _proj(self, x: torch.Tensor, name: str) -> torch.Tensor:
+        """x W^T for a layer projection: fp32, or W8A8 (e4m3 x e4m3 products are exact in fp32; the sum is fp32)."""
+        if not self.w8a8:
+            return x @ self.w[name].T
+        xq, sx = quant_rows_e4m3(x)
+        wq, sw = self.wq[name]
+        return (xq @ wq.T) * sx[:, None] * sw[None, :]
+
     def _rmsnorm(self, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
         var = x.pow(2).mean(-1, keepdim=True)
         return w * (x * torch.rsqrt(var + self.d.rms_eps))
@@ -102,9 +140,9 @@ class RefLlama:
         for l in range(d.n_layers):
             p = f"model.layers.{l}."
             x = self._rmsnorm(h, self.w[p + "input_layernorm.weight"])
-            q = (x @ self.w[p + "self_attn.q_proj.weight"].T).view(T, d.n_heads, d.head_dim)
-            k = (x @ self.w[p + "self_attn.k_proj.weight"].T).view(T, d.n_heads, d.head_dim)
-            v = (x @ self.w[p + "self_attn.v_proj.weight"].T).view(T, d.n_heads, d.head_dim)
+            q = self._proj(x, p + "self_attn.q_proj.weight").view(T, d.n_heads, d.head_dim)
+            k = self._proj(x, p + "self_attn.k_proj.weight").view(T, d.n_heads, d.head_dim)
+            v = self._proj(x, p + "self_attn.v_proj.weight").view(T, d.n_heads, d.head_dim)
             q = self._rope(q, pos)
             k = self._rope(k, pos)
             self.kcache[l, slots] = k
@@ -115,11 +153,11 @@ class RefLlama:
             sc = torch.where(vis[None], sc, torch.full_like(sc, neg))
             pr = torch.softmax(sc, dim=-1, dtype=torch.float32)
             a = torch.einsum("hts,shd->thd", pr, V).reshape(T, d.hidden)
-            h = h + a @ self.w[p + "self_attn.o_proj.weight"].T
+            h = h + self._proj(a, p + "self_attn.o_proj.weight")
             x = self._rmsnorm(h, self.w[p + "post_attention_layernorm.weight"])
-            g = x @ self.w[p + "mlp.gate_proj.weight"].T
-            u = x @ self.w[p + "mlp.up_proj.weight"].T
-            h = h + (torch.nn.functional.silu(g) * u) @ self.w[p + "mlp.down_proj.weight"].T
+            g = self._proj(x, p + "mlp.gate_proj.weight")
+            u = self._proj(x, p + "mlp.up_proj.weight")
+            h = h + self._proj(torch.nn.functional.silu(g) * u, p + "mlp.down_proj.weight")
         if n_logit_rows is not None:
             h = h[T - n_logit_rows:]
         x = self._rmsnorm(h, self.w["model.norm.weight"])

@@ -312,38 +312,6 @@ def test_python_mask_callable_errors():
         target_generate(tgt, inputs, 2, prefix_allowed_tokens_fn=lambda b, s: None)
 
 
-def test_fp8_target_batch_close_to_bf16():
-    """BASELINE config 5: fp8 (W8A8 e4m3) target projections in the batched forwards.  Not bit-comparable with bf16 by
-    construction; the check is that decoding still works end to end, scores stay close and the drift is reported."""
-    from atspeed_amd.beamSD import BSSD_batch
-    V = synth.BEAUTY.vocab_size
-    tdims = synth.LlamaDims(V, 512, 2, 4, 1536)
-    ddims = synth.LlamaDims(V, 256, 2, 4, 704)
-    kw = dict(max_slots=512, max_tokens=512, max_logit_rows=448)
-    fn = atspeed_amd.PositionSetConstraint(synth.BEAUTY.allowed_tokens(), synth.RESPONSE_SEP)
-    prompts = [synth.synthetic_prompt(50 + 9 * (u % 7), 300 + u) for u in range(12)]
-    inputs = [{"input_ids": torch.from_numpy(p)[None].cuda()} for p in prompts]
-    res = {}
-    for mode in ("bf16", "fp8"):
-        tgt = HipLlama.from_synthetic(tdims, 31, std=0.03, head_std=0.2, dtype=torch.bfloat16, num_beams=20, **kw)
-        drf = HipLlama.from_synthetic(ddims, 32, std=0.03, head_std=0.2, dtype=torch.bfloat16, num_beams=40, **kw)
-        if mode == "fp8":
-            tgt.enable_fp8()
-        res[mode] = BSSD_batch(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=fn)
-    overlap, dscore = [], []
-    for a, b, p in zip(res["bf16"], res["fp8"], prompts):
-        P = len(p)
-        sa = {tuple(x) for x in a["beam_sequence"][:, P:].cpu().tolist()}
-        sb = {tuple(x) for x in b["beam_sequence"][:, P:].cpu().tolist()}
-        overlap.append(len(sa & sb) / 20.0)
-        dscore.append(abs(float(a["beam_scores"][0]) - float(b["beam_scores"][0])))
-        assert b["n_valid"] == 20 and torch.isfinite(b["beam_scores"]).all()
-    print("fp8 vs bf16: mean top-20 item overlap", np.mean(overlap), "best-score drift", np.mean(dscore),
-          "accept steps bf16/fp8", sum(r["total_accept_steps"] for r in res["bf16"]), sum(r["total_accept_steps"] for r in res["fp8"]))
-    assert np.mean(dscore) < 0.5
-    assert np.mean(overlap) > 0.3
-
-
 def test_aligned_synthetic_pair_brackets_acceptance():
     """HipLlama.from_synthetic(align_to=..): with the layers' residual writes scaled to ~0 a narrow draft and a wide target
     share one bigram table, so every draft step is accepted (n_run=1, 3 steps: SURVEY.md 8c property iii); a large
