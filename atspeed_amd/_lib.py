@@ -60,6 +60,7 @@ SIGNATURES = {
     "atspeed_llama_profile_big": (C.c_int, [_P, _P, _P, _P]),
     "atspeed_llama_logits_ld": (_I, [_P]),
     "atspeed_lse_rows": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "atspeed_lmhead_lse": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _SZ, C.POINTER(_I), _P]),
     "atspeed_beam_expand_prune": (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P]),
     "atspeed_accept": (C.c_int, [_P, _P, _I, _P, _I, _P, _P, _P, _P]),
     "atspeed_decoder_create": (C.c_int, [_P, _P, _I, C.POINTER(_P)]),

@@ -104,13 +104,19 @@ extern "C" int atspeed_fsm_create(const int32_t* row_ptr, const int32_t* tok, co
     ATS_HIP(hipMemcpy(f->d_nxt, nxt, (size_t)n_edges * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   f->dev = FsmDev{f->d_row_ptr, f->d_tok, f->d_nxt, n_nodes, n_edges, vocab_size};
+  // which 256-column tiles of a logit row a step can ever read: the fused lm_head epilogue stores only those (gemm.hip EPI_F32_LSE)
+  unsigned char tiles[256];
+  memset(tiles, 0, sizeof(tiles));
+  for (int e = 0; e < n_edges; ++e) if (tok[e] / 256 < 256) tiles[tok[e] / 256] = 1;
+  ATS_HIP(hipMalloc((void**)&f->d_tile_store, sizeof(tiles)));
+  ATS_HIP(hipMemcpy(f->d_tile_store, tiles, sizeof(tiles), hipMemcpyHostToDevice));
   *out = f;
   return ATSPEED_OK;
 }
 
 extern "C" void atspeed_fsm_destroy(atspeed_fsm* f) {
   if (!f) return;
-  hipFree(f->d_row_ptr); hipFree(f->d_tok); hipFree(f->d_nxt);
+  hipFree(f->d_row_ptr); hipFree(f->d_tok); hipFree(f->d_nxt); hipFree(f->d_tile_store);
   delete f;
 }
 
@@ -163,6 +169,7 @@ struct ActCtx {
   void *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *act = nullptr, *gath = nullptr;
   float* logits = nullptr;                       // [cap_rows][logits_ld]
   float* lse = nullptr;                          // [cap_rows]
+  float* lse_part = nullptr; size_t lse_part_bytes = 0;   // [cap_rows][vocab tiles] (max, sum exp) partials of the fused lm_head epilogue
   void* xq = nullptr; float* sx = nullptr;       // fp8 activations [cap_tok][max(hidden, ffn)] + per-token scales
   void* ws = nullptr; size_t ws_bytes = 0;       // split-K slabs
   // forwards of a recurring shape are replayed as hipGraphs (one launch instead of ~9 per layer: a user's later rounds are
@@ -247,7 +254,7 @@ static size_t gemm_ws_for(const atspeed_llama_config& c, int max_tok, int max_ro
 static void act_free(ActCtx* cx) {
   if (!cx) return;
   hipFree(cx->h); hipFree(cx->xn); hipFree(cx->qkv); hipFree(cx->att); hipFree(cx->act); hipFree(cx->gath);
-  hipFree(cx->logits); hipFree(cx->lse); hipFree(cx->ws); hipFree(cx->xq); hipFree(cx->sx);
+  hipFree(cx->logits); hipFree(cx->lse); hipFree(cx->lse_part); hipFree(cx->ws); hipFree(cx->xq); hipFree(cx->sx);
   for (hipEvent_t e : cx->prof_ev) hipEventDestroy(e);
   for (auto& g : cx->graphs) hipGraphExecDestroy(g.second);
   if (cx->cap_stream) hipStreamDestroy(cx->cap_stream);
@@ -274,6 +281,8 @@ static int ensure_act(atspeed_llama* m, int tok, int rows) {
   ATS_HIP(hipMalloc(&cx->gath, (size_t)cx->cap_rows * H * e));
   ATS_HIP(hipMalloc((void**)&cx->logits, (size_t)cx->cap_rows * m->logits_ld * sizeof(float)));
   ATS_HIP(hipMalloc((void**)&cx->lse, (size_t)cx->cap_rows * sizeof(float)));
+  cx->lse_part_bytes = ats_lmhead_lse_part_bytes(cx->cap_rows, c.vocab_size);
+  ATS_HIP(hipMalloc((void**)&cx->lse_part, cx->lse_part_bytes));
   ATS_HIP(hipMalloc(&cx->xq, T * (size_t)std::max(c.hidden, c.ffn)));
   ATS_HIP(hipMalloc((void**)&cx->sx, T * sizeof(float)));
   cx->ws_bytes = gemm_ws_for(c, cx->cap_tok, cx->cap_rows);
@@ -370,6 +379,20 @@ extern "C" int atspeed_llama_profile_big(atspeed_llama* m, double* ms_out, int64
   return ATSPEED_OK;
 }
 
+extern "C" int atspeed_lmhead_lse(const void* x, const void* w, float* logits, float* lse, int32_t rows, int32_t vocab, int32_t hidden, int32_t ld,
+                                  const atspeed_fsm* fsm, void* workspace, size_t workspace_bytes, int32_t* fused_out, void* stream) {
+  ATS_REQUIRE(x && w && logits && lse && rows >= 0 && vocab > 0 && hidden > 0 && ld >= vocab, ATSPEED_ERR_INVALID, "lmhead_lse: bad arguments");
+  const size_t pb = ats_lmhead_lse_part_bytes(rows, vocab);
+  const bool have = workspace && workspace_bytes >= pb && ((uintptr_t)workspace & 15) == 0;
+  char* rest = have ? (char*)workspace + (pb + 255) / 256 * 256 : (char*)workspace;
+  const size_t rest_bytes = have ? (workspace_bytes > (pb + 255) / 256 * 256 ? workspace_bytes - (pb + 255) / 256 * 256 : 0) : workspace_bytes;
+  int fused = 0;
+  const int rc = ats_lmhead_lse(x, w, logits, rows, vocab, hidden, hidden, ld, ATSPEED_BF16, fsm ? fsm->d_tile_store : nullptr, have ? (float*)workspace : nullptr,
+                                have ? pb : 0, lse, rest, rest_bytes, (hipStream_t)stream, &fused);
+  if (fused_out) *fused_out = fused;
+  return rc;
+}
+
 extern "C" int atspeed_llama_fp8_counters(atspeed_llama* m, int64_t* fp8_out, int64_t* other_out, int32_t reset) {
   ATS_REQUIRE(m, ATSPEED_ERR_INVALID, "fp8_counters: null model");
   for (int i = 0; i < 4; ++i) {
@@ -419,9 +442,13 @@ static int proj_fp8(atspeed_llama* m, const void* x, const void* wq, const float
 
 // One forward over the tokens of every segment (user) of the table.  Logits of each segment's last n_logit rows land
 // in act->logits rows [logit_row0, ..) (or in logits_out), their log-sum-exp in act->lse.
-static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTable* dtab, float* logits_out, hipStream_t st);
+static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTable* dtab, float* logits_out, hipStream_t st,
+                              const unsigned char* tile_store);
 
-static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits_out, hipStream_t st) {
+// tile_store (device bytes, one per 256 vocabulary columns; NULL = every column): which logit tiles the caller will read.  The decoder
+// passes its automaton's (atspeed_fsm::d_tile_store): rows then get their full-vocabulary normaliser from the lm_head epilogue and
+// only those tiles are written to the logits buffer.
+static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits_out, hipStream_t st, const unsigned char* tile_store = nullptr) {
   const atspeed_llama_config& c = m->cfg;
   ActCtx* cx = m->act;
   const int T = t.total_tok;
@@ -448,7 +475,7 @@ static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits
     if (it == cx->graphs.end() && cx->graphs.size() < 64 && ++cx->graph_seen[key] >= 2) {   // a shape seen twice recurs (K + dl*DK tokens)
       if (!cx->cap_stream) ATS_HIP(hipStreamCreateWithFlags(&cx->cap_stream, hipStreamNonBlocking));
       ATS_HIP(hipStreamBeginCapture(cx->cap_stream, hipStreamCaptureModeThreadLocal));
-      const int rc = llama_forward_body(m, t, dtab, nullptr, cx->cap_stream);
+      const int rc = llama_forward_body(m, t, dtab, nullptr, cx->cap_stream, nullptr);
       hipGraph_t g = nullptr;
       hipError_t e = hipStreamEndCapture(cx->cap_stream, &g);
       if (rc != ATSPEED_OK) { if (g) hipGraphDestroy(g); return rc; }
@@ -464,11 +491,12 @@ static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits
       return ATSPEED_OK;
     }
   }
-  return llama_forward_body(m, t, dtab, logits_out, st);
+  return llama_forward_body(m, t, dtab, logits_out, st, logits_out ? nullptr : tile_store);
 }
 
 // the launches of one forward (also the body of a captured graph: no allocation, no synchronisation, no staging in here)
-static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTable* dtab, float* logits_out, hipStream_t st) {
+static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTable* dtab, float* logits_out, hipStream_t st,
+                              const unsigned char* tile_store) {
   const atspeed_llama_config& c = m->cfg;
   ActCtx* cx = m->act;
   const int T = t.total_tok;
@@ -544,9 +572,15 @@ static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTabl
     ATS_TRY(ats_gather_logit_rows(cx->h, t, dtab, cx->gath, H, dt, st));
     ATS_TRY(ats_rmsnorm(cx->gath, m->final_norm, cx->xn, R, H, c.rms_eps, dt, st));
     float* lo = logits_out ? logits_out : cx->logits;
-    { ProfBracket pb(m, 4, R, st);
-      ATS_TRY(ats_gemm(cx->xn, m->lm_head, lo, R, c.vocab_size, H, H, m->logits_ld, dt, EPI_F32, cx->ws, cx->ws_bytes, st)); }
-    ATS_TRY(ats_lse_rows(lo, R, c.vocab_size, m->logits_ld, cx->lse, st));     // beamSD.py:58,285: full-vocab normaliser
+    if (tile_store) {      // decoder forwards: logits + full-vocabulary normaliser (beamSD.py:58,285) from ONE kernel where the batch is large enough
+      ProfBracket pb(m, 4, R, st);
+      ATS_TRY(ats_lmhead_lse(cx->xn, m->lm_head, lo, R, c.vocab_size, H, H, m->logits_ld, dt, tile_store, cx->lse_part, cx->lse_part_bytes, cx->lse,
+                             cx->ws, cx->ws_bytes, st));
+    } else {
+      { ProfBracket pb(m, 4, R, st);
+        ATS_TRY(ats_gemm(cx->xn, m->lm_head, lo, R, c.vocab_size, H, H, m->logits_ld, dt, EPI_F32, cx->ws, cx->ws_bytes, st)); }
+      ATS_TRY(ats_lse_rows(lo, R, c.vocab_size, m->logits_ld, cx->lse, st));     // beamSD.py:58,285: full-vocab normaliser
+    }
   }
   return ATSPEED_OK;
 }
@@ -861,7 +895,7 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
         r.s.n_draft_forwards++;
       }
       ATS_TRY(seg_finish(t));
-      ATS_TRY(llama_forward_segs(D, t, nullptr, st));
+      ATS_TRY(llama_forward_segs(D, t, nullptr, st, decs[0]->run.fsm->d_tile_store));
       for (size_t j = 0; j < us.size(); ++j) {
         atspeed_decoder* d = us[j];
         atspeed_decoder::Run& r = d->run;
@@ -901,7 +935,7 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
         r.s.n_target_forwards++;
       }
       ATS_TRY(seg_finish(t));
-      ATS_TRY(llama_forward_segs(T, t, nullptr, st));
+      ATS_TRY(llama_forward_segs(T, t, nullptr, st, decs[0]->run.fsm->d_tile_store));
       hipEventRecord(g_ev[2], st);
       // ---- 3. verify (:242-456) for the verifying users, one workgroup each
       std::vector<VerifyArgs> vargs;
@@ -1053,7 +1087,7 @@ extern "C" int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt
     t.n = 1;
     t.seg[0] = make_seg(tb_offset(tin, row0, W), n_in, base + n_in, nb, d->tkv);
     ATS_TRY(seg_finish(t));
-    ATS_TRY(llama_forward_segs(T, t, nullptr, st));
+    ATS_TRY(llama_forward_segs(T, t, nullptr, st, fsm->d_tile_store));
     s.n_target_forwards++;
     BeamStepArgs a{};
     a.src = d->round_beams[cur]; a.n_src = nb; a.gen_len = g;
@@ -1113,7 +1147,7 @@ extern "C" int atspeed_target_generate_batch(atspeed_decoder** decs, int32_t n, 
     for (int u = 0; u < n; ++u)
       t.seg[t.n++] = make_seg(tb_offset(decs[u]->tin[0], s[u].row0, W), s[u].n_in, s[u].base + s[u].n_in, s[u].nb, decs[u]->tkv);
     ATS_TRY(seg_finish(t));
-    ATS_TRY(llama_forward_segs(T, t, nullptr, st));
+    ATS_TRY(llama_forward_segs(T, t, nullptr, st, fsm->d_tile_store));
     std::vector<BeamStepArgs> args;
     for (int u = 0; u < n; ++u) {
       atspeed_decoder* d = decs[u];

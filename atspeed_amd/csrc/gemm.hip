@@ -437,7 +437,8 @@ template <int EPI, int MT2, bool FP8, bool SPLITK = false, int NA = 4>
 __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const void* __restrict__ X, const void* __restrict__ W,
                                                            const float* __restrict__ sx, const float* __restrict__ sw,
                                                            void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
-                                                           int tiles_n, int tiles_m, int GM, int n_split = 1) {
+                                                           int tiles_n, int tiles_m, int GM, int n_split = 1,
+                                                           float* __restrict__ lse_part = nullptr, const unsigned char* __restrict__ tile_store = nullptr) {
   constexpr int BT = 256, RB = 64, ESZ = FP8 ? 1 : 2;
   constexpr int BK = RB / ESZ;                                   // k per stage: 32 (bf16) or 64 (fp8)
   constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
@@ -621,7 +622,50 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
       }
     }
   }
-  if constexpr (SPLITK) big_epilogue<EPI_F32, NA, MT2>(acc, reinterpret_cast<float*>(Cv) + (size_t)zpart * M * N, M, N, N, m0, n0, wn, wm, lq, g);
+  if constexpr (EPI == EPI_F32_LSE) {
+    // lm_head fused with the full-vocabulary normaliser (beamSD.py:58,285: log-softmax over ALL columns before masking): this tile's
+    // (max, sum exp) per token row goes to lse_part[row][tile_n]; the fp32 logits themselves are stored only when some column of the
+    // tile can ever be asked for (tile_store[tn]: tiles holding a token of the constraint automaton).  A wave holds 64 of the tile's
+    // 256 columns for its rows: lane-local over the 16 registers, across the four column groups g by two shuffles, across the four
+    // waves wn through 8 KB of LDS behind the ring (the ring itself may still be read by slower waves).
+    float* red = reinterpret_cast<float*>(smem + 4 * STAGE);      // [XR rows][4 wn][2]
+#pragma unroll
+    for (int j = 0; j < MT2; ++j) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int gn = n0 + wn * (NA * 16) + i * 16 + g * 4 + r; if (gn < N) mx = fmaxf(mx, acc[i][j][r]); }
+      float sm = 0.f;
+      if (mx > -INFINITY) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int gn = n0 + wn * (NA * 16) + i * 16 + g * 4 + r; if (gn < N) sm += __expf(acc[i][j][r] - mx); }
+      }
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        const float om = __shfl_xor(mx, o, 64), os = __shfl_xor(sm, o, 64);
+        const float nm = fmaxf(mx, om);
+        sm = (nm > -INFINITY) ? sm * __expf(mx - nm) + os * __expf(om - nm) : 0.f;
+        mx = nm;
+      }
+      if (g == 0) { float2* dst = reinterpret_cast<float2*>(red) + (size_t)(wm * (MT2 * 16) + j * 16 + lq) * 4 + wn; *dst = make_float2(mx, sm); }
+    }
+    __syncthreads();
+    if (tid < XR && m0 + tid < M) {
+      const float2* src = reinterpret_cast<const float2*>(red) + (size_t)tid * 4;
+      float mx = src[0].x, sm = src[0].y;
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+        const float nm = fmaxf(mx, src[q].x);
+        sm = (nm > -INFINITY) ? sm * __expf(mx - nm) + src[q].y * __expf(src[q].x - nm) : 0.f;
+        mx = nm;
+      }
+      reinterpret_cast<float2*>(lse_part)[(size_t)(m0 + tid) * tiles_n + tn] = make_float2(mx, sm);
+    }
+    if (tile_store == nullptr || tile_store[tn]) big_epilogue<EPI_F32, NA, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
+  } else if constexpr (SPLITK) big_epilogue<EPI_F32, NA, MT2>(acc, reinterpret_cast<float*>(Cv) + (size_t)zpart * M * N, M, N, N, m0, n0, wn, wm, lq, g);
   else                  big_epilogue<EPI, NA, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
 #ifdef ATS_RING_STAMPS
   // tuning build: sw carries the stamp buffer [workgroup][wave][8] = loop cycles in {issue, lgkmcnt wait, vmcnt wait, barrier}, then
@@ -649,6 +693,9 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
 // evenly between them.  Register budget as before: 128 accumulators + 96 fragment registers (double buffered).
 typedef unsigned int u32x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+#ifndef ATS_MX_ABLATE      // tuning builds only (make ablate, tools/mx_ablate.py): 1 = no DMA, 2 = no fragment reads, 3 = no MFMAs in the main loop
+#define ATS_MX_ABLATE 0
+#endif
 #define ATS_MFMA_MX(c, a, b, s) \
   asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(a), "v"(b), "v"(s))
 
@@ -845,11 +892,12 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_mx_kernel(const void* __rest
       const int idx = i * TB + j;                                                                        \
       _Pragma("unroll") for (int t = 0; t < NIT; ++t) {                                                  \
         if (t * NMF / NIT == idx) {                                                                      \
-          if (t < NR) { if (RD) read_one(((Q) + 1) & 3, ((Q) + 1) & 1, t); }                             \
-          else if (DMA) dma_piece((Q), (ks) + 4, t - NR);                                                \
+          if (t < NR) { if (RD && ATS_MX_ABLATE != 2) read_one(((Q) + 1) & 3, ((Q) + 1) & 1, t); }       \
+          else if (DMA && ATS_MX_ABLATE != 1) dma_piece((Q), (ks) + 4, t - NR);                          \
         }                                                                                                \
       }                                                                                                  \
-      ATS_MFMA_MX(acc[i][j], ATS_CAT8(fal[(Q) & 1][i], fah[(Q) & 1][i]), ATS_CAT8(fbl[(Q) & 1][j], fbh[(Q) & 1][j]), unit_scale); \
+      if (ATS_MX_ABLATE != 3)                                                                            \
+        ATS_MFMA_MX(acc[i][j], ATS_CAT8(fal[(Q) & 1][i], fah[(Q) & 1][i]), ATS_CAT8(fbl[(Q) & 1][j], fbh[(Q) & 1][j]), unit_scale); \
     }                                                                                                    \
     if (RD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
     if ((VM) >= 0) {                                                                                     \
@@ -935,6 +983,49 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
   }
   if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, none, stamps, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
   else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+// lse[row] = log sum over the row's per-tile (max, sum exp) partials of the fused lm_head epilogue; one wave per row
+__global__ __launch_bounds__(256) void lse_combine_kernel(const float2* __restrict__ part, int rows, int tiles_n, float* __restrict__ lse) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float mx = -INFINITY, sm = 0.f;
+  for (int t = lane; t < tiles_n; t += 64) {
+    const float2 p = part[(size_t)row * tiles_n + t];
+    const float nm = fmaxf(mx, p.x);
+    sm = (nm > -INFINITY) ? sm * __expf(mx - nm) + p.y * __expf(p.x - nm) : 0.f;
+    mx = nm;
+  }
+  const float gm = wave_max_f32(mx);
+  sm = (mx > -INFINITY) ? sm * expf(mx - gm) : 0.f;
+  sm = wave_sum_f32(sm);
+  if (lane == 0) lse[row] = gm + logf(sm);
+}
+
+// lm_head over the batched rows with the normaliser fused into the epilogue (gemm_ring_kernel<EPI_F32_LSE>)
+int launch_big_lse(const bf16_t* x, const bf16_t* w, float* c, int m, int n, int k, int ldx, int ldc, float* part, const unsigned char* tile_store,
+                   float* lse, hipStream_t st) {
+  static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
+  const int tiles_n = (n + 255) / 256;
+  static thread_local AtsPerDeviceFlag attr_flag;
+  bool& attr_done = attr_flag.cur();
+  if (!attr_done) {
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI_F32_LSE, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI_F32_LSE, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    attr_done = true;
+  }
+  const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
+  const float* none = nullptr;
+  if (big_use_256_rows(t256, t128))
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32_LSE, 8, false>), dim3(t256), dim3(512), 136 * 1024, st, (const void*)x, (const void*)w, none, none, (void*)c, m, n, k,
+                       ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, part, tile_store);
+  else
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32_LSE, 4, false>), dim3(t128), dim3(512), 100 * 1024, st, (const void*)x, (const void*)w, none, none, (void*)c, m, n, k,
+                       ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, part, tile_store);
+  ATS_LAUNCH_CHECK();
+  lse_combine_kernel<<<(m + 3) / 4, 256, 0, st>>>(reinterpret_cast<const float2*>(part), m, tiles_n, lse);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -1255,6 +1346,27 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
   }
   atspeed_set_error("gemm: unknown dtype %d", dtype);
   return ATSPEED_ERR_INVALID;
+}
+
+size_t ats_lmhead_lse_part_bytes(int m, int n) { return (size_t)m * ((n + 255) / 256) * 2 * sizeof(float); }
+
+// logits = a * w^T (fp32) and lse[row] = log sum exp over ALL n columns of the row.  On the batched path (bf16, ring kernel) the
+// normaliser comes out of the GEMM epilogue and only the 256-column tiles flagged in tile_store (device bytes, one per tile; NULL = all)
+// are written; otherwise the plain GEMM + the streaming lse_rows_kernel.  *fused_out tells which.
+int ats_lmhead_lse(const void* a, const void* w, float* logits, int m, int n, int k, int lda, int ldc, int dtype, const unsigned char* tile_store,
+                   float* part, size_t part_bytes, float* lse, void* workspace, size_t workspace_bytes, hipStream_t st, int* fused_out) {
+  static const int fuse = env_int("ATSPEED_FUSE_LSE", 1);
+  if (fused_out) *fused_out = 0;
+  if (m <= 0) return ATSPEED_OK;
+  if (fuse && dtype == ATSPEED_BF16 && part && part_bytes >= ats_lmhead_lse_part_bytes(m, n) && ((uintptr_t)part & 7) == 0 &&
+      big_kernel_applies(m, n, k, lda, ldc, dtype, EPI_F32)) {
+    ATS_REQUIRE(a && w && logits && lse, ATSPEED_ERR_INVALID, "lmhead_lse: null operand");
+    ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "lmhead_lse: operands must be 16-byte aligned");
+    if (fused_out) *fused_out = 1;
+    return launch_big_lse((const bf16_t*)a, (const bf16_t*)w, logits, m, n, k, lda, ldc, part, tile_store, lse, st);
+  }
+  ATS_TRY(ats_gemm(a, w, logits, m, n, k, lda, ldc, dtype, EPI_F32, workspace, workspace_bytes, st));
+  return ats_lse_rows(logits, m, n, ldc, lse, st);
 }
 
 // h += a * w^T, then xn = rmsnorm(h) * norm_w  (split-K path fuses the reduce, the residual and the norm)

@@ -45,7 +45,7 @@ int ats_rope_kv(void* qkv, const int32_t* pos, const int32_t* slots, const float
                 hipStream_t st);
 
 // ---- gemm.hip -------------------------------------------------------------------------
-enum { EPI_STORE = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_SWIGLU = 3 };
+enum { EPI_STORE = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_SWIGLU = 3, EPI_F32_LSE = 4 /* ring kernel only: fp32 store + per-tile (max, sum exp) */ };
 size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype);
 int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int dtype, int epilogue,
              void* workspace, size_t workspace_bytes, hipStream_t st);
@@ -61,6 +61,10 @@ int ats_rmsnorm_quant_fp8(const void* x, const void* w, void* y, void* q, float*
 bool ats_gemm_fp8_applies(int m, int n, int k, int ldc, int epilogue);
 int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int m, int n, int k, int ldc,
                  int epilogue, hipStream_t st);
+
+size_t ats_lmhead_lse_part_bytes(int m, int n);
+int ats_lmhead_lse(const void* a, const void* w, float* logits, int m, int n, int k, int lda, int ldc, int dtype, const unsigned char* tile_store,
+                   float* part, size_t part_bytes, float* lse, void* workspace, size_t workspace_bytes, hipStream_t st, int* fused_out = nullptr);
 
 int ats_gemm_partials(const void* a, const void* w, int m, int n, int k, int lda, int dtype, void* workspace, size_t workspace_bytes,
                       hipStream_t st, int* splits_out);
@@ -83,6 +87,7 @@ struct FsmDev {
 struct atspeed_fsm {
   FsmDev dev;
   int32_t *d_row_ptr, *d_tok, *d_nxt;
+  unsigned char* d_tile_store;   // [256] device bytes: 1 = some edge token lies in columns [256 t, 256 t + 256) (the logit tiles a step can read)
 };
 
 struct TokBuf {       // inputs of a forward: one row per token

@@ -151,6 +151,17 @@ int atspeed_llama_enable_fp8(atspeed_llama* m, void* stream);
  * really ran its projections in fp8 rather than fell back by shape.  Either output may be NULL.  No reference counterpart. */
 int atspeed_llama_fp8_counters(atspeed_llama* m, int64_t* fp8_out, int64_t* other_out, int32_t reset);
 
+/* lm_head fused with the full-vocabulary normaliser of beamSD.py:58,285 (log_softmax over ALL columns, before masking): bf16
+ * x [rows, hidden] times w [vocab, hidden]^T -> fp32 logits (row stride ld) and lse[row] = log sum_v exp(logits[row][v]).  On the
+ * batched path (rows >= 257 and a tile grid that fills the chip) the (max, sum exp) partials come out of the GEMM epilogue, the
+ * logits are never re-read, and with `fsm` given only the 256-column tiles that hold a token of the automaton are written (the
+ * others are never read by a step: Beauty 5 of 129 tiles) -- *fused_out = 1; otherwise the plain GEMM + atspeed_lse_rows (0).
+ * workspace: at least rows * ceil(vocab / 256) * 8 bytes for the fused path (+ the split-K slabs of the small path).  This is what
+ * the decoder's forwards run; standalone for tests and benches. */
+int atspeed_lmhead_lse(const void* x_dev, const void* w_dev, float* logits_dev, float* lse_dev, int32_t rows, int32_t vocab,
+                       int32_t hidden, int32_t ld, const atspeed_fsm* fsm /* may be NULL */, void* workspace_dev, size_t workspace_bytes,
+                       int32_t* fused_out /* may be NULL */, void* stream);
+
 /* ------------------------------------------------------------------ scan kernels
  * log-softmax normaliser over the FULL vocabulary, before masking (beamSD.py:58,285):
  * lse[r] = log(sum_v exp(logits[r][v])).  Rows are `ld` floats apart. */

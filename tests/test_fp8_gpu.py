@@ -130,12 +130,12 @@ def test_fp8_accept_length_drift_on_an_aligned_pair():
     inputs = [{"input_ids": torch.from_numpy(synth.synthetic_prompt(P, 900 + u))[None].cuda()} for u in range(U)]
     mean_acc = lambda outs: sum(o["total_accept_steps"] for o in outs) / max(1, sum(o["n_run"] for o in outs))
     seen = {}
-    for rs in (1e-3, 3e-3, 1e-2, 3e-2):
+    for rs in (3e-4, 5e-4, 1e-3):
         drf = HipLlama.from_synthetic(synth.LlamaDims(V, 256, 2, 4, 704), 32, std=0.02, head_std=0.02, num_beams=40, resid_scale=rs, **kw)
         tgt = HipLlama.from_synthetic(synth.LlamaDims(V, H, LAYERS, HEADS, F), 31, std=0.02, head_std=0.02, num_beams=20, resid_scale=rs, align_to=drf, **kw)
         a_bf = mean_acc(BSSD_batch(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=fn))
         seen[rs] = [a_bf]
-        if 0.4 < a_bf < 2.6:
+        if 0.2 < a_bf < 2.8:
             tgt.enable_fp8()
             a_f8 = mean_acc(BSSD_batch(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=fn))
             seen[rs].append(a_f8)

@@ -426,6 +426,49 @@ def test_gemm_fp8(lib, m, n, k, epi):
     np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=tol, rtol=0)
 
 
+@pytest.mark.parametrize("rows,vocab,hidden", [(700, 32859, 512), (1300, 33014, 256), (2100, 5000, 768), (90, 32859, 256)])
+def test_lmhead_lse_fused_epilogue(lib, rows, vocab, hidden):
+    """lm_head + full-vocabulary normaliser in one kernel (beamSD.py:58,285): lse equals logsumexp of the fp32 product over ALL columns
+    (tail tile of a vocabulary that is no multiple of 256 included), the logit tiles of the automaton's tokens are the plain GEMM's bit for
+    bit, every other tile is left untouched (never written: that is the HBM traffic the fusion removes).  90 rows: the small path
+    (plain GEMM + streaming LSE), same answers, everything written."""
+    x = _rand((rows, hidden), 61, 1.0).to(torch.bfloat16).cuda()
+    w = _rand((vocab, hidden), 62, 0.08).to(torch.bfloat16).cuda()
+    ld = (vocab + 63) // 64 * 64
+    ref = x.float().cpu().double() @ w.float().cpu().double().T
+    ref_lse = torch.logsumexp(ref, dim=1)
+    plain = torch.zeros(rows, ld, dtype=torch.float32, device="cuda")
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.atspeed_gemm(x.data_ptr(), w.data_ptr(), plain.data_ptr(), rows, vocab, hidden, hidden, ld, _lib.ATSPEED_BF16, _lib.EPI_F32,
+                                ws.data_ptr(), ws.numel(), _st()))
+    # automaton over a few token ids: tiles {0, last two full ones, tail}
+    toks = sorted({2, 300 % vocab, vocab - 600, vocab - 300, vocab - 1})
+    row_ptr = np.array([0, len(toks), len(toks)], np.int32); tok = np.array(toks, np.int32); nxt = np.ones(len(toks), np.int32)
+    fsm = C.c_void_p()
+    _lib.check(lib.atspeed_fsm_create(row_ptr.ctypes.data, tok.ctypes.data, nxt.ctypes.data, 2, len(toks), vocab, C.byref(fsm)))
+    try:
+        for use_fsm in (False, True):
+            SENT = -12345.0
+            logits = torch.full((rows, ld), SENT, dtype=torch.float32, device="cuda")
+            lse = torch.empty(rows, dtype=torch.float32, device="cuda")
+            fused = C.c_int32(-1)
+            _lib.check(lib.atspeed_lmhead_lse(x.data_ptr(), w.data_ptr(), logits.data_ptr(), lse.data_ptr(), rows, vocab, hidden, ld,
+                                              fsm if use_fsm else None, ws.data_ptr(), ws.numel(), C.byref(fused), _st()))
+            torch.cuda.synchronize()
+            assert fused.value == (1 if rows >= 257 else 0)
+            np.testing.assert_allclose(lse.cpu().double().numpy(), ref_lse.numpy(), atol=2e-4, rtol=0)
+            stored = {t // 256 for t in toks} if (use_fsm and fused.value) else set(range((vocab + 255) // 256))
+            for t in range((vocab + 255) // 256):
+                lo, hi = t * 256, min(vocab, t * 256 + 256)
+                got = logits[:, lo:hi]
+                if t in stored:
+                    assert torch.equal(got, plain[:, lo:hi]), f"tile {t} differs from the plain GEMM"
+                else:
+                    assert bool((got == SENT).all()), f"tile {t} was written although no token of the automaton lies in it"
+    finally:
+        lib.atspeed_fsm_destroy(fsm)
+
+
 def test_measured_peak_probes_are_plausible(lib):
     """bench.py's measured peaks: the probes run, synchronise and return numbers between a loose floor and the
     nominal peaks of /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF dense bf16, 8 TB/s)."""
