@@ -590,6 +590,7 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   asm volatile("s_barrier" ::: "memory");                          // k-step 1 published, stage 0 read by everyone
 
 #ifdef ATS_RING_STAMPS
+  const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz reference: cycles / ticks = the clock the chip holds
   const unsigned long long st_loop0 = st_last = __builtin_readcyclecounter();
 #endif
   int ks = ks0;
@@ -606,6 +607,7 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
 #undef ATS_RING_SEGMENT
 #ifdef ATS_RING_STAMPS
   const unsigned long long st_loop1 = __builtin_readcyclecounter();
+  const unsigned long long st_rt1 = __builtin_amdgcn_s_memrealtime();
 #endif
 #undef ATS_STAMP
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");               // MFMA results -> VALU reads (the compiler cannot see the asm MFMAs)
@@ -668,13 +670,15 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   } else if constexpr (SPLITK) big_epilogue<EPI_F32, NA, MT2>(acc, reinterpret_cast<float*>(Cv) + (size_t)zpart * M * N, M, N, N, m0, n0, wn, wm, lq, g);
   else                  big_epilogue<EPI, NA, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
 #ifdef ATS_RING_STAMPS
-  // tuning build: sw carries the stamp buffer [workgroup][wave][8] = loop cycles in {issue, lgkmcnt wait, vmcnt wait, barrier}, then
-  // the absolute counter at kernel entry, loop start, loop end and after the epilogue's stores have been acknowledged
+  // tuning build: sw carries the stamp buffer [workgroup][wave][10] = loop cycles in {issue, lgkmcnt wait, vmcnt wait, barrier}, then
+  // the absolute counter at kernel entry, loop start, loop end and after the epilogue's stores have been acknowledged, then the
+  // 100 MHz real-time counter at loop start and end
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0 && (FP8 ? false : sw != nullptr)) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(sw)) + ((size_t)blockIdx.x * NWV + wave) * 8;
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(sw)) + ((size_t)blockIdx.x * NWV + wave) * 10;
     dbg[0] = st_t[0]; dbg[1] = st_t[1]; dbg[2] = st_t[2]; dbg[3] = st_t[3];
     dbg[4] = st_entry; dbg[5] = st_loop0; dbg[6] = st_loop1; dbg[7] = __builtin_readcyclecounter();
+    dbg[8] = st_rt0; dbg[9] = st_rt1;
   }
 #endif
 }

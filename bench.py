@@ -366,8 +366,22 @@ def main():
         torch.cuda.synchronize(dev)
         us = e0.elapsed_time(e1) * 1e3 / 20
         scan = dict(kernel="lse_rows_kernel", rows=rows, bytes_per_launch=rows * V * 4, avg_launch_us=us, bound="hbm",
-                    achieved=rows * V * 4 / (us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=rows * V * 4 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+                    achieved=rows * V * 4 / (us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=rows * V * 4 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    where="standalone launch of atspeed_lse_rows on a synthetic buffer of one verification round's shape: the kernel the one-user path "
+                          "and the C-ABI keep.  The lock-step decode loop no longer runs it (see in_situ)")
         del lg, lse
+        # in situ: since round 2 the batched forwards take the normaliser out of the lm_head GEMM's epilogue and write only the logit tiles that
+        # hold a token of the constraint automaton, so the verify step's former HBM-bound pass (write + re-read of every logit) is gone
+        lm = prof["lm_head"]
+        tiles_all = (V + 255) // 256
+        tiles_kept = len({int(t) // 256 for t in fn.compile(prompts[0].tolist()).tok})
+        avg_rows = lm["rows"] / max(1, lm["count"])
+        scan["in_situ"] = dict(kernel="gemm_ring_kernel<4 (EPI_F32_LSE), 8, false> + lse_combine_kernel (lm_head with the fused full-vocabulary normaliser)",
+                               launches=lm["count"], avg_rows=avg_rows, avg_launch_us=1e3 * lm["ms"] / max(1, lm["count"]),
+                               logit_tiles_written=tiles_kept, logit_tiles_total=tiles_all,
+                               bytes_written_per_launch=avg_rows * (tiles_kept * 256 * 4 + tiles_all * 8),
+                               bytes_avoided_per_launch=avg_rows * ((tiles_all - tiles_kept) * 256 * 4 + V * 4),
+                               note="avoided = logit tiles never written + the LSE pass's re-read of every logit (what lse_rows_kernel streamed)")
 
     # ---- measured peaks of THIS box: register-only bf16 MFMA loop on random operands, read-only HBM stream over 2 GiB
     measured = None
@@ -418,7 +432,9 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         bound, peak, unit = "hbm", HBM_PEAK_GBS, "GB/s"
     epi = {"qkv": 0, "o_proj": 2, "gate_up": 3, "down": 2, "lm_head": 1}[kind]
-    kname = (f"gemm_ring_kernel<{epi}, 8, {'true' if args.target_fp8 else 'false'}, false, 4> [{kind}] N={N} K={K} avg_M={avg_m:.0f} (launches of >= 1024 tokens)"
+    ring = (f"gemm_ring_mx_kernel<{epi}, 8>" if (args.target_fp8 and kind != "lm_head" and os.environ.get("ATSPEED_FP8_MX", "1") != "0")
+            else f"gemm_ring_kernel<{4 if kind == 'lm_head' else epi}, 8, {'true' if (args.target_fp8 and kind != 'lm_head') else 'false'}, false, 4>")
+    kname = (f"{ring} [{kind}] N={N} K={K} avg_M={avg_m:.0f} (launches of >= 1024 tokens)"
              if one_kernel else f"projection GEMM [{kind}] N={N} K={K} avg_M={avg_m:.0f} (all launches)")
     # PMC traffic was collected on the bf16 headline workload: it says nothing about the fp8 kernels or other batch shapes
     traffic, traffic_source = traffic_from_profiles(kind) if (one_kernel and not args.target_fp8 and args.streams == 256) else (None, None)
