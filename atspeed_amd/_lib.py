@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libatspeed_hip.so")
 
 ATSPEED_F32, ATSPEED_BF16 = 0, 1
+WEIGHTS_ROW_MAJOR, WEIGHTS_PACKED = 0, 1
 MAX_BEAMS, MAX_NEW_TOKENS, MAX_GAMMA = 64, 16, 8
 ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_CONSTRAINT, ERR_NO_DEVICE = -1, -2, -3, -4, -5
 EPI_STORE, EPI_F32, EPI_RESID, EPI_SWIGLU = 0, 1, 2, 3
@@ -26,7 +27,7 @@ class LlamaLayerWeights(C.Structure):
 class LlamaConfig(C.Structure):
     _fields_ = [("vocab_size", C.c_int32), ("hidden", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32),
                 ("ffn", C.c_int32), ("rope_theta", C.c_float), ("rms_eps", C.c_float), ("dtype", C.c_int32),
-                ("max_slots", C.c_int32), ("max_tokens", C.c_int32), ("max_logit_rows", C.c_int32)]
+                ("max_slots", C.c_int32), ("max_tokens", C.c_int32), ("max_logit_rows", C.c_int32), ("weight_layout", C.c_int32)]
 
 
 class GenStats(C.Structure):
@@ -72,6 +73,10 @@ SIGNATURES = {
     "atspeed_target_generate_batch": (C.c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "atspeed_decoder_trace": (C.c_int, [_P, _P, _I]),
     "atspeed_gemm": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "atspeed_gemm_packed": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "atspeed_gemm_fp8_packed": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "atspeed_pack_rows": (C.c_int, [_P, _P, _I, _I, _P]),
+    "atspeed_unpack_rows": (C.c_int, [_P, _P, _I, _I, _P]),
     "atspeed_rmsnorm": (C.c_int, [_P, _P, _P, _I, _I, _F, _I, _P]),
     "atspeed_rmsnorm_quant_fp8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "atspeed_tree_attention": (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),

@@ -22,7 +22,7 @@ namespace {
 constexpr int kMaxSlots = 2048;
 template <typename T>
 __global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q, int ldq, const SegTable* __restrict__ tab, size_t layer_off,
-                                                        int vis_words, T* __restrict__ out, int ldo,
+                                                        int vis_words, T* __restrict__ out, int ldo, int pk,
                                                         int n_heads, int head_dim, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -94,11 +94,10 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const T* __restrict__ q,
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   // phase 3: out[d] = sum_i p_i V[slot_i][d]
-  T* orow = out + (size_t)t * ldo + h * head_dim;
   for (int d = lane; d < head_dim; d += 64) {
     float acc = 0.f;
     for (int i = 0; i < n_vis; ++i) acc += prob[i] * Elt<T>::load(vc + (size_t)slot_list[i] * hidden + h * head_dim + d);
-    Elt<T>::store(orow + d, acc * inv);
+    Elt<T>::store(out + ats_opnd_idx<sizeof(T)>(pk, t, h * head_dim + d, ldo), acc * inv);      // the o_proj operand: packed when pk
   }
 }
 
@@ -125,7 +124,7 @@ __device__ __forceinline__ void tr_read_2pairs(u32x2_t& a0, u32x2_t& b0, u32x2_t
 template <int DH, int NW>   // NW waves per workgroup = 16*NW query rows per tile
 __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* __restrict__ q, int ldq, const SegTable* __restrict__ tab,
                                                              size_t layer_off, int vis_words,
-                                                             bf16_t* __restrict__ out, int ldo,
+                                                             bf16_t* __restrict__ out, int ldo, int pk,
                                                              int n_heads, float scale) {
   constexpr int KCH = DH / 8;                 // 16-byte chunks per K row
   constexpr int VROW = DH * 2 + 32;           // V tile row stride in bytes: 8 rows x 32 B of a transposed read cover all 64 banks
@@ -271,12 +270,11 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
   l_run += __shfl_xor(l_run, 32, 64);
   if (qok) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    bf16_t* orow = out + (size_t)qrow * ldo + h * DH;
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
-      ushort4 pk;
-      pk.x = f2bf(o[d][0] * inv); pk.y = f2bf(o[d][1] * inv); pk.z = f2bf(o[d][2] * inv); pk.w = f2bf(o[d][3] * inv);
-      *reinterpret_cast<ushort4*>(orow + d * 16 + g * 4) = pk;
+      ushort4 v4;
+      v4.x = f2bf(o[d][0] * inv); v4.y = f2bf(o[d][1] * inv); v4.z = f2bf(o[d][2] * inv); v4.w = f2bf(o[d][3] * inv);
+      *reinterpret_cast<ushort4*>(out + ats_opnd_idx<2>(pk, qrow, h * DH + d * 16 + g * 4, ldo)) = v4;
     }
   }
 }
@@ -299,7 +297,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 template <int DH, int NW>   // NW waves per workgroup = 32*NW query rows per tile
 __global__ __launch_bounds__(64 * NW, 2) void tree_attn32_kernel(const bf16_t* __restrict__ q, int ldq, const SegTable* __restrict__ tab,
-                                                                 size_t layer_off, int vis_words, bf16_t* __restrict__ out, int ldo,
+                                                                 size_t layer_off, int vis_words, bf16_t* __restrict__ out, int ldo, int pk,
                                                                  int n_heads, float scale) {
   constexpr int KCH = DH / 8;                 // 16-byte chunks per K row
   constexpr int VROW = DH * 2 + 32;           // V tile row stride in bytes
@@ -447,15 +445,14 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn32_kernel(const bf16_t* _
   l_run += __shfl_xor(l_run, 32, 64);
   if (qok) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    bf16_t* orow = out + (size_t)qrow * ldo + h * DH;
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
       for (int i4 = 0; i4 < 4; ++i4) {
-        ushort4 pk;
-        pk.x = f2bf(o[d][i4 * 4 + 0] * inv); pk.y = f2bf(o[d][i4 * 4 + 1] * inv);
-        pk.z = f2bf(o[d][i4 * 4 + 2] * inv); pk.w = f2bf(o[d][i4 * 4 + 3] * inv);
-        *reinterpret_cast<ushort4*>(orow + d * 32 + 8 * i4 + 4 * hi) = pk;
+        ushort4 v4;
+        v4.x = f2bf(o[d][i4 * 4 + 0] * inv); v4.y = f2bf(o[d][i4 * 4 + 1] * inv);
+        v4.z = f2bf(o[d][i4 * 4 + 2] * inv); v4.w = f2bf(o[d][i4 * 4 + 3] * inv);
+        *reinterpret_cast<ushort4*>(out + ats_opnd_idx<2>(pk, qrow, h * DH + d * 32 + 8 * i4 + 4 * hi, ldo)) = v4;
       }
   }
 }
@@ -463,8 +460,9 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn32_kernel(const bf16_t* _
 }  // namespace
 
 int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const SegTable* dt, size_t layer_off_bytes, int vis_words,
-                            void* out, int ldo, int n_heads, int head_dim, int dtype, hipStream_t st, int rows_per_wave) {
+                            void* out, int ldo, int n_heads, int head_dim, int dtype, hipStream_t st, int rows_per_wave, int pk) {
   if (t.total_tok <= 0) return ATSPEED_OK;
+  ATS_REQUIRE(!pk || (dtype == ATSPEED_BF16 && ldo % 32 == 0), ATSPEED_ERR_INVALID, "attention: packed output needs bf16 and ldo %% 32 == 0");
   ATS_REQUIRE(head_dim % 8 == 0 && head_dim <= 256, ATSPEED_ERR_INVALID, "attention: head_dim %d unsupported", head_dim);
   ATS_REQUIRE(vis_words * 64 <= kMaxSlots, ATSPEED_ERR_CAPACITY, "attention: visibility bitset too wide (%d words)", vis_words);
   for (int i = 0; i < t.n; ++i)
@@ -487,7 +485,7 @@ int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const Seg
       attr_done = true;                                                                                                        \
     }                                                                                                                          \
     tree_attn32_kernel<DHV, NWV><<<mgrid, 64 * NWV, lds_bytes, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words,    \
-                                                                     (bf16_t*)out, ldo, n_heads, scale);                       \
+                                                                     (bf16_t*)out, ldo, pk, n_heads, scale);                       \
   }
       if (head_dim == 128) { if (t.qtile_rows == 256) ATS_ATTN32(128, 8) else if (t.qtile_rows == 128) ATS_ATTN32(128, 4) else ATS_ATTN32(128, 2) }
       else                 { if (t.qtile_rows == 256) ATS_ATTN32(64, 8)  else if (t.qtile_rows == 128) ATS_ATTN32(64, 4)  else ATS_ATTN32(64, 2) }
@@ -497,19 +495,19 @@ int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const Seg
     }
     if (t.qtile_rows == 256) {
       if (head_dim == 128)
-        tree_attn_mfma_kernel<128, 16><<<mgrid, 1024, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+        tree_attn_mfma_kernel<128, 16><<<mgrid, 1024, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, pk, n_heads, scale);
       else
-        tree_attn_mfma_kernel<64, 16><<<mgrid, 1024, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+        tree_attn_mfma_kernel<64, 16><<<mgrid, 1024, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, pk, n_heads, scale);
     } else if (t.qtile_rows == 128) {
       if (head_dim == 128)
-        tree_attn_mfma_kernel<128, 8><<<mgrid, 512, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+        tree_attn_mfma_kernel<128, 8><<<mgrid, 512, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, pk, n_heads, scale);
       else
-        tree_attn_mfma_kernel<64, 8><<<mgrid, 512, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+        tree_attn_mfma_kernel<64, 8><<<mgrid, 512, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, pk, n_heads, scale);
     } else {
       if (head_dim == 128)
-        tree_attn_mfma_kernel<128, 4><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+        tree_attn_mfma_kernel<128, 4><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, pk, n_heads, scale);
       else
-        tree_attn_mfma_kernel<64, 4><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, scale);
+        tree_attn_mfma_kernel<64, 4><<<mgrid, 256, 0, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, pk, n_heads, scale);
     }
     ATS_LAUNCH_CHECK();
     return ATSPEED_OK;
@@ -517,9 +515,9 @@ int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const Seg
   dim3 grid(t.total_tok, (n_heads + 3) / 4);
   size_t lds = (size_t)4 * (head_dim + 2 * vis_words * 64) * sizeof(float);
   if (dtype == ATSPEED_F32)
-    tree_attn_kernel<float><<<grid, 256, lds, st>>>((const float*)q, ldq, dt, layer_off_bytes, vis_words, (float*)out, ldo, n_heads, head_dim, scale);
+    tree_attn_kernel<float><<<grid, 256, lds, st>>>((const float*)q, ldq, dt, layer_off_bytes, vis_words, (float*)out, ldo, 0, n_heads, head_dim, scale);
   else
-    tree_attn_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, n_heads, head_dim, scale);
+    tree_attn_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, (bf16_t*)out, ldo, pk, n_heads, head_dim, scale);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -540,7 +538,7 @@ int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* v
   for (int j = 0; j * t.qtile_rows < n_tokens; ++j) { t.qtile_seg[t.n_qtiles] = 0; t.qtile_idx[t.n_qtiles++] = (unsigned char)j; }
   const void* dt = nullptr;
   ATS_TRY(ats_stage(&t, sizeof(t), &dt, st));
-  return ats_tree_attention_segs(q, ldq, t, (const SegTable*)dt, 0, vis_words, out, ldo, n_heads, head_dim, dtype, st, rows_per_wave);
+  return ats_tree_attention_segs(q, ldq, t, (const SegTable*)dt, 0, vis_words, out, ldo, n_heads, head_dim, dtype, st, rows_per_wave, 0);
 }
 
 extern "C" int atspeed_tree_attention(const void* q, int32_t ldq, const void* kcache, const void* vcache,

@@ -56,6 +56,23 @@ struct AtsPerDeviceFlag {
   bool& cur() { return done[ats_cur_device()]; }
 };
 
+// ---------------------------------------------------------------- packed GEMM-operand layout
+// What the LDS-DMA of the ring GEMMs wants from HBM (measured, tools/probe/dma_depth.hip: 83 GB/s per CU against 55 GB/s): every
+// 1 KB DMA piece (16 rows x 64 bytes of K) made of FULL 128-byte lines.  A row-major operand gives it 16 half lines.  In the packed
+// layout two consecutive rows share a line per 64-byte k-block:
+//   byte b of row r  ->  ((r >> 1) * (row_bytes / 64) + (b >> 6)) * 128 + (r & 1) * 64 + (b & 63)
+// (row_bytes % 64 == 0, buffers hold an even number of rows).  The bf16 / fp8 engine keeps every GEMM operand in it -- projection
+// weights, lm_head, and the activations a projection reads (RMSNorm output, attention output, SwiGLU output, their e4m3 forms) --
+// written that way by their producers; everything else (residual stream, qkv, logits, KV cache, fp32 parity mode) stays row-major.
+__host__ __device__ inline size_t ats_pk_byte(size_t row, size_t byte_in_row, size_t row_bytes) {
+  return ((row >> 1) * (row_bytes >> 6) + (byte_in_row >> 6)) * 128 + (row & 1) * 64 + (byte_in_row & 63);
+}
+// element index of (row, col) in an operand of `ld` elements per row, element size 2^esz_log2 bytes, packed or row-major
+template <int ESZ>
+__host__ __device__ inline size_t ats_opnd_idx(int pk, size_t row, size_t col, size_t ld) {
+  return pk ? ats_pk_byte(row, col * ESZ, ld * ESZ) / ESZ : row * ld + col;
+}
+
 // counter-based hash shared by the synthetic-weight fill and the sampling kernels (= atspeed_amd/synth.py:hash_u32)
 __host__ __device__ inline uint32_t ats_fmix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;

@@ -62,10 +62,9 @@ int ats_embed(const void* table, const int32_t* ids, void* out, int n_tokens, in
 // one workgroup per row; fp32 statistics (HF LlamaRMSNorm upcasts); y = w * (x * rsqrt(mean(x^2)+eps))
 template <typename T>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y,
-                                                      int hidden, float eps) {
+                                                      int hidden, float eps, int pk) {
   __shared__ float red[4];
   const T* xr = x + (size_t)blockIdx.x * hidden;
-  T* yr = y + (size_t)blockIdx.x * hidden;
   float ss = 0.f;
   for (int i = threadIdx.x; i < hidden; i += 256) { float v = Elt<T>::load(xr + i); ss += v * v; }
   ss = wave_sum_f32(ss);
@@ -76,7 +75,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, c
   for (int i = threadIdx.x; i < hidden; i += 256) {
     float v = Elt<T>::load(xr + i) * rs;
     if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));    // HF casts the normalised value to the input dtype first
-    Elt<T>::store(yr + i, Elt<T>::load(w + i) * v);
+    Elt<T>::store(y + ats_opnd_idx<sizeof(T)>(pk, blockIdx.x, i, hidden), Elt<T>::load(w + i) * v);   // y: a GEMM operand (packed when pk)
   }
 }
 
@@ -86,12 +85,11 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, c
 template <int NC, bool QUANT>
 __global__ __launch_bounds__(256) void rmsnorm_bf16_vec_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                                bf16_t* __restrict__ y, int hidden, float eps,
-                                                               unsigned char* __restrict__ q, float* __restrict__ scale) {
+                                                               unsigned char* __restrict__ q, float* __restrict__ scale, int pk) {
   __shared__ float red[4], red2[4];
   const int nchunk = hidden >> 3;
   const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)blockIdx.x * hidden);
   const uint4* wr = reinterpret_cast<const uint4*>(w);
-  uint4* yr = y ? reinterpret_cast<uint4*>(y + (size_t)blockIdx.x * hidden) : nullptr;
   uint4 v[NC];
   float ss = 0.f;
 #pragma unroll
@@ -121,7 +119,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bf16_vec_kernel(const bf16_t* __r
         oe[j] = f2bf(bf2f(we[j]) * bf2f(f2bf(bf2f(e[j]) * rs)));   // HF casts the normalised value first
         if constexpr (QUANT) amax = fmaxf(amax, fabsf(bf2f(oe[j])));
       }
-      if (yr) yr[i] = o;
+      if (y) *reinterpret_cast<uint4*>(y + ats_opnd_idx<2>(pk, blockIdx.x, (size_t)i * 8, hidden)) = o;   // outputs are GEMM operands: packed when pk
       v[c] = o;
     }
   }
@@ -133,7 +131,6 @@ __global__ __launch_bounds__(256) void rmsnorm_bf16_vec_kernel(const bf16_t* __r
     const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
     const float inv = 1.0f / sc;
     if (threadIdx.x == 0) scale[blockIdx.x] = sc;
-    unsigned char* qr = q + (size_t)blockIdx.x * hidden;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int i = threadIdx.x + c * 256;
@@ -147,44 +144,45 @@ __global__ __launch_bounds__(256) void rmsnorm_bf16_vec_kernel(const bf16_t* __r
         lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
-        *reinterpret_cast<uint2*>(qr + i * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+        *reinterpret_cast<uint2*>(q + ats_opnd_idx<1>(pk, blockIdx.x, (size_t)i * 8, hidden)) = make_uint2((unsigned)lo, (unsigned)hi);
       }
     }
   }
 }
 
 // RMSNorm whose consumer is a W8A8 projection: y (bf16, optional) and the e4m3 row + scale in one pass
-int ats_rmsnorm_quant_fp8(const void* x, const void* w, void* y, void* q, float* scale, int rows, int hidden, float eps, hipStream_t st) {
+int ats_rmsnorm_quant_fp8(const void* x, const void* w, void* y, void* q, float* scale, int rows, int hidden, float eps, hipStream_t st, int pk) {
   if (rows <= 0) return ATSPEED_OK;
   ATS_REQUIRE(hidden % 8 == 0 && hidden <= 8192 && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)q) & 15) == 0,
               ATSPEED_ERR_INVALID, "rmsnorm_quant: hidden %d unsupported", hidden);
   const bf16_t *xb = (const bf16_t*)x, *wb = (const bf16_t*)w;
   bf16_t* yb = (bf16_t*)y;
   unsigned char* qb = (unsigned char*)q;
-  if (hidden <= 2048)      rmsnorm_bf16_vec_kernel<1, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale);
-  else if (hidden <= 4096) rmsnorm_bf16_vec_kernel<2, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale);
-  else                     rmsnorm_bf16_vec_kernel<4, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale);
+  if (hidden <= 2048)      rmsnorm_bf16_vec_kernel<1, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale, pk);
+  else if (hidden <= 4096) rmsnorm_bf16_vec_kernel<2, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale, pk);
+  else                     rmsnorm_bf16_vec_kernel<4, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale, pk);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
 
-int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, float eps, int dtype, hipStream_t st) {
+int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, float eps, int dtype, hipStream_t st, int pk) {
   if (rows <= 0) return ATSPEED_OK;
+  ATS_REQUIRE(!pk || (dtype == ATSPEED_BF16 && hidden % 32 == 0), ATSPEED_ERR_INVALID, "rmsnorm: packed output needs bf16 and hidden %% 32 == 0");
   const bool vec_ok = dtype == ATSPEED_BF16 && hidden % 8 == 0 && hidden <= 8192 &&
                       (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0;
   if (vec_ok) {
     const bf16_t *xb = (const bf16_t*)x, *wb = (const bf16_t*)w;
     bf16_t* yb = (bf16_t*)y;
-    if (hidden <= 2048)      rmsnorm_bf16_vec_kernel<1, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr);
-    else if (hidden <= 4096) rmsnorm_bf16_vec_kernel<2, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr);
-    else                     rmsnorm_bf16_vec_kernel<4, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr);
+    if (hidden <= 2048)      rmsnorm_bf16_vec_kernel<1, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr, pk);
+    else if (hidden <= 4096) rmsnorm_bf16_vec_kernel<2, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr, pk);
+    else                     rmsnorm_bf16_vec_kernel<4, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr, pk);
     ATS_LAUNCH_CHECK();
     return ATSPEED_OK;
   }
   if (dtype == ATSPEED_F32)
-    rmsnorm_kernel<float><<<rows, 256, 0, st>>>((const float*)x, (const float*)w, (float*)y, hidden, eps);
+    rmsnorm_kernel<float><<<rows, 256, 0, st>>>((const float*)x, (const float*)w, (float*)y, hidden, eps, 0);
   else
-    rmsnorm_kernel<bf16_t><<<rows, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, hidden, eps);
+    rmsnorm_kernel<bf16_t><<<rows, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, hidden, eps, pk);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -192,13 +190,13 @@ int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, flo
 extern "C" int atspeed_rmsnorm_quant_fp8(const void* x, const void* w, void* y, void* q, float* scale, int32_t rows, int32_t hidden,
                                          float eps, void* stream) {
   ATS_REQUIRE(x && w && q && scale && hidden > 0, ATSPEED_ERR_INVALID, "rmsnorm_quant_fp8: bad arguments");
-  return ats_rmsnorm_quant_fp8(x, w, y, q, scale, rows, hidden, eps, (hipStream_t)stream);
+  return ats_rmsnorm_quant_fp8(x, w, y, q, scale, rows, hidden, eps, (hipStream_t)stream, 0);
 }
 
 extern "C" int atspeed_rmsnorm(const void* x, const void* w, void* y, int32_t rows, int32_t hidden, float eps,
                                int32_t dtype, void* stream) {
   ATS_REQUIRE(x && w && y && hidden > 0, ATSPEED_ERR_INVALID, "rmsnorm: bad arguments");
-  return ats_rmsnorm(x, w, y, rows, hidden, eps, dtype, (hipStream_t)stream);
+  return ats_rmsnorm(x, w, y, rows, hidden, eps, dtype, (hipStream_t)stream, 0);
 }
 
 // ---------------------------------------------------------------------------- rope + kv scatter
@@ -472,13 +470,11 @@ int ats_gather_logit_rows(const void* h, const SegTable& t, const SegTable* dt, 
 // One workgroup per row, 16-byte loads, 8-byte stores.  Used once for the weights and per forward for the activations
 // feeding the fp8 projections (BASELINE config 5).
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, int cols, int ld,
-                                                             unsigned char* __restrict__ q, float* __restrict__ scale) {
+                                                             unsigned char* __restrict__ q, float* __restrict__ scale, int pk) {
   __shared__ float red[4];
-  const bf16_t* xr = x + (size_t)blockIdx.x * ld;
-  unsigned char* qr = q + (size_t)blockIdx.x * cols;
   float amax = 0.f;
   for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
-    uint4 v = *reinterpret_cast<const uint4*>(xr + c);
+    uint4 v = *reinterpret_cast<const uint4*>(x + ats_opnd_idx<2>(pk, blockIdx.x, c, ld));      // input and output are GEMM operands: both packed when pk
     const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(bf2f(e[j])));
@@ -491,7 +487,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
   const float inv = 1.0f / sc;
   if (threadIdx.x == 0) scale[blockIdx.x] = sc;
   for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
-    uint4 v = *reinterpret_cast<const uint4*>(xr + c);
+    uint4 v = *reinterpret_cast<const uint4*>(x + ats_opnd_idx<2>(pk, blockIdx.x, c, ld));
     const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
     float f[8];
 #pragma unroll
@@ -501,19 +497,52 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
     lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
     hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
     hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
-    *reinterpret_cast<uint2*>(qr + c) = make_uint2((unsigned)lo, (unsigned)hi);
+    *reinterpret_cast<uint2*>(q + ats_opnd_idx<1>(pk, blockIdx.x, c, cols)) = make_uint2((unsigned)lo, (unsigned)hi);
   }
 }
 
-int ats_quant_rows_fp8(const void* x, int rows, int cols, int ld, void* q, float* scale, hipStream_t st) {
+int ats_quant_rows_fp8(const void* x, int rows, int cols, int ld, void* q, float* scale, hipStream_t st, int pk) {
   if (rows <= 0) return ATSPEED_OK;
   ATS_REQUIRE(cols % 8 == 0 && ld % 8 == 0, ATSPEED_ERR_INVALID, "quant_fp8: cols=%d / ld=%d must be multiples of 8", cols, ld);
-  quant_rows_fp8_kernel<<<rows, 256, 0, st>>>((const bf16_t*)x, cols, ld, (unsigned char*)q, scale);
+  ATS_REQUIRE(!pk || (cols % 64 == 0 && ld == cols), ATSPEED_ERR_INVALID, "quant_fp8: packed operands need cols %% 64 == 0 and ld == cols");
+  quant_rows_fp8_kernel<<<rows, 256, 0, st>>>((const bf16_t*)x, cols, ld, (unsigned char*)q, scale, pk);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
 
 extern "C" int atspeed_quant_rows_fp8(const void* x, int32_t rows, int32_t cols, void* q, float* scale, void* stream) {
   ATS_REQUIRE(x && q && scale, ATSPEED_ERR_INVALID, "quant_fp8: null argument");
-  return ats_quant_rows_fp8(x, rows, cols, cols, q, scale, (hipStream_t)stream);
+  return ats_quant_rows_fp8(x, rows, cols, cols, q, scale, (hipStream_t)stream, 0);
+}
+
+
+// ---------------------------------------------------------------------------- packed operand layout (common.h: ats_pk_byte)
+// row-major [rows][row_bytes] <-> packed; 16-byte chunks, one thread each; the pad row of an odd row count is written as zeros
+__global__ void pack_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int rows, int row_bytes, int to_packed) {
+  const size_t cpr = (size_t)row_bytes >> 4;                     // 16-byte chunks per row
+  const size_t rows_even = ((size_t)rows + 1) & ~(size_t)1;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows_even * cpr) return;
+  const size_t r = i / cpr, c = i % cpr;
+  const size_t pk = ats_pk_byte(r, c << 4, (size_t)row_bytes) >> 4;
+  if (to_packed) dst[pk] = r < (size_t)rows ? src[r * cpr + c] : make_uint4(0, 0, 0, 0);
+  else if (r < (size_t)rows) dst[r * cpr + c] = src[pk];
+}
+
+int ats_pack_rows(const void* src, void* dst, int rows, int row_bytes, int to_packed, hipStream_t st) {
+  if (rows <= 0) return ATSPEED_OK;
+  ATS_REQUIRE(src && dst && src != dst && row_bytes > 0 && row_bytes % 64 == 0, ATSPEED_ERR_INVALID,
+              "pack_rows: row size %d must be a positive multiple of 64 bytes (out of place)", row_bytes);
+  ATS_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, ATSPEED_ERR_INVALID, "pack_rows: buffers must be 16-byte aligned");
+  const size_t n = (((size_t)rows + 1) & ~(size_t)1) * ((size_t)row_bytes >> 4);
+  pack_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const uint4*)src, (uint4*)dst, rows, row_bytes, to_packed);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+extern "C" int atspeed_pack_rows(const void* src, void* dst, int32_t rows, int32_t row_bytes, void* stream) {
+  return ats_pack_rows(src, dst, rows, row_bytes, 1, (hipStream_t)stream);
+}
+extern "C" int atspeed_unpack_rows(const void* src, void* dst, int32_t rows, int32_t row_bytes, void* stream) {
+  return ats_pack_rows(src, dst, rows, row_bytes, 0, (hipStream_t)stream);
 }

@@ -190,6 +190,7 @@ struct atspeed_llama {
   const void *embed, *final_norm, *lm_head;
   std::vector<atspeed_llama_layer_weights> layers;
   int esz, head_dim, vis_words, logits_ld;
+  int pk;                                        // 1: weights and GEMM-operand activations in the packed operand layout (common.h), bf16 only
   size_t layer_kv_bytes;
   float *cos_tab, *sin_tab;                      // [max_slots][head_dim/2]
   // optional fp8 (e4m3, per-output-row scales) copies of the layer projections, library-owned (atspeed_llama_enable_fp8)
@@ -314,6 +315,8 @@ extern "C" int atspeed_llama_create(const atspeed_llama_config* cfg, const void*
               "llama_create: max_slots must be a multiple of 64, <= 2048");
   ATS_REQUIRE(cfg->max_tokens > 0 && cfg->max_logit_rows > 0 && cfg->max_logit_rows <= cfg->max_tokens, ATSPEED_ERR_INVALID,
               "llama_create: bad token limits");
+  ATS_REQUIRE(cfg->weight_layout == ATSPEED_WEIGHTS_ROW_MAJOR || cfg->weight_layout == ATSPEED_WEIGHTS_PACKED, ATSPEED_ERR_INVALID,
+              "llama_create: weight_layout must be ATSPEED_WEIGHTS_ROW_MAJOR (0) or ATSPEED_WEIGHTS_PACKED (1)");
   atspeed_llama* m = new atspeed_llama();
   m->cfg = *cfg;
   m->embed = embed; m->final_norm = final_norm; m->lm_head = lm_head;
@@ -323,6 +326,12 @@ extern "C" int atspeed_llama_create(const atspeed_llama_config* cfg, const void*
   m->vis_words = cfg->max_slots / 64;
   m->logits_ld = (cfg->vocab_size + 63) / 64 * 64;
   m->layer_kv_bytes = (size_t)cfg->max_slots * cfg->hidden * m->esz;
+  m->pk = cfg->weight_layout == ATSPEED_WEIGHTS_PACKED ? 1 : 0;
+  if (m->pk && !(cfg->dtype == ATSPEED_BF16 && cfg->hidden % 32 == 0 && cfg->ffn % 32 == 0)) {
+    atspeed_set_error("llama_create: packed weights need bf16 and hidden / ffn multiples of 32 (hidden %d, ffn %d)", cfg->hidden, cfg->ffn);
+    delete m;
+    return ATSPEED_ERR_INVALID;
+  }
   m->act = nullptr;
   ATS_TRY(kv_create(m, &m->kv0));
   ATS_TRY(ensure_act(m, cfg->max_tokens, cfg->max_logit_rows));
@@ -413,10 +422,10 @@ extern "C" int atspeed_llama_enable_fp8(atspeed_llama* m, void* stream) {
   if (!m->fp8.empty()) return ATSPEED_OK;
   hipStream_t st = (hipStream_t)stream;
   const int H = m->cfg.hidden, F = m->cfg.ffn;
-  auto quant = [&](const void* w, int rows, int cols, void** q, float** sc) -> int {
-    ATS_HIP(hipMalloc(q, (size_t)rows * cols));
+  auto quant = [&](const void* w, int rows, int cols, void** q, float** sc) -> int {     // packed bf16 rows -> packed e4m3 rows (or row-major both)
+    ATS_HIP(hipMalloc(q, (size_t)((rows + 1) & ~1) * cols));
     ATS_HIP(hipMalloc((void**)sc, (size_t)rows * sizeof(float)));
-    return ats_quant_rows_fp8(w, rows, cols, cols, *q, *sc, st);
+    return ats_quant_rows_fp8(w, rows, cols, cols, *q, *sc, st, m->pk);
   };
   m->fp8.resize(m->cfg.n_layers);
   for (int l = 0; l < m->cfg.n_layers; ++l) {
@@ -436,8 +445,8 @@ extern "C" int atspeed_llama_enable_fp8(atspeed_llama* m, void* stream) {
 static int proj_fp8(atspeed_llama* m, const void* x, const void* wq, const float* sw, void* out, int M, int N, int K, int ldc,
                     int epi, hipStream_t st) {
   ActCtx* cx = m->act;
-  if (x) ATS_TRY(ats_quant_rows_fp8(x, M, K, K, cx->xq, cx->sx, st));
-  return ats_gemm_fp8(cx->xq, cx->sx, wq, sw, out, M, N, K, ldc, epi, st);
+  if (x) ATS_TRY(ats_quant_rows_fp8(x, M, K, K, cx->xq, cx->sx, st, m->pk));
+  return ats_gemm_fp8(cx->xq, cx->sx, wq, sw, out, M, N, K, ldc, epi, st, m->pk);
 }
 
 // One forward over the tokens of every segment (user) of the table.  Logits of each segment's last n_logit rows land
@@ -500,14 +509,14 @@ static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTabl
   const atspeed_llama_config& c = m->cfg;
   ActCtx* cx = m->act;
   const int T = t.total_tok;
-  const int H = c.hidden, dt = c.dtype;
+  const int H = c.hidden, dt = c.dtype, pk = m->pk;
   ATS_TRY(ats_embed_segs(m->embed, t, dtab, cx->h, H, c.vocab_size, dt, st));
   // fp8 projections fed by an RMSNorm take their e4m3 rows + scales straight from the norm kernel (no quantisation pass, no bf16 xn)
   const bool f8_qkv = !m->fp8.empty() && H <= 8192 && ats_gemm_fp8_applies(T, 3 * H, H, 3 * H, EPI_STORE);
   const bool f8_gu = !m->fp8.empty() && H <= 8192 && ats_gemm_fp8_applies(T, 2 * c.ffn, H, c.ffn, EPI_SWIGLU);
   bool xq_ready = false;
-  if (f8_qkv) { ATS_TRY(ats_rmsnorm_quant_fp8(cx->h, m->layers[0].input_norm, nullptr, cx->xq, cx->sx, T, H, c.rms_eps, st)); xq_ready = true; }
-  else ATS_TRY(ats_rmsnorm(cx->h, m->layers[0].input_norm, cx->xn, T, H, c.rms_eps, dt, st));
+  if (f8_qkv) { ATS_TRY(ats_rmsnorm_quant_fp8(cx->h, m->layers[0].input_norm, nullptr, cx->xq, cx->sx, T, H, c.rms_eps, st, pk)); xq_ready = true; }
+  else ATS_TRY(ats_rmsnorm(cx->h, m->layers[0].input_norm, cx->xn, T, H, c.rms_eps, dt, st, pk));
   for (int l = 0; l < c.n_layers; ++l) {
     const atspeed_llama_layer_weights& w = m->layers[l];
     const size_t loff = (size_t)l * m->layer_kv_bytes;
@@ -522,23 +531,23 @@ static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTabl
       } else {
         m->other_cnt[0]++;
         // one user's forward: the projection leaves fp32 split-K slabs and RoPE sums them itself (one launch less per layer)
-        if (fuse_qkv_reduce && m->head_dim % 16 == 0) ATS_TRY(ats_gemm_partials(cx->xn, w.wqkv, T, 3 * H, H, H, dt, cx->ws, cx->ws_bytes, st, &qkv_splits));
-        if (qkv_splits == 0) ATS_TRY(ats_gemm(cx->xn, w.wqkv, cx->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, cx->ws, cx->ws_bytes, st));
+        if (fuse_qkv_reduce && m->head_dim % 16 == 0) ATS_TRY(ats_gemm_partials(cx->xn, w.wqkv, T, 3 * H, H, H, dt, cx->ws, cx->ws_bytes, st, &qkv_splits, pk));
+        if (qkv_splits == 0) ATS_TRY(ats_gemm(cx->xn, w.wqkv, cx->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, cx->ws, cx->ws_bytes, st, pk));
       } }
     if (qkv_splits > 0)
       ATS_TRY(ats_rope_kv_segs_slabs((const float*)cx->ws, qkv_splits, cx->qkv, t, dtab, m->cos_tab, m->sin_tab, loff, c.n_heads, m->head_dim, c.max_slots, st));
     else
       ATS_TRY(ats_rope_kv_segs(cx->qkv, t, dtab, m->cos_tab, m->sin_tab, loff, c.n_heads, m->head_dim, c.max_slots, dt, st));
-    ATS_TRY(ats_tree_attention_segs(cx->qkv, 3 * H, t, dtab, loff, m->vis_words, cx->att, H, c.n_heads, m->head_dim, dt, st));
+    ATS_TRY(ats_tree_attention_segs(cx->qkv, 3 * H, t, dtab, loff, m->vis_words, cx->att, H, c.n_heads, m->head_dim, dt, st, 0, pk));
     { ProfBracket pb(m, 1, T, st);     // h += att Wo^T ; xn = rmsnorm(h) * post_norm
       if (f8 && ats_gemm_fp8_applies(T, H, H, H, EPI_RESID)) {
         m->fp8_cnt[1]++;
         ATS_TRY(proj_fp8(m, cx->att, m->fp8[l].wo, m->fp8[l].so, cx->h, T, H, H, H, EPI_RESID, st));
-        if (f8_gu) { ATS_TRY(ats_rmsnorm_quant_fp8(cx->h, w.post_norm, nullptr, cx->xq, cx->sx, T, H, c.rms_eps, st)); xq_ready = true; }
-        else { ATS_TRY(ats_rmsnorm(cx->h, w.post_norm, cx->xn, T, H, c.rms_eps, dt, st)); xq_ready = false; }
+        if (f8_gu) { ATS_TRY(ats_rmsnorm_quant_fp8(cx->h, w.post_norm, nullptr, cx->xq, cx->sx, T, H, c.rms_eps, st, pk)); xq_ready = true; }
+        else { ATS_TRY(ats_rmsnorm(cx->h, w.post_norm, cx->xn, T, H, c.rms_eps, dt, st, pk)); xq_ready = false; }
       } else {
         m->other_cnt[1]++;
-        ATS_TRY(ats_gemm_resid_norm(cx->att, w.wo, cx->h, T, H, H, H, H, dt, w.post_norm, cx->xn, c.rms_eps, cx->ws, cx->ws_bytes, st));
+        ATS_TRY(ats_gemm_resid_norm(cx->att, w.wo, cx->h, T, H, H, H, H, dt, w.post_norm, cx->xn, c.rms_eps, cx->ws, cx->ws_bytes, st, pk));
         xq_ready = false;
       } }
     { ProfBracket pb(m, 2, T, st);
@@ -547,7 +556,7 @@ static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTabl
         ATS_TRY(proj_fp8(m, xq_ready ? nullptr : cx->xn, m->fp8[l].wgu, m->fp8[l].sgu, cx->act, T, 2 * c.ffn, H, c.ffn, EPI_SWIGLU, st));
       } else {
         m->other_cnt[2]++;
-        ATS_TRY(ats_gemm(cx->xn, w.wgu, cx->act, T, 2 * c.ffn, H, H, c.ffn, dt, EPI_SWIGLU, cx->ws, cx->ws_bytes, st));
+        ATS_TRY(ats_gemm(cx->xn, w.wgu, cx->act, T, 2 * c.ffn, H, H, c.ffn, dt, EPI_SWIGLU, cx->ws, cx->ws_bytes, st, pk));
       } }
     { ProfBracket pb(m, 3, T, st);     // h += act Wd^T ; xn = rmsnorm(h) * next layer's input_norm
       m->fp8_cnt[3] += (f8 && ats_gemm_fp8_applies(T, H, c.ffn, H, EPI_RESID)) ? 1 : 0;
@@ -556,29 +565,29 @@ static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTabl
         ATS_TRY(proj_fp8(m, cx->act, m->fp8[l].wd, m->fp8[l].sd, cx->h, T, H, c.ffn, H, EPI_RESID, st));
         xq_ready = false;
         if (l + 1 < c.n_layers) {
-          if (f8_qkv) { ATS_TRY(ats_rmsnorm_quant_fp8(cx->h, m->layers[l + 1].input_norm, nullptr, cx->xq, cx->sx, T, H, c.rms_eps, st)); xq_ready = true; }
-          else ATS_TRY(ats_rmsnorm(cx->h, m->layers[l + 1].input_norm, cx->xn, T, H, c.rms_eps, dt, st));
+          if (f8_qkv) { ATS_TRY(ats_rmsnorm_quant_fp8(cx->h, m->layers[l + 1].input_norm, nullptr, cx->xq, cx->sx, T, H, c.rms_eps, st, pk)); xq_ready = true; }
+          else ATS_TRY(ats_rmsnorm(cx->h, m->layers[l + 1].input_norm, cx->xn, T, H, c.rms_eps, dt, st, pk));
         }
       } else if (l + 1 < c.n_layers) {
         ATS_TRY(ats_gemm_resid_norm(cx->act, w.wd, cx->h, T, H, c.ffn, c.ffn, H, dt, m->layers[l + 1].input_norm, cx->xn, c.rms_eps,
-                                    cx->ws, cx->ws_bytes, st));
+                                    cx->ws, cx->ws_bytes, st, pk));
         xq_ready = false;
       } else {
-        ATS_TRY(ats_gemm(cx->act, w.wd, cx->h, T, H, c.ffn, c.ffn, H, dt, EPI_RESID, cx->ws, cx->ws_bytes, st));
+        ATS_TRY(ats_gemm(cx->act, w.wd, cx->h, T, H, c.ffn, c.ffn, H, dt, EPI_RESID, cx->ws, cx->ws_bytes, st, pk));
       } }
   }
   if (t.total_logit > 0) {
     const int R = t.total_logit;
     ATS_TRY(ats_gather_logit_rows(cx->h, t, dtab, cx->gath, H, dt, st));
-    ATS_TRY(ats_rmsnorm(cx->gath, m->final_norm, cx->xn, R, H, c.rms_eps, dt, st));
+    ATS_TRY(ats_rmsnorm(cx->gath, m->final_norm, cx->xn, R, H, c.rms_eps, dt, st, pk));
     float* lo = logits_out ? logits_out : cx->logits;
     if (tile_store) {      // decoder forwards: logits + full-vocabulary normaliser (beamSD.py:58,285) from ONE kernel where the batch is large enough
       ProfBracket pb(m, 4, R, st);
       ATS_TRY(ats_lmhead_lse(cx->xn, m->lm_head, lo, R, c.vocab_size, H, H, m->logits_ld, dt, tile_store, cx->lse_part, cx->lse_part_bytes, cx->lse,
-                             cx->ws, cx->ws_bytes, st));
+                             cx->ws, cx->ws_bytes, st, nullptr, pk));
     } else {
       { ProfBracket pb(m, 4, R, st);
-        ATS_TRY(ats_gemm(cx->xn, m->lm_head, lo, R, c.vocab_size, H, H, m->logits_ld, dt, EPI_F32, cx->ws, cx->ws_bytes, st)); }
+        ATS_TRY(ats_gemm(cx->xn, m->lm_head, lo, R, c.vocab_size, H, H, m->logits_ld, dt, EPI_F32, cx->ws, cx->ws_bytes, st, pk)); }
       ATS_TRY(ats_lse_rows(lo, R, c.vocab_size, m->logits_ld, cx->lse, st));     // beamSD.py:58,285: full-vocab normaliser
     }
   }

@@ -58,7 +58,8 @@ struct TileCfg {
 template <typename T, int BM, int BN, int WM, int WN, int EPI, bool SPLIT>
 __global__ __launch_bounds__(kThreads) void gemm_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                         void* __restrict__ Cv, int M, int N, int K, int lda, int ldc,
-                                                        int k_per_split, float* __restrict__ partial) {
+                                                        int k_per_split, float* __restrict__ partial, int pk) {
+  // pk: A, W (and the SwiGLU output, itself the next projection's operand) are in the packed operand layout (common.h)
   using Cfg = TileCfg<T, BM, BN, WM, WN>;
   constexpr int BK = GemmTraits<T>::BK;
   constexpr int EPC = GemmTraits<T>::EPC;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const T* __restrict__ A,
         int r = q >> 3, c = q & 7;
         int gm = min(m0 + r, M - 1);
         int gk = kbase + c * EPC;
-        ra[i] = (gk < kz1) ? *reinterpret_cast<const uint4*>(A + (size_t)gm * lda + gk) : make_uint4(0, 0, 0, 0);
+        ra[i] = (gk < kz1) ? *reinterpret_cast<const uint4*>(A + ats_opnd_idx<sizeof(T)>(pk, gm, gk, lda)) : make_uint4(0, 0, 0, 0);
       }
     }
 #pragma unroll
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const T* __restrict__ A,
         int r = q >> 3, c = q & 7;
         int gn = min(n0 + r, N - 1);
         int gk = kbase + c * EPC;
-        rw[i] = (gk < kz1) ? *reinterpret_cast<const uint4*>(W + (size_t)gn * K + gk) : make_uint4(0, 0, 0, 0);
+        rw[i] = (gk < kz1) ? *reinterpret_cast<const uint4*>(W + ats_opnd_idx<sizeof(T)>(pk, gn, gk, K)) : make_uint4(0, 0, 0, 0);
       }
     }
   };
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const T* __restrict__ A,
             float g = acc[i][j][r], u = acc[i][j + 1][r];
             if constexpr (sizeof(T) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
             float s = g / (1.f + __expf(-g));
-            Elt<T>::store(C + (size_t)gm * ldc + (gn >> 1) + ccol, s * u);
+            Elt<T>::store(C + ats_opnd_idx<sizeof(T)>(pk, gm, (gn >> 1) + ccol, ldc), s * u);
           }
         }
   } else {
@@ -251,7 +252,7 @@ __device__ __forceinline__ void sum_slabs(const float* __restrict__ p, size_t sl
 // V = 4 needs N % 4 == 0 and ldc % 4 == 0 (N % 32 == 0 holds for SwiGLU).
 template <typename T, int EPI, int V>
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, void* __restrict__ Cv, int M, int N, int ldc,
-                                     int splits) {
+                                     int splits, int pk) {
   const size_t mn = (size_t)M * N;
   if constexpr (EPI == EPI_SWIGLU) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;   // over M * N/2 outputs
@@ -263,7 +264,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, void* __
     float g[V], u[V];
     sum_slabs<V>(partial + gi, mn, splits, g);
     sum_slabs<V>(partial + ui, mn, splits, u);
-    T* out = reinterpret_cast<T*>(Cv) + (size_t)m * ldc + o;
+    T* out = reinterpret_cast<T*>(Cv) + ats_opnd_idx<sizeof(T)>(pk, m, o, ldc);     // the SwiGLU output is the down projection's operand (V <= 4 stays inside a k-block)
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       float gj = g[j], uj = u[j];
@@ -298,7 +299,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, void* __
 // m = m0 + wm*MT2*16 + j*16 + lq.
 template <int EPI, int NA, int MT2>
 __device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[NA][MT2], void* __restrict__ Cv, int M, int N, int ldc, int m0, int n0,
-                                             int wn, int wm, int lq, int g) {
+                                             int wn, int wm, int lq, int g, int pk = 0) {
   const bool vec = (ldc & 3) == 0;
   if constexpr (EPI == EPI_RESID) {
     // read-modify-write of h: the loads of a row group must not wait behind the previous group's stores (same pointer: the compiler
@@ -348,7 +349,7 @@ __device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[NA][MT2], void* __re
           const uint32_t res = f2bf_pk(g0 / (1.f + __expf(-g0)) * bf_lo(upk), g1 / (1.f + __expf(-g1)) * bf_hi(upk));
           if (r == 0) o.x = res; else o.y = res;
         }
-        *reinterpret_cast<uint2*>(C + (size_t)gm * ldc + (gn >> 1) + g * 4) = o;
+        *reinterpret_cast<uint2*>(C + ats_opnd_idx<2>(pk, gm, (gn >> 1) + g * 4, ldc)) = o;      // the down projection's operand: packed when pk
       }
     } else {
 #pragma unroll
@@ -438,7 +439,10 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
                                                            const float* __restrict__ sx, const float* __restrict__ sw,
                                                            void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
                                                            int tiles_n, int tiles_m, int GM, int n_split = 1,
-                                                           float* __restrict__ lse_part = nullptr, const unsigned char* __restrict__ tile_store = nullptr) {
+                                                           float* __restrict__ lse_part = nullptr, const unsigned char* __restrict__ tile_store = nullptr,
+                                                           int pk = 0) {
+  // pk: X and W (and the SwiGLU output) are in the packed operand layout -- every 1 KB DMA piece is then eight FULL 128-byte lines
+  // (two rows x 64 bytes each) instead of sixteen half lines: 83 against 55 GB/s per CU from L2 (tools/probe/dma_depth.hip)
   constexpr int BT = 256, RB = 64, ESZ = FP8 ? 1 : 2;
   constexpr int BK = RB / ESZ;                                   // k per stage: 32 (bf16) or 64 (fp8)
   constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
@@ -484,17 +488,18 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   const unsigned lbase = lds_addr(smem);
 #pragma unroll
   for (int j = 0; j < WP; ++j) {
-    const int row = (wave * WP + j) * 16 + (lane >> 2);
-    woff[j] = (unsigned)min(n0 + row, N - 1) * (unsigned)(K * ESZ) + (((lane & 3) ^ swz(row)) * 16);
+    const int row = (wave * WP + j) * 16 + (lane >> 2), gr = min(n0 + row, N - 1);
+    woff[j] = (pk ? (unsigned)(gr >> 1) * (unsigned)(K * ESZ * 2) + (gr & 1) * 64 : (unsigned)gr * (unsigned)(K * ESZ)) + (((lane & 3) ^ swz(row)) * 16);
     m0w[j] = __builtin_amdgcn_readfirstlane((int)lbase + (wave * WP + j) * 1024);
   }
 #pragma unroll
   for (int j = 0; j < XP; ++j) {
-    const int row = (wave * XP + j) * 16 + (lane >> 2);
-    xoff[j] = (unsigned)min(m0 + row, M - 1) * (unsigned)(ldx * ESZ) + (((lane & 3) ^ swz(row)) * 16);
+    const int row = (wave * XP + j) * 16 + (lane >> 2), gr = min(m0 + row, M - 1);
+    xoff[j] = (pk ? (unsigned)(gr >> 1) * (unsigned)(ldx * ESZ * 2) + (gr & 1) * 64 : (unsigned)gr * (unsigned)(ldx * ESZ)) + (((lane & 3) ^ swz(row)) * 16);
     m0x[j] = __builtin_amdgcn_readfirstlane((int)lbase + BT * RB + (wave * XP + j) * 1024);
   }
   const unsigned long long wb = (unsigned long long)W, xb = (unsigned long long)X;
+  const unsigned long long kadv = pk ? 2 * RB : RB;               // bytes from one k-step's 64-byte block of a row to the next
   // fragment addresses: lane (lq, g) reads chunk g of row lq of each 16-row tile
   const unsigned lp = lq * RB + ((g ^ swz(lq)) * 16);
   unsigned aA[2], aB[2];                                          // stages {0,1} and {2,3}
@@ -511,8 +516,8 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   u32x4_t fa[2][NA], fb[2][MT2];
 
   auto dma_piece = [&](int q, int ks, int d) {                    // piece d of k-step ks into stage q (q, d compile-time after unrolling)
-    if (d < WP) ATS_DMA16(woff[d % WP], wb + (unsigned long long)ks * RB, m0w[d % WP] + q * STAGE);
-    else        ATS_DMA16(xoff[(d - WP) % XP], xb + (unsigned long long)ks * RB, m0x[(d - WP) % XP] + q * STAGE);
+    if (d < WP) ATS_DMA16(woff[d % WP], wb + (unsigned long long)ks * kadv, m0w[d % WP] + q * STAGE);
+    else        ATS_DMA16(xoff[(d - WP) % XP], xb + (unsigned long long)ks * kadv, m0x[(d - WP) % XP] + q * STAGE);
   };
   auto read_one = [&](int q, int buf, int r) {                    // fragment read r of stage q into register buffer buf
     const unsigned a = aA[q >> 1], b = aB[q >> 1];
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
     }
     if (tile_store == nullptr || tile_store[tn]) big_epilogue<EPI_F32, NA, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
   } else if constexpr (SPLITK) big_epilogue<EPI_F32, NA, MT2>(acc, reinterpret_cast<float*>(Cv) + (size_t)zpart * M * N, M, N, N, m0, n0, wn, wm, lq, g);
-  else                  big_epilogue<EPI, NA, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
+  else                  big_epilogue<EPI, NA, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g, pk);
 #ifdef ATS_RING_STAMPS
   // tuning build: sw carries the stamp buffer [workgroup][wave][10] = loop cycles in {issue, lgkmcnt wait, vmcnt wait, barrier}, then
   // the absolute counter at kernel entry, loop start, loop end and after the epilogue's stores have been acknowledged, then the
@@ -702,10 +707,31 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #endif
 #define ATS_MFMA_MX(c, a, b, s) \
   asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(a), "v"(b), "v"(s))
+// accumulators in AGPRs (the one-wave-per-SIMD form: 256 accumulator registers do not fit the 256 architectural VGPRs beside the fragments)
+// (the host pass of hipcc checks asm constraints against x86, where "a" is rax: a 64-byte operand fails template substitution there and the
+// kernel's host stub silently disappears, so the statement exists in the device pass only)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ATS_MFMA_MX_A(c, a, b, s) \
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(c) : "v"(a), "v"(b), "v"(s))
+#else
+#define ATS_MFMA_MX_A(c, a, b, s) ((void)0)
+#endif
 
 // accumulator tile (it, jt) of a wave: m = m0w + jt*32 + (lane&31); registers 4q..4q+3 hold n = n0w + it*32 + 8q + 4(lane>>5) + r
+// The per-row scales of the W8A8 scheme (acc *= sx[m] * sw[n]) are applied tile by tile right where a tile is consumed: scaling all
+// accumulators first kept 256 of them live in VGPRs in the one-wave-per-SIMD form (they sit in AGPRs during the loop) and spilled.
+template <int TA, int TB>
+__device__ __forceinline__ void mx_scale_tile(f32x16_t& t, const float* __restrict__ sx, const float* __restrict__ sw, int gm, int gn0, int h, int M, int N) {
+  const float fx = sx[min(gm, M - 1)];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[4 * q + r] *= fx * sw[min(gn0 + 8 * q + 4 * h + r, N - 1)];
+}
+
 template <int EPI, int TA, int TB>
-__device__ __forceinline__ void mx_epilogue(f32x16_t (&acc)[TA][TB], void* __restrict__ Cv, int M, int N, int ldc, int m0w, int n0w, int lane) {
+__device__ __forceinline__ void mx_epilogue(f32x16_t (&acc)[TA][TB], void* __restrict__ Cv, int M, int N, int ldc, int m0w, int n0w, int lane,
+                                            const float* __restrict__ sx, const float* __restrict__ sw, int pk) {
   const int r32 = lane & 31, h = lane >> 5;
   const bool vec = (ldc & 3) == 0;
   if constexpr (EPI == EPI_RESID) {
@@ -725,7 +751,8 @@ __device__ __forceinline__ void mx_epilogue(f32x16_t (&acc)[TA][TB], void* __res
         const int gm = m0w + jt * 32 + r32;
         if (gm >= M) continue;
 #pragma unroll
-        for (int it = 0; it < TA; ++it)
+        for (int it = 0; it < TA; ++it) {
+          mx_scale_tile<TA, TB>(acc[it][jt], sx, sw, gm, n0w + it * 32, h, M, N);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const uint32_t p0 = f2bf_pk(acc[it][jt][4 * q], acc[it][jt][4 * q + 1]), p1 = f2bf_pk(acc[it][jt][4 * q + 2], acc[it][jt][4 * q + 3]);
@@ -734,6 +761,7 @@ __device__ __forceinline__ void mx_epilogue(f32x16_t (&acc)[TA][TB], void* __res
             o.y = f2bf_pk(bf_lo(rs[it][jt][q].y) + bf_lo(p1), bf_hi(rs[it][jt][q].y) + bf_hi(p1));
             *reinterpret_cast<uint2*>(Cb + (size_t)gm * ldc + n0w + it * 32 + 8 * q + 4 * h) = o;
           }
+        }
       }
       return;
     }
@@ -744,6 +772,7 @@ __device__ __forceinline__ void mx_epilogue(f32x16_t (&acc)[TA][TB], void* __res
     if (gm >= M) continue;
 #pragma unroll
     for (int it = 0; it < TA; ++it) {
+      mx_scale_tile<TA, TB>(acc[it][jt], sx, sw, gm, n0w + it * 32, h, M, N);
       if constexpr (EPI == EPI_SWIGLU) {
         // rows 0-15 of the 32-row weight tile are a gate group (q = 0, 1), rows 16-31 its up group (q = 2, 3): the pair sits in one lane
         bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
@@ -760,7 +789,7 @@ __device__ __forceinline__ void mx_epilogue(f32x16_t (&acc)[TA][TB], void* __res
             const uint32_t res = f2bf_pk(g0 / (1.f + __expf(-g0)) * bf_lo(upk), g1 / (1.f + __expf(-g1)) * bf_hi(upk));
             if (r == 0) o.x = res; else o.y = res;
           }
-          *reinterpret_cast<uint2*>(C + (size_t)gm * ldc + (gn0 >> 1) + 8 * q + 4 * h) = o;
+          *reinterpret_cast<uint2*>(C + ats_opnd_idx<2>(pk, gm, (gn0 >> 1) + 8 * q + 4 * h, ldc)) = o;      // the down projection's operand
         }
       } else {
 #pragma unroll
@@ -802,15 +831,19 @@ __device__ __forceinline__ void mx_epilogue(f32x16_t (&acc)[TA][TB], void* __res
   }
 }
 
-template <int EPI, int MT2>
-__global__ __launch_bounds__(512, 1) void gemm_ring_mx_kernel(const void* __restrict__ X, const void* __restrict__ W, const float* __restrict__ sx,
+// NWV = 8: waves 4 (n) x 2 (m), wave tile 64 x MT2*16 (2 x MT2/2 tiles of 32x32), two waves per SIMD.  NWV = 4: waves 2 x 2, wave tile
+// 128 x MT2*16 (4 x MT2/2 tiles), ONE wave per SIMD with up to 512 registers: a third fewer LDS fragment bytes per flop and no two waves
+// contending for a SIMD's matrix pipe and issue slots (selected by ATSPEED_FP8_MX_WAVES, see launch_big_fp8).
+template <int EPI, int MT2, int NWV = 8>
+__global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* __restrict__ X, const void* __restrict__ W, const float* __restrict__ sx,
                                                               const float* __restrict__ sw, void* __restrict__ Cv, int M, int N, int K, int ldc,
-                                                              int tiles_n, int tiles_m, int GM) {
+                                                              int tiles_n, int tiles_m, int GM, int pk) {
   constexpr int BT = 256, RB = 64;                                // 64-byte LDS rows = 64 k of e4m3 per stage
   constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
-  constexpr int WP = 2, XP = XR / 128, NP = WP + XP;             // DMA pieces (16 rows x 64 B) per wave per k-step
+  constexpr int WP = 16 / NWV, XP = XR / (16 * NWV), NP = WP + XP;   // DMA pieces (16 rows x 64 B) per wave per k-step
   constexpr int STAGE = (BT + XR) * RB;
-  constexpr int TA = 2, TB = MT2 / 2;                            // 32x32 tiles per wave: weight rows x token rows
+  constexpr int TA = 16 / NWV, TB = MT2 / 2;                     // 32x32 tiles per wave: weight rows x token rows (NWV/2 waves along n, 2 along m)
+  static_assert(XP >= 1, "token tile too small for this wave count");
   constexpr int NR = 2 * (TA + TB);                              // ds_read_b128 per wave per k-step
   constexpr int NMF = TA * TB;                                   // MFMAs per wave per k-step
   constexpr int NIT = NR + NP;                                   // reads + DMA pieces placed between the MFMAs of a k-step
@@ -827,7 +860,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_mx_kernel(const void* __rest
   const int band_rows = min(GM, tiles_m - band * GM);
   const int tn = rem / band_rows, tm = band * GM + rem % band_rows;
   const int n0 = tn * BT, m0 = tm * XR;
-  const int wn = wave >> 1, wm = wave & 1;
+  const int wn = wave >> 1, wm = wave & 1;                        // NWV/2 waves along the weight rows, 2 along the token rows
   const int nks = K / 64;                                         // launcher: K % 256 == 0
 
   auto swz = [](int row) { return (0xD2 >> (((row >> 2) & 3) * 2)) & 3; };   // f = {2,0,1,3}
@@ -836,17 +869,18 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_mx_kernel(const void* __rest
   const unsigned lbase = lds_addr(smem);
 #pragma unroll
   for (int j = 0; j < WP; ++j) {
-    const int row = (wave * WP + j) * 16 + (lane >> 2);
-    woff[j] = (unsigned)min(n0 + row, N - 1) * (unsigned)K + (((lane & 3) ^ swz(row)) * 16);
+    const int row = (wave * WP + j) * 16 + (lane >> 2), gr = min(n0 + row, N - 1);
+    woff[j] = (pk ? (unsigned)(gr >> 1) * (unsigned)(K * 2) + (gr & 1) * 64 : (unsigned)gr * (unsigned)K) + (((lane & 3) ^ swz(row)) * 16);
     m0w_[j] = __builtin_amdgcn_readfirstlane((int)lbase + (wave * WP + j) * 1024);
   }
 #pragma unroll
   for (int j = 0; j < XP; ++j) {
-    const int row = (wave * XP + j) * 16 + (lane >> 2);
-    xoff[j] = (unsigned)min(m0 + row, M - 1) * (unsigned)K + (((lane & 3) ^ swz(row)) * 16);
+    const int row = (wave * XP + j) * 16 + (lane >> 2), gr = min(m0 + row, M - 1);
+    xoff[j] = (pk ? (unsigned)(gr >> 1) * (unsigned)(K * 2) + (gr & 1) * 64 : (unsigned)gr * (unsigned)K) + (((lane & 3) ^ swz(row)) * 16);
     m0x_[j] = __builtin_amdgcn_readfirstlane((int)lbase + BT * RB + (wave * XP + j) * 1024);
   }
   const unsigned long long wb = (unsigned long long)W, xb = (unsigned long long)X;
+  const unsigned long long kadv = pk ? 2 * RB : RB;               // packed operands: full 128-byte lines per DMA piece (see gemm_ring_kernel)
   // fragment addresses: lane (r32, h) reads chunks 2h and 2h+1 of row r32 of each 32-row tile
   const unsigned lp_lo = r32 * RB + (((2 * h) ^ swz(r32)) * 16), lp_hi = r32 * RB + (((2 * h + 1) ^ swz(r32)) * 16);
   unsigned aAl[2], aAh[2], aBl[2], aBh[2];                        // stages {0,1} and {2,3}
@@ -865,26 +899,18 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_mx_kernel(const void* __rest
   const unsigned unit_scale = 0x7f7f7f7fu;                        // E8M0 1.0 for every 32-k block of both operands
 
   auto dma_piece = [&](int q, int ks, int d) {
-    if (d < WP) ATS_DMA16(woff[d % WP], wb + (unsigned long long)ks * RB, m0w_[d % WP] + q * STAGE);
-    else        ATS_DMA16(xoff[(d - WP) % XP], xb + (unsigned long long)ks * RB, m0x_[(d - WP) % XP] + q * STAGE);
+    if (d < WP) ATS_DMA16(woff[d % WP], wb + (unsigned long long)ks * kadv, m0w_[d % WP] + q * STAGE);
+    else        ATS_DMA16(xoff[(d - WP) % XP], xb + (unsigned long long)ks * kadv, m0x_[(d - WP) % XP] + q * STAGE);
   };
   auto read_one = [&](int q, int buf, int r) {                    // read r of stage q into register buffer buf (all compile-time after unrolling)
-    const unsigned al = aAl[q >> 1], ah = aAh[q >> 1], bl = aBl[q >> 1], bh = aBh[q >> 1];
-    const int so = (q & 1) * STAGE;
-    switch (r) {
-      case 0: ATS_DS_READ_B128(fal[buf][0], al, so); break;
-      case 1: ATS_DS_READ_B128(fah[buf][0], ah, so); break;
-      case 2: ATS_DS_READ_B128(fal[buf][1], al, so + 2048); break;
-      case 3: ATS_DS_READ_B128(fah[buf][1], ah, so + 2048); break;
-      case 4: ATS_DS_READ_B128(fbl[buf][0], bl, so); break;
-      case 5: ATS_DS_READ_B128(fbh[buf][0], bh, so); break;
-      case 6: ATS_DS_READ_B128(fbl[buf][1], bl, so + 2048); break;
-      case 7: ATS_DS_READ_B128(fbh[buf][1], bh, so + 2048); break;
-      case 8:  if constexpr (TB == 4) ATS_DS_READ_B128(fbl[buf][TB - 2], bl, so + 4096); break;
-      case 9:  if constexpr (TB == 4) ATS_DS_READ_B128(fbh[buf][TB - 2], bh, so + 4096); break;
-      case 10: if constexpr (TB == 4) ATS_DS_READ_B128(fbl[buf][TB - 1], bl, so + 6144); break;
-      case 11: if constexpr (TB == 4) ATS_DS_READ_B128(fbh[buf][TB - 1], bh, so + 6144); break;
-      default: break;
+    const int so = (q & 1) * STAGE, tile = r >> 1;
+    if (r < 2 * TA) {
+      if (r & 1) ATS_DS_READ_B128(fah[buf][tile], aAh[q >> 1], so + tile * 2048);
+      else       ATS_DS_READ_B128(fal[buf][tile], aAl[q >> 1], so + tile * 2048);
+    } else {
+      const int tb = tile - TA;
+      if (r & 1) ATS_DS_READ_B128(fbh[buf][tb], aBh[q >> 1], so + tb * 2048);
+      else       ATS_DS_READ_B128(fbl[buf][tb], aBl[q >> 1], so + tb * 2048);
     }
   };
 #define ATS_CAT8(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
@@ -900,8 +926,12 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_mx_kernel(const void* __rest
           else if (DMA && ATS_MX_ABLATE != 1) dma_piece((Q), (ks) + 4, t - NR);                          \
         }                                                                                                \
       }                                                                                                  \
-      if (ATS_MX_ABLATE != 3)                                                                            \
-        ATS_MFMA_MX(acc[i][j], ATS_CAT8(fal[(Q) & 1][i], fah[(Q) & 1][i]), ATS_CAT8(fbl[(Q) & 1][j], fbh[(Q) & 1][j]), unit_scale); \
+      if (ATS_MX_ABLATE != 3) {                                                                          \
+        if constexpr (NWV == 4)                                                                          \
+          ATS_MFMA_MX_A(acc[i][j], ATS_CAT8(fal[(Q) & 1][i], fah[(Q) & 1][i]), ATS_CAT8(fbl[(Q) & 1][j], fbh[(Q) & 1][j]), unit_scale); \
+        else                                                                                             \
+          ATS_MFMA_MX(acc[i][j], ATS_CAT8(fal[(Q) & 1][i], fah[(Q) & 1][i]), ATS_CAT8(fbl[(Q) & 1][j], fbh[(Q) & 1][j]), unit_scale); \
+      }                                                                                                  \
     }                                                                                                    \
     if (RD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
     if ((VM) >= 0) {                                                                                     \
@@ -938,25 +968,12 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_mx_kernel(const void* __rest
 #undef ATS_CAT8
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // 16-pass MFMA results -> VALU reads (the compiler cannot see the asm MFMAs)
 
-  // per-row scales of the W8A8 scheme: acc *= sx[m] * sw[n]
   const int m0w = m0 + wm * (TB * 32), n0w = n0 + wn * (TA * 32);
-#pragma unroll
-  for (int jt = 0; jt < TB; ++jt) {
-    const float fx = sx[min(m0w + jt * 32 + r32, M - 1)];
-#pragma unroll
-    for (int it = 0; it < TA; ++it)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int gn = n0w + it * 32 + 8 * q + 4 * h;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[it][jt][4 * q + r] *= fx * sw[min(gn + r, N - 1)];
-      }
-  }
-  mx_epilogue<EPI, TA, TB>(acc, Cv, M, N, ldc, m0w, n0w, lane);
+  mx_epilogue<EPI, TA, TB>(acc, Cv, M, N, ldc, m0w, n0w, lane, sx, sw, pk);
 }
 
 template <int EPI>
-int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st) {
+int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st, int pk) {
   static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
   static const int force_mt = env_int("ATSPEED_GEMM_FORCE_MT", 0);     // tuning: 8 / 4 = always 256- / 128-row token tiles
   const int tiles_n = (n + 255) / 256;
@@ -981,12 +998,12 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
     static thread_local AtsPerDeviceFlag a4_flag;
     bool& a4 = a4_flag.cur();
     if (!a4) { ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); a4 = true; }
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false, false, 8>), dim3(t256), dim3(256), 128 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false, false, 8>), dim3(t256), dim3(256), 128 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk);
     ATS_LAUNCH_CHECK();
     return ATSPEED_OK;
   }
-  if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, none, stamps, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm);
-  else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm);
+  if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, none, stamps, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk);
+  else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -1010,7 +1027,7 @@ __global__ __launch_bounds__(256) void lse_combine_kernel(const float2* __restri
 
 // lm_head over the batched rows with the normaliser fused into the epilogue (gemm_ring_kernel<EPI_F32_LSE>)
 int launch_big_lse(const bf16_t* x, const bf16_t* w, float* c, int m, int n, int k, int ldx, int ldc, float* part, const unsigned char* tile_store,
-                   float* lse, hipStream_t st) {
+                   float* lse, hipStream_t st, int pk) {
   static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
   const int tiles_n = (n + 255) / 256;
   static thread_local AtsPerDeviceFlag attr_flag;
@@ -1024,10 +1041,10 @@ int launch_big_lse(const bf16_t* x, const bf16_t* w, float* c, int m, int n, int
   const float* none = nullptr;
   if (big_use_256_rows(t256, t128))
     hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32_LSE, 8, false>), dim3(t256), dim3(512), 136 * 1024, st, (const void*)x, (const void*)w, none, none, (void*)c, m, n, k,
-                       ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, part, tile_store);
+                       ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, part, tile_store, pk);
   else
     hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32_LSE, 4, false>), dim3(t128), dim3(512), 100 * 1024, st, (const void*)x, (const void*)w, none, none, (void*)c, m, n, k,
-                       ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, part, tile_store);
+                       ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, part, tile_store, pk);
   ATS_LAUNCH_CHECK();
   lse_combine_kernel<<<(m + 3) / 4, 256, 0, st>>>(reinterpret_cast<const float2*>(part), m, tiles_n, lse);
   ATS_LAUNCH_CHECK();
@@ -1042,7 +1059,7 @@ int launch_big_lse(const bf16_t* x, const bf16_t* w, float* c, int m, int n, int
 template <typename T, int NPT, int V>
 __global__ __launch_bounds__(1024) void splitk_resid_rmsnorm_kernel(const float* __restrict__ partial, T* __restrict__ h,
                                                                     const T* __restrict__ norm_w, T* __restrict__ xn, int M, int N,
-                                                                    int ldh, int splits, float eps) {
+                                                                    int ldh, int splits, float eps, int pk) {
   // thread t owns columns (t + i*1024) * V .. + V-1, i < NPT / V   (V = 4: 16-byte slab loads; needs N % 4 == 0)
   __shared__ float red[16];
   const int m = blockIdx.x;
@@ -1089,7 +1106,7 @@ __global__ __launch_bounds__(1024) void splitk_resid_rmsnorm_kernel(const float*
       for (int j = 0; j < V; ++j) {
         float v = vals[i * V + j] * rs;
         if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
-        Elt<T>::store(xn + (size_t)m * N + n + j, Elt<T>::load(norm_w + n + j) * v);
+        Elt<T>::store(xn + ats_opnd_idx<sizeof(T)>(pk, m, n + j, N), Elt<T>::load(norm_w + n + j) * v);   // xn: the next projection's operand
       }
     }
   }
@@ -1097,7 +1114,7 @@ __global__ __launch_bounds__(1024) void splitk_resid_rmsnorm_kernel(const float*
 
 template <int EPI>
 int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char* w, const float* sw, void* c, int m, int n, int k,
-                   int ldc, hipStream_t st) {
+                   int ldc, hipStream_t st, int pk) {
   static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
   const int tiles_n = (n + 255) / 256;
   static thread_local AtsPerDeviceFlag attr_flag;
@@ -1115,20 +1132,24 @@ int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char*
     bool& mx_done = mx_flag.cur();
     if (!mx_done) {
       ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_mx_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_mx_kernel<EPI, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
       ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_mx_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       mx_done = true;
     }
-    if (big_use_256_rows(t256, t128))
-      hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 255) / 256, gm);
+    static const int mx_waves = env_int("ATSPEED_FP8_MX_WAVES", 8);      // 4: one wave per SIMD, 128 x 128 per wave (256-row token tiles only)
+    if (big_use_256_rows(t256, t128) && mx_waves == 4)
+      hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 8, 4>), dim3(t256), dim3(256), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 255) / 256, gm, pk);
+    else if (big_use_256_rows(t256, t128))
+      hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 255) / 256, gm, pk);
     else
-      hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 127) / 128, gm);
+      hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 127) / 128, gm, pk);
     ATS_LAUNCH_CHECK();
     return ATSPEED_OK;
   }
   if (big_use_256_rows(t256, t128))
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, true>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 255) / 256, gm);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, true>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 255) / 256, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk);
   else
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, true>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 127) / 128, gm);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, true>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 127) / 128, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -1174,16 +1195,16 @@ struct FusedNorm { const void* w; void* xn; float eps; bool done; };
 
 // second pass of a split-K GEMM: sum the fp32 slabs and apply the epilogue (fused with the next RMSNorm for the residual projections)
 template <typename T, int EPI>
-int reduce_splits(const float* partial, void* c, int m, int n, int ldc, int splits, hipStream_t st, FusedNorm* fn) {
+int reduce_splits(const float* partial, void* c, int m, int n, int ldc, int splits, hipStream_t st, FusedNorm* fn, int pk) {
   const bool v4 = (n % 4) == 0 && (ldc % 4) == 0 && ((uintptr_t)partial & 15) == 0;
   if constexpr (EPI == EPI_RESID) {
     if (fn && n <= 8192) {
       if (n <= 4096) {
-        if (v4) splitk_resid_rmsnorm_kernel<T, 4, 4><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps);
-        else    splitk_resid_rmsnorm_kernel<T, 4, 1><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps);
+        if (v4) splitk_resid_rmsnorm_kernel<T, 4, 4><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps, pk);
+        else    splitk_resid_rmsnorm_kernel<T, 4, 1><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps, pk);
       } else {
-        if (v4) splitk_resid_rmsnorm_kernel<T, 8, 4><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps);
-        else    splitk_resid_rmsnorm_kernel<T, 8, 1><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps);
+        if (v4) splitk_resid_rmsnorm_kernel<T, 8, 4><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps, pk);
+        else    splitk_resid_rmsnorm_kernel<T, 8, 1><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps, pk);
       }
       ATS_LAUNCH_CHECK();
       fn->done = true;
@@ -1191,8 +1212,8 @@ int reduce_splits(const float* partial, void* c, int m, int n, int ldc, int spli
     }
   }
   size_t outs = EPI == EPI_SWIGLU ? (size_t)m * (n / 2) : (size_t)m * n;
-  if (v4) splitk_reduce_kernel<T, EPI, 4><<<(unsigned)((outs / 4 + 255) / 256), 256, 0, st>>>(partial, c, m, n, ldc, splits);
-  else    splitk_reduce_kernel<T, EPI, 1><<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(partial, c, m, n, ldc, splits);
+  if (v4) splitk_reduce_kernel<T, EPI, 4><<<(unsigned)((outs / 4 + 255) / 256), 256, 0, st>>>(partial, c, m, n, ldc, splits, pk);
+  else    splitk_reduce_kernel<T, EPI, 1><<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(partial, c, m, n, ldc, splits, pk);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -1216,7 +1237,7 @@ static int ring_split_count(int m, int n, int k) {
 }
 template <int EPI>
 int launch_ring_split(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, int lda, int ldc, int splits, float* partial,
-                      hipStream_t st, FusedNorm* fn) {
+                      hipStream_t st, FusedNorm* fn, int pk) {
   static thread_local AtsPerDeviceFlag attr_flag;
   bool& attr_done = attr_flag.cur();
   if (!attr_done) {
@@ -1235,29 +1256,29 @@ int launch_ring_split(const bf16_t* a, const bf16_t* w, void* c, int m, int n, i
   const int tiles_m = (m + 255) / 256;
   if (m > 128)
     hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 8, false, true>), dim3(tiles_n * tiles_m * splits), dim3(512), 128 * 1024, st, (const void*)a, (const void*)w,
-                       none, stamps, (void*)partial, m, n, k, lda, n, tiles_n, tiles_m, 1, splits);
+                       none, stamps, (void*)partial, m, n, k, lda, n, tiles_n, tiles_m, 1, splits, (float*)nullptr, (const unsigned char*)nullptr, pk);
   else
     hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 4, false, true>), dim3(tiles_n * splits), dim3(512), 96 * 1024, st, (const void*)a, (const void*)w,
-                       none, stamps, (void*)partial, m, n, k, lda, n, tiles_n, 1, 1, splits);
+                       none, stamps, (void*)partial, m, n, k, lda, n, tiles_n, 1, 1, splits, (float*)nullptr, (const unsigned char*)nullptr, pk);
   ATS_LAUNCH_CHECK();
   if (c == nullptr) return ATSPEED_OK;          // partials only: the caller's next kernel sums the slabs itself (ats_gemm_partials)
-  return reduce_splits<bf16_t, EPI>(partial, c, m, n, ldc, splits, st, fn);
+  return reduce_splits<bf16_t, EPI>(partial, c, m, n, ldc, splits, st, fn, pk);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int EPI>
 int launch_cfg(const T* a, const T* w, void* c, int m, int n, int k, int lda, int ldc, const Plan& p, float* partial,
-               hipStream_t st, FusedNorm* fn = nullptr) {
+               hipStream_t st, FusedNorm* fn, int pk) {
   using Cfg = TileCfg<T, BM, BN, WM, WN>;
   dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM, p.splits);
   size_t lds = 2 * Cfg::STAGE_BYTES;
   if (p.splits > 1) {
     auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI, true>;
-    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a, w, c, m, n, k, lda, ldc, p.k_per_split, partial);
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a, w, c, m, n, k, lda, ldc, p.k_per_split, partial, pk);
     ATS_LAUNCH_CHECK();
-    return reduce_splits<T, EPI>(partial, c, m, n, ldc, p.splits, st, fn);
+    return reduce_splits<T, EPI>(partial, c, m, n, ldc, p.splits, st, fn, pk);
   } else {
     auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI, false>;
-    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a, w, c, m, n, k, lda, ldc, p.k_per_split, partial);
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a, w, c, m, n, k, lda, ldc, p.k_per_split, partial, pk);
     ATS_LAUNCH_CHECK();
   }
   return ATSPEED_OK;
@@ -1265,11 +1286,11 @@ int launch_cfg(const T* a, const T* w, void* c, int m, int n, int k, int lda, in
 
 template <typename T, int EPI>
 int launch_epi(const T* a, const T* w, void* c, int m, int n, int k, int lda, int ldc, float* partial, size_t ws_bytes,
-               hipStream_t st, FusedNorm* fn = nullptr) {
+               hipStream_t st, FusedNorm* fn, int pk) {
   if constexpr (sizeof(T) == 2) {
     const int rs = ring_split_count(m, n, k);
     if (rs >= 1 && (lda % 8) == 0 && (size_t)rs * m * n * sizeof(float) <= ws_bytes && (EPI != EPI_SWIGLU || n % 32 == 0))
-      return launch_ring_split<EPI>(a, w, c, m, n, k, lda, ldc, rs, partial, st, fn);
+      return launch_ring_split<EPI>(a, w, c, m, n, k, lda, ldc, rs, partial, st, fn, pk);
   }
   Plan p = make_plan<T>(m, n, k);
   if (p.bn == 64 && p.bm != 128) p.bn = 128;
@@ -1277,24 +1298,24 @@ int launch_epi(const T* a, const T* w, void* c, int m, int n, int k, int lda, in
     p.splits = 1;
     p.k_per_split = ((k + GemmTraits<T>::BK - 1) / GemmTraits<T>::BK) * GemmTraits<T>::BK;
   }
-  if (p.bn == 64 && p.bm == 128) return launch_cfg<T, 128, 64, 2, 2, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn);
+  if (p.bn == 64 && p.bm == 128) return launch_cfg<T, 128, 64, 2, 2, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn, pk);
   switch (p.bm) {
-    case 16:  return launch_cfg<T, 16, 128, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn);
-    case 32:  return launch_cfg<T, 32, 128, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn);
-    case 64:  return launch_cfg<T, 64, 128, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn);
-    default:  return launch_cfg<T, 128, 128, 2, 2, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn);
+    case 16:  return launch_cfg<T, 16, 128, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn, pk);
+    case 32:  return launch_cfg<T, 32, 128, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn, pk);
+    case 64:  return launch_cfg<T, 64, 128, 1, 4, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn, pk);
+    default:  return launch_cfg<T, 128, 128, 2, 2, EPI>(a, w, c, m, n, k, lda, ldc, p, partial, st, fn, pk);
   }
 }
 
 template <typename T>
 int launch_typed(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int epi, void* ws,
-                 size_t ws_bytes, hipStream_t st) {
+                 size_t ws_bytes, hipStream_t st, int pk) {
   const T* A = (const T*)a; const T* Wt = (const T*)w; float* P = (float*)ws;
   switch (epi) {
-    case EPI_STORE:  return launch_epi<T, EPI_STORE>(A, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
-    case EPI_F32:    return launch_epi<T, EPI_F32>(A, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
-    case EPI_RESID:  return launch_epi<T, EPI_RESID>(A, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
-    case EPI_SWIGLU: return launch_epi<T, EPI_SWIGLU>(A, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st);
+    case EPI_STORE:  return launch_epi<T, EPI_STORE>(A, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st, nullptr, pk);
+    case EPI_F32:    return launch_epi<T, EPI_F32>(A, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st, nullptr, pk);
+    case EPI_RESID:  return launch_epi<T, EPI_RESID>(A, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st, nullptr, pk);
+    case EPI_SWIGLU: return launch_epi<T, EPI_SWIGLU>(A, Wt, c, m, n, k, lda, ldc, P, ws_bytes, st, nullptr, pk);
   }
   atspeed_set_error("gemm: unknown epilogue %d", epi);
   return ATSPEED_ERR_INVALID;
@@ -1315,38 +1336,41 @@ static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype,
 // slabs while it reads them (RoPE + KV scatter after the qkv projection: one launch less per layer).  *splits_out = 0 when this shape does
 // not take the split-K ring path (the caller then runs the ordinary ats_gemm).
 int ats_gemm_partials(const void* a, const void* w, int m, int n, int k, int lda, int dtype, void* workspace, size_t workspace_bytes,
-                      hipStream_t st, int* splits_out) {
+                      hipStream_t st, int* splits_out, int pk) {
   *splits_out = 0;
   if (dtype != ATSPEED_BF16 || m <= 0 || big_kernel_applies(m, n, k, lda, n, dtype, EPI_STORE)) return ATSPEED_OK;
   const int rs = ring_split_count(m, n, k);
   if (rs < 1 || (lda % 8) != 0 || (n % 4) != 0 || ((uintptr_t)workspace & 15) != 0 || (size_t)rs * m * n * sizeof(float) > workspace_bytes) return ATSPEED_OK;
   ATS_REQUIRE(a && w && workspace, ATSPEED_ERR_INVALID, "gemm: null operand");
   ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "gemm: operands must be 16-byte aligned");
-  ATS_TRY(launch_ring_split<EPI_STORE>((const bf16_t*)a, (const bf16_t*)w, nullptr, m, n, k, lda, n, rs, (float*)workspace, st, nullptr));
+  ATS_TRY(launch_ring_split<EPI_STORE>((const bf16_t*)a, (const bf16_t*)w, nullptr, m, n, k, lda, n, rs, (float*)workspace, st, nullptr, pk));
   *splits_out = rs;
   return ATSPEED_OK;
 }
 
 int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int dtype, int epilogue,
-             void* workspace, size_t workspace_bytes, hipStream_t st) {
+             void* workspace, size_t workspace_bytes, hipStream_t st, int pk) {
   if (m <= 0 || n <= 0) return ATSPEED_OK;
   int epc = dtype == ATSPEED_F32 ? 4 : 8;
+  // packed operands (common.h): bf16 only, K and the row strides multiples of one 64-byte k-block, SwiGLU output rows likewise
+  ATS_REQUIRE(!pk || (dtype == ATSPEED_BF16 && k % 32 == 0 && lda == k && (epilogue != EPI_SWIGLU || ldc % 32 == 0)), ATSPEED_ERR_INVALID,
+              "gemm: packed operands need bf16, K %% 32 == 0, lda == K (K=%d lda=%d ldc=%d)", k, lda, ldc);
   ATS_REQUIRE(a && w && c && k > 0, ATSPEED_ERR_INVALID, "gemm: null operand");
   ATS_REQUIRE(k % epc == 0 && lda % epc == 0, ATSPEED_ERR_INVALID, "gemm: K=%d / lda=%d must be multiples of %d", k, lda, epc);
   ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "gemm: operands must be 16-byte aligned");
   ATS_REQUIRE(epilogue != EPI_SWIGLU || n % 32 == 0, ATSPEED_ERR_INVALID, "gemm: SwiGLU needs N %% 32 == 0 (N=%d)", n);
-  if (dtype == ATSPEED_F32) return launch_typed<float>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st);
+  if (dtype == ATSPEED_F32) return launch_typed<float>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st, 0);
   if (dtype == ATSPEED_BF16) {
     if (big_kernel_applies(m, n, k, lda, ldc, dtype, epilogue)) {
       const bf16_t* X = (const bf16_t*)a; const bf16_t* Wt = (const bf16_t*)w;
       switch (epilogue) {
-        case EPI_STORE:  return launch_big<EPI_STORE>(X, Wt, c, m, n, k, lda, ldc, st);
-        case EPI_F32:    return launch_big<EPI_F32>(X, Wt, c, m, n, k, lda, ldc, st);
-        case EPI_RESID:  return launch_big<EPI_RESID>(X, Wt, c, m, n, k, lda, ldc, st);
-        case EPI_SWIGLU: return launch_big<EPI_SWIGLU>(X, Wt, c, m, n, k, lda, ldc, st);
+        case EPI_STORE:  return launch_big<EPI_STORE>(X, Wt, c, m, n, k, lda, ldc, st, pk);
+        case EPI_F32:    return launch_big<EPI_F32>(X, Wt, c, m, n, k, lda, ldc, st, pk);
+        case EPI_RESID:  return launch_big<EPI_RESID>(X, Wt, c, m, n, k, lda, ldc, st, pk);
+        case EPI_SWIGLU: return launch_big<EPI_SWIGLU>(X, Wt, c, m, n, k, lda, ldc, st, pk);
       }
     }
-    return launch_typed<bf16_t>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st);
+    return launch_typed<bf16_t>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st, pk);
   }
   atspeed_set_error("gemm: unknown dtype %d", dtype);
   return ATSPEED_ERR_INVALID;
@@ -1358,7 +1382,7 @@ size_t ats_lmhead_lse_part_bytes(int m, int n) { return (size_t)m * ((n + 255) /
 // normaliser comes out of the GEMM epilogue and only the 256-column tiles flagged in tile_store (device bytes, one per tile; NULL = all)
 // are written; otherwise the plain GEMM + the streaming lse_rows_kernel.  *fused_out tells which.
 int ats_lmhead_lse(const void* a, const void* w, float* logits, int m, int n, int k, int lda, int ldc, int dtype, const unsigned char* tile_store,
-                   float* part, size_t part_bytes, float* lse, void* workspace, size_t workspace_bytes, hipStream_t st, int* fused_out) {
+                   float* part, size_t part_bytes, float* lse, void* workspace, size_t workspace_bytes, hipStream_t st, int* fused_out, int pk) {
   static const int fuse = env_int("ATSPEED_FUSE_LSE", 1);
   if (fused_out) *fused_out = 0;
   if (m <= 0) return ATSPEED_OK;
@@ -1367,9 +1391,9 @@ int ats_lmhead_lse(const void* a, const void* w, float* logits, int m, int n, in
     ATS_REQUIRE(a && w && logits && lse, ATSPEED_ERR_INVALID, "lmhead_lse: null operand");
     ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "lmhead_lse: operands must be 16-byte aligned");
     if (fused_out) *fused_out = 1;
-    return launch_big_lse((const bf16_t*)a, (const bf16_t*)w, logits, m, n, k, lda, ldc, part, tile_store, lse, st);
+    return launch_big_lse((const bf16_t*)a, (const bf16_t*)w, logits, m, n, k, lda, ldc, part, tile_store, lse, st, pk);
   }
-  ATS_TRY(ats_gemm(a, w, logits, m, n, k, lda, ldc, dtype, EPI_F32, workspace, workspace_bytes, st));
+  ATS_TRY(ats_gemm(a, w, logits, m, n, k, lda, ldc, dtype, EPI_F32, workspace, workspace_bytes, st, pk));
   return ats_lse_rows(logits, m, n, ldc, lse, st);
 }
 
@@ -1387,21 +1411,21 @@ static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype,
 }
 
 int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int k, int lda, int ldh, int dtype,
-                        const void* norm_w, void* xn, float eps, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                        const void* norm_w, void* xn, float eps, void* workspace, size_t workspace_bytes, hipStream_t st, int pk) {
   if (m <= 0) return ATSPEED_OK;
   FusedNorm fn{norm_w, xn, eps, false};
   int epc = dtype == ATSPEED_F32 ? 4 : 8;
   if (!big_kernel_applies(m, n, k, lda, ldh, dtype, EPI_RESID) && k % epc == 0 && lda % epc == 0) {
     int rc;
     if (dtype == ATSPEED_F32)
-      rc = launch_epi<float, EPI_RESID>((const float*)a, (const float*)w, h, m, n, k, lda, ldh, (float*)workspace, workspace_bytes, st, &fn);
+      rc = launch_epi<float, EPI_RESID>((const float*)a, (const float*)w, h, m, n, k, lda, ldh, (float*)workspace, workspace_bytes, st, &fn, 0);
     else
-      rc = launch_epi<bf16_t, EPI_RESID>((const bf16_t*)a, (const bf16_t*)w, h, m, n, k, lda, ldh, (float*)workspace, workspace_bytes, st, &fn);
+      rc = launch_epi<bf16_t, EPI_RESID>((const bf16_t*)a, (const bf16_t*)w, h, m, n, k, lda, ldh, (float*)workspace, workspace_bytes, st, &fn, pk);
     if (rc != ATSPEED_OK) return rc;
   } else {
-    ATS_TRY(ats_gemm(a, w, h, m, n, k, lda, ldh, dtype, EPI_RESID, workspace, workspace_bytes, st));
+    ATS_TRY(ats_gemm(a, w, h, m, n, k, lda, ldh, dtype, EPI_RESID, workspace, workspace_bytes, st, pk));
   }
-  if (!fn.done) return ats_rmsnorm(h, norm_w, xn, m, n, eps, dtype, st);
+  if (!fn.done) return ats_rmsnorm(h, norm_w, xn, m, n, eps, dtype, st, pk);
   return ATSPEED_OK;
 }
 
@@ -1413,16 +1437,16 @@ bool ats_gemm_fp8_applies(int m, int n, int k, int ldc, int epilogue) {
 }
 
 int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int m, int n, int k, int ldc,
-                 int epilogue, hipStream_t st) {
+                 int epilogue, hipStream_t st, int pk) {
   ATS_REQUIRE(xq && sx && wq && sw && c, ATSPEED_ERR_INVALID, "gemm_fp8: null argument");
   ATS_REQUIRE(m >= 1 && n >= 1 && k % 256 == 0, ATSPEED_ERR_INVALID, "gemm_fp8: K=%d must be a multiple of 256", k);
   ATS_REQUIRE(epilogue != EPI_SWIGLU || ((ldc & 3) == 0 && n % 32 == 0), ATSPEED_ERR_INVALID, "gemm_fp8: SwiGLU needs N %% 32 == 0 and ldc %% 4 == 0");
   const unsigned char* X = (const unsigned char*)xq; const unsigned char* Wq = (const unsigned char*)wq;
   switch (epilogue) {
-    case EPI_STORE:  return launch_big_fp8<EPI_STORE>(X, sx, Wq, sw, c, m, n, k, ldc, st);
-    case EPI_F32:    return launch_big_fp8<EPI_F32>(X, sx, Wq, sw, c, m, n, k, ldc, st);
-    case EPI_RESID:  return launch_big_fp8<EPI_RESID>(X, sx, Wq, sw, c, m, n, k, ldc, st);
-    case EPI_SWIGLU: return launch_big_fp8<EPI_SWIGLU>(X, sx, Wq, sw, c, m, n, k, ldc, st);
+    case EPI_STORE:  return launch_big_fp8<EPI_STORE>(X, sx, Wq, sw, c, m, n, k, ldc, st, pk);
+    case EPI_F32:    return launch_big_fp8<EPI_F32>(X, sx, Wq, sw, c, m, n, k, ldc, st, pk);
+    case EPI_RESID:  return launch_big_fp8<EPI_RESID>(X, sx, Wq, sw, c, m, n, k, ldc, st, pk);
+    case EPI_SWIGLU: return launch_big_fp8<EPI_SWIGLU>(X, sx, Wq, sw, c, m, n, k, ldc, st, pk);
   }
   atspeed_set_error("gemm_fp8: unknown epilogue %d", epilogue);
   return ATSPEED_ERR_INVALID;
@@ -1430,11 +1454,22 @@ int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* s
 
 extern "C" int atspeed_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int32_t m, int32_t n,
                                 int32_t k, int32_t ldc, int32_t epilogue, void* stream) {
-  return ats_gemm_fp8(xq, sx, wq, sw, c, m, n, k, ldc, epilogue, (hipStream_t)stream);
+  return ats_gemm_fp8(xq, sx, wq, sw, c, m, n, k, ldc, epilogue, (hipStream_t)stream, 0);
 }
 
 extern "C" int atspeed_gemm(const void* a, const void* w, void* c, int32_t m, int32_t n, int32_t k, int32_t lda,
                             int32_t ldc, int32_t dtype, int32_t epilogue, void* workspace, size_t workspace_bytes,
                             void* stream) {
-  return ats_gemm(a, w, c, m, n, k, lda, ldc, dtype, epilogue, workspace, workspace_bytes, (hipStream_t)stream);
+  return ats_gemm(a, w, c, m, n, k, lda, ldc, dtype, epilogue, workspace, workspace_bytes, (hipStream_t)stream, 0);
+}
+
+// the same GEMMs on operands in the packed layout (what the bf16 / fp8 engine runs; atspeed_pack_rows makes them): a, w packed;
+// the SwiGLU epilogue's output packed too (it is the down projection's operand), every other output row-major
+extern "C" int atspeed_gemm_packed(const void* a, const void* w, void* c, int32_t m, int32_t n, int32_t k, int32_t ldc, int32_t epilogue,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  return ats_gemm(a, w, c, m, n, k, k, ldc, ATSPEED_BF16, epilogue, workspace, workspace_bytes, (hipStream_t)stream, 1);
+}
+extern "C" int atspeed_gemm_fp8_packed(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int32_t m, int32_t n,
+                                       int32_t k, int32_t ldc, int32_t epilogue, void* stream) {
+  return ats_gemm_fp8(xq, sx, wq, sw, c, m, n, k, ldc, epilogue, (hipStream_t)stream, 1);
 }

@@ -9,6 +9,7 @@ PyTorch is plumbing here: it owns the device memory of the weights and provides 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional
 
@@ -47,9 +48,20 @@ class HipLlama:
                                       eos_token_id=2, use_cache=True)
         self.max_slots, self.max_tokens, self.max_logit_rows = max_slots, max_tokens, max_logit_rows
         lib = _lib.load()
+        # bf16: the projection weights and the lm_head go into the library's packed operand layout (two rows per 128-byte line and 64-byte
+        # k-block: full cache lines for every LDS-DMA piece of the GEMMs); ATSPEED_PACK=0 keeps HF's row-major layout (A/B runs, slower)
+        self.weights_packed = (dtype == torch.bfloat16 and dims.hidden % 32 == 0 and dims.ffn % 32 == 0
+                               and os.environ.get("ATSPEED_PACK", "1") != "0")
+        if self.weights_packed:
+            with torch.cuda.device(device):
+                for lw in packed["layers"]:
+                    for k in ("wqkv", "wo", "wgu", "wd"):
+                        lw[k] = self._pack_rows(lw[k])
+                packed["lm_head"] = self._pack_rows(packed["lm_head"])
         cfg = _lib.LlamaConfig(dims.vocab_size, dims.hidden, dims.n_layers, dims.n_heads, dims.ffn, dims.rope_theta,
                                dims.rms_eps, _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16,
-                               max_slots, max_tokens, max_logit_rows)
+                               max_slots, max_tokens, max_logit_rows,
+                               _lib.WEIGHTS_PACKED if self.weights_packed else _lib.WEIGHTS_ROW_MAJOR)
         layers = (_lib.LlamaLayerWeights * dims.n_layers)()
         for l, lw in enumerate(packed["layers"]):
             layers[l] = _lib.LlamaLayerWeights(lw["input_norm"].data_ptr(), lw["wqkv"].data_ptr(), lw["wo"].data_ptr(),
@@ -60,6 +72,20 @@ class HipLlama:
                                                 packed["lm_head"].data_ptr(), layers, C.byref(h)))
         self._handle = h
         self.logits_ld = int(lib.atspeed_llama_logits_ld(h))
+
+    @staticmethod
+    def _pack_rows(t: torch.Tensor) -> torch.Tensor:
+        """row-major [rows, cols] -> the packed operand layout (atspeed_pack_rows); rows rounded up to even."""
+        rows, cols = t.shape
+        out = torch.empty((rows + 1) // 2 * 2, cols, dtype=t.dtype, device=t.device)
+        _lib.check(_lib.load().atspeed_pack_rows(t.data_ptr(), out.data_ptr(), rows, cols * t.element_size(), _lib.stream_ptr(t.device)))
+        return out
+
+    @staticmethod
+    def _unpack_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
+        out = torch.empty(rows, t.shape[1], dtype=t.dtype, device=t.device)
+        _lib.check(_lib.load().atspeed_unpack_rows(t.data_ptr(), out.data_ptr(), rows, t.shape[1] * t.element_size(), _lib.stream_ptr(t.device)))
+        return out
 
     # ---- attributes the reference path reads ---------------------------------------
     @property
@@ -162,7 +188,7 @@ class HipLlama:
                     raise ValueError("align_to: same vocabulary and a hidden size <= this model's are required")
                 sd["model.embed_tokens.weight"].zero_()
                 sd["model.embed_tokens.weight"][:, :hd] = src["embed"]
-                sd["lm_head.weight"][:, :hd] = src["lm_head"]
+                sd["lm_head.weight"][:, :hd] = (align_to._unpack_rows(src["lm_head"], dims.vocab_size) if align_to.weights_packed else src["lm_head"])
                 # RMS over `hidden` coordinates of which `hd` carry the signal: rescale so norm(x)[:hd] matches the draft's
                 sd["model.norm.weight"][:hd] = (src["final_norm"].float() * (hd / dims.hidden) ** 0.5).to(dtype)
             packed = cls._pack(sd, dims)
@@ -213,8 +239,13 @@ class HipLlama:
         oracle on exactly the weights the device holds."""
         d, pk = self.dims, self._packed
         f = lambda t: t.detach().to("cpu", torch.float32)
-        sd = {"model.embed_tokens.weight": f(pk["embed"]), "model.norm.weight": f(pk["final_norm"]), "lm_head.weight": f(pk["lm_head"])}
-        for l, lw in enumerate(pk["layers"]):
+        with torch.cuda.device(self._device):
+            u = (lambda t, rows: self._unpack_rows(t, rows)) if self.weights_packed else (lambda t, rows: t)
+            sd = {"model.embed_tokens.weight": f(pk["embed"]), "model.norm.weight": f(pk["final_norm"]),
+                  "lm_head.weight": f(u(pk["lm_head"], d.vocab_size))}
+            layers = [{k: (u(v, {"wqkv": 3 * d.hidden, "wo": d.hidden, "wgu": 2 * d.ffn, "wd": d.hidden}[k]) if k in ("wqkv", "wo", "wgu", "wd") else v)
+                       for k, v in lw.items()} for lw in pk["layers"]] if self.weights_packed else pk["layers"]
+        for l, lw in enumerate(layers):
             p = f"model.layers.{l}."
             qkv = f(lw["wqkv"])
             sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"] = \

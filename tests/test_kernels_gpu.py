@@ -469,6 +469,89 @@ def test_lmhead_lse_fused_epilogue(lib, rows, vocab, hidden):
         lib.atspeed_fsm_destroy(fsm)
 
 
+# ------------------------------------------------------------------ packed operand layout (what the bf16 / fp8 engine feeds its GEMMs)
+def _pack(lib, t):
+    rows, cols = t.shape
+    out = torch.empty((rows + 1) // 2 * 2, cols, dtype=t.dtype, device="cuda")
+    _lib.check(lib.atspeed_pack_rows(t.data_ptr(), out.data_ptr(), rows, cols * t.element_size(), _st()))
+    return out
+
+
+def _unpack(lib, t, rows):
+    out = torch.empty(rows, t.shape[1], dtype=t.dtype, device="cuda")
+    _lib.check(lib.atspeed_unpack_rows(t.data_ptr(), out.data_ptr(), rows, t.shape[1] * t.element_size(), _st()))
+    return out
+
+
+def test_pack_rows_layout_and_round_trip(lib):
+    """byte b of row r -> ((r >> 1) * (row_bytes / 64) + (b >> 6)) * 128 + (r & 1) * 64 + (b & 63); odd row counts get a zero pad row."""
+    for rows, cols, dt in ((7, 96, torch.bfloat16), (64, 4096, torch.bfloat16), (33, 256, torch.uint8), (2, 32, torch.bfloat16)):
+        src = (torch.arange(rows * cols, dtype=torch.int32) % 251).reshape(rows, cols).to(dt).cuda()
+        pk = _pack(lib, src)
+        torch.cuda.synchronize()
+        rb = cols * src.element_size()
+        flat_src = src.contiguous().view(torch.uint8).cpu().numpy().reshape(rows, rb)
+        flat_pk = pk.view(torch.uint8).cpu().numpy().reshape(-1)
+        r, b = np.meshgrid(np.arange(rows), np.arange(rb), indexing="ij")
+        off = ((r >> 1) * (rb // 64) + (b >> 6)) * 128 + (r & 1) * 64 + (b & 63)
+        assert np.array_equal(flat_pk[off], flat_src)
+        if rows % 2:
+            rr = np.full(rb, rows); bb = np.arange(rb)
+            assert not flat_pk[((rr >> 1) * (rb // 64) + (bb >> 6)) * 128 + (rr & 1) * 64 + (bb & 63)].any()
+        assert torch.equal(_unpack(lib, pk, rows), src)
+    with pytest.raises(_lib.AtSpeedError):
+        x = torch.zeros(4, 40, dtype=torch.bfloat16, device="cuda")          # 80-byte rows: not a multiple of 64
+        lib_out = torch.zeros(4, 40, dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.atspeed_pack_rows(x.data_ptr(), lib_out.data_ptr(), 4, 80, _st()))
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(20, 768, 256, 0), (100, 12288, 512, 0), (228, 4096, 4096, 2), (228, 22016, 512, 3), (121, 32859, 256, 1),
+                                      (1300, 1024, 1280, 2), (900, 2752, 512, 3), (4200, 8192, 256, 0), (1543, 1001, 256, 1), (777, 4096, 11008, 2)])
+def test_gemm_packed_equals_row_major_bit_for_bit(lib, m, n, k, epi):
+    """Every bf16 GEMM path (LDS-tiled, its split-K + reduce, the split-K ring, the 256-wide ring) on packed operands: the same products
+    in the same order as on row-major operands, so the outputs are IDENTICAL (the SwiGLU output comes back packed)."""
+    a = _rand((m, k), 71, 1.0).to(torch.bfloat16).cuda()
+    w = _rand((n, k), 72, 0.05).to(torch.bfloat16).cuda()
+    ws = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+    if epi == _lib.EPI_F32:
+        ldc = (n + 63) // 64 * 64; mk = lambda: torch.zeros(m, ldc, dtype=torch.float32, device="cuda")
+    elif epi == _lib.EPI_SWIGLU:
+        ldc = n // 2; mk = lambda: torch.zeros((m + 1) // 2 * 2, ldc, dtype=torch.bfloat16, device="cuda")
+    else:
+        ldc = n; base = _rand((m, n), 73).to(torch.bfloat16).cuda(); mk = lambda: (base.clone() if epi == _lib.EPI_RESID else torch.zeros_like(base))
+    c0, c1 = mk(), mk()
+    _lib.check(lib.atspeed_gemm(a.data_ptr(), w.data_ptr(), c0.data_ptr(), m, n, k, k, ldc, _lib.ATSPEED_BF16, epi, ws.data_ptr(), ws.numel(), _st()))
+    ap, wp = _pack(lib, a), _pack(lib, w)
+    _lib.check(lib.atspeed_gemm_packed(ap.data_ptr(), wp.data_ptr(), c1.data_ptr(), m, n, k, ldc, epi, ws.data_ptr(), ws.numel(), _st()))
+    torch.cuda.synchronize()
+    if epi == _lib.EPI_SWIGLU:
+        assert torch.equal(_unpack(lib, c1, m), c0[:m])
+    else:
+        assert torch.equal(c1[:, :n], c0[:, :n])
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(1024, 2304, 768, 0), (1300, 1024, 1280, 2), (900, 2752, 512, 3), (4200, 8448, 256, 3), (8300, 4096, 512, 2)])
+def test_gemm_fp8_packed_equals_row_major_bit_for_bit(lib, m, n, k, epi):
+    x = _rand((m, k), 51, 1.5).to(torch.bfloat16).cuda()
+    w = _rand((n, k), 52, 0.05).to(torch.bfloat16).cuda()
+    xq = torch.empty(m, k, dtype=torch.uint8, device="cuda"); sx = torch.empty(m, device="cuda")
+    wq = torch.empty(n, k, dtype=torch.uint8, device="cuda"); sw = torch.empty(n, device="cuda")
+    _lib.check(lib.atspeed_quant_rows_fp8(x.data_ptr(), m, k, xq.data_ptr(), sx.data_ptr(), _st()))
+    _lib.check(lib.atspeed_quant_rows_fp8(w.data_ptr(), n, k, wq.data_ptr(), sw.data_ptr(), _st()))
+    ldc = n // 2 if epi == _lib.EPI_SWIGLU else n
+    base = _rand((m, ldc), 53).to(torch.bfloat16).cuda()
+    mk = lambda: torch.cat((base, torch.zeros(m % 2, ldc, dtype=torch.bfloat16, device="cuda"))) if epi != _lib.EPI_SWIGLU else torch.zeros((m + 1) // 2 * 2, ldc, dtype=torch.bfloat16, device="cuda")
+    c0, c1 = mk(), mk()
+    _lib.check(lib.atspeed_gemm_fp8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), c0.data_ptr(), m, n, k, ldc, epi, _st()))
+    xp, wp = _pack(lib, xq), _pack(lib, wq)
+    _lib.check(lib.atspeed_gemm_fp8_packed(xp.data_ptr(), sx.data_ptr(), wp.data_ptr(), sw.data_ptr(), c1.data_ptr(), m, n, k, ldc, epi, _st()))
+    torch.cuda.synchronize()
+    if epi == _lib.EPI_SWIGLU:
+        assert torch.equal(_unpack(lib, c1, m), c0[:m])
+    else:
+        assert torch.equal(c1[:m], c0[:m])
+
+
 def test_measured_peak_probes_are_plausible(lib):
     """bench.py's measured peaks: the probes run, synchronise and return numbers between a loose floor and the
     nominal peaks of /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF dense bf16, 8 TB/s)."""

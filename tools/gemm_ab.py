@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from atspeed_amd import _lib
+if os.environ.get("ATSPEED_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["ATSPEED_LIB"])     # a tuning build (make stamps / ablate / exppack)
 lib = _lib.load(); st = _lib.stream_ptr()
 ws = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
 Ms = [int(x) for x in sys.argv[1:]] or [3200, 7040]
