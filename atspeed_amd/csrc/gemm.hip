@@ -594,6 +594,9 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
   asm volatile("s_barrier" ::: "memory");                          // k-step 1 published, stage 0 read by everyone
 
+#if defined(ATS_EXP_PRIO)      // tuning build: static priority for the second-dispatched half of the workgroup (guide: Two waves per SIMD, item 4)
+  if (wave >= NWV / 2) __builtin_amdgcn_s_setprio(ATS_EXP_PRIO);
+#endif
 #ifdef ATS_RING_STAMPS
   const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz reference: cycles / ticks = the clock the chip holds
   const unsigned long long st_loop0 = st_last = __builtin_readcyclecounter();

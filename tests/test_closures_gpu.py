@@ -182,3 +182,43 @@ def test_decoder_cache_does_not_keep_models_alive():
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20, "device memory grew across the sweep"
+
+
+def test_bf16_engine_without_packed_operands_equals_packed_one():
+    """The packed operand layout is an address change only: a bf16 model whose dims do not allow it (ffn % 32 != 0) keeps HF's row-major layout
+    and works; and for dims that allow both, the engine with ATSPEED_PACK=0 (row-major weights, `weight_layout = 0`) returns exactly what the
+    packed engine returns -- one user's forwards (small-M kernels, split-K) and a lock-step batch (ring kernels)."""
+    import os
+    V = synth.TINY.vocab_size
+    fn = atspeed_amd.PositionSetConstraint(synth.TINY.allowed_tokens(), synth.RESPONSE_SEP)
+    kw = dict(dtype=torch.bfloat16, max_slots=512, max_tokens=512, max_logit_rows=448)
+    odd = HipLlama.from_synthetic(synth.LlamaDims(V, 160, 2, 5, 208), 3, std=0.05, head_std=0.3, num_beams=8, **kw)
+    assert not odd.weights_packed
+    inp = {"input_ids": torch.from_numpy(synth.synthetic_prompt(40, 5))[None].cuda()}
+    out = target_generate(odd, inp, 4, prefix_allowed_tokens_fn=fn)
+    assert out["n_valid"] == 8 and bool(torch.isfinite(out["beam_scores"]).all())
+    dims_t, dims_d = synth.LlamaDims(V, 512, 2, 4, 1408), synth.LlamaDims(V, 256, 2, 4, 704)
+    prompts = [{"input_ids": torch.from_numpy(synth.synthetic_prompt(30 + 3 * u, 40 + u))[None].cuda()} for u in range(24)]
+    res = {}
+    old = os.environ.get("ATSPEED_PACK")
+    try:
+        for mode in ("1", "0"):
+            os.environ["ATSPEED_PACK"] = mode
+            t = HipLlama.from_synthetic(dims_t, 7, std=0.04, head_std=0.3, num_beams=20, **kw)
+            d = HipLlama.from_synthetic(dims_d, 8, std=0.04, head_std=0.3, num_beams=40, **kw)
+            assert t.weights_packed == (mode == "1") and d.weights_packed == (mode == "1")
+            sd = t.export_state_dict()
+            res[mode] = (BSSD(t, d, prompts[0], 4, 4, prefix_allowed_tokens_fn=fn), BSSD_batch(t, d, prompts, 4, 4, prefix_allowed_tokens_fn=fn),
+                         sd["model.layers.1.mlp.up_proj.weight"], sd["lm_head.weight"])
+            release_decoders(t, d)
+    finally:
+        if old is None:
+            os.environ.pop("ATSPEED_PACK", None)
+        else:
+            os.environ["ATSPEED_PACK"] = old
+    a, b = res["1"], res["0"]
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])                    # export undoes the packing
+    assert torch.equal(a[0]["beam_sequence"], b[0]["beam_sequence"]) and torch.equal(a[0]["beam_scores"], b[0]["beam_scores"])
+    for x, y in zip(a[1], b[1]):
+        assert torch.equal(x["beam_sequence"], y["beam_sequence"]) and torch.equal(x["beam_scores"], y["beam_scores"])
+        assert x["accept_steps"] == y["accept_steps"]

@@ -13,7 +13,10 @@ for name, n, k in (("qkv", 12288, 4096), ("gate_up", 22016, 4096), ("down", 4096
         a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
         w = (torch.randn(n, k, device="cuda") * 0.02).to(torch.bfloat16)
         c = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
-        f = lambda: _lib.check(lib.atspeed_gemm(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, k, n, _lib.ATSPEED_BF16, _lib.EPI_STORE, ws.data_ptr(), ws.numel(), st))
+        if os.environ.get("GEMM_AB_ROWMAJOR"):
+            f = lambda: _lib.check(lib.atspeed_gemm(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, k, n, _lib.ATSPEED_BF16, _lib.EPI_STORE, ws.data_ptr(), ws.numel(), st))
+        else:         # the engine's layout: packed operands (the random values do not care that they were not run through atspeed_pack_rows)
+            f = lambda: _lib.check(lib.atspeed_gemm_packed(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, n, _lib.EPI_STORE, ws.data_ptr(), ws.numel(), st))
         for _ in range(3): f()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
