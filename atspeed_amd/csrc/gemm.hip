@@ -75,26 +75,46 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const T* __restrict__ A,
 
   uint4 ra[Cfg::A_PER_THREAD], rw[Cfg::W_PER_THREAD];
 
+  // per-thread source offsets (bytes) of its 16-byte chunks at k-tile 0, computed once: row-major  row * ld * esz + chunk * 16;
+  // packed  (row >> 1) * 2 * ld * esz + (row & 1) * 64 + (chunk >> 2) * 128 + (chunk & 3) * 16  (a 128-byte k-tile is two 64-byte blocks,
+  // each in the line its row pair shares).  A k-tile later is 128 bytes further on row-major rows, 256 on packed ones.
+  constexpr int ESZ = (int)sizeof(T);
+  const size_t kstep = pk ? 256 : 128;
+  size_t aoff[Cfg::A_PER_THREAD], woff[Cfg::W_PER_THREAD];
+  const size_t k0b = (size_t)kz0 * ESZ;                       // multiple of 128 (k_per_split is a multiple of BK)
+#pragma unroll
+  for (int i = 0; i < Cfg::A_PER_THREAD; ++i) {
+    const int q = tid + i * kThreads, r = q >> 3, c = q & 7;
+    const size_t gm = (size_t)min(m0 + r, M - 1);
+    aoff[i] = pk ? (gm >> 1) * ((size_t)lda * ESZ * 2) + (gm & 1) * 64 + (k0b * 2) + (size_t)(c >> 2) * 128 + (c & 3) * 16
+                 : gm * ((size_t)lda * ESZ) + k0b + (size_t)c * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < Cfg::W_PER_THREAD; ++i) {
+    const int q = tid + i * kThreads, r = q >> 3, c = q & 7;
+    const size_t gn = (size_t)min(n0 + r, N - 1);
+    woff[i] = pk ? (gn >> 1) * ((size_t)K * ESZ * 2) + (gn & 1) * 64 + (k0b * 2) + (size_t)(c >> 2) * 128 + (c & 3) * 16
+                 : gn * ((size_t)K * ESZ) + k0b + (size_t)c * 16;
+  }
+  const unsigned char* Ab = reinterpret_cast<const unsigned char*>(A);
+  const unsigned char* Wb = reinterpret_cast<const unsigned char*>(W);
+
   auto load_tile = [&](int kt) {
     const int kbase = kz0 + kt * BK;
 #pragma unroll
     for (int i = 0; i < Cfg::A_PER_THREAD; ++i) {
       int q = tid + i * kThreads;
       if (q < Cfg::A_CHUNKS) {
-        int r = q >> 3, c = q & 7;
-        int gm = min(m0 + r, M - 1);
-        int gk = kbase + c * EPC;
-        ra[i] = (gk < kz1) ? *reinterpret_cast<const uint4*>(A + ats_opnd_idx<sizeof(T)>(pk, gm, gk, lda)) : make_uint4(0, 0, 0, 0);
+        int gk = kbase + (q & 7) * EPC;
+        ra[i] = (gk < kz1) ? *reinterpret_cast<const uint4*>(Ab + aoff[i] + (size_t)kt * kstep) : make_uint4(0, 0, 0, 0);
       }
     }
 #pragma unroll
     for (int i = 0; i < Cfg::W_PER_THREAD; ++i) {
       int q = tid + i * kThreads;
       if (q < Cfg::W_CHUNKS) {
-        int r = q >> 3, c = q & 7;
-        int gn = min(n0 + r, N - 1);
-        int gk = kbase + c * EPC;
-        rw[i] = (gk < kz1) ? *reinterpret_cast<const uint4*>(W + ats_opnd_idx<sizeof(T)>(pk, gn, gk, K)) : make_uint4(0, 0, 0, 0);
+        int gk = kbase + (q & 7) * EPC;
+        rw[i] = (gk < kz1) ? *reinterpret_cast<const uint4*>(Wb + woff[i] + (size_t)kt * kstep) : make_uint4(0, 0, 0, 0);
       }
     }
   };
@@ -1105,11 +1125,12 @@ __global__ __launch_bounds__(1024) void splitk_resid_rmsnorm_kernel(const float*
   for (int i = 0; i < NPT / V; ++i) {
     const int n = (threadIdx.x + i * 1024) * V;
     if (n < N) {
+      T* xo = xn + ats_opnd_idx<sizeof(T)>(pk, m, n, N);      // xn: the next projection's operand (V <= 4 consecutive columns stay inside one 64-byte block)
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         float v = vals[i * V + j] * rs;
         if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
-        Elt<T>::store(xn + ats_opnd_idx<sizeof(T)>(pk, m, n + j, N), Elt<T>::load(norm_w + n + j) * v);   // xn: the next projection's operand
+        Elt<T>::store(xo + j, Elt<T>::load(norm_w + n + j) * v);
       }
     }
   }
