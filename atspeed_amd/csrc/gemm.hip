@@ -473,7 +473,7 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   constexpr int STAGE = (BT + XR) * RB;                          // 32 or 24 KB
   constexpr int NR = NA + MT2;                                   // fragment reads per wave per k-step
   constexpr int NMF = NA * MT2;                                  // MFMAs per wave per k-step
-  constexpr int RG = (NMF * 3 / 4) / NR;                         // one read every RG MFMAs, from the segment's start
+  constexpr int RG = (NMF * 3 / 4) / NR;                         // one read every RG MFMAs, from the segment's start (RG = 1: +0.0-0.6 %, not kept)
   constexpr int DG = (NMF - NR * RG) / NP;                       // then one DMA piece every DG MFMAs
   static_assert(RG >= 1 && DG >= 1, "segment too short for its reads and DMA pieces");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -614,9 +614,6 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
   asm volatile("s_barrier" ::: "memory");                          // k-step 1 published, stage 0 read by everyone
 
-#if defined(ATS_EXP_PRIO)      // tuning build: static priority for the second-dispatched half of the workgroup (guide: Two waves per SIMD, item 4)
-  if (wave >= NWV / 2) __builtin_amdgcn_s_setprio(ATS_EXP_PRIO);
-#endif
 #ifdef ATS_RING_STAMPS
   const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz reference: cycles / ticks = the clock the chip holds
   const unsigned long long st_loop0 = st_last = __builtin_readcyclecounter();

@@ -461,7 +461,8 @@ def main():
                                f"{'position-set mask' if args.mask == 'position' else 'strict item trie'}",
                    "users_per_step": ups, "users_per_gpu": n_timed, "streams": args.streams,
                    "mean_prompt_len": float(np.mean([len(p) for p in prompts[n_warm:]])),
-                   "parallelism": f"user-shard x{world}"},
+                   "parallelism": f"user-shard x{world}",
+                   "operand_layout": "packed (row pairs per 128-byte line)" if getattr(target, "weights_packed", False) else "row-major"},
         "mean_accept_len": mean_accept,
         "accept_note": "unrelated random draft/target weights accept ~0 draft steps: worst-case bracket (3 verify rounds + 1 final step = 4 target forwards per user)",
         "per_user": {"n_run": total_runs / users, "target_forwards": n_tf / n_timed, "draft_forwards": n_df / n_timed,
