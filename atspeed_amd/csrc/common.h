@@ -102,6 +102,10 @@ __device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
 }
 __device__ __forceinline__ float bf_lo(uint32_t pk) { return __uint_as_float(pk << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t pk) { return __uint_as_float(pk & 0xffff0000u); }
+// The rotary pair (x0, x1) = (x[d], x[d + head_dim/2]) of the bf16 engine, with the contraction spelled out: the separate RoPE pass, the
+// slab-summing one and the qkv GEMM's fused epilogue must round identically (the compiler is otherwise free to pick which product it fuses).
+__device__ __forceinline__ float rope_first(float x0, float x1, float c, float s) { return __fmaf_rn(x0, c, -__fmul_rn(x1, s)); }    // x0 cos - x1 sin
+__device__ __forceinline__ float rope_second(float x0, float x1, float c, float s) { return __fmaf_rn(x1, c, __fmul_rn(x0, s)); }    // x1 cos + x0 sin
 
 template <typename T> struct Elt;
 template <> struct Elt<float> {

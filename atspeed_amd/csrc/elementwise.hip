@@ -254,6 +254,26 @@ __device__ __forceinline__ int seg_of_row(const SegTable* t, int row) {
   return lo;
 }
 
+// Per batched row: the caches of the row's user, its cache slot and its (clamped) rotation index -- resolved once per forward so that
+// the qkv projection's epilogue (gemm.hip: EPI_QKV_ROPE) finds them with one 24-byte load instead of a segment search per layer.
+__global__ void row_info_kernel(const SegTable* __restrict__ t, RowInfo* __restrict__ out, int max_pos) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= t->total_tok) return;
+  const Seg& sg = t->seg[seg_of_row(t, row)];
+  const int lt = row - sg.row0;
+  int ps = sg.pos[lt];
+  ps = ps < 0 ? 0 : (ps >= max_pos ? max_pos - 1 : ps);
+  out[row] = RowInfo{sg.kc, sg.vc, ps, sg.slot[lt]};
+}
+
+int ats_row_info(const SegTable& t, const SegTable* dt, RowInfo* out, int max_pos, hipStream_t st) {
+  if (t.total_tok <= 0) return ATSPEED_OK;
+  ATS_REQUIRE(dt && out, ATSPEED_ERR_INVALID, "row_info: null argument");
+  row_info_kernel<<<(t.total_tok + 255) / 256, 256, 0, st>>>(dt, out, max_pos);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
 __global__ void embed_segs_kernel(const uint4* __restrict__ table, const SegTable* __restrict__ t, uint4* __restrict__ out,
                                   int chunks_per_row, int vocab) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -332,10 +352,10 @@ __global__ void rope_kv_segs_vec_kernel(bf16_t* __restrict__ qkv, const SegTable
 #pragma unroll
   for (int e = 0; e < 4; ++e) {                                   // two elements per packed register
     const float ca = cp[2 * e], sa = sp[2 * e], cb = cp[2 * e + 1], sb = sp[2 * e + 1];
-    a0[e] = f2bf_pk(bf_lo(q0[e]) * ca - bf_lo(q1[e]) * sa, bf_hi(q0[e]) * cb - bf_hi(q1[e]) * sb);
-    a1[e] = f2bf_pk(bf_lo(q1[e]) * ca + bf_lo(q0[e]) * sa, bf_hi(q1[e]) * cb + bf_hi(q0[e]) * sb);
-    b0[e] = f2bf_pk(bf_lo(k0[e]) * ca - bf_lo(k1[e]) * sa, bf_hi(k0[e]) * cb - bf_hi(k1[e]) * sb);
-    b1[e] = f2bf_pk(bf_lo(k1[e]) * ca + bf_lo(k0[e]) * sa, bf_hi(k1[e]) * cb + bf_hi(k0[e]) * sb);
+    a0[e] = f2bf_pk(rope_first(bf_lo(q0[e]), bf_lo(q1[e]), ca, sa), rope_first(bf_hi(q0[e]), bf_hi(q1[e]), cb, sb));
+    a1[e] = f2bf_pk(rope_second(bf_lo(q0[e]), bf_lo(q1[e]), ca, sa), rope_second(bf_hi(q0[e]), bf_hi(q1[e]), cb, sb));
+    b0[e] = f2bf_pk(rope_first(bf_lo(k0[e]), bf_lo(k1[e]), ca, sa), rope_first(bf_hi(k0[e]), bf_hi(k1[e]), cb, sb));
+    b1[e] = f2bf_pk(rope_second(bf_lo(k0[e]), bf_lo(k1[e]), ca, sa), rope_second(bf_hi(k0[e]), bf_hi(k1[e]), cb, sb));
   }
   *reinterpret_cast<uint4*>(r + d0) = qo0; *reinterpret_cast<uint4*>(r + d1) = qo1;
   *reinterpret_cast<uint4*>(kc + d0) = ko0; *reinterpret_cast<uint4*>(kc + d1) = ko1;
@@ -402,8 +422,8 @@ __global__ void rope_kv_segs_slab_kernel(const float* __restrict__ slabs, int sp
       // the projection's bf16 outputs first (what the reduce pass stored), then the rotation on those
       const uint32_t x0 = f2bf_pk(lo[e], lo[e + 1]), x1 = f2bf_pk(hi[e], hi[e + 1]);
       const float ca = cp[e], sa = sp[e], cb = cp[e + 1], sb = sp[e + 1];
-      w0[e >> 1] = f2bf_pk(bf_lo(x0) * ca - bf_lo(x1) * sa, bf_hi(x0) * cb - bf_hi(x1) * sb);
-      w1[e >> 1] = f2bf_pk(bf_lo(x1) * ca + bf_lo(x0) * sa, bf_hi(x1) * cb + bf_hi(x0) * sb);
+      w0[e >> 1] = f2bf_pk(rope_first(bf_lo(x0), bf_lo(x1), ca, sa), rope_first(bf_hi(x0), bf_hi(x1), cb, sb));
+      w1[e >> 1] = f2bf_pk(rope_second(bf_lo(x0), bf_lo(x1), ca, sa), rope_second(bf_hi(x0), bf_hi(x1), cb, sb));
     }
   }
   bf16_t* dst;

@@ -170,6 +170,7 @@ struct ActCtx {
   float* logits = nullptr;                       // [cap_rows][logits_ld]
   float* lse = nullptr;                          // [cap_rows]
   float* lse_part = nullptr; size_t lse_part_bytes = 0;   // [cap_rows][vocab tiles] (max, sum exp) partials of the fused lm_head epilogue
+  RowInfo* rowinfo = nullptr;                    // [cap_tok] cache / slot / rotation of each batched row (qkv projection's fused epilogue)
   void* xq = nullptr; float* sx = nullptr;       // fp8 activations [cap_tok][max(hidden, ffn)] + per-token scales
   void* ws = nullptr; size_t ws_bytes = 0;       // split-K slabs
   // forwards of a recurring shape are replayed as hipGraphs (one launch instead of ~9 per layer: a user's later rounds are
@@ -209,6 +210,7 @@ struct atspeed_llama {
   long prof_big_rows[5] = {0, 0, 0, 0, 0};
   // how often each layer projection (0 qkv, 1 o_proj, 2 gate_up, 3 down) ran as an fp8 / as a bf16 (fp32) GEMM (atspeed_llama_fp8_counters)
   long fp8_cnt[4] = {0, 0, 0, 0}, other_cnt[4] = {0, 0, 0, 0};
+  long rope_fused_cnt = 0;                       // qkv projections that carried RoPE + the KV scatter in their epilogue (atspeed_llama_rope_fused_launches)
 };
 constexpr int ATS_PROF_BIG_ROWS = 1024;
 
@@ -255,7 +257,7 @@ static size_t gemm_ws_for(const atspeed_llama_config& c, int max_tok, int max_ro
 static void act_free(ActCtx* cx) {
   if (!cx) return;
   hipFree(cx->h); hipFree(cx->xn); hipFree(cx->qkv); hipFree(cx->att); hipFree(cx->act); hipFree(cx->gath);
-  hipFree(cx->logits); hipFree(cx->lse); hipFree(cx->lse_part); hipFree(cx->ws); hipFree(cx->xq); hipFree(cx->sx);
+  hipFree(cx->logits); hipFree(cx->lse); hipFree(cx->lse_part); hipFree(cx->ws); hipFree(cx->xq); hipFree(cx->sx); hipFree(cx->rowinfo);
   for (hipEvent_t e : cx->prof_ev) hipEventDestroy(e);
   for (auto& g : cx->graphs) hipGraphExecDestroy(g.second);
   if (cx->cap_stream) hipStreamDestroy(cx->cap_stream);
@@ -286,6 +288,7 @@ static int ensure_act(atspeed_llama* m, int tok, int rows) {
   ATS_HIP(hipMalloc((void**)&cx->lse_part, cx->lse_part_bytes));
   ATS_HIP(hipMalloc(&cx->xq, T * (size_t)std::max(c.hidden, c.ffn)));
   ATS_HIP(hipMalloc((void**)&cx->sx, T * sizeof(float)));
+  ATS_HIP(hipMalloc((void**)&cx->rowinfo, T * sizeof(RowInfo)));
   cx->ws_bytes = gemm_ws_for(c, cx->cap_tok, cx->cap_rows);
   ATS_HIP(hipMalloc(&cx->ws, cx->ws_bytes));
   ATS_HIP(hipMalloc((void**)&cx->segtab_dev, sizeof(SegTable)));
@@ -412,6 +415,13 @@ extern "C" int atspeed_llama_fp8_counters(atspeed_llama* m, int64_t* fp8_out, in
   return ATSPEED_OK;
 }
 
+extern "C" int64_t atspeed_llama_rope_fused_launches(atspeed_llama* m, int32_t reset) {
+  if (!m) return -1;
+  const int64_t n = m->rope_fused_cnt;
+  if (reset) m->rope_fused_cnt = 0;
+  return n;
+}
+
 extern "C" float* atspeed_llama_logits(atspeed_llama* m) { return m && m->act ? m->act->logits : nullptr; }
 extern "C" int32_t atspeed_llama_logits_ld(const atspeed_llama* m) { return m ? m->logits_ld : 0; }
 
@@ -517,6 +527,10 @@ static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTabl
   bool xq_ready = false;
   if (f8_qkv) { ATS_TRY(ats_rmsnorm_quant_fp8(cx->h, m->layers[0].input_norm, nullptr, cx->xq, cx->sx, T, H, c.rms_eps, st, pk)); xq_ready = true; }
   else ATS_TRY(ats_rmsnorm(cx->h, m->layers[0].input_norm, cx->xn, T, H, c.rms_eps, dt, st, pk));
+  // batched bf16 forwards: RoPE and the KV scatter ride in the qkv projection's epilogue (one pass over qkv less per layer)
+  const bool qkv_in_fp8 = !m->fp8.empty() && ats_gemm_fp8_applies(T, 3 * H, H, 3 * H, EPI_STORE);
+  const bool qkv_rope_fused = qkv_in_fp8 ? ats_gemm_fp8_qkv_rope_applies(T, H, m->head_dim) : ats_gemm_qkv_rope_applies(T, H, m->head_dim, dt);
+  if (qkv_rope_fused) ATS_TRY(ats_row_info(t, dtab, cx->rowinfo, c.max_slots, st));
   for (int l = 0; l < c.n_layers; ++l) {
     const atspeed_llama_layer_weights& w = m->layers[l];
     const size_t loff = (size_t)l * m->layer_kv_bytes;
@@ -525,16 +539,25 @@ static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTabl
     static const bool fuse_qkv_reduce = !(getenv("ATSPEED_FUSE_QKV_REDUCE") && atoi(getenv("ATSPEED_FUSE_QKV_REDUCE")) == 0);
     int qkv_splits = 0;
     { ProfBracket pb(m, 0, T, st);
-      if (f8 && ats_gemm_fp8_applies(T, 3 * H, H, 3 * H, EPI_STORE)) {
+      if (qkv_in_fp8) {
         m->fp8_cnt[0]++;
-        ATS_TRY(proj_fp8(m, xq_ready ? nullptr : cx->xn, m->fp8[l].wqkv, m->fp8[l].sqkv, cx->qkv, T, 3 * H, H, 3 * H, EPI_STORE, st));
+        if (qkv_rope_fused) {
+          m->rope_fused_cnt++;
+          if (!xq_ready) ATS_TRY(ats_quant_rows_fp8(cx->xn, T, H, H, cx->xq, cx->sx, st, pk));
+          ATS_TRY(ats_gemm_fp8_qkv_rope(cx->xq, cx->sx, m->fp8[l].wqkv, m->fp8[l].sqkv, cx->qkv, T, H,
+                                        RopeEpi{cx->rowinfo, m->cos_tab, m->sin_tab, loff, H}, st, pk));
+        } else ATS_TRY(proj_fp8(m, xq_ready ? nullptr : cx->xn, m->fp8[l].wqkv, m->fp8[l].sqkv, cx->qkv, T, 3 * H, H, 3 * H, EPI_STORE, st));
+      } else if (qkv_rope_fused) {
+        m->other_cnt[0]++; m->rope_fused_cnt++;
+        ATS_TRY(ats_gemm_qkv_rope(cx->xn, w.wqkv, cx->qkv, T, H, RopeEpi{cx->rowinfo, m->cos_tab, m->sin_tab, loff, H}, st, pk));
       } else {
         m->other_cnt[0]++;
         // one user's forward: the projection leaves fp32 split-K slabs and RoPE sums them itself (one launch less per layer)
         if (fuse_qkv_reduce && m->head_dim % 16 == 0) ATS_TRY(ats_gemm_partials(cx->xn, w.wqkv, T, 3 * H, H, H, dt, cx->ws, cx->ws_bytes, st, &qkv_splits, pk));
         if (qkv_splits == 0) ATS_TRY(ats_gemm(cx->xn, w.wqkv, cx->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, cx->ws, cx->ws_bytes, st, pk));
       } }
-    if (qkv_splits > 0)
+    if (qkv_rope_fused) {}
+    else if (qkv_splits > 0)
       ATS_TRY(ats_rope_kv_segs_slabs((const float*)cx->ws, qkv_splits, cx->qkv, t, dtab, m->cos_tab, m->sin_tab, loff, c.n_heads, m->head_dim, c.max_slots, st));
     else
       ATS_TRY(ats_rope_kv_segs(cx->qkv, t, dtab, m->cos_tab, m->sin_tab, loff, c.n_heads, m->head_dim, c.max_slots, dt, st));

@@ -410,6 +410,72 @@ __device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[NA][MT2], void* __re
   }
 }
 
+// Epilogue of the batched qkv projection (EPI_QKV_ROPE): RoPE and the KV-cache scatter on the accumulators, so that the projection's
+// output is never re-read (the separate pass moved 3 x tokens x hidden x 2 x 2 bytes per layer).  hidden % 256 == 0: a 256-column tile
+// lies inside one of q / k / v and holds two heads of head_dim 128; wave (wn, wm) accumulated the half (wn & 1) of head (wn >> 1) for the
+// rows of wm.  v tiles go to the cache as they are.  q / k tiles pass through the (drained) ring's LDS as bf16 and are re-divided by
+// ROWS: a wave then rotates both halves of both heads for a quarter of wm's rows, so each (cos, sin) is fetched once per row and pair
+// index instead of once per wave that holds the column (4 x fewer table bytes through the L1 -- the first form's cost).  Numerics are
+// those of ats_gemm + rope_kv_segs_vec_kernel: the projection rounded to bf16, the rotation in fp32 on those values, one more rounding.
+template <int NA, int MT2>
+__device__ __forceinline__ void qkv_rope_epilogue(f32x4_t (&acc)[NA][MT2], bf16_t* __restrict__ qkv, int M, int ldc, int m0, int n0,
+                                                  int wave, int lane, const RopeEpi& rp, unsigned char* smem) {
+  static_assert(NA == 4 && MT2 % 4 == 0, "eight-wave tiling: a wave holds 64 columns");
+  const int wn = wave >> 1, wm = wave & 1, lq = lane & 15, g = lane >> 4;
+  const int H = rp.hidden;
+  const int sec = n0 / H;                                         // 0 q, 1 k, 2 v (uniform over the workgroup)
+  const int fsec = n0 - sec * H;                                  // the tile's first column inside q / k / v
+  if (sec == 2) {
+#pragma unroll
+    for (int j = 0; j < MT2; ++j) {
+      const int row = m0 + wm * (MT2 * 16) + j * 16 + lq;
+      if (row >= M) continue;
+      const RowInfo ri = rp.rows[row];
+      bf16_t* dst = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.vc) + rp.layer_off) + (size_t)ri.slot * H + fsec + wn * 64 + g * 4;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        *reinterpret_cast<uint2*>(dst + i * 16) = make_uint2(f2bf_pk(acc[i][j][0], acc[i][j][1]), f2bf_pk(acc[i][j][2], acc[i][j][3]));
+    }
+    return;
+  }
+  uint2* ex = reinterpret_cast<uint2*>(smem);                     // [wave][j][i][lane]: 8 x MT2 x 4 x 64 x 8 B = 128 / 64 KB, within the ring's own size
+  __syncthreads();                                                // slower waves may still be reading the ring's last stages
+#pragma unroll
+  for (int j = 0; j < MT2; ++j)
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      ex[((wave * MT2 + j) * NA + i) * 64 + lane] = make_uint2(f2bf_pk(acc[i][j][0], acc[i][j][1]), f2bf_pk(acc[i][j][2], acc[i][j][3]));
+  __syncthreads();
+  constexpr int JW = MT2 / 4;                                     // 16-row groups per wave after the re-division
+#pragma unroll
+  for (int jj = 0; jj < JW; ++jj) {
+    const int j = wn * JW + jj;
+    const int row = m0 + wm * (MT2 * 16) + j * 16 + lq;
+    if (row >= M) continue;
+    const RowInfo ri = rp.rows[row];
+    bf16_t* dst = (sec == 0 ? qkv + (size_t)row * ldc
+                            : reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.kc) + rp.layer_off) + (size_t)ri.slot * H) + fsec + g * 4;
+    const float* cp = rp.cos_tab + (size_t)ri.pos * 64 + g * 4;   // pair index inside the head: i * 16 + g * 4 + r
+    const float* sp = rp.sin_tab + (size_t)ri.pos * 64 + g * 4;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const float4 c = *reinterpret_cast<const float4*>(cp + i * 16), s = *reinterpret_cast<const float4*>(sp + i * 16);
+#pragma unroll
+      for (int hd = 0; hd < 2; ++hd) {
+        const uint2 x = ex[((((hd * 2 + 0) * 2 + wm) * MT2 + j) * NA + i) * 64 + lane];      // x[d]      (wave wn = 2 hd)
+        const uint2 y = ex[((((hd * 2 + 1) * 2 + wm) * MT2 + j) * NA + i) * 64 + lane];      // x[d + 64] (wave wn = 2 hd + 1)
+        uint2 o0, o1;
+        o0.x = f2bf_pk(rope_first(bf_lo(x.x), bf_lo(y.x), c.x, s.x), rope_first(bf_hi(x.x), bf_hi(y.x), c.y, s.y));
+        o0.y = f2bf_pk(rope_first(bf_lo(x.y), bf_lo(y.y), c.z, s.z), rope_first(bf_hi(x.y), bf_hi(y.y), c.w, s.w));
+        o1.x = f2bf_pk(rope_second(bf_lo(x.x), bf_lo(y.x), c.x, s.x), rope_second(bf_hi(x.x), bf_hi(y.x), c.y, s.y));
+        o1.y = f2bf_pk(rope_second(bf_lo(x.y), bf_lo(y.y), c.z, s.z), rope_second(bf_hi(x.y), bf_hi(y.y), c.w, s.w));
+        *reinterpret_cast<uint2*>(dst + hd * 128 + i * 16) = o0;
+        *reinterpret_cast<uint2*>(dst + hd * 128 + 64 + i * 16) = o1;
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
 }
@@ -460,7 +526,7 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
                                                            void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
                                                            int tiles_n, int tiles_m, int GM, int n_split = 1,
                                                            float* __restrict__ lse_part = nullptr, const unsigned char* __restrict__ tile_store = nullptr,
-                                                           int pk = 0) {
+                                                           int pk = 0, RopeEpi rope = RopeEpi{}) {
   // pk: X and W (and the SwiGLU output) are in the packed operand layout -- every 1 KB DMA piece is then eight FULL 128-byte lines
   // (two rows x 64 bytes each) instead of sixteen half lines: 83 against 55 GB/s per CU from L2 (tools/probe/dma_depth.hip)
   constexpr int BT = 256, RB = 64, ESZ = FP8 ? 1 : 2;
@@ -692,7 +758,8 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
       reinterpret_cast<float2*>(lse_part)[(size_t)(m0 + tid) * tiles_n + tn] = make_float2(mx, sm);
     }
     if (tile_store == nullptr || tile_store[tn]) big_epilogue<EPI_F32, NA, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g);
-  } else if constexpr (SPLITK) big_epilogue<EPI_F32, NA, MT2>(acc, reinterpret_cast<float*>(Cv) + (size_t)zpart * M * N, M, N, N, m0, n0, wn, wm, lq, g);
+  } else if constexpr (EPI == EPI_QKV_ROPE) qkv_rope_epilogue<NA, MT2>(acc, reinterpret_cast<bf16_t*>(Cv), M, ldc, m0, n0, wave, lane, rope, smem);
+  else if constexpr (SPLITK) big_epilogue<EPI_F32, NA, MT2>(acc, reinterpret_cast<float*>(Cv) + (size_t)zpart * M * N, M, N, N, m0, n0, wn, wm, lq, g);
   else                  big_epilogue<EPI, NA, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g, pk);
 #ifdef ATS_RING_STAMPS
   // tuning build: sw carries the stamp buffer [workgroup][wave][10] = loop cycles in {issue, lgkmcnt wait, vmcnt wait, barrier}, then
@@ -851,13 +918,86 @@ __device__ __forceinline__ void mx_epilogue(f32x16_t (&acc)[TA][TB], void* __res
   }
 }
 
+// EPI_QKV_ROPE on the block-scaled kernel's accumulator layout (eight waves: TA = 2): the same scheme as qkv_rope_epilogue -- v tiles
+// straight to the cache; q / k tiles through the drained ring's LDS as bf16, then re-divided so that a wave rotates both halves of both
+// heads for a quarter of wm's (32-row group, 32-column group) pairs and fetches each (cos, sin) once.
+template <int TA, int TB>
+__device__ __forceinline__ void mx_qkv_rope_epilogue(f32x16_t (&acc)[TA][TB], bf16_t* __restrict__ qkv, int M, int N, int ldc, int m0, int n0, int wave,
+                                                     int lane, const float* __restrict__ sx, const float* __restrict__ sw, const RopeEpi& rp,
+                                                     unsigned char* smem) {
+  static_assert(TA == 2 && TB % 2 == 0, "eight-wave tiling: a wave holds 64 columns");
+  const int wn = wave >> 1, wm = wave & 1, r32 = lane & 31, h = lane >> 5;
+  const int H = rp.hidden;
+  const int sec = n0 / H, fsec = n0 - sec * H;                    // 0 q, 1 k, 2 v; the tile's first column inside it
+  const int m0w = m0 + wm * (TB * 32), n0w = n0 + wn * 64;
+  if (sec == 2) {
+#pragma unroll
+    for (int jt = 0; jt < TB; ++jt) {
+      const int row = m0w + jt * 32 + r32;
+      if (row >= M) continue;
+      const RowInfo ri = rp.rows[row];
+      bf16_t* dst = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.vc) + rp.layer_off) + (size_t)ri.slot * H + fsec + wn * 64 + 4 * h;
+#pragma unroll
+      for (int it = 0; it < TA; ++it) {
+        mx_scale_tile<TA, TB>(acc[it][jt], sx, sw, row, n0w + it * 32, h, M, N);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<uint2*>(dst + it * 32 + 8 * q) = make_uint2(f2bf_pk(acc[it][jt][4 * q], acc[it][jt][4 * q + 1]), f2bf_pk(acc[it][jt][4 * q + 2], acc[it][jt][4 * q + 3]));
+      }
+    }
+    return;
+  }
+  uint2* ex = reinterpret_cast<uint2*>(smem);                     // [wave][jt][it][q][lane]: 8 x TB x 2 x 4 x 64 x 8 B = 128 / 64 KB
+  __syncthreads();                                                // slower waves may still be reading the ring's last stages
+#pragma unroll
+  for (int jt = 0; jt < TB; ++jt) {
+    const int row = m0w + jt * 32 + r32;
+#pragma unroll
+    for (int it = 0; it < TA; ++it) {
+      mx_scale_tile<TA, TB>(acc[it][jt], sx, sw, row, n0w + it * 32, h, M, N);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        ex[(((wave * TB + jt) * TA + it) * 4 + q) * 64 + lane] = make_uint2(f2bf_pk(acc[it][jt][4 * q], acc[it][jt][4 * q + 1]), f2bf_pk(acc[it][jt][4 * q + 2], acc[it][jt][4 * q + 3]));
+    }
+  }
+  __syncthreads();
+  constexpr int PW = TB * TA / 4;                                 // (jt, it) pairs per wave after the re-division
+#pragma unroll
+  for (int pp = 0; pp < PW; ++pp) {
+    const int p = wn * PW + pp, jt = p / TA, it = p % TA;
+    const int row = m0w + jt * 32 + r32;
+    if (row >= M) continue;
+    const RowInfo ri = rp.rows[row];
+    bf16_t* dst = (sec == 0 ? qkv + (size_t)row * ldc
+                            : reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.kc) + rp.layer_off) + (size_t)ri.slot * H) + fsec + it * 32 + 4 * h;
+    const float* cp = rp.cos_tab + (size_t)ri.pos * 64 + it * 32 + 4 * h;   // pair index inside the head: it * 32 + 8 q + 4 h + r
+    const float* sp = rp.sin_tab + (size_t)ri.pos * 64 + it * 32 + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 c = *reinterpret_cast<const float4*>(cp + 8 * q), s = *reinterpret_cast<const float4*>(sp + 8 * q);
+#pragma unroll
+      for (int hd = 0; hd < 2; ++hd) {
+        const uint2 x = ex[(((((hd * 2 + 0) * 2 + wm) * TB + jt) * TA + it) * 4 + q) * 64 + lane];      // x[d]      (wave wn = 2 hd)
+        const uint2 y = ex[(((((hd * 2 + 1) * 2 + wm) * TB + jt) * TA + it) * 4 + q) * 64 + lane];      // x[d + 64] (wave wn = 2 hd + 1)
+        uint2 o0, o1;
+        o0.x = f2bf_pk(rope_first(bf_lo(x.x), bf_lo(y.x), c.x, s.x), rope_first(bf_hi(x.x), bf_hi(y.x), c.y, s.y));
+        o0.y = f2bf_pk(rope_first(bf_lo(x.y), bf_lo(y.y), c.z, s.z), rope_first(bf_hi(x.y), bf_hi(y.y), c.w, s.w));
+        o1.x = f2bf_pk(rope_second(bf_lo(x.x), bf_lo(y.x), c.x, s.x), rope_second(bf_hi(x.x), bf_hi(y.x), c.y, s.y));
+        o1.y = f2bf_pk(rope_second(bf_lo(x.y), bf_lo(y.y), c.z, s.z), rope_second(bf_hi(x.y), bf_hi(y.y), c.w, s.w));
+        *reinterpret_cast<uint2*>(dst + hd * 128 + 8 * q) = o0;
+        *reinterpret_cast<uint2*>(dst + hd * 128 + 64 + 8 * q) = o1;
+      }
+    }
+  }
+}
+
 // NWV = 8: waves 4 (n) x 2 (m), wave tile 64 x MT2*16 (2 x MT2/2 tiles of 32x32), two waves per SIMD.  NWV = 4: waves 2 x 2, wave tile
 // 128 x MT2*16 (4 x MT2/2 tiles), ONE wave per SIMD with up to 512 registers: a third fewer LDS fragment bytes per flop and no two waves
 // contending for a SIMD's matrix pipe and issue slots (selected by ATSPEED_FP8_MX_WAVES, see launch_big_fp8).
 template <int EPI, int MT2, int NWV = 8>
 __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* __restrict__ X, const void* __restrict__ W, const float* __restrict__ sx,
                                                               const float* __restrict__ sw, void* __restrict__ Cv, int M, int N, int K, int ldc,
-                                                              int tiles_n, int tiles_m, int GM, int pk) {
+                                                              int tiles_n, int tiles_m, int GM, int pk, RopeEpi rope = RopeEpi{}) {
   constexpr int BT = 256, RB = 64;                                // 64-byte LDS rows = 64 k of e4m3 per stage
   constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
   constexpr int WP = 16 / NWV, XP = XR / (16 * NWV), NP = WP + XP;   // DMA pieces (16 rows x 64 B) per wave per k-step
@@ -988,12 +1128,16 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* _
 #undef ATS_CAT8
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // 16-pass MFMA results -> VALU reads (the compiler cannot see the asm MFMAs)
 
-  const int m0w = m0 + wm * (TB * 32), n0w = n0 + wn * (TA * 32);
-  mx_epilogue<EPI, TA, TB>(acc, Cv, M, N, ldc, m0w, n0w, lane, sx, sw, pk);
+  if constexpr (EPI == EPI_QKV_ROPE) {
+    mx_qkv_rope_epilogue<TA, TB>(acc, reinterpret_cast<bf16_t*>(Cv), M, N, ldc, m0, n0, wave, lane, sx, sw, rope, smem);
+  } else {
+    const int m0w = m0 + wm * (TB * 32), n0w = n0 + wn * (TA * 32);
+    mx_epilogue<EPI, TA, TB>(acc, Cv, M, N, ldc, m0w, n0w, lane, sx, sw, pk);
+  }
 }
 
 template <int EPI>
-int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st, int pk) {
+int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st, int pk, const RopeEpi& rope = RopeEpi{}) {
   static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
   static const int force_mt = env_int("ATSPEED_GEMM_FORCE_MT", 0);     // tuning: 8 / 4 = always 256- / 128-row token tiles
   const int tiles_n = (n + 255) / 256;
@@ -1014,7 +1158,7 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
   const float* stamps = nullptr;
 #endif
   static const int four_waves = env_int("ATSPEED_GEMM_4WAVE", 0);
-  if (use256 && four_waves) {
+  if constexpr (EPI != EPI_QKV_ROPE) if (use256 && four_waves) {
     static thread_local AtsPerDeviceFlag a4_flag;
     bool& a4 = a4_flag.cur();
     if (!a4) { ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); a4 = true; }
@@ -1022,8 +1166,8 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
     ATS_LAUNCH_CHECK();
     return ATSPEED_OK;
   }
-  if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, none, stamps, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk);
-  else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk);
+  if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, none, stamps, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk, rope);
+  else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk, rope);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -1135,7 +1279,7 @@ __global__ __launch_bounds__(1024) void splitk_resid_rmsnorm_kernel(const float*
 
 template <int EPI>
 int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char* w, const float* sw, void* c, int m, int n, int k,
-                   int ldc, hipStream_t st, int pk) {
+                   int ldc, hipStream_t st, int pk, const RopeEpi& rope = RopeEpi{}) {
   static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
   const int tiles_n = (n + 255) / 256;
   static thread_local AtsPerDeviceFlag attr_flag;
@@ -1153,24 +1297,29 @@ int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char*
     bool& mx_done = mx_flag.cur();
     if (!mx_done) {
       ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_mx_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_mx_kernel<EPI, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      if constexpr (EPI != EPI_QKV_ROPE) ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_mx_kernel<EPI, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
       ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_mx_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       mx_done = true;
     }
     static const int mx_waves = env_int("ATSPEED_FP8_MX_WAVES", 8);      // 4: one wave per SIMD, 128 x 128 per wave (256-row token tiles only)
-    if (big_use_256_rows(t256, t128) && mx_waves == 4)
-      hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 8, 4>), dim3(t256), dim3(256), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 255) / 256, gm, pk);
+    bool launched = false;
+    if constexpr (EPI != EPI_QKV_ROPE)                              // the fused RoPE epilogue exists for the eight-wave tiling only
+      if (big_use_256_rows(t256, t128) && mx_waves == 4) {
+        hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 8, 4>), dim3(t256), dim3(256), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 255) / 256, gm, pk);
+        launched = true;
+      }
+    if (launched) {}
     else if (big_use_256_rows(t256, t128))
-      hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 255) / 256, gm, pk);
+      hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 255) / 256, gm, pk, rope);
     else
-      hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 127) / 128, gm, pk);
+      hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 127) / 128, gm, pk, rope);
     ATS_LAUNCH_CHECK();
     return ATSPEED_OK;
   }
   if (big_use_256_rows(t256, t128))
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, true>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 255) / 256, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, true>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 255) / 256, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk, rope);
   else
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, true>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 127) / 128, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, true>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, k, ldc, tiles_n, (m + 127) / 128, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk, rope);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -1397,6 +1546,19 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
   return ATSPEED_ERR_INVALID;
 }
 
+bool ats_gemm_qkv_rope_applies(int m, int hidden, int head_dim, int dtype) {
+  const char* e = getenv("ATSPEED_FUSE_QKV_ROPE");                 // read per forward: tests compare both paths in one process
+  return !(e && atoi(e) == 0) && dtype == ATSPEED_BF16 && head_dim == 128 && hidden % 256 == 0 && big_kernel_applies(m, 3 * hidden, hidden, hidden, 3 * hidden, dtype, EPI_STORE);
+}
+
+int ats_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, int m, int hidden, const RopeEpi& rope, hipStream_t st, int pk) {
+  ATS_REQUIRE(x && wqkv && qkv && rope.rows && rope.cos_tab && rope.sin_tab && rope.hidden == hidden, ATSPEED_ERR_INVALID, "gemm_qkv_rope: null / inconsistent argument");
+  ATS_REQUIRE(hidden % 256 == 0 && big_kernel_applies(m, 3 * hidden, hidden, hidden, 3 * hidden, ATSPEED_BF16, EPI_STORE), ATSPEED_ERR_INVALID,
+              "gemm_qkv_rope: shape %d x %d is not the batched kernel's", m, hidden);
+  ATS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wqkv & 15) == 0 && ((uintptr_t)qkv & 7) == 0, ATSPEED_ERR_INVALID, "gemm_qkv_rope: operands must be 16-byte aligned");
+  return launch_big<EPI_QKV_ROPE>((const bf16_t*)x, (const bf16_t*)wqkv, qkv, m, 3 * hidden, hidden, hidden, 3 * hidden, st, pk, rope);
+}
+
 size_t ats_lmhead_lse_part_bytes(int m, int n) { return (size_t)m * ((n + 255) / 256) * 2 * sizeof(float); }
 
 // logits = a * w^T (fp32) and lse[row] = log sum exp over ALL n columns of the row.  On the batched path (bf16, ring kernel) the
@@ -1471,6 +1633,21 @@ int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* s
   }
   atspeed_set_error("gemm_fp8: unknown epilogue %d", epilogue);
   return ATSPEED_ERR_INVALID;
+}
+
+// the fp8 qkv projection with RoPE + the KV scatter in its epilogue (see ats_gemm_qkv_rope); the caller checks ats_gemm_fp8_applies,
+// head_dim == 128 and hidden % 256 == 0 (ats_gemm_fp8_qkv_rope_applies)
+bool ats_gemm_fp8_qkv_rope_applies(int m, int hidden, int head_dim) {
+  const char* e = getenv("ATSPEED_FUSE_QKV_ROPE");
+  return !(e && atoi(e) == 0) && head_dim == 128 && hidden % 256 == 0 && ats_gemm_fp8_applies(m, 3 * hidden, hidden, 3 * hidden, EPI_STORE);
+}
+
+int ats_gemm_fp8_qkv_rope(const void* xq, const float* sx, const void* wq, const float* sw, void* qkv, int m, int hidden, const RopeEpi& rope,
+                          hipStream_t st, int pk) {
+  ATS_REQUIRE(xq && sx && wq && sw && qkv && rope.rows && rope.cos_tab && rope.sin_tab && rope.hidden == hidden, ATSPEED_ERR_INVALID,
+              "gemm_fp8_qkv_rope: null / inconsistent argument");
+  ATS_REQUIRE(m >= 1 && hidden % 256 == 0, ATSPEED_ERR_INVALID, "gemm_fp8_qkv_rope: hidden=%d must be a multiple of 256", hidden);
+  return launch_big_fp8<EPI_QKV_ROPE>((const unsigned char*)xq, sx, (const unsigned char*)wq, sw, qkv, m, 3 * hidden, hidden, 3 * hidden, st, pk, rope);
 }
 
 extern "C" int atspeed_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int32_t m, int32_t n,

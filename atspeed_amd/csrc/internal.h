@@ -22,6 +22,9 @@ struct SegTable {
   Seg seg[ATS_MAX_SEGS];
   unsigned char qtile_seg[ATS_MAX_QTILES], qtile_idx[ATS_MAX_QTILES];
 };
+// per batched row, resolved once per forward (ats_row_info): where the row's K / V go and which rotation it takes
+struct RowInfo { void* kc; void* vc; int pos; int slot; };        // caches' layer-0 bases of the row's user; pos clamped to the RoPE table
+struct RopeEpi { const RowInfo* rows = nullptr; const float* cos_tab = nullptr; const float* sin_tab = nullptr; size_t layer_off = 0; int hidden = 0; };
 // copy a host object to device memory, stream ordered (pinned staging ring); returns the device address
 int ats_stage(const void* host_obj, size_t bytes, const void** dev_out, hipStream_t st);
 int ats_stage_to(const void* host_obj, size_t bytes, void* dev_dst, hipStream_t st);   // same, to a fixed device address
@@ -35,6 +38,7 @@ int ats_rope_kv_segs_slabs(const float* qkv_slabs, int splits, void* qkv, const 
                            const float* sin_tab, size_t layer_off_bytes, int n_heads, int head_dim, int max_pos, hipStream_t st);
 int ats_rope_kv_segs(void* qkv, const SegTable& t, const SegTable* dt, const float* cos_tab, const float* sin_tab, size_t layer_off_bytes,
                      int n_heads, int head_dim, int max_pos, int dtype, hipStream_t st);
+int ats_row_info(const SegTable& t, const SegTable* dt, RowInfo* out, int max_pos, hipStream_t st);
 int ats_gather_logit_rows(const void* h, const SegTable& t, const SegTable* dt, void* out, int hidden, int dtype, hipStream_t st);
 int ats_embed(const void* table, const int32_t* ids, void* out, int n_tokens, int hidden, int vocab, int dtype,
               hipStream_t st);
@@ -47,7 +51,8 @@ int ats_rope_kv(void* qkv, const int32_t* pos, const int32_t* slots, const float
                 hipStream_t st);
 
 // ---- gemm.hip -------------------------------------------------------------------------
-enum { EPI_STORE = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_SWIGLU = 3, EPI_F32_LSE = 4 /* ring kernel only: fp32 store + per-tile (max, sum exp) */ };
+enum { EPI_STORE = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_SWIGLU = 3, EPI_F32_LSE = 4 /* ring kernel only: fp32 store + per-tile (max, sum exp) */,
+       EPI_QKV_ROPE = 5 /* ring kernel only: qkv projection with RoPE + KV-cache scatter in the epilogue (ats_gemm_qkv_rope) */ };
 size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype);
 // pk = 1: a and w (and a SwiGLU output) are in the packed operand layout of common.h (bf16 / fp8 engine); 0: row-major (HF layout, fp32 mode, ABI tests)
 int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int dtype, int epilogue,
@@ -55,6 +60,14 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
 
 int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int k, int lda, int ldh, int dtype,
                         const void* norm_w, void* xn, float eps, void* workspace, size_t workspace_bytes, hipStream_t st, int pk = 0);
+// The batched qkv projection with the rotation and the cache scatter in its epilogue: qkv[m][3*hidden] receives only the rotated q,
+// rotated k and v go straight to the caches (bit-identical to ats_gemm + ats_rope_kv_segs: both round the projection to bf16 first).
+// Applies to bf16, head_dim 128, hidden % 256 == 0 at shapes the ring kernel takes; the caller asks first.
+bool ats_gemm_qkv_rope_applies(int m, int hidden, int head_dim, int dtype);
+int ats_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, int m, int hidden, const RopeEpi& rope, hipStream_t st, int pk = 0);
+bool ats_gemm_fp8_qkv_rope_applies(int m, int hidden, int head_dim);
+int ats_gemm_fp8_qkv_rope(const void* xq, const float* sx, const void* wq, const float* sw, void* qkv, int m, int hidden, const RopeEpi& rope,
+                          hipStream_t st, int pk = 0);
 
 // fp8 (e4m3, per-row scales) variants of the batched projections; returns ATSPEED_ERR_INVALID if the shape does not
 // qualify (ats_gemm_fp8_applies)

@@ -209,6 +209,10 @@ class HipLlama:
         _lib.check(_lib.load().atspeed_llama_fp8_counters(self._handle, f8, other, 1 if reset else 0))
         return {k: dict(fp8=int(f8[i]), other=int(other[i])) for i, k in enumerate(self.GEMM_KINDS[:4])}
 
+    def rope_fused_launches(self, reset: bool = False) -> int:
+        """qkv projections that carried RoPE + the KV scatter in their epilogue since the last reset (atspeed_llama_rope_fused_launches)."""
+        return int(_lib.load().atspeed_llama_rope_fused_launches(self._handle, 1 if reset else 0))
+
     # ---- measurement hooks --------------------------------------------------------------
     GEMM_KINDS = ("qkv", "o_proj", "gate_up", "down", "lm_head")
 

@@ -162,6 +162,11 @@ int atspeed_llama_enable_fp8(atspeed_llama* m, void* stream);
  * (fp8_out[4]) and how many as a bf16 / fp32 GEMM (other_out[4]) since the last reset: lets a test or a bench state that config 5
  * really ran its projections in fp8 rather than fell back by shape.  Either output may be NULL.  No reference counterpart. */
 int atspeed_llama_fp8_counters(atspeed_llama* m, int64_t* fp8_out, int64_t* other_out, int32_t reset);
+/* how many qkv projections (one per layer per forward) ran with the rotary embedding and the KV-cache scatter in the GEMM's epilogue
+ * (batched bf16 forwards, head_dim 128, hidden % 256 == 0: the reference's apply_rotary_pos_emb + cache update, modeling_llama.py as
+ * called from beamSD.py:120, without re-reading the projection) rather than as the separate pass, since the last reset; -1 on a NULL
+ * model.  ATSPEED_FUSE_QKV_ROPE=0 in the environment (read at each forward) selects the separate pass: results are bit-identical. */
+int64_t atspeed_llama_rope_fused_launches(atspeed_llama* m, int32_t reset);
 
 /* lm_head fused with the full-vocabulary normaliser of beamSD.py:58,285 (log_softmax over ALL columns, before masking): bf16
  * x [rows, hidden] times w [vocab, hidden]^T -> fp32 logits (row stride ld) and lse[row] = log sum_v exp(logits[row][v]).  On the

@@ -14,7 +14,7 @@ import atspeed_amd
 from atspeed_amd import synth
 from atspeed_amd.beamSD import BSSD, BSSD_batch, _Decoder, last_trace, release_decoders, target_generate
 from atspeed_amd.generation_trie import SuffixTrieConstraint, Trie, prefix_allowed_tokens_fn
-from atspeed_amd.model import HipLlama
+from atspeed_amd.model import HipLlama, vis_bits_from_bool
 from oracle import beamsd_ref as R
 from oracle.llama_ref import RefLlama
 from oracle.trie_ref import RefTrie, ref_whole_sentence_fn
@@ -222,3 +222,56 @@ def test_bf16_engine_without_packed_operands_equals_packed_one():
     for x, y in zip(a[1], b[1]):
         assert torch.equal(x["beam_sequence"], y["beam_sequence"]) and torch.equal(x["beam_scores"], y["beam_scores"])
         assert x["accept_steps"] == y["accept_steps"]
+
+
+@pytest.mark.parametrize("n_seq,fp8", [(24, False), (56, False), (24, True), (56, True)])
+def test_rope_and_kv_scatter_in_the_qkv_epilogue_equal_the_separate_pass(n_seq, fp8):
+    """Batched bf16 forwards at head_dim 128 rotate q / k and scatter k / v to the caches inside the qkv projection's epilogue
+    (gemm.hip: EPI_QKV_ROPE).  Same roundings as the projection + the separate RoPE pass, so logits are BIT-identical to the engine with
+    ATSPEED_FUSE_QKV_ROPE=0 -- for a prefill (ragged lengths, a hidden slot) and for a second forward that attends to the cached K / V of
+    the first (which checks what the epilogue wrote to the caches); 24 / 56 sequences: the 128- and the 256-row token tiles; fp8: the
+    block-scaled kernel's epilogue (its own accumulator layout)."""
+    import os
+    V = 32000 + 256
+    dims = synth.LlamaDims(V, 1024, 2, 8, 2816)
+    m = HipLlama.from_synthetic(dims, 91, dtype=torch.bfloat16, max_slots=256, max_tokens=256, max_logit_rows=256)
+    if fp8:
+        m.enable_fp8()
+    g = torch.Generator().manual_seed(11)
+    first, second = [], []
+    for i in range(n_seq):
+        T = 100 if i < 2 else int(torch.randint(61, 100, (1,), generator=g))
+        ids = torch.randint(3, V, (T,), generator=g).to(torch.int32)
+        vis = torch.tril(torch.ones(T, T, dtype=torch.bool))
+        vis[8:, 3] = False
+        ar = torch.arange(T, dtype=torch.int32)
+        first.append((ids, ar, ar.clone(), vis_bits_from_bool(vis, 256), T, 3))
+        B = 70 + i % 7                                            # second forward: B new tokens after the T cached ones, tree-masked
+        ids2 = torch.randint(3, V, (B,), generator=g).to(torch.int32)
+        vis2 = torch.zeros(B, T + B, dtype=torch.bool)
+        vis2[:, :T] = True
+        vis2[:, 3] = False
+        vis2[:, T:] = torch.tril(torch.ones(B, B, dtype=torch.bool))
+        vis2[5:, T + 2] = False
+        second.append((ids2, torch.arange(T, T + B, dtype=torch.int32), torch.arange(T, T + B, dtype=torch.int32), vis_bits_from_bool(vis2, 256), T + B, 5))
+    res = {}
+    old = os.environ.get("ATSPEED_FUSE_QKV_ROPE")
+    try:
+        for mode in ("1", "0"):
+            os.environ["ATSPEED_FUSE_QKV_ROPE"] = mode
+            m.rope_fused_launches(reset=True)
+            m.fp8_counters(reset=True)
+            a = [o.clone() for o in m.forward_raw_batch(first)]
+            b = [o.clone() for o in m.forward_raw_batch(second)]
+            torch.cuda.synchronize()
+            res[mode] = (a, b, m.rope_fused_launches())
+            assert m.fp8_counters()["qkv"] == (dict(fp8=2 * dims.n_layers, other=0) if fp8 else dict(fp8=0, other=2 * dims.n_layers))
+    finally:
+        if old is None:
+            os.environ.pop("ATSPEED_FUSE_QKV_ROPE", None)
+        else:
+            os.environ["ATSPEED_FUSE_QKV_ROPE"] = old
+    assert res["1"][2] == 2 * dims.n_layers and res["0"][2] == 0, (res["1"][2], res["0"][2])
+    for k in (0, 1):
+        for x, y in zip(res["1"][k], res["0"][k]):
+            assert bool(torch.isfinite(x).all()) and torch.equal(x, y), f"forward {k}: max |diff| {float((x - y).abs().max()):.3e} of max |logit| {float(y.abs().max()):.3f}"
