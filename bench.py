@@ -431,7 +431,8 @@ def main():
     else:
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         bound, peak, unit = "hbm", HBM_PEAK_GBS, "GB/s"
-    epi = {"qkv": 0, "o_proj": 2, "gate_up": 3, "down": 2, "lm_head": 1}[kind]
+    # qkv: 5 = RoPE + KV scatter in the epilogue (head_dim 128 targets), as the engine's counter says
+    epi = {"qkv": 5 if target.rope_fused_launches() > 0 else 0, "o_proj": 2, "gate_up": 3, "down": 2, "lm_head": 1}[kind]
     ring = (f"gemm_ring_mx_kernel<{epi}, 8>" if (args.target_fp8 and kind != "lm_head" and os.environ.get("ATSPEED_FP8_MX", "1") != "0")
             else f"gemm_ring_kernel<{4 if kind == 'lm_head' else epi}, 8, {'true' if (args.target_fp8 and kind != 'lm_head') else 'false'}, false, 4>")
     kname = (f"{ring} [{kind}] N={N} K={K} avg_M={avg_m:.0f} (launches of >= 1024 tokens)"

@@ -8,7 +8,7 @@ import collections, csv, glob, json, os, sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_traffic.json"
-KINDS = {"gate_up": "gemm_ring_kernel<3, 8, false, false", "qkv": "gemm_ring_kernel<0, 8, false, false", "o_proj+down": "gemm_ring_kernel<2, 8, false, false", "lm_head+lse": "gemm_ring_kernel<4, 8, false, false",
+KINDS = {"gate_up": "gemm_ring_kernel<3, 8, false, false", "qkv": "gemm_ring_kernel<0, 8, false, false", "qkv+rope": "gemm_ring_kernel<5, 8, false, false", "o_proj+down": "gemm_ring_kernel<2, 8, false, false", "lm_head+lse": "gemm_ring_kernel<4, 8, false, false",
          "lm_head": "gemm_ring_kernel<1, 8, false, false", "gate_up_128": "gemm_ring_kernel<3, 4, false, false", "attention": "tree_attn32_kernel<128, 4>",
          "lse": "lse_rows_kernel"}
 
