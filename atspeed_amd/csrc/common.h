@@ -102,6 +102,14 @@ __device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
 }
 __device__ __forceinline__ float bf_lo(uint32_t pk) { return __uint_as_float(pk << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t pk) { return __uint_as_float(pk & 0xffff0000u); }
+// SiLU.  bf16 engine (EXACT = false): the quotient through the hardware reciprocal (v_rcp_f32, 1 ulp of fp32 -- far below the bf16 rounding that
+// follows); the correctly rounded fp32 division is a ten-instruction sequence and made the ring GEMM's SwiGLU epilogue VALU-bound (64 outputs per
+// thread).  fp32 engine (parity mode): the exact quotient.
+template <bool EXACT> __device__ __forceinline__ float ats_silu(float g) {
+  const float d = 1.f + __expf(-g);
+  if constexpr (EXACT) return g / d;
+  else return g * __builtin_amdgcn_rcpf(d);
+}
 // The rotary pair (x0, x1) = (x[d], x[d + head_dim/2]) of the bf16 engine, with the contraction spelled out: the separate RoPE pass, the
 // slab-summing one and the qkv GEMM's fused epilogue must round identically (the compiler is otherwise free to pick which product it fuses).
 __device__ __forceinline__ float rope_first(float x0, float x1, float c, float s) { return __fmaf_rn(x0, c, -__fmul_rn(x1, s)); }    // x0 cos - x1 sin

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const T* __restrict__ A,
           if (gm < M && gn < N) {
             float g = acc[i][j][r], u = acc[i][j + 1][r];
             if constexpr (sizeof(T) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
-            float s = g / (1.f + __expf(-g));
+            float s = ats_silu<sizeof(T) == 4>(g);
             Elt<T>::store(C + ats_opnd_idx<sizeof(T)>(pk, gm, (gn >> 1) + ccol, ldc), s * u);
           }
         }
@@ -289,7 +289,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, void* __
     for (int j = 0; j < V; ++j) {
       float gj = g[j], uj = u[j];
       if constexpr (sizeof(T) == 2) { gj = bf2f(f2bf(gj)); uj = bf2f(f2bf(uj)); }
-      float sj = gj / (1.f + __expf(-gj));
+      float sj = ats_silu<sizeof(T) == 4>(gj);
       Elt<T>::store(out + j, sj * uj);
     }
   } else {
@@ -315,96 +315,138 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, void* __
 }
 
 
-// Epilogue of the 256-wide kernels: wave (wn, wm) holds NA x MT2 accumulator tiles, n = n0 + wn*NA*16 + i*16 + g*4 + r,
-// m = m0 + wm*MT2*16 + j*16 + lq.
+// Order of the weight rows inside each 64-row quarter of the ring kernel's LDS image: which weight row the DMA puts at LDS row rho.
+// The MFMA leaves lane (lq, g) with FOUR consecutive positions p = g*4 + r of every 16-row tile i.  In weight order those are 4 output
+// columns per tile: eight-byte stores, each instruction touching 16 token rows x 32 bytes.  Since the DMA's per-lane source address is
+// free, the quarter's rows are laid into LDS in an order that makes a lane's positions of tiles i = 0..3 ADJACENT output columns:
+//   ROWS_LANE16  (store / residual / qkv+RoPE): LDS row i*16 + p holds weight row (p>>2)*16 + i*4 + (p&3): lane (., g) owns columns
+//                g*16 .. g*16+15 of the quarter -- two 16-byte stores per token row, a full 128-byte line per (row, wave);
+//   ROWS_SWIGLU8 (gate_up, weights interleaved in 16-row gate / up groups): tiles (0, 1) and (2, 3) are (gate, up) of outputs
+//                g*8 + r and g*8 + 4 + r: one 16-byte store per token row.
+// No cost in the main loop (fragment reads and swizzle see LDS rows only; rows still come in groups of four, so the packed layout's
+// full 128-byte lines per DMA piece are kept).  Timing-only forms of the store pattern on the Llama-7B projections at 26 k tokens
+// (profiles/README.md): no stores at all +9-12 % (qkv, gate_up; down +4 %), the same bytes fully coalesced +4 %, this form +2.4-2.8 %.
+enum { ROWS_IDENTITY = 0, ROWS_LANE16 = 1, ROWS_SWIGLU8 = 2 };
+template <int EPI> constexpr int ring_row_order() {
+  return (EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_QKV_ROPE) ? ROWS_LANE16 : EPI == EPI_SWIGLU ? ROWS_SWIGLU8 : ROWS_IDENTITY;
+}
+template <int ORD> __device__ __forceinline__ int ring_src_row(int rho) {        // LDS row -> weight row, both 0..63 inside the quarter
+  const int i = rho >> 4, p = rho & 15;
+  if constexpr (ORD == ROWS_LANE16) return (p >> 2) * 16 + i * 4 + (p & 3);
+  if constexpr (ORD == ROWS_SWIGLU8) { const int o = (p >> 2) * 8 + (i >> 1) * 4 + (p & 3); return (o >> 4) * 32 + (i & 1) * 16 + (o & 15); }
+  return rho;
+}
+
+// Epilogue of the 256-wide kernels: wave (wn, wm) holds NA x MT2 accumulator tiles; token row m = m0 + wm*MT2*16 + j*16 + lq; the
+// weight row of acc[i][j][r] is n0 + wn*NA*16 + (i>>2)*64 + ring_src_row<order of EPI>((i&3)*16 + g*4 + r).
 template <int EPI, int NA, int MT2>
 __device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[NA][MT2], void* __restrict__ Cv, int M, int N, int ldc, int m0, int n0,
                                              int wn, int wm, int lq, int g, int pk = 0) {
-  const bool vec = (ldc & 3) == 0;
-  if constexpr (EPI == EPI_RESID) {
-    // read-modify-write of h: the loads of a row group must not wait behind the previous group's stores (same pointer: the compiler
-    // keeps them in order, one memory round trip per 8 bytes -- 30 k cycles per tile), so all of a wave's residuals are fetched first
-    if (vec && n0 + wn * (NA * 16) + NA * 16 <= N) {              // whole 64-column span inside N (else the element-wise path below)
-      bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
-      uint2 rs[NA][MT2];
+  const int nw = n0 + wn * (NA * 16);                             // the wave's first weight row
+  if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
+    if ((ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(Cv) & 15) == 0 && nw + NA * 16 <= N) {
+      // lane (., g) owns columns nw + q*64 + g*16 + [0, 16): tiles 4q + (0, 1) are the first eight, 4q + (2, 3) the second eight
+      auto pack8 = [&](int i0, int j) {
+        return make_uint4(f2bf_pk(acc[i0][j][0], acc[i0][j][1]), f2bf_pk(acc[i0][j][2], acc[i0][j][3]),
+                          f2bf_pk(acc[i0 + 1][j][0], acc[i0 + 1][j][1]), f2bf_pk(acc[i0 + 1][j][2], acc[i0 + 1][j][3]));
+      };
+      auto col8 = [&](int i0) { return nw + (i0 >> 2) * 64 + g * 16 + ((i0 & 3) >> 1) * 8; };
+      if constexpr (EPI == EPI_RESID) {
+        // read-modify-write of h: the loads of a row group must not wait behind the previous group's stores (same pointer: the compiler
+        // keeps them in order, one memory round trip per store), so all residuals of a 64-column quarter are fetched first
 #pragma unroll
-      for (int j = 0; j < MT2; ++j) {
-        const int gm = min(m0 + wm * (MT2 * 16) + j * 16 + lq, M - 1);
+        for (int q = 0; q < NA / 4; ++q) {                          // (NA = 8: 64 residual registers at a time, not 128)
+          uint4 rs[2][MT2];
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
-          rs[i][j] = *reinterpret_cast<const uint2*>(Cb + (size_t)gm * ldc + n0 + wn * (NA * 16) + i * 16 + g * 4);
-      }
+          for (int j = 0; j < MT2; ++j) {
+            const int gm = min(m0 + wm * (MT2 * 16) + j * 16 + lq, M - 1);
 #pragma unroll
-      for (int j = 0; j < MT2; ++j) {
-        const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
-        if (gm >= M) continue;
+            for (int h = 0; h < 2; ++h) rs[h][j] = *reinterpret_cast<const uint4*>(Cb + (size_t)gm * ldc + col8(4 * q + 2 * h));
+          }
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-          const uint32_t p0 = f2bf_pk(acc[i][j][0], acc[i][j][1]), p1 = f2bf_pk(acc[i][j][2], acc[i][j][3]);
-          uint2 o;
-          o.x = f2bf_pk(bf_lo(rs[i][j].x) + bf_lo(p0), bf_hi(rs[i][j].x) + bf_hi(p0));
-          o.y = f2bf_pk(bf_lo(rs[i][j].y) + bf_lo(p1), bf_hi(rs[i][j].y) + bf_hi(p1));
-          *reinterpret_cast<uint2*>(Cb + (size_t)gm * ldc + n0 + wn * (NA * 16) + i * 16 + g * 4) = o;
+          for (int j = 0; j < MT2; ++j) {
+            const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
+            if (gm >= M) continue;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint4 p = pack8(4 * q + 2 * h, j), r = rs[h][j];
+              uint4 o;
+              o.x = f2bf_pk(bf_lo(r.x) + bf_lo(p.x), bf_hi(r.x) + bf_hi(p.x));
+              o.y = f2bf_pk(bf_lo(r.y) + bf_lo(p.y), bf_hi(r.y) + bf_hi(p.y));
+              o.z = f2bf_pk(bf_lo(r.z) + bf_lo(p.z), bf_hi(r.z) + bf_hi(p.z));
+              o.w = f2bf_pk(bf_lo(r.w) + bf_lo(p.w), bf_hi(r.w) + bf_hi(p.w));
+              *reinterpret_cast<uint4*>(Cb + (size_t)gm * ldc + col8(4 * q + 2 * h)) = o;
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < MT2; ++j) {
+          const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
+          if (gm >= M) continue;
+#pragma unroll
+          for (int h = 0; h < NA / 2; ++h) *reinterpret_cast<uint4*>(Cb + (size_t)gm * ldc + col8(2 * h)) = pack8(2 * h, j);
         }
       }
       return;
     }
-  }
+    // tiles that straddle N, odd strides: element by element
 #pragma unroll
-  for (int j = 0; j < MT2; ++j) {
-    const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
-    if (gm >= M) continue;
-    if constexpr (EPI == EPI_SWIGLU) {
-      bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
+    for (int j = 0; j < MT2; ++j) {
+      const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
+      if (gm >= M) continue;
 #pragma unroll
-      for (int i = 0; i < NA; i += 2) {
-        const int gn = n0 + wn * (NA * 16) + i * 16;
-        if (gn >= N) continue;
-        // gate and up rounded to bf16 first (the reference's two projections are bf16 tensors), packed conversions throughout
-        uint2 o;
+      for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-          const uint32_t gp = f2bf_pk(acc[i][j][r], acc[i][j][r + 1]), upk = f2bf_pk(acc[i + 1][j][r], acc[i + 1][j][r + 1]);
-          const float g0 = bf_lo(gp), g1 = bf_hi(gp);
-          const uint32_t res = f2bf_pk(g0 / (1.f + __expf(-g0)) * bf_lo(upk), g1 / (1.f + __expf(-g1)) * bf_hi(upk));
-          if (r == 0) o.x = res; else o.y = res;
+        for (int r = 0; r < 4; ++r) {
+          const int gn = nw + (i >> 2) * 64 + g * 16 + (i & 3) * 4 + r;
+          if (gn >= N) continue;
+          bf16_t* C = Cb + (size_t)gm * ldc + gn;
+          float v = acc[i][j][r];
+          if constexpr (EPI == EPI_RESID) v = bf2f(*C) + bf2f(f2bf(v));
+          *C = f2bf(v);
         }
-        *reinterpret_cast<uint2*>(C + ats_opnd_idx<2>(pk, gm, (gn >> 1) + g * 4, ldc)) = o;      // the down projection's operand: packed when pk
+    }
+  } else if constexpr (EPI == EPI_SWIGLU) {
+    // lane (., g) owns outputs q*32 + g*8 + [0, 8) of the wave's NA*8: gate in tiles 4q and 4q+2, up in 4q+1 and 4q+3.  gate and up are rounded to
+    // bf16 first (the reference's two projections are bf16 tensors), packed conversions throughout
+    bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
+    const bool vec16 = (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(Cv) & 15) == 0;
+    auto silu_mul = [&](int ig, int j, int r) {
+      const uint32_t gp = f2bf_pk(acc[ig][j][r], acc[ig][j][r + 1]), upk = f2bf_pk(acc[ig + 1][j][r], acc[ig + 1][j][r + 1]);
+      return f2bf_pk(ats_silu<false>(bf_lo(gp)) * bf_lo(upk), ats_silu<false>(bf_hi(gp)) * bf_hi(upk));
+    };
+#pragma unroll
+    for (int j = 0; j < MT2; ++j) {
+      const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
+      if (gm >= M) continue;
+#pragma unroll
+      for (int q = 0; q < NA / 4; ++q) {
+        if (nw + q * 64 + (g >> 1) * 32 >= N) continue;            // N % 32 == 0: a (gate, up) group of 16 outputs is inside N or not at all
+        const int oc = (nw >> 1) + q * 32 + g * 8;
+        const uint4 o = make_uint4(silu_mul(4 * q, j, 0), silu_mul(4 * q, j, 2), silu_mul(4 * q + 2, j, 0), silu_mul(4 * q + 2, j, 2));
+        bf16_t* dst = C + ats_opnd_idx<2>(pk, gm, oc, ldc);        // the down projection's operand: packed when pk (8 outputs stay inside a 64-byte block)
+        if (vec16) *reinterpret_cast<uint4*>(dst) = o;
+        else { *reinterpret_cast<uint2*>(dst) = make_uint2(o.x, o.y); *reinterpret_cast<uint2*>(dst + 4) = make_uint2(o.z, o.w); }
       }
-    } else {
+    }
+  } else {
+    static_assert(EPI == EPI_F32, "fp32 store");
+    const bool vec = (ldc & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < MT2; ++j) {
+      const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
+      if (gm >= M) continue;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const int gn = n0 + wn * (NA * 16) + i * 16 + g * 4;
+        const int gn = nw + i * 16 + g * 4;
         if (gn >= N) continue;
-        if constexpr (EPI == EPI_F32) {
-          float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
-          if (gn + 3 < N && vec) *reinterpret_cast<float4*>(C) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-          else
+        float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
+        if (gn + 3 < N && vec) *reinterpret_cast<float4*>(C) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        else
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[i][j][r];
-        } else {
-          bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
-          if (gn + 3 < N && vec) {
-            uint2 o;
-            const uint32_t p0 = f2bf_pk(acc[i][j][0], acc[i][j][1]), p1 = f2bf_pk(acc[i][j][2], acc[i][j][3]);
-            if constexpr (EPI == EPI_RESID) {
-              const uint2 rs = *reinterpret_cast<const uint2*>(C);
-              o.x = f2bf_pk(bf_lo(rs.x) + bf_lo(p0), bf_hi(rs.x) + bf_hi(p0));
-              o.y = f2bf_pk(bf_lo(rs.y) + bf_lo(p1), bf_hi(rs.y) + bf_hi(p1));
-            } else {
-              o.x = p0; o.y = p1;
-            }
-            *reinterpret_cast<uint2*>(C) = o;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (gn + r < N) {
-                float v = acc[i][j][r];
-                if constexpr (EPI == EPI_RESID) v = bf2f(C[r]) + bf2f(f2bf(v));
-                C[r] = f2bf(v);
-              }
-          }
-        }
+          for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[i][j][r];
       }
     }
   }
@@ -421,20 +463,24 @@ template <int NA, int MT2>
 __device__ __forceinline__ void qkv_rope_epilogue(f32x4_t (&acc)[NA][MT2], bf16_t* __restrict__ qkv, int M, int ldc, int m0, int n0,
                                                   int wave, int lane, const RopeEpi& rp, unsigned char* smem) {
   static_assert(NA == 4 && MT2 % 4 == 0, "eight-wave tiling: a wave holds 64 columns");
+  // weight rows in ROWS_LANE16 order: lane (lq, g) holds columns wn*64 + g*16 + i*4 + r of the tile, i.e. 16 adjacent columns
   const int wn = wave >> 1, wm = wave & 1, lq = lane & 15, g = lane >> 4;
   const int H = rp.hidden;
   const int sec = n0 / H;                                         // 0 q, 1 k, 2 v (uniform over the workgroup)
   const int fsec = n0 - sec * H;                                  // the tile's first column inside q / k / v
+  auto pack4 = [&](int i, int j) { return make_uint2(f2bf_pk(acc[i][j][0], acc[i][j][1]), f2bf_pk(acc[i][j][2], acc[i][j][3])); };
   if (sec == 2) {
 #pragma unroll
     for (int j = 0; j < MT2; ++j) {
       const int row = m0 + wm * (MT2 * 16) + j * 16 + lq;
       if (row >= M) continue;
       const RowInfo ri = rp.rows[row];
-      bf16_t* dst = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.vc) + rp.layer_off) + (size_t)ri.slot * H + fsec + wn * 64 + g * 4;
+      bf16_t* dst = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.vc) + rp.layer_off) + (size_t)ri.slot * H + fsec + wn * 64 + g * 16;
 #pragma unroll
-      for (int i = 0; i < NA; ++i)
-        *reinterpret_cast<uint2*>(dst + i * 16) = make_uint2(f2bf_pk(acc[i][j][0], acc[i][j][1]), f2bf_pk(acc[i][j][2], acc[i][j][3]));
+      for (int h = 0; h < 2; ++h) {
+        const uint2 a = pack4(2 * h, j), b = pack4(2 * h + 1, j);
+        *reinterpret_cast<uint4*>(dst + h * 8) = make_uint4(a.x, a.y, b.x, b.y);
+      }
     }
     return;
   }
@@ -443,8 +489,7 @@ __device__ __forceinline__ void qkv_rope_epilogue(f32x4_t (&acc)[NA][MT2], bf16_
 #pragma unroll
   for (int j = 0; j < MT2; ++j)
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
-      ex[((wave * MT2 + j) * NA + i) * 64 + lane] = make_uint2(f2bf_pk(acc[i][j][0], acc[i][j][1]), f2bf_pk(acc[i][j][2], acc[i][j][3]));
+    for (int i = 0; i < NA; ++i) ex[((wave * MT2 + j) * NA + i) * 64 + lane] = pack4(i, j);
   __syncthreads();
   constexpr int JW = MT2 / 4;                                     // 16-row groups per wave after the re-division
 #pragma unroll
@@ -454,23 +499,29 @@ __device__ __forceinline__ void qkv_rope_epilogue(f32x4_t (&acc)[NA][MT2], bf16_
     if (row >= M) continue;
     const RowInfo ri = rp.rows[row];
     bf16_t* dst = (sec == 0 ? qkv + (size_t)row * ldc
-                            : reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.kc) + rp.layer_off) + (size_t)ri.slot * H) + fsec + g * 4;
-    const float* cp = rp.cos_tab + (size_t)ri.pos * 64 + g * 4;   // pair index inside the head: i * 16 + g * 4 + r
-    const float* sp = rp.sin_tab + (size_t)ri.pos * 64 + g * 4;
+                            : reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.kc) + rp.layer_off) + (size_t)ri.slot * H) + fsec + g * 16;
+    const float* cp = rp.cos_tab + (size_t)ri.pos * 64 + g * 16;  // pair index inside the head: g * 16 + i * 4 + r
+    const float* sp = rp.sin_tab + (size_t)ri.pos * 64 + g * 16;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const float4 c = *reinterpret_cast<const float4*>(cp + i * 16), s = *reinterpret_cast<const float4*>(sp + i * 16);
+    for (int h = 0; h < 2; ++h) {                                 // eight adjacent pair indices per 16-byte store
+      float4 c[2], s[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { c[e] = *reinterpret_cast<const float4*>(cp + (2 * h + e) * 4); s[e] = *reinterpret_cast<const float4*>(sp + (2 * h + e) * 4); }
 #pragma unroll
       for (int hd = 0; hd < 2; ++hd) {
-        const uint2 x = ex[((((hd * 2 + 0) * 2 + wm) * MT2 + j) * NA + i) * 64 + lane];      // x[d]      (wave wn = 2 hd)
-        const uint2 y = ex[((((hd * 2 + 1) * 2 + wm) * MT2 + j) * NA + i) * 64 + lane];      // x[d + 64] (wave wn = 2 hd + 1)
-        uint2 o0, o1;
-        o0.x = f2bf_pk(rope_first(bf_lo(x.x), bf_lo(y.x), c.x, s.x), rope_first(bf_hi(x.x), bf_hi(y.x), c.y, s.y));
-        o0.y = f2bf_pk(rope_first(bf_lo(x.y), bf_lo(y.y), c.z, s.z), rope_first(bf_hi(x.y), bf_hi(y.y), c.w, s.w));
-        o1.x = f2bf_pk(rope_second(bf_lo(x.x), bf_lo(y.x), c.x, s.x), rope_second(bf_hi(x.x), bf_hi(y.x), c.y, s.y));
-        o1.y = f2bf_pk(rope_second(bf_lo(x.y), bf_lo(y.y), c.z, s.z), rope_second(bf_hi(x.y), bf_hi(y.y), c.w, s.w));
-        *reinterpret_cast<uint2*>(dst + hd * 128 + i * 16) = o0;
-        *reinterpret_cast<uint2*>(dst + hd * 128 + 64 + i * 16) = o1;
+        uint32_t o0[4], o1[4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int i = 2 * h + e;
+          const uint2 x = ex[((((hd * 2 + 0) * 2 + wm) * MT2 + j) * NA + i) * 64 + lane];      // x[d]      (wave wn = 2 hd)
+          const uint2 y = ex[((((hd * 2 + 1) * 2 + wm) * MT2 + j) * NA + i) * 64 + lane];      // x[d + 64] (wave wn = 2 hd + 1)
+          o0[2 * e] = f2bf_pk(rope_first(bf_lo(x.x), bf_lo(y.x), c[e].x, s[e].x), rope_first(bf_hi(x.x), bf_hi(y.x), c[e].y, s[e].y));
+          o0[2 * e + 1] = f2bf_pk(rope_first(bf_lo(x.y), bf_lo(y.y), c[e].z, s[e].z), rope_first(bf_hi(x.y), bf_hi(y.y), c[e].w, s[e].w));
+          o1[2 * e] = f2bf_pk(rope_second(bf_lo(x.x), bf_lo(y.x), c[e].x, s[e].x), rope_second(bf_hi(x.x), bf_hi(y.x), c[e].y, s[e].y));
+          o1[2 * e + 1] = f2bf_pk(rope_second(bf_lo(x.y), bf_lo(y.y), c[e].z, s[e].z), rope_second(bf_hi(x.y), bf_hi(y.y), c[e].w, s[e].w));
+        }
+        *reinterpret_cast<uint4*>(dst + hd * 128 + h * 8) = make_uint4(o0[0], o0[1], o0[2], o0[3]);
+        *reinterpret_cast<uint4*>(dst + hd * 128 + 64 + h * 8) = make_uint4(o1[0], o1[1], o1[2], o1[3]);
       }
     }
   }
@@ -542,6 +593,7 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   constexpr int RG = (NMF * 3 / 4) / NR;                         // one read every RG MFMAs, from the segment's start (RG = 1: +0.0-0.6 %, not kept)
   constexpr int DG = (NMF - NR * RG) / NP;                       // then one DMA piece every DG MFMAs
   static_assert(RG >= 1 && DG >= 1, "segment too short for its reads and DMA pieces");
+  constexpr int ORD = SPLITK ? ROWS_IDENTITY : ring_row_order<EPI>();   // order of the weight rows in the LDS image (see big_epilogue)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef ATS_RING_STAMPS
   const unsigned long long st_entry = __builtin_readcyclecounter();
@@ -574,7 +626,8 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   const unsigned lbase = lds_addr(smem);
 #pragma unroll
   for (int j = 0; j < WP; ++j) {
-    const int row = (wave * WP + j) * 16 + (lane >> 2), gr = min(n0 + row, N - 1);
+    const int row = (wave * WP + j) * 16 + (lane >> 2);          // LDS row; its weight row follows the epilogue's row order (ring_src_row)
+    const int gr = min(n0 + (row & ~63) + ring_src_row<ORD>(row & 63), N - 1);
     woff[j] = (pk ? (unsigned)(gr >> 1) * (unsigned)(K * ESZ * 2) + (gr & 1) * 64 : (unsigned)gr * (unsigned)(K * ESZ)) + (((lane & 3) ^ swz(row)) * 16);
     m0w[j] = __builtin_amdgcn_readfirstlane((int)lbase + (wave * WP + j) * 1024);
   }
@@ -709,7 +762,7 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
       const float fx = sx[min(m0 + wm * (MT2 * 16) + j * 16 + lq, M - 1)];
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const int gn = n0 + wn * (NA * 16) + i * 16 + g * 4;
+        const int gn = n0 + wn * (NA * 16) + (i >> 2) * 64 + ring_src_row<ORD>((i & 3) * 16 + g * 4);   // weight row of acc[i][j][0]; r: the next three
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] *= fx * sw[min(gn + r, N - 1)];
       }
@@ -1555,7 +1608,7 @@ int ats_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, int m, int hid
   ATS_REQUIRE(x && wqkv && qkv && rope.rows && rope.cos_tab && rope.sin_tab && rope.hidden == hidden, ATSPEED_ERR_INVALID, "gemm_qkv_rope: null / inconsistent argument");
   ATS_REQUIRE(hidden % 256 == 0 && big_kernel_applies(m, 3 * hidden, hidden, hidden, 3 * hidden, ATSPEED_BF16, EPI_STORE), ATSPEED_ERR_INVALID,
               "gemm_qkv_rope: shape %d x %d is not the batched kernel's", m, hidden);
-  ATS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wqkv & 15) == 0 && ((uintptr_t)qkv & 7) == 0, ATSPEED_ERR_INVALID, "gemm_qkv_rope: operands must be 16-byte aligned");
+  ATS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wqkv & 15) == 0 && ((uintptr_t)qkv & 15) == 0, ATSPEED_ERR_INVALID, "gemm_qkv_rope: operands must be 16-byte aligned");
   return launch_big<EPI_QKV_ROPE>((const bf16_t*)x, (const bf16_t*)wqkv, qkv, m, 3 * hidden, hidden, hidden, 3 * hidden, st, pk, rope);
 }
 

@@ -395,7 +395,7 @@ def test_rmsnorm_quant_fp8_equals_norm_then_quant(lib, hidden):
 
 
 @pytest.mark.parametrize("m,n,k,epi", [(1024, 2304, 768, 0), (640, 12288, 512, 0), (1300, 1024, 1280, 2), (900, 2752, 512, 3), (1543, 1000, 256, 1),
-                                      (4200, 8192, 256, 0), (8300, 4096, 512, 2), (4200, 8448, 256, 3)])      # more than two tiles per CU
+                                      (4200, 8192, 256, 0), (8300, 4096, 512, 2), (4200, 8448, 256, 3), (4480, 3072, 1024, 0)])      # more than two tiles per CU
 def test_gemm_fp8(lib, m, n, k, epi):
     x = _rand((m, k), 51, 1.5).to(torch.bfloat16).cuda()
     w = _rand((n, k), 52, 0.05).to(torch.bfloat16).cuda()
@@ -530,7 +530,7 @@ def test_gemm_packed_equals_row_major_bit_for_bit(lib, m, n, k, epi):
         assert torch.equal(c1[:, :n], c0[:, :n])
 
 
-@pytest.mark.parametrize("m,n,k,epi", [(1024, 2304, 768, 0), (1300, 1024, 1280, 2), (900, 2752, 512, 3), (4200, 8448, 256, 3), (8300, 4096, 512, 2)])
+@pytest.mark.parametrize("m,n,k,epi", [(1024, 2304, 768, 0), (1300, 1024, 1280, 2), (900, 2752, 512, 3), (4200, 8448, 256, 3), (8300, 4096, 512, 2), (4480, 3072, 1024, 0)])
 def test_gemm_fp8_packed_equals_row_major_bit_for_bit(lib, m, n, k, epi):
     x = _rand((m, k), 51, 1.5).to(torch.bfloat16).cuda()
     w = _rand((n, k), 52, 0.05).to(torch.bfloat16).cuda()
