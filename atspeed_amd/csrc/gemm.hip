@@ -857,51 +857,34 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #define ATS_MFMA_MX_A(c, a, b, s) ((void)0)
 #endif
 
-// accumulator tile (it, jt) of a wave: m = m0w + jt*32 + (lane&31); registers 4q..4q+3 of lane (., h) hold POSITIONS 8q + 4h + r of the 32-row weight
-// tile `it`.  As in the bf16 kernel (big_epilogue) the DMA lays the tile's weight rows into LDS in an order that makes a lane's positions adjacent output
-// columns: ROWS_LANE16: position 8q + 4h + r holds weight row h*16 + q*4 + r (a lane owns 16 adjacent columns of the tile: two 16-byte stores);
-// ROWS_SWIGLU8 (rows 0-15 of a weight tile are a gate group, 16-31 its up group): positions with q = 0, 1 hold the gates and q = 2, 3 the ups of
-// outputs h*8 + (q&1)*4 + r (one 16-byte store per tile).
-template <int ORD> __device__ __forceinline__ int mx_src_row(int pos) {           // LDS row -> weight row, both 0..31 inside the 32-row tile
-  if constexpr (ORD == ROWS_LANE16) return ((pos >> 2) & 1) * 16 + (pos >> 3) * 4 + (pos & 3);
-  if constexpr (ORD == ROWS_SWIGLU8) return (pos >> 4) * 16 + ((pos >> 2) & 1) * 8 + ((pos >> 3) & 1) * 4 + (pos & 3);
-  return pos;
-}
+// accumulator tile (it, jt) of a wave: m = m0w + jt*32 + (lane&31); registers 4q..4q+3 hold n = n0w + it*32 + 8q + 4(lane>>5) + r
 // The per-row scales of the W8A8 scheme (acc *= sx[m] * sw[n]) are applied tile by tile right where a tile is consumed: scaling all
 // accumulators first kept 256 of them live in VGPRs in the one-wave-per-SIMD form (they sit in AGPRs during the loop) and spilled.
-template <int ORD>
+template <int TA, int TB>
 __device__ __forceinline__ void mx_scale_tile(f32x16_t& t, const float* __restrict__ sx, const float* __restrict__ sw, int gm, int gn0, int h, int M, int N) {
   const float fx = sx[min(gm, M - 1)];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int wr = gn0 + mx_src_row<ORD>(8 * q + 4 * h);          // r: the next three weight rows in every order
+  for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) t[4 * q + r] *= fx * sw[min(wr + r, N - 1)];
-  }
+    for (int r = 0; r < 4; ++r) t[4 * q + r] *= fx * sw[min(gn0 + 8 * q + 4 * h + r, N - 1)];
 }
 
 template <int EPI, int TA, int TB>
 __device__ __forceinline__ void mx_epilogue(f32x16_t (&acc)[TA][TB], void* __restrict__ Cv, int M, int N, int ldc, int m0w, int n0w, int lane,
                                             const float* __restrict__ sx, const float* __restrict__ sw, int pk) {
-  constexpr int ORD = ring_row_order<EPI>();
   const int r32 = lane & 31, h = lane >> 5;
-  auto pack8 = [&](const f32x16_t& t, int q0) {                    // registers of q0 and q0 + 1: eight adjacent columns in ROWS_LANE16 order
-    return make_uint4(f2bf_pk(t[4 * q0], t[4 * q0 + 1]), f2bf_pk(t[4 * q0 + 2], t[4 * q0 + 3]), f2bf_pk(t[4 * q0 + 4], t[4 * q0 + 5]), f2bf_pk(t[4 * q0 + 6], t[4 * q0 + 7]));
-  };
-  if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
-    bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
-    if ((ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(Cv) & 15) == 0 && n0w + TA * 32 <= N) {
-      // lane (., h) owns columns n0w + it*32 + h*16 + [0, 16)
-      uint4 rs[EPI == EPI_RESID ? TA : 1][EPI == EPI_RESID ? TB : 1][2];
-      if constexpr (EPI == EPI_RESID) {                            // residuals of the whole wave tile fetched before the first store (see big_epilogue)
+  const bool vec = (ldc & 3) == 0;
+  if constexpr (EPI == EPI_RESID) {
+    if (vec && n0w + TA * 32 <= N) {       // residuals of the whole wave tile fetched before the first store (see big_epilogue)
+      bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
+      uint2 rs[TA][TB][4];
 #pragma unroll
-        for (int jt = 0; jt < TB; ++jt) {
-          const int gm = min(m0w + jt * 32 + r32, M - 1);
+      for (int jt = 0; jt < TB; ++jt) {
+        const int gm = min(m0w + jt * 32 + r32, M - 1);
 #pragma unroll
-          for (int it = 0; it < TA; ++it)
+        for (int it = 0; it < TA; ++it)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) rs[it][jt][e] = *reinterpret_cast<const uint4*>(Cb + (size_t)gm * ldc + n0w + it * 32 + h * 16 + e * 8);
-        }
+          for (int q = 0; q < 4; ++q) rs[it][jt][q] = *reinterpret_cast<const uint2*>(Cb + (size_t)gm * ldc + n0w + it * 32 + 8 * q + 4 * h);
       }
 #pragma unroll
       for (int jt = 0; jt < TB; ++jt) {
@@ -909,90 +892,79 @@ __device__ __forceinline__ void mx_epilogue(f32x16_t (&acc)[TA][TB], void* __res
         if (gm >= M) continue;
 #pragma unroll
         for (int it = 0; it < TA; ++it) {
-          mx_scale_tile<ORD>(acc[it][jt], sx, sw, gm, n0w + it * 32, h, M, N);
+          mx_scale_tile<TA, TB>(acc[it][jt], sx, sw, gm, n0w + it * 32, h, M, N);
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            uint4 o = pack8(acc[it][jt], 2 * e);
-            if constexpr (EPI == EPI_RESID) {
-              const uint4 r = rs[it][jt][e], p = o;
-              o.x = f2bf_pk(bf_lo(r.x) + bf_lo(p.x), bf_hi(r.x) + bf_hi(p.x));
-              o.y = f2bf_pk(bf_lo(r.y) + bf_lo(p.y), bf_hi(r.y) + bf_hi(p.y));
-              o.z = f2bf_pk(bf_lo(r.z) + bf_lo(p.z), bf_hi(r.z) + bf_hi(p.z));
-              o.w = f2bf_pk(bf_lo(r.w) + bf_lo(p.w), bf_hi(r.w) + bf_hi(p.w));
-            }
-            *reinterpret_cast<uint4*>(Cb + (size_t)gm * ldc + n0w + it * 32 + h * 16 + e * 8) = o;
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t p0 = f2bf_pk(acc[it][jt][4 * q], acc[it][jt][4 * q + 1]), p1 = f2bf_pk(acc[it][jt][4 * q + 2], acc[it][jt][4 * q + 3]);
+            uint2 o;
+            o.x = f2bf_pk(bf_lo(rs[it][jt][q].x) + bf_lo(p0), bf_hi(rs[it][jt][q].x) + bf_hi(p0));
+            o.y = f2bf_pk(bf_lo(rs[it][jt][q].y) + bf_lo(p1), bf_hi(rs[it][jt][q].y) + bf_hi(p1));
+            *reinterpret_cast<uint2*>(Cb + (size_t)gm * ldc + n0w + it * 32 + 8 * q + 4 * h) = o;
           }
         }
       }
       return;
     }
-    // tiles that straddle N, odd strides: element by element
+  }
 #pragma unroll
-    for (int jt = 0; jt < TB; ++jt) {
-      const int gm = m0w + jt * 32 + r32;
-      if (gm >= M) continue;
+  for (int jt = 0; jt < TB; ++jt) {
+    const int gm = m0w + jt * 32 + r32;
+    if (gm >= M) continue;
 #pragma unroll
-      for (int it = 0; it < TA; ++it) {
-        mx_scale_tile<ORD>(acc[it][jt], sx, sw, gm, n0w + it * 32, h, M, N);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int gn = n0w + it * 32 + h * 16 + q * 4 + r;
-            if (gn >= N) continue;
-            bf16_t* C = Cb + (size_t)gm * ldc + gn;
-            float v = acc[it][jt][4 * q + r];
-            if constexpr (EPI == EPI_RESID) v = bf2f(*C) + bf2f(f2bf(v));
-            *C = f2bf(v);
-          }
-      }
-    }
-  } else if constexpr (EPI == EPI_SWIGLU) {
-    // lane (., h) owns outputs h*8 + [0, 8) of the tile's 16: gates in q = 0, 1, ups in q = 2, 3
-    bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
-    const bool vec16 = (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(Cv) & 15) == 0;
-#pragma unroll
-    for (int jt = 0; jt < TB; ++jt) {
-      const int gm = m0w + jt * 32 + r32;
-      if (gm >= M) continue;
-#pragma unroll
-      for (int it = 0; it < TA; ++it) {
+    for (int it = 0; it < TA; ++it) {
+      mx_scale_tile<TA, TB>(acc[it][jt], sx, sw, gm, n0w + it * 32, h, M, N);
+      if constexpr (EPI == EPI_SWIGLU) {
+        // rows 0-15 of the 32-row weight tile are a gate group (q = 0, 1), rows 16-31 its up group (q = 2, 3): the pair sits in one lane
+        bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
         const int gn0 = n0w + it * 32;
         if (gn0 >= N) continue;
-        mx_scale_tile<ORD>(acc[it][jt], sx, sw, gm, gn0, h, M, N);
-        uint32_t res[4];
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < 2; ++q) {
+          uint2 o;
 #pragma unroll
           for (int r = 0; r < 4; r += 2) {
             const uint32_t gp = f2bf_pk(acc[it][jt][4 * q + r], acc[it][jt][4 * q + r + 1]);
             const uint32_t upk = f2bf_pk(acc[it][jt][4 * (q + 2) + r], acc[it][jt][4 * (q + 2) + r + 1]);
-            res[2 * q + (r >> 1)] = f2bf_pk(ats_silu<false>(bf_lo(gp)) * bf_lo(upk), ats_silu<false>(bf_hi(gp)) * bf_hi(upk));
+            const float g0 = bf_lo(gp), g1 = bf_hi(gp);
+            const uint32_t res = f2bf_pk(ats_silu<false>(g0) * bf_lo(upk), ats_silu<false>(g1) * bf_hi(upk));
+            if (r == 0) o.x = res; else o.y = res;
           }
-        bf16_t* dst = C + ats_opnd_idx<2>(pk, gm, (gn0 >> 1) + h * 8, ldc);      // the down projection's operand
-        if (vec16) *reinterpret_cast<uint4*>(dst) = make_uint4(res[0], res[1], res[2], res[3]);
-        else { *reinterpret_cast<uint2*>(dst) = make_uint2(res[0], res[1]); *reinterpret_cast<uint2*>(dst + 4) = make_uint2(res[2], res[3]); }
-      }
-    }
-  } else {
-    static_assert(EPI == EPI_F32, "fp32 store");
-    const bool vec = (ldc & 3) == 0;
-#pragma unroll
-    for (int jt = 0; jt < TB; ++jt) {
-      const int gm = m0w + jt * 32 + r32;
-      if (gm >= M) continue;
-#pragma unroll
-      for (int it = 0; it < TA; ++it) {
-        mx_scale_tile<ORD>(acc[it][jt], sx, sw, gm, n0w + it * 32, h, M, N);
+          *reinterpret_cast<uint2*>(C + ats_opnd_idx<2>(pk, gm, (gn0 >> 1) + 8 * q + 4 * h, ldc)) = o;      // the down projection's operand
+        }
+      } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int gn = n0w + it * 32 + 8 * q + 4 * h;
           if (gn >= N) continue;
-          float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
-          if (gn + 3 < N && vec) *reinterpret_cast<float4*>(C) = make_float4(acc[it][jt][4 * q], acc[it][jt][4 * q + 1], acc[it][jt][4 * q + 2], acc[it][jt][4 * q + 3]);
-          else
+          const float v0 = acc[it][jt][4 * q], v1 = acc[it][jt][4 * q + 1], v2 = acc[it][jt][4 * q + 2], v3 = acc[it][jt][4 * q + 3];
+          if constexpr (EPI == EPI_F32) {
+            float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
+            if (gn + 3 < N && vec) *reinterpret_cast<float4*>(C) = make_float4(v0, v1, v2, v3);
+            else { const float vv[4] = {v0, v1, v2, v3};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[it][jt][4 * q + r];
+              for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = vv[r]; }
+          } else {
+            bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
+            if (gn + 3 < N && vec) {
+              uint2 o;
+              const uint32_t p0 = f2bf_pk(v0, v1), p1 = f2bf_pk(v2, v3);
+              if constexpr (EPI == EPI_RESID) {
+                const uint2 rs = *reinterpret_cast<const uint2*>(C);
+                o.x = f2bf_pk(bf_lo(rs.x) + bf_lo(p0), bf_hi(rs.x) + bf_hi(p0));
+                o.y = f2bf_pk(bf_lo(rs.y) + bf_lo(p1), bf_hi(rs.y) + bf_hi(p1));
+              } else { o.x = p0; o.y = p1; }
+              *reinterpret_cast<uint2*>(C) = o;
+            } else {
+              const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (gn + r < N) {
+                  float v = vv[r];
+                  if constexpr (EPI == EPI_RESID) v = bf2f(C[r]) + bf2f(f2bf(v));
+                  C[r] = f2bf(v);
+                }
+            }
+          }
         }
       }
     }
@@ -1007,27 +979,23 @@ __device__ __forceinline__ void mx_qkv_rope_epilogue(f32x16_t (&acc)[TA][TB], bf
                                                      int lane, const float* __restrict__ sx, const float* __restrict__ sw, const RopeEpi& rp,
                                                      unsigned char* smem) {
   static_assert(TA == 2 && TB % 2 == 0, "eight-wave tiling: a wave holds 64 columns");
-  // weight rows in ROWS_LANE16 order: registers 4q + r of lane (., h) are columns it*32 + h*16 + q*4 + r of the wave's 64
   const int wn = wave >> 1, wm = wave & 1, r32 = lane & 31, h = lane >> 5;
   const int H = rp.hidden;
   const int sec = n0 / H, fsec = n0 - sec * H;                    // 0 q, 1 k, 2 v; the tile's first column inside it
   const int m0w = m0 + wm * (TB * 32), n0w = n0 + wn * 64;
-  auto pack4 = [&](const f32x16_t& t, int q) { return make_uint2(f2bf_pk(t[4 * q], t[4 * q + 1]), f2bf_pk(t[4 * q + 2], t[4 * q + 3])); };
   if (sec == 2) {
 #pragma unroll
     for (int jt = 0; jt < TB; ++jt) {
       const int row = m0w + jt * 32 + r32;
       if (row >= M) continue;
       const RowInfo ri = rp.rows[row];
-      bf16_t* dst = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.vc) + rp.layer_off) + (size_t)ri.slot * H + fsec + wn * 64 + h * 16;
+      bf16_t* dst = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.vc) + rp.layer_off) + (size_t)ri.slot * H + fsec + wn * 64 + 4 * h;
 #pragma unroll
       for (int it = 0; it < TA; ++it) {
-        mx_scale_tile<ROWS_LANE16>(acc[it][jt], sx, sw, row, n0w + it * 32, h, M, N);
+        mx_scale_tile<TA, TB>(acc[it][jt], sx, sw, row, n0w + it * 32, h, M, N);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const uint2 a = pack4(acc[it][jt], 2 * e), b = pack4(acc[it][jt], 2 * e + 1);
-          *reinterpret_cast<uint4*>(dst + it * 32 + e * 8) = make_uint4(a.x, a.y, b.x, b.y);
-        }
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<uint2*>(dst + it * 32 + 8 * q) = make_uint2(f2bf_pk(acc[it][jt][4 * q], acc[it][jt][4 * q + 1]), f2bf_pk(acc[it][jt][4 * q + 2], acc[it][jt][4 * q + 3]));
       }
     }
     return;
@@ -1039,9 +1007,10 @@ __device__ __forceinline__ void mx_qkv_rope_epilogue(f32x16_t (&acc)[TA][TB], bf
     const int row = m0w + jt * 32 + r32;
 #pragma unroll
     for (int it = 0; it < TA; ++it) {
-      mx_scale_tile<ROWS_LANE16>(acc[it][jt], sx, sw, row, n0w + it * 32, h, M, N);
+      mx_scale_tile<TA, TB>(acc[it][jt], sx, sw, row, n0w + it * 32, h, M, N);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) ex[(((wave * TB + jt) * TA + it) * 4 + q) * 64 + lane] = pack4(acc[it][jt], q);
+      for (int q = 0; q < 4; ++q)
+        ex[(((wave * TB + jt) * TA + it) * 4 + q) * 64 + lane] = make_uint2(f2bf_pk(acc[it][jt][4 * q], acc[it][jt][4 * q + 1]), f2bf_pk(acc[it][jt][4 * q + 2], acc[it][jt][4 * q + 3]));
     }
   }
   __syncthreads();
@@ -1053,29 +1022,23 @@ __device__ __forceinline__ void mx_qkv_rope_epilogue(f32x16_t (&acc)[TA][TB], bf
     if (row >= M) continue;
     const RowInfo ri = rp.rows[row];
     bf16_t* dst = (sec == 0 ? qkv + (size_t)row * ldc
-                            : reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.kc) + rp.layer_off) + (size_t)ri.slot * H) + fsec + it * 32 + h * 16;
-    const float* cp = rp.cos_tab + (size_t)ri.pos * 64 + it * 32 + h * 16;   // pair index inside the head: it * 32 + h * 16 + q * 4 + r
-    const float* sp = rp.sin_tab + (size_t)ri.pos * 64 + it * 32 + h * 16;
+                            : reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.kc) + rp.layer_off) + (size_t)ri.slot * H) + fsec + it * 32 + 4 * h;
+    const float* cp = rp.cos_tab + (size_t)ri.pos * 64 + it * 32 + 4 * h;   // pair index inside the head: it * 32 + 8 q + 4 h + r
+    const float* sp = rp.sin_tab + (size_t)ri.pos * 64 + it * 32 + 4 * h;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {                                 // eight adjacent pair indices per 16-byte store
-      float4 c[2], s[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) { c[u] = *reinterpret_cast<const float4*>(cp + (2 * e + u) * 4); s[u] = *reinterpret_cast<const float4*>(sp + (2 * e + u) * 4); }
+    for (int q = 0; q < 4; ++q) {
+      const float4 c = *reinterpret_cast<const float4*>(cp + 8 * q), s = *reinterpret_cast<const float4*>(sp + 8 * q);
 #pragma unroll
       for (int hd = 0; hd < 2; ++hd) {
-        uint32_t o0[4], o1[4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int q = 2 * e + u;
-          const uint2 x = ex[(((((hd * 2 + 0) * 2 + wm) * TB + jt) * TA + it) * 4 + q) * 64 + lane];      // x[d]      (wave wn = 2 hd)
-          const uint2 y = ex[(((((hd * 2 + 1) * 2 + wm) * TB + jt) * TA + it) * 4 + q) * 64 + lane];      // x[d + 64] (wave wn = 2 hd + 1)
-          o0[2 * u] = f2bf_pk(rope_first(bf_lo(x.x), bf_lo(y.x), c[u].x, s[u].x), rope_first(bf_hi(x.x), bf_hi(y.x), c[u].y, s[u].y));
-          o0[2 * u + 1] = f2bf_pk(rope_first(bf_lo(x.y), bf_lo(y.y), c[u].z, s[u].z), rope_first(bf_hi(x.y), bf_hi(y.y), c[u].w, s[u].w));
-          o1[2 * u] = f2bf_pk(rope_second(bf_lo(x.x), bf_lo(y.x), c[u].x, s[u].x), rope_second(bf_hi(x.x), bf_hi(y.x), c[u].y, s[u].y));
-          o1[2 * u + 1] = f2bf_pk(rope_second(bf_lo(x.y), bf_lo(y.y), c[u].z, s[u].z), rope_second(bf_hi(x.y), bf_hi(y.y), c[u].w, s[u].w));
-        }
-        *reinterpret_cast<uint4*>(dst + hd * 128 + e * 8) = make_uint4(o0[0], o0[1], o0[2], o0[3]);
-        *reinterpret_cast<uint4*>(dst + hd * 128 + 64 + e * 8) = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+        const uint2 x = ex[(((((hd * 2 + 0) * 2 + wm) * TB + jt) * TA + it) * 4 + q) * 64 + lane];      // x[d]      (wave wn = 2 hd)
+        const uint2 y = ex[(((((hd * 2 + 1) * 2 + wm) * TB + jt) * TA + it) * 4 + q) * 64 + lane];      // x[d + 64] (wave wn = 2 hd + 1)
+        uint2 o0, o1;
+        o0.x = f2bf_pk(rope_first(bf_lo(x.x), bf_lo(y.x), c.x, s.x), rope_first(bf_hi(x.x), bf_hi(y.x), c.y, s.y));
+        o0.y = f2bf_pk(rope_first(bf_lo(x.y), bf_lo(y.y), c.z, s.z), rope_first(bf_hi(x.y), bf_hi(y.y), c.w, s.w));
+        o1.x = f2bf_pk(rope_second(bf_lo(x.x), bf_lo(y.x), c.x, s.x), rope_second(bf_hi(x.x), bf_hi(y.x), c.y, s.y));
+        o1.y = f2bf_pk(rope_second(bf_lo(x.y), bf_lo(y.y), c.z, s.z), rope_second(bf_hi(x.y), bf_hi(y.y), c.w, s.w));
+        *reinterpret_cast<uint2*>(dst + hd * 128 + 8 * q) = o0;
+        *reinterpret_cast<uint2*>(dst + hd * 128 + 64 + 8 * q) = o1;
       }
     }
   }
@@ -1119,8 +1082,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* _
   const unsigned lbase = lds_addr(smem);
 #pragma unroll
   for (int j = 0; j < WP; ++j) {
-    const int row = (wave * WP + j) * 16 + (lane >> 2);          // LDS row; its weight row follows the epilogue's row order (mx_src_row)
-    const int gr = min(n0 + (row & ~31) + mx_src_row<ring_row_order<EPI>()>(row & 31), N - 1);
+    const int row = (wave * WP + j) * 16 + (lane >> 2), gr = min(n0 + row, N - 1);
     woff[j] = (pk ? (unsigned)(gr >> 1) * (unsigned)(K * 2) + (gr & 1) * 64 : (unsigned)gr * (unsigned)K) + (((lane & 3) ^ swz(row)) * 16);
     m0w_[j] = __builtin_amdgcn_readfirstlane((int)lbase + (wave * WP + j) * 1024);
   }
@@ -1248,15 +1210,8 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
 #else
   const float* stamps = nullptr;
 #endif
-  static const int four_waves = env_int("ATSPEED_GEMM_4WAVE", 0);
-  if constexpr (EPI != EPI_QKV_ROPE) if (use256 && four_waves) {
-    static thread_local AtsPerDeviceFlag a4_flag;
-    bool& a4 = a4_flag.cur();
-    if (!a4) { ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); a4 = true; }
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false, false, 8>), dim3(t256), dim3(256), 128 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk);
-    ATS_LAUNCH_CHECK();
-    return ATSPEED_OK;
-  }
+  // (a four-wave form, one wave per SIMD with 128 x 128 per wave and the accumulators in AGPRs, was 3 % slower on every projection and is
+  // not instantiated any more: profiles/README.md)
   if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, none, stamps, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk, rope);
   else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk, rope);
   ATS_LAUNCH_CHECK();
@@ -1388,19 +1343,11 @@ int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char*
     bool& mx_done = mx_flag.cur();
     if (!mx_done) {
       ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_mx_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      if constexpr (EPI != EPI_QKV_ROPE) ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_mx_kernel<EPI, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
       ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_mx_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       mx_done = true;
     }
-    static const int mx_waves = env_int("ATSPEED_FP8_MX_WAVES", 8);      // 4: one wave per SIMD, 128 x 128 per wave (256-row token tiles only)
-    bool launched = false;
-    if constexpr (EPI != EPI_QKV_ROPE)                              // the fused RoPE epilogue exists for the eight-wave tiling only
-      if (big_use_256_rows(t256, t128) && mx_waves == 4) {
-        hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 8, 4>), dim3(t256), dim3(256), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 255) / 256, gm, pk);
-        launched = true;
-      }
-    if (launched) {}
-    else if (big_use_256_rows(t256, t128))
+    // (the four-wave form of this kernel, NWV = 4, was 2-5 % slower and is not instantiated any more)
+    if (big_use_256_rows(t256, t128))
       hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 8>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 255) / 256, gm, pk, rope);
     else
       hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 127) / 128, gm, pk, rope);

@@ -1,60 +1,62 @@
 #!/usr/bin/env python3
-"""Static check of the ring GEMM kernels' ISA.  Their main loops are inline asm whose MFMAs the compiler cannot see, so any register move
-it inserts between them that READS an accumulator register (a live-range split, a permutation between the loop's and the tail's register
-assignment) reads results that may still be in the matrix pipe -- the hardware does not interlock these reads and LLVM pads them only
-behind MFMAs it emitted itself.  Seen twice on gemm_ring_mx_kernel (gemm.hip): silently wrong sums in one tile.
+"""Static check of the ring GEMM kernels' ISA (gemm.hip: gemm_ring_kernel, gemm_ring_mx_kernel).
 
-For every gemm_ring*_kernel in the assembly: the accumulator registers are the destinations of its v_mfma instructions; between the
-first and the last MFMA (in layout order) no v_mov / v_accvgpr_* / v_pk_mov / v_swap may have one of them as a source.  Exception: the
-zero fill that the compiler lays out inside that span (v_mov vX, 0 followed by copies of vX).  Exits 1 on a finding.
+Their main loops are volatile inline asm: MFMAs the compiler cannot see, and ASYNCHRONOUS ds_read / LDS-DMA statements whose results land
+long after the statement.  Wherever the register allocator is free to choose it is also free to put a COPY or a SPILL between two of those
+statements, and such a copy reads (a) an accumulator whose MFMA may still be in the matrix pipe -- the hardware does not interlock these
+reads, and LLVM's hazard recogniser pads them only behind MFMAs it emitted itself -- or (b) a fragment register whose LDS data has not
+landed.  Both were seen on gemm_ring_mx_kernel during round 2 (a live-range split inside the loop; a permutation of accumulator tuples
+between the loop's and the tail's register assignment; scratch spills of fragments in the tail): silently wrong sums in one tile,
+partly run-to-run different, in one instantiation and only for some K.
+
+Rule checked, per kernel, between its first and its last MFMA in layout order:
+  * no scratch_* / buffer spill instruction at all;
+  * no v_mov / v_accvgpr_* / v_pk_mov / v_swap whose source is a vector register -- except the accumulators' zero fill, which the
+    compiler lays out inside that span as runs of >= 8 consecutive moves from ONE source register (a splat), and moves of literals.
+Exits 1 on a finding.
 usage: hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o gemm.s atspeed_amd/csrc/gemm.hip && tools/scan_mfma_loops.py gemm.s"""
 import re, sys
 
-
-def regs_of(op):
-    """'v[2:5]' -> {('v',2),..}; 'a17' -> {('a',17)}; anything else -> empty"""
-    m = re.fullmatch(r'([va])\[(\d+):(\d+)\]', op)
-    if m:
-        return {(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
-    m = re.fullmatch(r'([va])(\d+)', op)
-    return {(m.group(1), int(m.group(2)))} if m else set()
+MOVE = re.compile(r'\s+(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32|v_accvgpr_read_b32|v_accvgpr_mov_b32|v_pk_mov_b32|v_swap_b32)\s+(\S+),\s*(\S+)')
 
 
 def scan(path, verbose=True):
     s = open(path).read()
-    findings = 0
+    findings, kernels = 0, 0
     for m in re.finditer(r'^(_Z\w*gemm_ring\w+):[^\n]*\n(.*?)s_endpgm', s, re.S | re.M):
         name, lines = m.group(1), m.group(2).splitlines()
         mf = [i for i, l in enumerate(lines) if re.match(r'\s+v_mfma', l)]
         if not mf:
             continue
-        acc = set()
-        for i in mf:
-            acc |= regs_of(lines[i].split()[1].rstrip(','))
-        zero_src = set()                                        # registers holding the zero of the accumulator fill
+        kernels += 1
+        moves = []                                              # (line, text, source operand) of register-to-register moves in the span
         bad = []
         for i in range(mf[0], mf[-1]):
-            t = lines[i].strip()
-            mm = re.match(r'(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32|v_accvgpr_read_b32|v_accvgpr_mov_b32|v_pk_mov_b32|v_swap_b32)\s+(\S+),\s*(\S+)', t)
-            if not mm:
+            t = lines[i]
+            if re.match(r'\s+(scratch_|buffer_(load|store)_dword.*offen)', t):
+                bad.append((i, t.strip()[:60]))
                 continue
-            dst, src = regs_of(mm.group(2)), regs_of(mm.group(3).rstrip(','))
-            if not src:                                          # immediate
-                if mm.group(3).rstrip(',') in ('0', '0x0'):
-                    zero_src |= dst
-                continue
-            if src <= zero_src:                                  # copy of the fill value
-                zero_src |= dst
-                continue
-            if src & acc:
-                bad.append((i, t))
+            mm = MOVE.match(t)
+            if mm and re.match(r'[va](\d+|\[)', mm.group(3).rstrip(',')):
+                moves.append((i, t.strip(), mm.group(3).rstrip(',')))
+        # runs of consecutive moves from one source register = the zero fill
+        k = 0
+        while k < len(moves):
+            e = k
+            while e + 1 < len(moves) and moves[e + 1][2] == moves[k][2] and moves[e + 1][0] - moves[e][0] <= 2:
+                e += 1
+            if e - k + 1 < 8:
+                bad.extend((i, t[:60]) for i, t, _ in moves[k:e + 1])
+            k = e + 1
         short = re.sub(r'EEvPKv.*', '', name)
         short = re.sub(r'^_ZN12_GLOBAL__N_1\d+', '', short)
         if verbose:
-            print(f"{short:42s} {len(mf):4d} MFMAs, {len(acc):3d} accumulator registers, {len(bad):3d} moves reading them between the MFMAs {bad[:2] if bad else ''}")
+            print(f"{short:40s} {len(mf):4d} MFMAs, {len(moves):4d} register moves between them (zero fill included), {len(bad):3d} findings {bad[:2] if bad else ''}")
         findings += len(bad)
-    return findings
+    return findings, kernels
 
 
 if __name__ == "__main__":
-    sys.exit(1 if scan(sys.argv[1]) else 0)
+    f, k = scan(sys.argv[1])
+    print(f"{k} ring kernels, {f} findings")
+    sys.exit(1 if f or not k else 0)
