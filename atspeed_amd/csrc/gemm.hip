@@ -1046,7 +1046,7 @@ __device__ __forceinline__ void mx_qkv_rope_epilogue(f32x16_t (&acc)[TA][TB], bf
 
 // NWV = 8: waves 4 (n) x 2 (m), wave tile 64 x MT2*16 (2 x MT2/2 tiles of 32x32), two waves per SIMD.  NWV = 4: waves 2 x 2, wave tile
 // 128 x MT2*16 (4 x MT2/2 tiles), ONE wave per SIMD with up to 512 registers: a third fewer LDS fragment bytes per flop and no two waves
-// contending for a SIMD's matrix pipe and issue slots (selected by ATSPEED_FP8_MX_WAVES, see launch_big_fp8).
+// contending for a SIMD's matrix pipe and issue slots (measured 2-5 % slower; the launcher instantiates NWV = 8 only).
 template <int EPI, int MT2, int NWV = 8>
 __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* __restrict__ X, const void* __restrict__ W, const float* __restrict__ sx,
                                                               const float* __restrict__ sw, void* __restrict__ Cv, int M, int N, int K, int ldc,

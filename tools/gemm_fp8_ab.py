@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time atspeed_gemm_fp8 on the Llama-7B projection shapes (A/B of env-selected kernel variants: ATSPEED_FP8_MX, ATSPEED_FP8_MX_WAVES).
+"""Time atspeed_gemm_fp8 on the Llama-7B projection shapes (A/B of env-selected kernel variants: ATSPEED_FP8_MX; ATSPEED_LIB = another build of the library).
 usage: gemm_fp8_ab.py [M ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
