@@ -5,6 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from atspeed_amd import _lib
+if os.environ.get("ATSPEED_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["ATSPEED_LIB"])     # another build of the library
 lib = _lib.load(); st = _lib.stream_ptr()
 Ms = [int(x) for x in sys.argv[1:]] or [7040, 26000]
 rnd = lambda r, k: (torch.randn(r, k, device="cuda").clamp(-3, 3) * 60).to(torch.float8_e4m3fn).view(torch.uint8)
