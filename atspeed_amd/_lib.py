@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libatspeed_hip.so")
+# ATSPEED_LIB: another build of the library (tuning builds under tools/probe); it must exist, there is no fallback
+LIB_PATH = os.path.abspath(os.environ["ATSPEED_LIB"]) if os.environ.get("ATSPEED_LIB") else os.path.join(_HERE, "lib", "libatspeed_hip.so")
 
 ATSPEED_F32, ATSPEED_BF16 = 0, 1
 WEIGHTS_ROW_MAJOR, WEIGHTS_PACKED = 0, 1

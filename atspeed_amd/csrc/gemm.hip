@@ -326,6 +326,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, void* __
 // No cost in the main loop (fragment reads and swizzle see LDS rows only; rows still come in groups of four, so the packed layout's
 // full 128-byte lines per DMA piece are kept).  Timing-only forms of the store pattern on the Llama-7B projections at 26 k tokens
 // (profiles/README.md): no stores at all +9-12 % (qkv, gate_up; down +4 %), the same bytes fully coalesced +4 %, this form +2.4-2.8 %.
+// 16-byte epilogue store.  -DATS_EPI_NT (tuning build): non-temporal -- the store-only GEMM gains 0.4-2.4 % at 26 k tokens, the bench nothing
+// (4846 / 4842 vs 4835 / 4838 items/s alternating on one box): every output is the next kernel's input.
+__device__ __forceinline__ void epi_store16(bf16_t* p, const uint4& v) {
+#ifdef ATS_EPI_NT
+  __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(p));
+#else
+  *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
 enum { ROWS_IDENTITY = 0, ROWS_LANE16 = 1, ROWS_SWIGLU8 = 2 };
 template <int EPI> constexpr int ring_row_order() {
   return (EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_QKV_ROPE) ? ROWS_LANE16 : EPI == EPI_SWIGLU ? ROWS_SWIGLU8 : ROWS_IDENTITY;
@@ -376,7 +385,7 @@ __device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[NA][MT2], void* __re
               o.y = f2bf_pk(bf_lo(r.y) + bf_lo(p.y), bf_hi(r.y) + bf_hi(p.y));
               o.z = f2bf_pk(bf_lo(r.z) + bf_lo(p.z), bf_hi(r.z) + bf_hi(p.z));
               o.w = f2bf_pk(bf_lo(r.w) + bf_lo(p.w), bf_hi(r.w) + bf_hi(p.w));
-              *reinterpret_cast<uint4*>(Cb + (size_t)gm * ldc + col8(4 * q + 2 * h)) = o;
+              epi_store16(Cb + (size_t)gm * ldc + col8(4 * q + 2 * h), o);
             }
           }
         }
@@ -386,7 +395,7 @@ __device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[NA][MT2], void* __re
           const int gm = m0 + wm * (MT2 * 16) + j * 16 + lq;
           if (gm >= M) continue;
 #pragma unroll
-          for (int h = 0; h < NA / 2; ++h) *reinterpret_cast<uint4*>(Cb + (size_t)gm * ldc + col8(2 * h)) = pack8(2 * h, j);
+          for (int h = 0; h < NA / 2; ++h) epi_store16(Cb + (size_t)gm * ldc + col8(2 * h), pack8(2 * h, j));
         }
       }
       return;
@@ -427,7 +436,7 @@ __device__ __forceinline__ void big_epilogue(f32x4_t (&acc)[NA][MT2], void* __re
         const int oc = (nw >> 1) + q * 32 + g * 8;
         const uint4 o = make_uint4(silu_mul(4 * q, j, 0), silu_mul(4 * q, j, 2), silu_mul(4 * q + 2, j, 0), silu_mul(4 * q + 2, j, 2));
         bf16_t* dst = C + ats_opnd_idx<2>(pk, gm, oc, ldc);        // the down projection's operand: packed when pk (8 outputs stay inside a 64-byte block)
-        if (vec16) *reinterpret_cast<uint4*>(dst) = o;
+        if (vec16) epi_store16(dst, o);
         else { *reinterpret_cast<uint2*>(dst) = make_uint2(o.x, o.y); *reinterpret_cast<uint2*>(dst + 4) = make_uint2(o.z, o.w); }
       }
     }
@@ -479,7 +488,7 @@ __device__ __forceinline__ void qkv_rope_epilogue(f32x4_t (&acc)[NA][MT2], bf16_
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const uint2 a = pack4(2 * h, j), b = pack4(2 * h + 1, j);
-        *reinterpret_cast<uint4*>(dst + h * 8) = make_uint4(a.x, a.y, b.x, b.y);
+        epi_store16(dst + h * 8, make_uint4(a.x, a.y, b.x, b.y));
       }
     }
     return;
@@ -520,8 +529,8 @@ __device__ __forceinline__ void qkv_rope_epilogue(f32x4_t (&acc)[NA][MT2], bf16_
           o1[2 * e] = f2bf_pk(rope_second(bf_lo(x.x), bf_lo(y.x), c[e].x, s[e].x), rope_second(bf_hi(x.x), bf_hi(y.x), c[e].y, s[e].y));
           o1[2 * e + 1] = f2bf_pk(rope_second(bf_lo(x.y), bf_lo(y.y), c[e].z, s[e].z), rope_second(bf_hi(x.y), bf_hi(y.y), c[e].w, s[e].w));
         }
-        *reinterpret_cast<uint4*>(dst + hd * 128 + h * 8) = make_uint4(o0[0], o0[1], o0[2], o0[3]);
-        *reinterpret_cast<uint4*>(dst + hd * 128 + 64 + h * 8) = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+        epi_store16(dst + hd * 128 + h * 8, make_uint4(o0[0], o0[1], o0[2], o0[3]));
+        epi_store16(dst + hd * 128 + 64 + h * 8, make_uint4(o1[0], o1[1], o1[2], o1[3]));
       }
     }
   }
