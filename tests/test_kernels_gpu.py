@@ -77,7 +77,9 @@ SHAPES = [(900, 1000, 512), (1024, 2304, 768), (1543, 300, 1024), (1, 128, 128),
           # 257-512 tokens: two 256-row token tiles per weight tile in the same mode
           (300, 12288, 640), (400, 8448, 256), (512, 9000, 384),
           # more than two tiles per CU, ragged last tiles
-          (4200, 8192, 256), (2100, 16700, 128), (8300, 4100, 384)]
+          (4200, 8192, 256), (2100, 16700, 128), (8300, 4100, 384),
+          # 16-byte epilogue stores (row stride % 8 == 0) with a last column tile that straddles N: per-wave fallback to element stores
+          (4200, 8200, 256)]
 
 
 @pytest.mark.parametrize("m,n,k", SHAPES)
@@ -95,7 +97,7 @@ def test_gemm_store_and_f32(lib, m, n, k, dtype):
     np.testing.assert_allclose(c.double().cpu().numpy(), ref.numpy(), atol=tol2, rtol=0)
 
 
-@pytest.mark.parametrize("m,n,k", [(7, 256, 128), (40, 768, 768), (228, 4096, 11008), (228, 4096, 4096), (1100, 768, 1024), (2000, 500, 256), (100, 8192, 512), (6400, 4096, 512), (8300, 4096, 512), (4500, 8192, 256)])
+@pytest.mark.parametrize("m,n,k", [(7, 256, 128), (40, 768, 768), (228, 4096, 11008), (228, 4096, 4096), (1100, 768, 1024), (2000, 500, 256), (100, 8192, 512), (6400, 4096, 512), (8300, 4096, 512), (4500, 8192, 256), (6400, 4104, 512)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_residual(lib, m, n, k, dtype):
     a = _rand((m, k), 3).to(dtype).cuda()
@@ -107,7 +109,7 @@ def test_gemm_residual(lib, m, n, k, dtype):
     np.testing.assert_allclose(c.double().cpu().numpy(), ref.numpy(), atol=tol, rtol=0)
 
 
-@pytest.mark.parametrize("m,ffn,k", [(3, 32, 64), (40, 352, 128), (228, 11008, 4096), (20, 3072, 768), (1300, 1376, 512), (800, 496, 256), (300, 4224, 256), (4200, 4224, 256)])
+@pytest.mark.parametrize("m,ffn,k", [(3, 32, 64), (40, 352, 128), (228, 11008, 4096), (20, 3072, 768), (1300, 1376, 512), (800, 496, 256), (300, 4224, 256), (4200, 4224, 256), (4200, 4240, 256)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_swiglu(lib, m, ffn, k, dtype):
     from atspeed_amd.model import _interleave_gate_up
