@@ -16,7 +16,7 @@ LIB_PATH = os.path.abspath(os.environ["ATSPEED_LIB"]) if os.environ.get("ATSPEED
 ATSPEED_F32, ATSPEED_BF16 = 0, 1
 WEIGHTS_ROW_MAJOR, WEIGHTS_PACKED = 0, 1
 MAX_BEAMS, MAX_NEW_TOKENS, MAX_GAMMA = 64, 16, 8
-ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_CONSTRAINT, ERR_NO_DEVICE = -1, -2, -3, -4, -5
+ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_CONSTRAINT, ERR_NO_DEVICE, ERR_FILTERED = -1, -2, -3, -4, -5, -6
 EPI_STORE, EPI_F32, EPI_RESID, EPI_SWIGLU = 0, 1, 2, 3
 
 
@@ -46,6 +46,10 @@ SIGNATURES = {
     "atspeed_fill_hash_normal": (C.c_int, [_P, _SZ, _U32, _F, _F, C.c_int, _U64, _P]),
     "atspeed_fsm_create": (C.c_int, [_P, _P, _P, _I, _I, _I, C.POINTER(_P)]),
     "atspeed_fsm_destroy": (None, [_P]),
+    "atspeed_fsm_create_free": (C.c_int, [_I, C.POINTER(_P)]),
+    "atspeed_fsm_set_id_filter": (C.c_int, [_P, _I, _I]),
+    "atspeed_row_topk": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
+    "atspeed_beam_expand_prune_free": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "atspeed_trie_flatten": (C.c_int, [_P, _P, _I, _P, _P, _P, C.POINTER(_I), C.POINTER(_I)]),
     "atspeed_llama_create": (C.c_int, [C.POINTER(LlamaConfig), _P, _P, _P, C.POINTER(LlamaLayerWeights), C.POINTER(_P)]),
     "atspeed_llama_destroy": (None, [_P]),
@@ -63,6 +67,7 @@ SIGNATURES = {
     "atspeed_llama_profile_big": (C.c_int, [_P, _P, _P, _P]),
     "atspeed_llama_logits_ld": (_I, [_P]),
     "atspeed_lse_rows": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "atspeed_log_softmax_rows": (C.c_int, [_P, _I, _P, _I, _I, _P, _I, _P]),
     "atspeed_lmhead_lse": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _SZ, C.POINTER(_I), _P]),
     "atspeed_beam_expand_prune": (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P]),
     "atspeed_accept": (C.c_int, [_P, _P, _I, _P, _I, _P, _P, _P, _P]),
@@ -73,7 +78,10 @@ SIGNATURES = {
     "atspeed_bssd_generate_batch": (C.c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "atspeed_target_generate": (C.c_int, [_P, _P, _I, _P, _I, _I, _I, _P, _P, C.POINTER(GenStats), _P]),
     "atspeed_target_generate_batch": (C.c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "atspeed_assemble_sequences": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "atspeed_decoder_trace": (C.c_int, [_P, _P, _I]),
+    "atspeed_decoder_set_trace": (C.c_int, [_P, _I]),
+    "atspeed_decoder_decisions": (C.c_int64, [_P, _P, C.c_int64]),
     "atspeed_gemm": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "atspeed_gemm_packed": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "atspeed_gemm_fp8_packed": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -18,8 +18,10 @@ Mask functions that can `compile()` (PositionSetConstraint, SuffixTrieConstraint
 as a device automaton; any other callable is served by `hostmask.py` the way the reference does it (one host call per
 beam per step, all arithmetic still in HIP).  `generation_config.do_sample` selects the sampling branch
 (beamSD.py:65-75,293-321,332-369) with counter-based draws (`seed=` or torch's generator picks the stream).
-Not on this path (raise): extra `logits_processor` entries (the reference always passes None, inference.py:175-176),
-no mask at all, sampling with a non-compilable mask callable.
+No mask at all (`prefix_allowed_tokens_fn=None`, legal in the reference: beamSD.py:460-481) runs on the device too: every token is a
+candidate, the id filter of :80-86 is off as in the reference.  Extra `logits_processor` entries (the reference always passes None,
+inference.py:175-176) are torch callables and are served by the host path: each step's log-softmax rows go through them between the
+library's forward and its expand + top-K.  Not on this path (raise): sampling with a host-side mask or processor.
 """
 from __future__ import annotations
 
@@ -32,7 +34,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .generation_trie import ConstraintFSM
+from .generation_trie import ConstraintFSM, free_constraint
 from .model import HipLlama
 
 
@@ -81,8 +83,13 @@ class _DeviceFSM:
         self.arrays = (np.ascontiguousarray(fsm.row_ptr, np.int32), np.ascontiguousarray(fsm.tok, np.int32),
                        np.ascontiguousarray(fsm.nxt, np.int32))
         h = C.c_void_p()
-        _lib.check(lib.atspeed_fsm_create(self.arrays[0].ctypes.data, self.arrays[1].ctypes.data, self.arrays[2].ctypes.data,
-                                          fsm.n_nodes, len(self.arrays[1]), vocab_size, C.byref(h)))
+        if fsm.free:
+            _lib.check(lib.atspeed_fsm_create_free(vocab_size, C.byref(h)))
+        else:
+            _lib.check(lib.atspeed_fsm_create(self.arrays[0].ctypes.data, self.arrays[1].ctypes.data, self.arrays[2].ctypes.data,
+                                              fsm.n_nodes, len(self.arrays[1]), vocab_size, C.byref(h)))
+        if fsm.id_filter is not None and not fsm.free:
+            _lib.check(lib.atspeed_fsm_set_id_filter(h, int(fsm.id_filter[0]), int(fsm.id_filter[1])))
         self.handle = h
         self.src = fsm.row_ptr       # keeps id() stable while cached
 
@@ -97,7 +104,7 @@ class _DeviceFSM:
 
     @classmethod
     def get(cls, fsm: ConstraintFSM, vocab_size: int) -> "_DeviceFSM":
-        key = (id(fsm.row_ptr), id(fsm.tok), vocab_size)
+        key = (id(fsm.row_ptr), id(fsm.tok), vocab_size, fsm.id_filter)
         d = cls._cache.get(key)
         if d is None or d.src is not fsm.row_ptr:
             d = cls(fsm, vocab_size)
@@ -166,11 +173,16 @@ def release_decoders(*models) -> int:
 
 
 def _compile_constraint(fn, prompt):
-    if fn is None:
-        raise NotImplementedError(
-            "unconstrained beam search is not on the MI355X hot path: the reference's harness always installs a "
-            "prefix_allowed_tokens_fn (code/inference.py:131,175)")
+    if fn is None:               # no mask: every token is a candidate (beamSD.py:469-478 builds an empty processor list)
+        return free_constraint()
     return fn.compile(prompt)
+
+
+def _host_path(logits_processor, prefix_allowed_tokens_fn) -> bool:
+    """True when a step must call back into Python: extra logits processors, or a mask callable that cannot compile() itself."""
+    if logits_processor is not None and len(logits_processor) != 0:
+        return True
+    return prefix_allowed_tokens_fn is not None and not hasattr(prefix_allowed_tokens_fn, "compile")
 
 
 def _prompt_lists(prompts):
@@ -212,6 +224,14 @@ def _set_sampling(decs, mode, per_user: bool = True):
         _lib.check(lib.atspeed_decoder_set_sampling(d.handle, 1 if do else 0, temp, (seed + (u if per_user else 0)) & 0xFFFFFFFF))
 
 
+def _set_trace(decs, on: bool):
+    lib = _lib.load()
+    for d in decs:
+        if getattr(d, "trace_on", False) != bool(on):
+            _lib.check(lib.atspeed_decoder_set_trace(d.handle, 1 if on else 0))
+            d.trace_on = bool(on)
+
+
 def _prompt_row(inputs) -> torch.Tensor:
     ids = inputs["input_ids"]
     if ids.dim() == 2:
@@ -225,18 +245,28 @@ def _batch_buffers(prompts, k: int, max_new_tokens: int, dev):
     lens = [int(p.numel()) for p in prompts]
     flat = torch.cat([p.reshape(-1) for p in prompts]).to(torch.int32)          # two kernels for the whole batch
     starts = [0]
-    for n_tok in lens[:-1]:
+    for n_tok in lens:
         starts.append(starts[-1] + n_tok)
     ids32 = [flat[s0: s0 + n_tok] for s0, n_tok in zip(starts, lens)]
     toks = torch.empty(len(prompts), k, max_new_tokens, dtype=torch.int32, device=dev)
     scores = torch.empty(len(prompts), k, dtype=torch.float32, device=dev)
-    return ids32, toks, scores, flat
+    return ids32, toks, scores, (flat, starts)
 
 
-def _batch_results(prompts, toks: torch.Tensor, scores: torch.Tensor, k: int):
-    toks64 = toks.to(torch.int64)                     # one conversion for all users; a user's rows are then one cat of two views
-    return [{"beam_sequence": torch.cat((p.to(torch.int64)[None, :].expand(k, -1), toks64[i]), dim=1), "beam_scores": scores[i]}
-            for i, p in enumerate(prompts)]
+def _batch_results(keep, toks: torch.Tensor, scores: torch.Tensor, k: int):
+    """`beam_sequence` [k, P + L] int64 of every user (prompt ++ suffix per beam, beamSD.py:87,383) as views of ONE buffer written by one
+    launch (atspeed_assemble_sequences) instead of a torch.cat per user."""
+    flat, starts = keep
+    n, L = toks.shape[0], toks.shape[2]
+    off = np.asarray(starts, dtype=np.int64)
+    out = torch.empty(k * (int(off[-1]) + n * L), dtype=torch.int64, device=toks.device)
+    _lib.check(_lib.load().atspeed_assemble_sequences(flat.data_ptr(), off.ctypes.data, toks.data_ptr(), n, k, L, out.data_ptr(),
+                                                      _lib.stream_ptr(toks.device)))
+    res = []
+    for i in range(n):
+        o0, P = k * (int(off[i]) + i * L), int(off[i + 1] - off[i])
+        res.append({"beam_sequence": out[o0: o0 + k * (P + L)].view(k, P + L), "beam_scores": scores[i]})
+    return res
 
 
 def _result(prompt: torch.Tensor, toks: torch.Tensor, scores: torch.Tensor, k: int) -> Dict:
@@ -247,27 +277,28 @@ def _result(prompt: torch.Tensor, toks: torch.Tensor, scores: torch.Tensor, k: i
 @Timer()
 @torch.no_grad()
 def BSSD(target_model, draft_model, inputs: Dict, gamma: int, max_new_tokens: int,
-         logits_processor=None, prefix_allowed_tokens_fn=None, seed=None) -> Dict:
+         logits_processor=None, prefix_allowed_tokens_fn=None, seed=None, trace_decisions: bool = False) -> Dict:
     _check_models(target_model, draft_model)
     mode = _sampling(target_model, seed)
-    if logits_processor is not None and len(logits_processor) != 0:
-        raise NotImplementedError("extra logits processors are not on this path (reference passes None)")
     lib = _lib.load()
     dev = target_model.device
     prompt = _prompt_row(inputs).to(dev)
     P = int(prompt.numel())
     k = int(target_model.generation_config.num_beams)                 # beamSD.py:482
     dk = int(draft_model.generation_config.num_beams)                 # beamSD.py:483
-    if prefix_allowed_tokens_fn is not None and not hasattr(prefix_allowed_tokens_fn, "compile"):
-        # arbitrary Python callable: served like the reference does, one host call per beam per step (hostmask.py)
+    if _host_path(logits_processor, prefix_allowed_tokens_fn):
+        # arbitrary Python callables (a mask closure, extra logits processors): served like the reference does, one host call per
+        # beam per step (hostmask.py); stage times are wall clock with a device sync, like the reference's Timer
         if mode[0]:
-            raise NotImplementedError("sampling needs a compilable constraint (PositionSetConstraint / SuffixTrieConstraint / Trie)")
+            raise NotImplementedError("sampling needs a compilable constraint (PositionSetConstraint / SuffixTrieConstraint / Trie) "
+                                      "and no extra logits processors")
         from .hostmask import bssd_host_mask
         r = bssd_host_mask(target_model, draft_model, prompt.cpu().numpy().astype(np.int64), int(gamma), int(max_new_tokens),
-                           prefix_allowed_tokens_fn)
+                           prefix_allowed_tokens_fn, list(logits_processor or ()))
         out = {"beam_sequence": torch.from_numpy(r["beam_sequence"]).to(dev), "beam_scores": torch.from_numpy(r["beam_scores"]).to(dev)}
-        out.update({kk: r[kk] for kk in ("n_run", "total_accept_steps", "total_accept_tokens", "ave_accept_tokens", "accept_steps")})
-        out.update({"draft_time_cost": 0.0, "target_time_cost": 0.0, "verify_time_cost": 0.0, "n_valid": int(len(r["beam_scores"]))})
+        out.update({kk: r[kk] for kk in ("n_run", "total_accept_steps", "total_accept_tokens", "ave_accept_tokens", "accept_steps",
+                                         "draft_time_cost", "target_time_cost", "verify_time_cost")})
+        out["n_valid"] = int(len(r["beam_scores"]))
         return out
     # the mask functions look at the prompt (position of "Response:", data.py:97-102): one D2H copy per
     # user, where the reference does one per beam per step (generation_trie.py:94, data.py:98)
@@ -275,6 +306,7 @@ def BSSD(target_model, draft_model, inputs: Dict, gamma: int, max_new_tokens: in
     dfsm = _DeviceFSM.get(fsm, target_model.dims.vocab_size)
     dec = _Decoder.get(target_model, draft_model, P)
     _set_sampling([dec], mode)
+    _set_trace([dec], trace_decisions)
     with torch.cuda.device(dev):
         ids32 = prompt.to(torch.int32).contiguous()
         toks = torch.empty(k, max_new_tokens, dtype=torch.int32, device=dev)
@@ -309,7 +341,7 @@ MAX_USERS_PER_CALL = 256
 
 @torch.no_grad()
 def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_tokens: int,
-               prefix_allowed_tokens_fn=None, seed=None):
+               prefix_allowed_tokens_fn=None, seed=None, trace_decisions: bool = False):
     """BSSD for several independent users at once (one result dict per user, same keys as BSSD).
 
     The reference decodes users strictly one after another (inference.py:162-176).  Here the users advance in
@@ -323,7 +355,7 @@ def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_token
         outs = []
         for i in range(0, len(inputs_list), MAX_USERS_PER_CALL):
             outs += BSSD_batch(target_model, draft_model, inputs_list[i:i + MAX_USERS_PER_CALL], gamma, max_new_tokens,
-                               prefix_allowed_tokens_fn, seed=(mode[2] + i) if mode[0] else None)
+                               prefix_allowed_tokens_fn, seed=(mode[2] + i) if mode[0] else None, trace_decisions=trace_decisions)
         return outs
     lib = _lib.load()
     dev = target_model.device
@@ -339,6 +371,7 @@ def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_token
             raise ValueError("BSSD_batch needs one shared constraint automaton (only the start node may differ per user)")
     decs = [_Decoder.get(target_model, draft_model, int(p.numel()), lane=i) for i, p in enumerate(prompts)]
     _set_sampling(decs, mode)
+    _set_trace(decs, trace_decisions)
     with torch.cuda.device(dev):
         ids32, toks, scores, _keep = _batch_buffers(prompts, k, max_new_tokens, dev)
         stats = (_lib.GenStats * n)()
@@ -350,7 +383,7 @@ def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_token
             arr_p(*[t.data_ptr() for t in scores]), stats, _lib.stream_ptr(dev)))
     wall = time.time() - t0
     outs = []
-    results = _batch_results(prompts, toks, scores, k)
+    results = _batch_results(_keep, toks, scores, k)
     for i in range(n):
         st = stats[i]
         out = results[i]
@@ -372,18 +405,18 @@ def target_generate(model, inputs: Dict, max_new_tokens: int, logits_processor=N
                     prefix_allowed_tokens_fn=None, seed=None) -> Dict:
     _check_models(model)
     mode = _sampling(model, seed)
-    if logits_processor is not None and len(logits_processor) != 0:
-        raise NotImplementedError("extra logits processors are not on this path (reference passes None)")
     lib = _lib.load()
     dev = model.device
     prompt = _prompt_row(inputs).to(dev)
     P = int(prompt.numel())
     k = int(model.generation_config.num_beams)                        # beamSD.py:553
-    if prefix_allowed_tokens_fn is not None and not hasattr(prefix_allowed_tokens_fn, "compile"):
+    if _host_path(logits_processor, prefix_allowed_tokens_fn):
         if mode[0]:
-            raise NotImplementedError("sampling needs a compilable constraint (PositionSetConstraint / SuffixTrieConstraint / Trie)")
+            raise NotImplementedError("sampling needs a compilable constraint (PositionSetConstraint / SuffixTrieConstraint / Trie) "
+                                      "and no extra logits processors")
         from .hostmask import target_generate_host_mask
-        r = target_generate_host_mask(model, prompt.cpu().numpy().astype(np.int64), int(max_new_tokens), prefix_allowed_tokens_fn)
+        r = target_generate_host_mask(model, prompt.cpu().numpy().astype(np.int64), int(max_new_tokens), prefix_allowed_tokens_fn,
+                                      list(logits_processor or ()))
         return {"beam_sequence": torch.from_numpy(r["beam_sequence"]).to(dev), "beam_scores": torch.from_numpy(r["beam_scores"]).to(dev),
                 "n_valid": int(len(r["beam_scores"]))}
     fsm = _compile_constraint(prefix_allowed_tokens_fn, prompt.tolist())
@@ -439,7 +472,7 @@ def target_generate_batch(model, inputs_list, max_new_tokens: int, prefix_allowe
             _lib.stream_ptr(dev)))
     wall = time.time() - t0
     outs = []
-    results = _batch_results(prompts, toks, scores, k)
+    results = _batch_results(_keep, toks, scores, k)
     for i in range(n):
         out = results[i]
         out.update({"n_valid": int(stats[i].n_valid), "device_time_cost": stats[i].total_ms * 1e-3, "time_cost": wall / n})
@@ -463,4 +496,50 @@ def last_trace(target_model, draft_model):
         ids = [[int(buf[i + s * dk + j]) for j in range(dk)] for s in range(dl)]
         i += dl * dk
         rounds.append(dict(draft_len=int(dl), n_matches=int(nm), n_beams=int(nb), draft_ids=ids))
+    return rounds
+
+
+def last_decisions(target_model, draft_model, lane: int = 0):
+    """Decision trace of the last BSSD / BSSD_batch call made with `trace_decisions=True` for the user in `lane`
+    (`atspeed_decoder_decisions`): one dict per round with the beams the round started from, the draft's blocks, the target's picks of
+    every verify step (the decisions of beamSD.py:297-298,323-328) and n_matches; a final single step (beamSD.py:505-509) is a round
+    of kind "final".  Sequences are the generated suffixes (lists of token ids), scores fp32."""
+    lib = _lib.load()
+    dec = _Decoder._cache[(id(target_model), id(draft_model) if draft_model is not None else None, lane)]
+    n = int(lib.atspeed_decoder_decisions(dec.handle, None, 0))
+    buf = np.zeros(max(n, 1), dtype=np.int32)
+    lib.atspeed_decoder_decisions(dec.handle, buf.ctypes.data, n)
+    B, L, G1 = _lib.MAX_BEAMS, _lib.MAX_NEW_TOKENS, _lib.MAX_GAMMA + 1
+    bw = 5 * B + B * L
+
+    def block(words, n_valid, seq_len):
+        sc = words[:B].view(np.float32)
+        parent, tok, flat = words[2 * B: 3 * B], words[3 * B: 4 * B], words[4 * B: 5 * B]
+        seq = words[5 * B:].reshape(B, L)
+        rows = [j for j in range(n_valid) if flat[j] >= 0]
+        return dict(score=[float(sc[j]) for j in rows], seq=[[int(t) for t in seq[j, :seq_len]] for j in rows],
+                    parent=[int(parent[j]) for j in rows], tok=[int(tok[j]) for j in rows], index=rows)
+
+    rounds, i = [], 0
+    while i < n:
+        kind, nb, dl, nm, gen0, k, dk, nblk = (int(x) for x in buf[i: i + 8])
+        i += 8
+        blocks = [buf[i + b * bw: i + (b + 1) * bw] for b in range(nblk)]
+        i += nblk * bw
+        if kind == 1:
+            rounds.append(dict(kind="final", gen0=gen0, k=k, parents=block(blocks[0], nb, gen0), result=block(blocks[1], k, gen0 + 1)))
+            continue
+        vt = buf[i: i + G1 * 3 * B].reshape(G1, 3, B)
+        i += G1 * 3 * B
+        start = block(blocks[0], nb, gen0)
+        draft = [block(blocks[s], dk, gen0 + s) for s in range(1, dl + 1)]
+        picks = []
+        for s in range(nm + 1):
+            src_full = blocks[s][5 * B:].reshape(B, L)
+            sc, par, tok = vt[s, 0].view(np.float32), vt[s, 1], vt[s, 2]
+            rows = [j for j in range(k) if tok[j] >= 0]
+            picks.append(dict(score=[float(sc[j]) for j in rows], parent=[int(par[j]) for j in rows], tok=[int(tok[j]) for j in rows],
+                              seq=[[int(t) for t in src_full[par[j], :gen0 + s]] + [int(tok[j])] for j in rows]))
+        rounds.append(dict(kind="verify", gen0=gen0, k=k, dk=dk, draft_len=dl, n_matches=nm, start=start, draft=draft, picks=picks,
+                           result=block(blocks[dl + 1], k, gen0 + nm + 1)))
     return rounds

@@ -45,15 +45,18 @@ void atspeed_set_error(const char* fmt, ...);
 
 // per-(thread, device) state: one process may drive several GPUs from one thread, so staging buffers, events and the
 // "function attribute set" flags are kept per HIP device, selected by the device current at the call
-constexpr int ATS_MAX_DEVICES = 16;
+constexpr int ATS_MAX_DEVICES = 64;
+// index of the current HIP device in the per-device tables, or -1 when hipGetDevice fails or the id is beyond the tables: callers
+// must not alias another device's staging memory / events (they return ATSPEED_ERR_NO_DEVICE)
 inline int ats_cur_device() {
   int d = 0;
-  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= ATS_MAX_DEVICES) d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= ATS_MAX_DEVICES) return -1;
   return d;
 }
 struct AtsPerDeviceFlag {
   bool done[ATS_MAX_DEVICES] = {};
-  bool& cur() { return done[ats_cur_device()]; }
+  bool never = false;                 // unknown device: "not done yet" every time (the attribute call is simply repeated)
+  bool& cur() { const int d = ats_cur_device(); if (d < 0) { never = false; return never; } return done[d]; }
 };
 
 // ---------------------------------------------------------------- packed GEMM-operand layout

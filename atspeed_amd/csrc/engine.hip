@@ -45,7 +45,9 @@ constexpr size_t kStageBytes = 8u << 20;
 }  // namespace
 
 int ats_stage(const void* host_obj, size_t bytes, const void** dev_out, hipStream_t st) {
-  StageRing& r = g_stage_dev[ats_cur_device()];
+  const int dev = ats_cur_device();
+  ATS_REQUIRE(dev >= 0, ATSPEED_ERR_NO_DEVICE, "staging: no current HIP device, or its id is >= %d", ATS_MAX_DEVICES);
+  StageRing& r = g_stage_dev[dev];
   if (!r.host) {
     ATS_HIP(hipHostMalloc((void**)&r.host, kStageBytes));
     ATS_HIP(hipMalloc((void**)&r.dev, kStageBytes));
@@ -62,7 +64,9 @@ int ats_stage(const void* host_obj, size_t bytes, const void** dev_out, hipStrea
 }
 // the same through the pinned ring, but to a device address of the caller's choice
 int ats_stage_to(const void* host_obj, size_t bytes, void* dev_dst, hipStream_t st) {
-  StageRing& r = g_stage_dev[ats_cur_device()];
+  const int dev = ats_cur_device();
+  ATS_REQUIRE(dev >= 0, ATSPEED_ERR_NO_DEVICE, "staging: no current HIP device, or its id is >= %d", ATS_MAX_DEVICES);
+  StageRing& r = g_stage_dev[dev];
   if (!r.host) {
     ATS_HIP(hipHostMalloc((void**)&r.host, kStageBytes));
     ATS_HIP(hipMalloc((void**)&r.dev, kStageBytes));
@@ -76,7 +80,7 @@ int ats_stage_to(const void* host_obj, size_t bytes, void* dev_dst, hipStream_t 
   r.used += need;
   return ATSPEED_OK;
 }
-void ats_stage_reset() { g_stage_dev[ats_cur_device()].used = 0; }
+void ats_stage_reset() { const int dev = ats_cur_device(); if (dev >= 0) g_stage_dev[dev].used = 0; }
 
 // ---------------------------------------------------------------------------- FSM
 extern "C" int atspeed_fsm_create(const int32_t* row_ptr, const int32_t* tok, const int32_t* nxt, int32_t n_nodes,
@@ -103,14 +107,37 @@ extern "C" int atspeed_fsm_create(const int32_t* row_ptr, const int32_t* tok, co
     ATS_HIP(hipMemcpy(f->d_tok, tok, (size_t)n_edges * sizeof(int32_t), hipMemcpyHostToDevice));
     ATS_HIP(hipMemcpy(f->d_nxt, nxt, (size_t)n_edges * sizeof(int32_t), hipMemcpyHostToDevice));
   }
-  f->dev = FsmDev{f->d_row_ptr, f->d_tok, f->d_nxt, n_nodes, n_edges, vocab_size};
+  f->dev = FsmDev{f->d_row_ptr, f->d_tok, f->d_nxt, n_nodes, n_edges, vocab_size, 32000, 2};     // id filter of beamSD.py:80-86
   // which 256-column tiles of a logit row a step can ever read: the fused lm_head epilogue stores only those (gemm.hip EPI_F32_LSE)
-  unsigned char tiles[256];
-  memset(tiles, 0, sizeof(tiles));
-  for (int e = 0; e < n_edges; ++e) if (tok[e] / 256 < 256) tiles[tok[e] / 256] = 1;
-  ATS_HIP(hipMalloc((void**)&f->d_tile_store, sizeof(tiles)));
-  ATS_HIP(hipMemcpy(f->d_tile_store, tiles, sizeof(tiles), hipMemcpyHostToDevice));
+  // one byte per 256-column tile of THIS vocabulary (the epilogue indexes it with every tile of the lm_head's grid)
+  std::vector<unsigned char> tiles((size_t)(vocab_size + 255) / 256, 0);
+  for (int e = 0; e < n_edges; ++e) tiles[tok[e] / 256] = 1;
+  ATS_HIP(hipMalloc((void**)&f->d_tile_store, tiles.size()));
+  ATS_HIP(hipMemcpy(f->d_tile_store, tiles.data(), tiles.size(), hipMemcpyHostToDevice));
   *out = f;
+  return ATSPEED_OK;
+}
+
+// "no mask": BSSD(..., prefix_allowed_tokens_fn=None) with an empty processor list (beamSD.py:469-478 builds no processor, :60-64 is
+// the identity, :80-86 is skipped): every token of the vocabulary is a candidate of every beam
+extern "C" int atspeed_fsm_create_free(int32_t vocab_size, atspeed_fsm** out) {
+  ATS_REQUIRE(out && vocab_size > 0, ATSPEED_ERR_INVALID, "fsm_create_free: bad arguments");
+  ATS_REQUIRE((int64_t)ATSPEED_MAX_BEAMS * vocab_size < (int64_t)0x7fffffff, ATSPEED_ERR_CAPACITY, "fsm_create_free: vocab too large for 32-bit flat ids");
+  atspeed_fsm* f = new atspeed_fsm();
+  memset(f, 0, sizeof(*f));
+  f->dev = FsmDev{nullptr, nullptr, nullptr, 0, 0, vocab_size, 0, -1};
+  std::vector<unsigned char> tiles((size_t)(vocab_size + 255) / 256, 1);      // every logit tile can be read
+  ATS_HIP(hipMalloc((void**)&f->d_tile_store, tiles.size()));
+  ATS_HIP(hipMemcpy(f->d_tile_store, tiles.data(), tiles.size(), hipMemcpyHostToDevice));
+  *out = f;
+  return ATSPEED_OK;
+}
+
+extern "C" int atspeed_fsm_set_id_filter(atspeed_fsm* f, int32_t min_item_token, int32_t eos_token) {
+  ATS_REQUIRE(f, ATSPEED_ERR_INVALID, "fsm_set_id_filter: null automaton");
+  ATS_REQUIRE(f->dev.n_nodes > 0, ATSPEED_ERR_INVALID, "fsm_set_id_filter: a mask-free automaton has no id filter (beamSD.py:80 applies it only with a processor)");
+  f->dev.filter_min = min_item_token;
+  f->dev.filter_eos = eos_token;
   return ATSPEED_OK;
 }
 
@@ -170,6 +197,7 @@ struct ActCtx {
   float* logits = nullptr;                       // [cap_rows][logits_ld]
   float* lse = nullptr;                          // [cap_rows]
   float* lse_part = nullptr; size_t lse_part_bytes = 0;   // [cap_rows][vocab tiles] (max, sum exp) partials of the fused lm_head epilogue
+  int32_t* row_cand = nullptr;                   // [cap_rows][ATSPEED_MAX_BEAMS] best tokens per logit row (mask-free search only)
   RowInfo* rowinfo = nullptr;                    // [cap_tok] cache / slot / rotation of each batched row (qkv projection's fused epilogue)
   void* xq = nullptr; float* sx = nullptr;       // fp8 activations [cap_tok][max(hidden, ffn)] + per-token scales
   void* ws = nullptr; size_t ws_bytes = 0;       // split-K slabs
@@ -258,6 +286,7 @@ static void act_free(ActCtx* cx) {
   if (!cx) return;
   hipFree(cx->h); hipFree(cx->xn); hipFree(cx->qkv); hipFree(cx->att); hipFree(cx->act); hipFree(cx->gath);
   hipFree(cx->logits); hipFree(cx->lse); hipFree(cx->lse_part); hipFree(cx->ws); hipFree(cx->xq); hipFree(cx->sx); hipFree(cx->rowinfo);
+  hipFree(cx->row_cand);
   for (hipEvent_t e : cx->prof_ev) hipEventDestroy(e);
   for (auto& g : cx->graphs) hipGraphExecDestroy(g.second);
   if (cx->cap_stream) hipStreamDestroy(cx->cap_stream);
@@ -273,8 +302,9 @@ static int ensure_act(atspeed_llama* m, int tok, int rows) {
   ActCtx* cx = new ActCtx();
   // 25 % headroom: the next batch's token count differs by a few prompt tokens, and growing costs a device synchronisation plus
   // the re-allocation of every activation buffer (seen as 30-40 ms hiccups inside timed regions)
-  cx->cap_tok = std::max((tok + tok / 4 + 255) / 256 * 256, c.max_tokens);
-  cx->cap_rows = std::max((rows + rows / 4 + 63) / 64 * 64, c.max_logit_rows);
+  // even counts: the packed operand layout stores row pairs, a last row with an even index still owns a full 128-byte line pair
+  cx->cap_tok = (std::max((tok + tok / 4 + 255) / 256 * 256, c.max_tokens) + 1) & ~1;
+  cx->cap_rows = (std::max((rows + rows / 4 + 63) / 64 * 64, c.max_logit_rows) + 1) & ~1;
   size_t T = cx->cap_tok, H = c.hidden, e = m->esz;
   ATS_HIP(hipMalloc(&cx->h, T * H * e));
   ATS_HIP(hipMalloc(&cx->xn, T * H * e));
@@ -284,6 +314,7 @@ static int ensure_act(atspeed_llama* m, int tok, int rows) {
   ATS_HIP(hipMalloc(&cx->gath, (size_t)cx->cap_rows * H * e));
   ATS_HIP(hipMalloc((void**)&cx->logits, (size_t)cx->cap_rows * m->logits_ld * sizeof(float)));
   ATS_HIP(hipMalloc((void**)&cx->lse, (size_t)cx->cap_rows * sizeof(float)));
+  ATS_HIP(hipMalloc((void**)&cx->row_cand, (size_t)cx->cap_rows * ATSPEED_MAX_BEAMS * sizeof(int32_t)));
   cx->lse_part_bytes = ats_lmhead_lse_part_bytes(cx->cap_rows, c.vocab_size);
   ATS_HIP(hipMalloc((void**)&cx->lse_part, cx->lse_part_bytes));
   ATS_HIP(hipMalloc(&cx->xq, T * (size_t)std::max(c.hidden, c.ffn)));
@@ -688,6 +719,13 @@ struct atspeed_decoder {
   Mailbox* mail_host;       // pinned
   int32_t* trace_host;      // pinned: per round [dl][MAXB] draft flat ids
   std::vector<int32_t> trace;   // rounds: {dl, n_matches, nb, flat ids...}
+  // decision trace (atspeed_decoder_set_trace level 1): after every round the whole beam area (round beams, draft blocks) and the
+  // verify walk's picks travel to the host; one record per round in `decisions` (format: include/atspeed_hip.h)
+  int trace_level = 0;
+  char* beam_area = nullptr; size_t beam_area_bytes = 0, bs_bytes = 0;
+  int32_t* vtrace_dev = nullptr;
+  char* dump_host = nullptr;    // pinned, beam_area_bytes (allocated on first use)
+  std::vector<int32_t> decisions;
   // sampling mode (atspeed_decoder_set_sampling): off by default = the greedy path of every BASELINE config
   bool sample = false; float temperature = 1.f; uint32_t seed = 0;
   float* tab_score = nullptr;   // [ATSPEED_MAX_GAMMA][ATS_MAX_CAND] the draft's candidate scores per step (allocated on first use)
@@ -734,16 +772,19 @@ extern "C" int atspeed_decoder_create(atspeed_llama* target, atspeed_llama* draf
   d->tok_cap = max_prompt + ATSPEED_MAX_GAMMA * MAXB + MAXB;
   size_t tb_bytes = 3 * align_up((size_t)d->tok_cap * 4, 256) + align_up((size_t)d->tok_cap * d->W * 8, 256);
   size_t bs_bytes = 5 * 256 + align_up((size_t)MAXB * LMAX * 4, 256);
-  size_t total = 3 * tb_bytes + (2 + NBLK) * bs_bytes + 256;
+  size_t vt_bytes = align_up((size_t)NBLK * 3 * MAXB * sizeof(int32_t), 256);
+  size_t total = 3 * tb_bytes + (2 + NBLK) * bs_bytes + vt_bytes + 256;
   ATS_HIP(hipMalloc((void**)&d->arena, total));
   ATS_HIP(hipMemset(d->arena, 0, total));
   char* p = d->arena;
   carve_tokbuf(p, d->tin[0], d->tok_cap, d->W);
   carve_tokbuf(p, d->tin[1], d->tok_cap, d->W);
   carve_tokbuf(p, d->dround, d->tok_cap, d->W);
+  d->beam_area = p; d->bs_bytes = bs_bytes; d->beam_area_bytes = (2 + NBLK) * bs_bytes + vt_bytes;
   carve_beams(p, d->round_beams[0]);
   carve_beams(p, d->round_beams[1]);
   for (int i = 0; i < NBLK; ++i) carve_beams(p, d->blk[i]);
+  d->vtrace_dev = (int32_t*)p; p += vt_bytes;
   p += 256;
   // the mailbox is pinned host memory the kernels write directly (16 bytes per round over PCIe): the host reads it after the
   // round's stream synchronisation, no copy to enqueue per user
@@ -764,6 +805,7 @@ extern "C" void atspeed_decoder_destroy(atspeed_decoder* d) {
   hipFree(d->arena);
   hipHostFree(d->mail_host);
   hipHostFree(d->trace_host);
+  if (d->dump_host) hipHostFree(d->dump_host);
   delete d;
 }
 
@@ -777,6 +819,37 @@ extern "C" int atspeed_decoder_set_sampling(atspeed_decoder* d, int32_t do_sampl
     ATS_HIP(hipMalloc((void**)&d->tab_lse, sizeof(float) * ATSPEED_MAX_GAMMA));
   }
   return ATSPEED_OK;
+}
+
+extern "C" int atspeed_decoder_set_trace(atspeed_decoder* d, int32_t level) {
+  ATS_REQUIRE(d && (level == 0 || level == 1), ATSPEED_ERR_INVALID, "set_trace: level must be 0 or 1");
+  if (level == 1 && !d->dump_host) ATS_HIP(hipHostMalloc((void**)&d->dump_host, d->beam_area_bytes));
+  d->trace_level = level;
+  return ATSPEED_OK;
+}
+
+extern "C" int64_t atspeed_decoder_decisions(atspeed_decoder* d, int32_t* out, int64_t cap_words) {
+  if (!d) return 0;
+  const int64_t n = (int64_t)d->decisions.size();
+  if (out && cap_words > 0) memcpy(out, d->decisions.data(), sizeof(int32_t) * (size_t)std::min(n, cap_words));
+  return n;
+}
+
+// one record of the decision trace from the host copy of the beam area: header {kind, nb, dl, nm, gen0, k, dk, n_blocks}, the blocks
+// (beam-set images in arena order: score, node, parent, tok, flat [MAXB] each, seq [MAXB][LMAX]) and, for a verify round, the walk's picks
+static void decisions_append(atspeed_decoder* d, int kind, int nb, int dl, int nm, int gen0, int k, int dk, const std::vector<int>& blocks) {
+  std::vector<int32_t>& v = d->decisions;
+  const int32_t hdr[8] = {kind, nb, dl, nm, gen0, k, dk, (int32_t)blocks.size()};
+  v.insert(v.end(), hdr, hdr + 8);
+  const size_t bw = d->bs_bytes / 4;
+  for (int b : blocks) {
+    const int32_t* src = (const int32_t*)(d->dump_host + (size_t)b * d->bs_bytes);
+    v.insert(v.end(), src, src + bw);
+  }
+  if (kind == 0) {
+    const int32_t* vt = (const int32_t*)(d->dump_host + (size_t)(2 + NBLK) * d->bs_bytes);
+    v.insert(v.end(), vt, vt + (size_t)NBLK * 3 * MAXB);
+  }
 }
 
 static TokBuf tb_offset(const TokBuf& t, int row, int W) {
@@ -793,7 +866,8 @@ static int check_common(atspeed_decoder* d, const int32_t* prompt, int P, const 
   ATS_REQUIRE(k >= 1 && k <= MAXB, ATSPEED_ERR_CAPACITY, "generate: beam size %d out of [1,%d]", k, MAXB);
   ATS_REQUIRE(fsm->dev.vocab == d->target->cfg.vocab_size, ATSPEED_ERR_INVALID, "generate: constraint vocab %d != model vocab %d",
               fsm->dev.vocab, d->target->cfg.vocab_size);
-  ATS_REQUIRE(start_node >= 0 && start_node < fsm->dev.n_nodes, ATSPEED_ERR_INVALID, "generate: start node out of range");
+  ATS_REQUIRE(start_node >= 0 && start_node < std::max(fsm->dev.n_nodes, 1), ATSPEED_ERR_INVALID, "generate: start node out of range");
+  ATS_REQUIRE(!(d->sample && fsm->dev.n_nodes == 0), ATSPEED_ERR_INVALID, "generate: sampling needs a constraint automaton (mask-free search is greedy only)");
   return ATSPEED_OK;
 }
 
@@ -801,6 +875,12 @@ static int mailbox_status(atspeed_decoder* d) {
   if (d->mail_host->status == ATSPEED_ERR_CONSTRAINT) {
     atspeed_set_error("`prefix_allowed_tokens_fn` returned an empty list for batch ID 0. This means that the constraint is unsatisfiable.");
     return ATSPEED_ERR_CONSTRAINT;
+  }
+  if (d->mail_host->status == ATSPEED_ERR_FILTERED) {
+    atspeed_set_error("every beam of a step was dropped by the post-top-k id filter (tokens below %d other than %d, beamSD.py:80-86): "
+                      "set the automaton's thresholds with atspeed_fsm_set_id_filter", d->run.fsm ? d->run.fsm->dev.filter_min : 32000,
+                      d->run.fsm ? d->run.fsm->dev.filter_eos : 2);
+    return ATSPEED_ERR_FILTERED;
   }
   if (d->mail_host->status != 0) {
     atspeed_set_error("decoder: device status %d (candidate capacity exceeded?)", d->mail_host->status);
@@ -813,7 +893,9 @@ static int mailbox_status(atspeed_decoder* d) {
 struct StageEvents { hipEvent_t ev[8]; bool init = false; };
 static thread_local StageEvents g_ev_dev[ATS_MAX_DEVICES];    // stage-time events, per device
 static int stage_events(hipEvent_t** out) {
-  StageEvents& s = g_ev_dev[ats_cur_device()];
+  const int dev = ats_cur_device();
+  ATS_REQUIRE(dev >= 0, ATSPEED_ERR_NO_DEVICE, "stage events: no current HIP device, or its id is >= %d", ATS_MAX_DEVICES);
+  StageEvents& s = g_ev_dev[dev];
   if (!s.init) { for (auto& e : s.ev) ATS_HIP(hipEventCreate(&e)); s.init = true; }
   *out = s.ev;
   return ATSPEED_OK;
@@ -856,9 +938,24 @@ static int seg_finish(SegTable& t) {
   return ATSPEED_OK;
 }
 
+// prompts of every user of a batch -> token buffers, start beams and mailboxes, one launch
+static int init_prompts_multi(atspeed_decoder** decs, int n, const int32_t* const* prompts, const int32_t* prompt_lens, const int32_t* start_nodes,
+                              hipStream_t st) {
+  std::vector<InitPromptArgs> ia(n);
+  int max_p = 1;
+  for (int u = 0; u < n; ++u) {
+    atspeed_decoder* d = decs[u];
+    ia[u] = InitPromptArgs{d->tin[0], prompts[u], prompt_lens[u], start_nodes[u], d->round_beams[0], d->mail_dev};
+    max_p = std::max(max_p, (int)prompt_lens[u]);
+  }
+  const InitPromptArgs* dev = nullptr;
+  ATS_TRY(stage_args(ia, &dev, st));
+  return ats_init_prompt_multi(dev, n, max_p, decs[0]->W, decs[0]->target->cfg.vocab_size, st);
+}
+
 static int bssd_begin(atspeed_decoder* d, const int32_t* prompt, int P, const atspeed_fsm* fsm, int start_node, int gamma,
                       int max_new, int k, int dk, int32_t* out_tokens, float* out_scores, atspeed_gen_stats* stats,
-                      hipStream_t st) {
+                      hipStream_t st, bool init_prompt = true) {
   ATS_TRY(check_common(d, prompt, P, fsm, start_node, max_new, k, out_tokens, out_scores));
   ATS_REQUIRE(d->draft, ATSPEED_ERR_INVALID, "bssd: decoder was created without a draft model");
   ATS_REQUIRE(dk >= k && dk <= MAXB, ATSPEED_ERR_CAPACITY, "bssd: draft beam size %d must be in [k=%d, %d]", dk, k, MAXB);
@@ -870,7 +967,8 @@ static int bssd_begin(atspeed_decoder* d, const int32_t* prompt, int P, const at
   r.cur = 0; r.gen = 0; r.base = 0; r.n0 = P; r.nb = 1; r.dl = 0;
   r.reingest = false; r.final_step = false; r.export_only = false; r.done = false;
   d->trace.clear();
-  ATS_TRY(ats_init_prompt(d->tin[0], prompt, P, d->W, d->round_beams[0], start_node, d->target->cfg.vocab_size, d->mail_dev, st));
+  d->decisions.clear();
+  if (init_prompt) ATS_TRY(ats_init_prompt(d->tin[0], prompt, P, d->W, d->round_beams[0], start_node, d->target->cfg.vocab_size, d->mail_dev, st));
   return ATSPEED_OK;
 }
 
@@ -928,6 +1026,8 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
       }
       ATS_TRY(seg_finish(t));
       ATS_TRY(llama_forward_segs(D, t, nullptr, st, decs[0]->run.fsm->d_tile_store));
+      const bool free_fsm = decs[0]->run.fsm->dev.n_nodes == 0;
+      if (free_fsm) ATS_TRY(ats_row_topk(D->act->logits, t.total_logit, D->cfg.vocab_size, D->logits_ld, decs[0]->run.dk, D->act->row_cand, st));
       for (size_t j = 0; j < us.size(); ++j) {
         atspeed_decoder* d = us[j];
         atspeed_decoder::Run& r = d->run;
@@ -936,7 +1036,8 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
         a.src = i == 0 ? d->round_beams[r.cur] : d->blk[i]; a.n_src = t.seg[j].n_logit; a.gen_len = r.gen + i;
         a.logits = D->act->logits + (size_t)t.seg[j].logit_row0 * D->logits_ld; a.ld = D->logits_ld;
         a.lse = D->act->lse + t.seg[j].logit_row0; a.fsm = r.fsm->dev; a.k = r.dk;
-        a.dst = d->blk[i + 1]; a.emit = 1; a.filter_ids = 1;
+        a.dst = d->blk[i + 1]; a.emit = 1; a.filter_ids = free_fsm ? 0 : 1;
+        a.row_cand = D->act->row_cand + (size_t)t.seg[j].logit_row0 * ATSPEED_MAX_BEAMS; a.n_row_cand = r.dk;
         a.in = tin; a.in_row0 = i == 0 ? r.n0 - r.nb : r.n0 + (i - 1) * r.dk;
         a.out = tin; a.out_row0 = r.n0 + i * r.dk; a.out_slot0 = r.base + r.n0 + i * r.dk; a.vis_words = W;
         a.mail = d->mail_dev;
@@ -968,6 +1069,8 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
       }
       ATS_TRY(seg_finish(t));
       ATS_TRY(llama_forward_segs(T, t, nullptr, st, decs[0]->run.fsm->d_tile_store));
+      const bool free_fsm = decs[0]->run.fsm->dev.n_nodes == 0;
+      if (free_fsm) ATS_TRY(ats_row_topk(T->act->logits, t.total_logit, T->cfg.vocab_size, T->logits_ld, decs[0]->run.k, T->act->row_cand, st));
       hipEventRecord(g_ev[2], st);
       // ---- 3. verify (:242-456) for the verifying users, one workgroup each
       std::vector<VerifyArgs> vargs;
@@ -980,8 +1083,10 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
         va.nb = r.nb; va.dl = r.dl; va.k = r.k; va.dk = r.dk; va.gen_len0 = r.gen;
         va.logits = T->act->logits + (size_t)t.seg[j].logit_row0 * T->logits_ld; va.ld = T->logits_ld;
         va.lse = T->act->lse + t.seg[j].logit_row0; va.fsm = r.fsm->dev;
+        va.row_cand = T->act->row_cand + (size_t)t.seg[j].logit_row0 * ATSPEED_MAX_BEAMS; va.n_row_cand = r.k;
         va.cur = d->tin[r.cur]; va.n0 = r.n0; va.next = d->tin[r.cur ^ 1]; va.dnext = d->dround; va.vis_words = W;
         va.res = d->round_beams[r.cur ^ 1]; va.mail = d->mail_dev;
+        va.vtrace = (d->trace_level >= 1 && !d->sample) ? d->vtrace_dev : nullptr;
         if (d->sample) {
           va.sample = 1; va.temperature = d->temperature; va.seed = d->seed; va.round = r.s.n_run;
           for (int i = 0; i < r.dl; ++i) {
@@ -1005,7 +1110,8 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
         a.src = d->round_beams[r.cur]; a.n_src = r.nb; a.gen_len = r.gen;
         a.logits = T->act->logits + (size_t)sg.logit_row0 * T->logits_ld; a.ld = T->logits_ld;
         a.lse = T->act->lse + sg.logit_row0; a.fsm = r.fsm->dev; a.k = r.k;
-        a.dst = d->round_beams[r.cur ^ 1]; a.emit = 0; a.filter_ids = 1; a.mail = d->mail_dev; a.vis_words = W;
+        a.dst = d->round_beams[r.cur ^ 1]; a.emit = 0; a.filter_ids = free_fsm ? 0 : 1; a.mail = d->mail_dev; a.vis_words = W;
+        a.row_cand = T->act->row_cand + (size_t)sg.logit_row0 * ATSPEED_MAX_BEAMS; a.n_row_cand = r.k;
         if (d->sample) { a.sample = 1; a.temperature = d->temperature; a.rng_sub = ats_rng_sub(d->seed, ATS_RNG_STEP, r.s.n_run, 0, 0); }
         fargs.push_back(a);
       }
@@ -1020,14 +1126,28 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
     }
     hipEventRecord(g_ev[3], st);
     // ---- 4. outputs of finished users, mailboxes, the round's single synchronisation
+    std::vector<ExportBeamsArgs> ex;                  // users finishing this round: one export launch for all of them
+    for (int u = 0; u < n; ++u) {
+      atspeed_decoder* d = decs[u];
+      atspeed_decoder::Run& r = d->run;
+      if (!r.done && r.final_step) ex.push_back(ExportBeamsArgs{d->round_beams[r.cur], r.out_tokens, r.out_scores, d->sample ? 1 : 0});
+    }
+    if (ex.size() == 1) ATS_TRY(ats_export_beams(ex[0].b, decs[0]->run.k, decs[0]->run.max_new, ex[0].out_tokens, ex[0].out_scores, st, ex[0].sort_desc != 0));
+    else if (!ex.empty()) {
+      const ExportBeamsArgs* de = nullptr;
+      ATS_TRY(stage_args(ex, &de, st));
+      ATS_TRY(ats_export_beams_multi(de, (int)ex.size(), decs[0]->run.k, decs[0]->run.max_new, st));
+    }
     for (int u = 0; u < n; ++u) {
       atspeed_decoder* d = decs[u];
       atspeed_decoder::Run& r = d->run;
       if (r.done) continue;
-      if (r.final_step) ATS_TRY(ats_export_beams(d->round_beams[r.cur], r.k, r.max_new, r.out_tokens, r.out_scores, st, d->sample));
+      if (r.final_step) {}
       else if (n <= 4)                      // trace of the draft's flat ids (parity tests drive one user at a time; batches skip the copies)
         for (int i = 1; i <= r.dl; ++i)
           ATS_HIP(hipMemcpyAsync(d->trace_host + (i - 1) * MAXB, d->blk[i].flat, sizeof(int32_t) * r.dk, hipMemcpyDeviceToHost, st));
+      if (d->trace_level >= 1 && !r.export_only)
+        ATS_HIP(hipMemcpyAsync(d->dump_host, d->beam_area, d->beam_area_bytes, hipMemcpyDeviceToHost, st));
     }
     ATS_HIP(hipStreamSynchronize(st));
     ats_stage_reset();
@@ -1046,6 +1166,8 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
       // stage times: the group's stage time shared equally by the users that were active in the round
       r.s.draft_ms += ms_d / n_act; r.s.target_ms += ms_t / n_act; r.s.verify_ms += ms_v / n_act;
       if (r.final_step) {
+        // `cur` was flipped when the step was launched: the parents are round_beams[cur ^ 1], the result round_beams[cur]
+        if (d->trace_level >= 1 && !r.export_only) decisions_append(d, 1, r.nb, 0, 0, r.gen - 1, r.k, r.dk, {r.cur ^ 1, r.cur});
         r.s.n_valid = d->mail_host->n_valid;
         r.s.total_ms = r.s.draft_ms + r.s.target_ms + r.s.verify_ms;
         if (r.stats_out) *r.stats_out = r.s;
@@ -1056,6 +1178,12 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
       if (n <= 4) {
         d->trace.push_back(dl); d->trace.push_back(nm); d->trace.push_back(r.nb);
         for (int i = 0; i < dl; ++i) for (int j = 0; j < dk; ++j) d->trace.push_back(d->trace_host[i * MAXB + j]);
+      }
+      if (d->trace_level >= 1) {
+        std::vector<int> blocks{r.cur};
+        for (int i = 1; i <= dl; ++i) blocks.push_back(2 + i);
+        blocks.push_back(r.cur ^ 1);
+        decisions_append(d, 0, r.nb, dl, nm, r.gen, r.k, dk, blocks);
       }
       if (r.s.n_run < ATSPEED_MAX_NEW_TOKENS) r.s.accept_steps[r.s.n_run] = nm;
       r.s.n_run++;
@@ -1083,8 +1211,9 @@ extern "C" int atspeed_bssd_generate_batch(atspeed_decoder** decs, int32_t n, co
                 "bssd_batch: decoders must share one target/draft pair");
     for (int j = 0; j < i; ++j) ATS_REQUIRE(decs[i] != decs[j], ATSPEED_ERR_INVALID, "bssd_batch: decoder %d used twice", i);
     ATS_TRY(bssd_begin(decs[i], prompts[i], prompt_lens[i], fsm, start_nodes[i], gamma, max_new, k, dk, out_tokens[i], out_scores[i],
-                       stats ? &stats[i] : nullptr, st));
+                       stats ? &stats[i] : nullptr, st, false));
   }
+  ATS_TRY(init_prompts_multi(decs, n, prompts, prompt_lens, start_nodes, st));
   return bssd_group_run(decs, n, st);
 }
 
@@ -1102,7 +1231,6 @@ extern "C" int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt
   hipStream_t st = (hipStream_t)stream;
   atspeed_llama* T = d->target;
   const int W = d->W, V = T->cfg.vocab_size;
-  (void)V;
   atspeed_gen_stats s;
   memset(&s, 0, sizeof(s));
   ATS_REQUIRE(P + max_new * k <= T->cfg.max_slots, ATSPEED_ERR_CAPACITY, "target_generate: KV slots exhausted");
@@ -1120,11 +1248,14 @@ extern "C" int atspeed_target_generate(atspeed_decoder* d, const int32_t* prompt
     t.seg[0] = make_seg(tb_offset(tin, row0, W), n_in, base + n_in, nb, d->tkv);
     ATS_TRY(seg_finish(t));
     ATS_TRY(llama_forward_segs(T, t, nullptr, st, fsm->d_tile_store));
+    const bool free_fsm = fsm->dev.n_nodes == 0;
+    if (free_fsm) ATS_TRY(ats_row_topk(T->act->logits, t.total_logit, V, T->logits_ld, k, T->act->row_cand, st));
     s.n_target_forwards++;
     BeamStepArgs a{};
     a.src = d->round_beams[cur]; a.n_src = nb; a.gen_len = g;
     a.logits = T->act->logits; a.ld = T->logits_ld; a.lse = T->act->lse; a.fsm = fsm->dev; a.k = k;
-    a.dst = d->round_beams[cur ^ 1]; a.emit = 1; a.filter_ids = 1;
+    a.dst = d->round_beams[cur ^ 1]; a.emit = 1; a.filter_ids = free_fsm ? 0 : 1;
+    a.row_cand = T->act->row_cand; a.n_row_cand = k;
     a.in = tin; a.in_row0 = row0 + n_in - nb;
     a.out = tin; a.out_row0 = row0 + n_in; a.out_slot0 = base + n_in; a.vis_words = W;
     a.mail = d->mail_dev;
@@ -1167,9 +1298,7 @@ extern "C" int atspeed_target_generate_batch(atspeed_decoder** decs, int32_t n, 
   ATS_TRY(ensure_act(T, cap_t, n * MAXB));
   hipEvent_t* g_ev = nullptr;
   ATS_TRY(stage_events(&g_ev));
-  for (int u = 0; u < n; ++u)
-    ATS_TRY(ats_init_prompt(decs[u]->tin[0], prompts[u], prompt_lens[u], W, decs[u]->round_beams[0], start_nodes[u], T->cfg.vocab_size,
-                            decs[u]->mail_dev, st));
+  ATS_TRY(init_prompts_multi(decs, n, prompts, prompt_lens, start_nodes, st));
   hipEventRecord(g_ev[0], st);
   struct St { int row0, n_in, nb, base, cur; };
   std::vector<St> s(n);
@@ -1180,6 +1309,8 @@ extern "C" int atspeed_target_generate_batch(atspeed_decoder** decs, int32_t n, 
       t.seg[t.n++] = make_seg(tb_offset(decs[u]->tin[0], s[u].row0, W), s[u].n_in, s[u].base + s[u].n_in, s[u].nb, decs[u]->tkv);
     ATS_TRY(seg_finish(t));
     ATS_TRY(llama_forward_segs(T, t, nullptr, st, fsm->d_tile_store));
+    const bool free_fsm = fsm->dev.n_nodes == 0;
+    if (free_fsm) ATS_TRY(ats_row_topk(T->act->logits, t.total_logit, T->cfg.vocab_size, T->logits_ld, k, T->act->row_cand, st));
     std::vector<BeamStepArgs> args;
     for (int u = 0; u < n; ++u) {
       atspeed_decoder* d = decs[u];
@@ -1187,7 +1318,8 @@ extern "C" int atspeed_target_generate_batch(atspeed_decoder** decs, int32_t n, 
       a.src = d->round_beams[s[u].cur]; a.n_src = s[u].nb; a.gen_len = g;
       a.logits = T->act->logits + (size_t)t.seg[u].logit_row0 * T->logits_ld; a.ld = T->logits_ld;
       a.lse = T->act->lse + t.seg[u].logit_row0; a.fsm = fsm->dev; a.k = k;
-      a.dst = d->round_beams[s[u].cur ^ 1]; a.emit = 1; a.filter_ids = 1;
+      a.dst = d->round_beams[s[u].cur ^ 1]; a.emit = 1; a.filter_ids = free_fsm ? 0 : 1;
+      a.row_cand = T->act->row_cand + (size_t)t.seg[u].logit_row0 * ATSPEED_MAX_BEAMS; a.n_row_cand = k;
       a.in = d->tin[0]; a.in_row0 = s[u].row0 + s[u].n_in - s[u].nb;
       a.out = d->tin[0]; a.out_row0 = s[u].row0 + s[u].n_in; a.out_slot0 = s[u].base + s[u].n_in; a.vis_words = W;
       a.mail = d->mail_dev;
@@ -1199,9 +1331,11 @@ extern "C" int atspeed_target_generate_batch(atspeed_decoder** decs, int32_t n, 
     ATS_TRY(stage_args(args, &dev_args, st));
     ATS_TRY(ats_beam_step_multi(dev_args, n, st));
   }
-  for (int u = 0; u < n; ++u) {
-    ATS_TRY(ats_export_beams(decs[u]->round_beams[s[u].cur], k, max_new, out_tokens[u], out_scores[u], st, decs[u]->sample));
-  }
+  { std::vector<ExportBeamsArgs> ex;
+    for (int u = 0; u < n; ++u) ex.push_back(ExportBeamsArgs{decs[u]->round_beams[s[u].cur], out_tokens[u], out_scores[u], decs[u]->sample ? 1 : 0});
+    const ExportBeamsArgs* de = nullptr;
+    ATS_TRY(stage_args(ex, &de, st));
+    ATS_TRY(ats_export_beams_multi(de, n, k, max_new, st)); }
   hipEventRecord(g_ev[1], st);
   ATS_HIP(hipStreamSynchronize(st));
   ats_stage_reset();

@@ -100,12 +100,15 @@ struct FsmDev {
   const int32_t* row_ptr;
   const int32_t* tok;
   const int32_t* nxt;
-  int32_t n_nodes, n_edges, vocab;
+  int32_t n_nodes, n_edges, vocab;     // n_nodes == 0: no mask at all (atspeed_fsm_create_free): candidates come from row_cand lists
+  // one_step_beam_search's post-top-k id filter (beamSD.py:80-86 hard-codes `tok >= 32000 | tok == 2`): picks with a token below
+  // filter_min that is not filter_eos are dropped; filter_min <= 0 keeps everything (atspeed_fsm_set_id_filter)
+  int32_t filter_min, filter_eos;
 };
 struct atspeed_fsm {
   FsmDev dev;
   int32_t *d_row_ptr, *d_tok, *d_nxt;
-  unsigned char* d_tile_store;   // [256] device bytes: 1 = some edge token lies in columns [256 t, 256 t + 256) (the logit tiles a step can read)
+  unsigned char* d_tile_store;   // [ceil(vocab / 256)] device bytes: 1 = some edge token lies in columns [256 t, 256 t + 256) (the logit tiles a step can read)
 };
 
 struct TokBuf {       // inputs of a forward: one row per token
@@ -130,6 +133,8 @@ struct Mailbox {      // device -> host, one per round
 };
 
 int ats_lse_rows(const float* logits, int n_rows, int vocab, int ld, float* lse, hipStream_t st);
+// out[row][ATSPEED_MAX_BEAMS]: the kk best columns of each row (value desc, column asc; -inf never; -1 = none)
+int ats_row_topk(const float* logits, int n_rows, int vocab, int ld, int kk, int32_t* out, hipStream_t st);
 
 struct BeamStepArgs {
   BeamSet src;  int n_src;  int gen_len;     // beams being expanded; tokens generated so far
@@ -142,6 +147,7 @@ struct BeamStepArgs {
   TokBuf in;   int in_row0;                   // rows of the src beams (for parent vis/pos)
   TokBuf out;  int out_row0;  int out_slot0;  int vis_words;
   Mailbox* mail;                              // status only
+  const int32_t* row_cand;  int n_row_cand;   // mask-free search (fsm.n_nodes == 0): [logit row][ATSPEED_MAX_BEAMS] best tokens per row (ats_row_topk)
   // sampling (generation_config.do_sample, beamSD.py:65-75): draw k of the candidates without replacement with probability
   // softmax(score / temperature); tab_* (optional) keep the draft's whole candidate distribution for the verification
   int sample;  float temperature;  uint32_t rng_sub;
@@ -162,9 +168,13 @@ struct VerifyArgs {
   int vis_words;
   BeamSet res;                                // new round beams (k)
   Mailbox* mail;
+  const int32_t* row_cand;  int n_row_cand;   // mask-free search: as in BeamStepArgs, rows aligned with `logits`
   // sampling verification (beamSD.py:293-321,332-369)
   int sample;  float temperature;  uint32_t seed;  int round;
   const float* dtab_score[ATSPEED_MAX_GAMMA];  const int32_t* dtab_off[ATSPEED_MAX_GAMMA];  const float* dtab_lse[ATSPEED_MAX_GAMMA];
+  // decision trace (atspeed_decoder_set_trace level 1, greedy walk only): step i's k picks as [i][3][ATSPEED_MAX_BEAMS] words
+  // (score bits, parent = index into blk[i], token; flat < 0 picks have token -1); NULL = off
+  int32_t* vtrace;
 };
 int ats_verify_walk(const VerifyArgs& a, hipStream_t st);
 int ats_verify_walk_multi(const VerifyArgs* dev_args, int n, hipStream_t st);
@@ -173,6 +183,11 @@ int ats_init_prompt(TokBuf tb, const int32_t* prompt, int prompt_len, int vis_wo
                     int vocab, Mailbox* mail, hipStream_t st);
 // out_tokens[k][max_new] / out_scores[k] from a beam set
 int ats_export_beams(BeamSet b, int k, int max_new, int32_t* out_tokens, float* out_scores, hipStream_t st, bool sort_desc = false);
+// the same for every user of a lock-step batch in one launch each; `dev_args` = DEVICE arrays of n argument blocks (ats_stage)
+struct InitPromptArgs { TokBuf tb; const int32_t* prompt; int prompt_len; int start_node; BeamSet beams; Mailbox* mail; };
+struct ExportBeamsArgs { BeamSet b; int32_t* out_tokens; float* out_scores; int sort_desc; };
+int ats_init_prompt_multi(const InitPromptArgs* dev_args, int n, int max_prompt_len, int vis_words, int vocab, hipStream_t st);
+int ats_export_beams_multi(const ExportBeamsArgs* dev_args, int n, int k, int max_new, hipStream_t st);
 constexpr int ATS_MAX_CAND = 16384;           // candidate capacity of one expand (scan.hip kMaxCand)
 
 int ats_accept(const int32_t* target_flat, const float* target_score, int k, const int32_t* draft_flat, int dk,

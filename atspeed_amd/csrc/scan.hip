@@ -110,10 +110,11 @@ __device__ __forceinline__ unsigned long long wave_topk_rounds(unsigned long lon
   return 0;
 }
 
-// every thread passes its kCPT candidate keys; afterwards sh.sel[0..k) holds the k largest, descending
-__device__ void block_topk(unsigned long long (&keys)[kCPT], int k, TopkShared& sh) {
+// every thread passes its NK candidate keys; afterwards sh.sel[0..k) holds the k largest, descending
+template <int NK>
+__device__ void block_topk(unsigned long long (&keys)[NK], int k, TopkShared& sh) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  wave_topk_rounds<kCPT>(keys, k, sh.wtop[wave], lane);
+  wave_topk_rounds<NK>(keys, k, sh.wtop[wave], lane);
   __syncthreads();
   if (wave == 0) {
     unsigned long long k2[kScanWaves];
@@ -154,15 +155,17 @@ struct ExpandShared {
 // Expand n_rows parent rows (sh.node/brow/lrow/bscore filled by the caller, first n_rows entries)
 // through the FSM and leave the k best candidates in sh.topk.sel.  beamSD.py:58-78.
 __device__ void expand_and_select(ExpandShared& sh, int n_rows, const float* __restrict__ logits, int ld,
-                                  const float* __restrict__ lse, const FsmDev& fsm, int k) {
+                                  const float* __restrict__ lse, const FsmDev& fsm, int k,
+                                  const int32_t* __restrict__ row_cand = nullptr, int n_row_cand = 0) {
   const int tid = threadIdx.x;
+  const bool free_mode = fsm.n_nodes == 0;            // no mask (prefix_allowed_tokens_fn = None): a row's candidates = its row_cand list
   if (tid < n_rows) sh.lse[tid] = lse[sh.lrow[tid]];
   if (tid == 0) {
     int tot = 0;
     for (int r = 0; r < n_rows; ++r) {
       sh.off[r] = tot;
       int nd = sh.node[r];
-      int deg = fsm.row_ptr[nd + 1] - fsm.row_ptr[nd];
+      int deg = free_mode ? n_row_cand : fsm.row_ptr[nd + 1] - fsm.row_ptr[nd];
       bool live = sh.bscore[r] > -INFINITY;
       if (live && deg == 0) sh.status = ATSPEED_ERR_CONSTRAINT;   // HF: "returned an empty list" ValueError
       tot += live ? deg : 0;
@@ -181,16 +184,48 @@ __device__ void expand_and_select(ExpandShared& sh, int n_rows, const float* __r
       int lo = 0, hi = n_rows;                        // last r with off[r] <= c
       while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (sh.off[mid] <= c) lo = mid; else hi = mid; }
       int r = lo;
-      int e = fsm.row_ptr[sh.node[r]] + (c - sh.off[r]);
-      int tok = fsm.tok[e];
-      float sc = (logits[(size_t)sh.lrow[r] * ld + tok] - sh.lse[r]) + sh.bscore[r];
-      uint32_t o = ford(sc);
-      uint32_t flat = (uint32_t)sh.brow[r] * (uint32_t)fsm.vocab + (uint32_t)tok;
-      if (o > kOrdNegInf || sc != sc) key = ((unsigned long long)o << 32) | (unsigned long long)(~flat);
+      int tok = free_mode ? row_cand[(size_t)sh.lrow[r] * MAXB + (c - sh.off[r])] : fsm.tok[fsm.row_ptr[sh.node[r]] + (c - sh.off[r])];
+      if (tok >= 0) {
+        float sc = (logits[(size_t)sh.lrow[r] * ld + tok] - sh.lse[r]) + sh.bscore[r];
+        uint32_t o = ford(sc);
+        uint32_t flat = (uint32_t)sh.brow[r] * (uint32_t)fsm.vocab + (uint32_t)tok;
+        if (o > kOrdNegInf || sc != sc) key = ((unsigned long long)o << 32) | (unsigned long long)(~flat);
+      }
     }
     keys[i] = key;
   }
-  block_topk(keys, k, sh.topk);
+  block_topk<kCPT>(keys, k, sh.topk);
+}
+
+// The k best columns of one logits row by (value desc, column asc), -inf excluded: with no mask the candidates of a beam are all V
+// tokens, and the k best (row, token) pairs of an expand lie among each row's k best tokens (within a row the score is the logit plus a
+// constant).  One workgroup per row; chunks of kMaxCand columns, the running best list rides along as a 17th key per thread.
+__global__ __launch_bounds__(kScanThreads) void row_topk_kernel(const float* __restrict__ logits, int vocab, int ld, int kk, int32_t* __restrict__ out) {
+  __shared__ TopkShared sh;
+  __shared__ unsigned long long best[MAXB];
+  const int tid = threadIdx.x;
+  const float* row = logits + (size_t)blockIdx.x * ld;
+  if (tid < MAXB) best[tid] = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < vocab; c0 += kMaxCand) {
+    unsigned long long keys[kCPT + 1];
+#pragma unroll
+    for (int i = 0; i < kCPT; ++i) {
+      const int col = c0 + tid + i * kScanThreads;
+      unsigned long long key = 0;
+      if (col < vocab) {
+        const float v = row[col];
+        const uint32_t o = ford(v);
+        if (o > kOrdNegInf || v != v) key = ((unsigned long long)o << 32) | (unsigned long long)(~(uint32_t)col);
+      }
+      keys[i] = key;
+    }
+    keys[kCPT] = tid < kk ? best[tid] : 0;
+    block_topk<kCPT + 1>(keys, kk, sh);
+    if (tid < kk) best[tid] = sh.sel[tid];
+    __syncthreads();
+  }
+  if (tid < MAXB) out[(size_t)blockIdx.x * MAXB + tid] = (tid < kk && best[tid]) ? (int32_t)(~(uint32_t)(best[tid] & 0xffffffffull)) : -1;
 }
 
 struct Pick { float score; int parent; int tok; int node; int flat; };
@@ -204,6 +239,7 @@ __device__ __forceinline__ Pick decode_pick(unsigned long long key, const FsmDev
   p.parent = (int)(flat / (uint32_t)fsm.vocab);
   p.tok = (int)(flat % (uint32_t)fsm.vocab);
   p.score = ford_inv((uint32_t)(key >> 32));
+  if (fsm.n_nodes == 0) { p.node = 0; return p; }       // no mask: there is no automaton to walk
   int nd = 0;
   for (int r = 0; r < n_rows; ++r) if (rows_brow[r] == p.parent) { nd = rows_node[r]; break; }
   int e = find_edge(fsm, nd, p.tok);
@@ -301,7 +337,7 @@ __device__ void sample_topn(ExpandShared& sh, const CandRegs& cr, const float (&
     }
     keys[i] = key;
   }
-  block_topk(keys, n, sh.topk);
+  block_topk<kCPT>(keys, n, sh.topk);
 }
 
 // a pick by flat id with the TRUE tempered score (sampling keys carry noise); rows describe the expand that produced it
@@ -326,7 +362,8 @@ __device__ Pick pick_of_flat(int flat, const FsmDev& fsm, const ExpandShared& sh
 __device__ void emit_block(const Pick& pk, int j, int k, const BeamSet& src, int gen_len, const BeamSet& dst, bool emit,
                            const TokBuf& in, int in_row0, const TokBuf& out, int out_row0, int out_slot0, int W) {
   if (j < k) {
-    dst.score[j] = pk.score; dst.parent[j] = pk.parent; dst.tok[j] = pk.tok; dst.node[j] = pk.node; dst.flat[j] = pk.flat;
+    dst.score[j] = pk.score; dst.parent[j] = pk.parent; dst.tok[j] = pk.tok; dst.flat[j] = pk.flat;
+    if (dst.node) dst.node[j] = pk.node;
     if (dst.seq) {
       for (int g = 0; g < gen_len; ++g) dst.seq[j * LMAX + g] = src.seq ? src.seq[pk.parent * LMAX + g] : 0;
       if (gen_len < LMAX) dst.seq[j * LMAX + gen_len] = pk.tok;
@@ -368,7 +405,7 @@ __device__ void beam_step_body(const BeamStepArgs& a) {
   const int tid = threadIdx.x;
   if (tid == 0) sh.status = 0;
   if (tid < a.n_src) {
-    sh.node[tid] = a.src.node[tid];
+    sh.node[tid] = a.src.node ? a.src.node[tid] : 0;
     sh.brow[tid] = tid;
     sh.lrow[tid] = tid;
     sh.bscore[tid] = a.src.score[tid];
@@ -393,7 +430,7 @@ __device__ void beam_step_body(const BeamStepArgs& a) {
       parents[tid] = pk.parent;
     }
   } else {
-    expand_and_select(sh, a.n_src, a.logits, a.ld, a.lse, a.fsm, a.k);
+    expand_and_select(sh, a.n_src, a.logits, a.ld, a.lse, a.fsm, a.k, a.row_cand, a.n_row_cand);
     if (tid < a.k) {
       pk = decode_pick(sh.topk.sel[tid], a.fsm, sh.brow, sh.node, a.n_src);
       parents[tid] = pk.parent;
@@ -406,9 +443,16 @@ __device__ void beam_step_body(const BeamStepArgs& a) {
     // beam set shrinks instead of lower-ranked candidates moving up; the survivors keep their order (stable compaction),
     // the freed slots hold "no beam" (flat = -1) at the end of the block
     __shared__ int keep[MAXB];
-    const bool ok = tid < a.k && pk.flat >= 0 && (pk.tok >= 32000 || pk.tok == 2);
+    const bool had = tid < a.k && pk.flat >= 0;
+    const bool ok = had && (pk.tok >= a.fsm.filter_min || pk.tok == a.fsm.filter_eos);     // reference: tok >= 32000 | tok == 2
     if (tid < MAXB) keep[tid] = ok ? 1 : 0;
-    __syncthreads();
+    const int n_had = __syncthreads_count(had);
+    if (tid == 0) {
+      int total = 0;
+      for (int j = 0; j < a.k; ++j) total += keep[j];
+      // every pick dropped: the reference goes on with an empty beam set and fails in the next forward (quirk 6); say what happened
+      if (n_had > 0 && total == 0) sh.status = ATSPEED_ERR_FILTERED;
+    }
     if (tid < a.k) {
       int before = 0, total = 0;
       for (int j = 0; j < a.k; ++j) { total += keep[j]; before += (j < tid) ? keep[j] : 0; }
@@ -630,10 +674,14 @@ __device__ void verify_walk_body(const VerifyArgs& a) {
       sh.bscore[tid] = i == 0 ? a.blk[0].score[tid] : sbh[tid];
     }
     __syncthreads();
-    expand_and_select(sh, n_rows, a.logits, a.ld, a.lse, a.fsm, k);     // :297-298,323-328
+    expand_and_select(sh, n_rows, a.logits, a.ld, a.lse, a.fsm, k, a.row_cand, a.n_row_cand);     // :297-298,323-328
     if (tid < k) {
       pk = decode_pick(sh.topk.sel[tid], a.fsm, sh.brow, sh.node, n_rows);
       t_parent[tid] = pk.parent;
+      if (a.vtrace) {                                                    // decision trace: what the target chose at step i
+        int32_t* vt = a.vtrace + (size_t)i * 3 * MAXB;
+        vt[tid] = (int32_t)__float_as_uint(pk.score); vt[MAXB + tid] = pk.parent; vt[2 * MAXB + tid] = pk.flat >= 0 ? pk.tok : -1;
+      }
     }
     if (i == a.dl) break;                                                // :329-330 (uniform)
     // acceptance: every target id must be among the draft's ids of step i+1 (:371-380)
@@ -681,38 +729,75 @@ __device__ void verify_walk_body(const VerifyArgs& a) {
 }
 
 // ---------------------------------------------------------------------------- prompt init / export / accept
+__device__ __forceinline__ void init_prompt_row(const TokBuf& tb, const int32_t* __restrict__ prompt, int t, int W, int vocab) {
+  int id = prompt[t];
+  tb.ids[t] = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  tb.pos[t] = t;
+  tb.slot[t] = t;
+  for (int w = 0; w < W; ++w) {                         // causal prefix: bits [0, t]
+    int lo = w * 64;
+    uint64_t bits = (t >= lo + 63) ? ~0ull : (t < lo ? 0ull : ((~0ull) >> (63 - (t - lo))));
+    tb.vis[(size_t)t * W + w] = bits;
+  }
+}
 __global__ void init_prompt_kernel(TokBuf tb, const int32_t* __restrict__ prompt, int P, int W, BeamSet beams,
                                    int start_node, int vocab, Mailbox* mail) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < P) {
-    int id = prompt[t];
-    tb.ids[t] = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    tb.pos[t] = t;
-    tb.slot[t] = t;
-    for (int w = 0; w < W; ++w) {                       // causal prefix: bits [0, t]
-      int lo = w * 64;
-      uint64_t bits = (t >= lo + 63) ? ~0ull : (t < lo ? 0ull : ((~0ull) >> (63 - (t - lo))));
-      tb.vis[(size_t)t * W + w] = bits;
-    }
-  }
+  if (t < P) init_prompt_row(tb, prompt, t, W, vocab);
   if (t == 0) {
     beams.score[0] = 0.f; beams.node[0] = start_node; beams.parent[0] = 0; beams.tok[0] = 0; beams.flat[0] = 0;
     mail->n_matches = 0; mail->status = 0; mail->n_valid = 1; mail->pad = 0;
   }
 }
 
+// every user of a lock-step batch in ONE launch (grid.y = user): 256 launches per batch less than the per-user form
+__global__ void init_prompt_multi_kernel(const InitPromptArgs* __restrict__ args, int W, int vocab) {
+  const InitPromptArgs a = args[blockIdx.y];
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < a.prompt_len) init_prompt_row(a.tb, a.prompt, t, W, vocab);
+  if (t == 0) {
+    a.beams.score[0] = 0.f; a.beams.node[0] = a.start_node; a.beams.parent[0] = 0; a.beams.tok[0] = 0; a.beams.flat[0] = 0;
+    a.mail->n_matches = 0; a.mail->status = 0; a.mail->n_valid = 1; a.mail->pad = 0;
+  }
+}
+
+__device__ __forceinline__ void export_beams_row(const BeamSet& b, int j, int k, int max_new, int32_t* out_tokens, float* out_scores, int sort_desc) {
+  int dst = j;
+  if (sort_desc) {                                     // beamSD.py:529-531: stable sort by score, best first
+    const float sj = b.score[j];
+    dst = 0;
+    for (int i = 0; i < k; ++i) { const float si = b.score[i]; dst += (si > sj || (si == sj && i < j)) ? 1 : 0; }
+  }
+  out_scores[dst] = b.score[j];
+  for (int g = 0; g < max_new; ++g) out_tokens[dst * max_new + g] = b.seq[j * LMAX + g];
+}
+__global__ void export_beams_multi_kernel(const ExportBeamsArgs* __restrict__ args, int k, int max_new) {
+  const ExportBeamsArgs a = args[blockIdx.x];
+  if ((int)threadIdx.x < k) export_beams_row(a.b, threadIdx.x, k, max_new, a.out_tokens, a.out_scores, a.sort_desc);
+}
+
+// beam_sequence of every user of a batch (beamSD.py:87,383: prompt ++ generated suffix per beam, int64) in one launch:
+// block (beam j, user u) writes row j of user u
+__global__ void assemble_sequences_kernel(const int32_t* __restrict__ prompts, const int64_t* __restrict__ off, const int32_t* __restrict__ toks,
+                                          int k, int L, int64_t* __restrict__ out) {
+  const int u = blockIdx.y, j = blockIdx.x;
+  const int64_t p0 = off[u];
+  const int P = (int)(off[u + 1] - p0);
+  int64_t* row = out + (int64_t)k * (p0 + (int64_t)u * L) + (int64_t)j * (P + L);
+  for (int t = threadIdx.x; t < P; t += blockDim.x) row[t] = prompts[p0 + t];
+  for (int t = threadIdx.x; t < L; t += blockDim.x) row[P + t] = toks[((size_t)u * k + j) * L + t];
+}
+
 __global__ void export_beams_kernel(BeamSet b, int k, int max_new, int32_t* out_tokens, float* out_scores, int sort_desc) {
   int j = threadIdx.x;
-  if (j < k) {
-    int dst = j;
-    if (sort_desc) {                                     // beamSD.py:529-531: stable sort by score, best first
-      const float sj = b.score[j];
-      dst = 0;
-      for (int i = 0; i < k; ++i) { const float si = b.score[i]; dst += (si > sj || (si == sj && i < j)) ? 1 : 0; }
-    }
-    out_scores[dst] = b.score[j];
-    for (int g = 0; g < max_new; ++g) out_tokens[dst * max_new + g] = b.seq[j * LMAX + g];
-  }
+  if (j < k) export_beams_row(b, j, k, max_new, out_tokens, out_scores, sort_desc);
+}
+
+// out[r][c] = logits[r][c] - lse[r]: the log-softmax rows a host-side logits processor receives (beamSD.py:58 -> :62-64)
+__global__ void log_softmax_rows_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ lse, int vocab, float* __restrict__ out, int ld_out) {
+  const float l = lse[blockIdx.y];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < vocab) out[(size_t)blockIdx.y * ld_out + c] = logits[(size_t)blockIdx.y * ld + c] - l;
 }
 
 __global__ void accept_kernel(const int32_t* __restrict__ tflat, const float* __restrict__ tscore, int k,
@@ -747,6 +832,14 @@ int ats_lse_rows(const float* logits, int n_rows, int vocab, int ld, float* lse,
   if (nt == 256)       lse_rows_kernel<256><<<n_rows, 256, 0, st>>>(logits, vocab, ld, lse);
   else if (nt == 1024) lse_rows_kernel<1024><<<n_rows, 1024, 0, st>>>(logits, vocab, ld, lse);
   else                 lse_rows_kernel<512><<<n_rows, 512, 0, st>>>(logits, vocab, ld, lse);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+int ats_row_topk(const float* logits, int n_rows, int vocab, int ld, int kk, int32_t* out, hipStream_t st) {
+  if (n_rows <= 0) return ATSPEED_OK;
+  ATS_REQUIRE(kk >= 1 && kk <= MAXB, ATSPEED_ERR_CAPACITY, "row_topk: k=%d out of [1,%d]", kk, MAXB);
+  row_topk_kernel<<<n_rows, kScanThreads, 0, st>>>(logits, vocab, ld, kk, out);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -788,6 +881,34 @@ int ats_init_prompt(TokBuf tb, const int32_t* prompt, int prompt_len, int vis_wo
   return ATSPEED_OK;
 }
 
+int ats_init_prompt_multi(const InitPromptArgs* dev_args, int n, int max_prompt_len, int vis_words, int vocab, hipStream_t st) {
+  if (n <= 0) return ATSPEED_OK;
+  init_prompt_multi_kernel<<<dim3((max_prompt_len + 255) / 256, n), 256, 0, st>>>(dev_args, vis_words, vocab);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+int ats_export_beams_multi(const ExportBeamsArgs* dev_args, int n, int k, int max_new, hipStream_t st) {
+  if (n <= 0) return ATSPEED_OK;
+  export_beams_multi_kernel<<<n, 64, 0, st>>>(dev_args, k, max_new);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+extern "C" int atspeed_assemble_sequences(const int32_t* prompts_flat, const int64_t* prompt_off_host, const int32_t* toks, int32_t n, int32_t k,
+                                          int32_t new_tokens, int64_t* out, void* stream) {
+  ATS_REQUIRE(prompts_flat && prompt_off_host && toks && out && n >= 1 && k >= 1 && k <= 65535 && new_tokens >= 0, ATSPEED_ERR_INVALID,
+              "assemble_sequences: bad arguments");
+  ATS_REQUIRE(n <= 65535, ATSPEED_ERR_CAPACITY, "assemble_sequences: %d users per call (max 65535)", n);
+  for (int u = 0; u < n; ++u)
+    ATS_REQUIRE(prompt_off_host[u + 1] >= prompt_off_host[u], ATSPEED_ERR_INVALID, "assemble_sequences: offsets not monotone at user %d", u);
+  const void* off_dev = nullptr;
+  ATS_TRY(ats_stage(prompt_off_host, (size_t)(n + 1) * sizeof(int64_t), &off_dev, (hipStream_t)stream));
+  assemble_sequences_kernel<<<dim3(k, n), 128, 0, (hipStream_t)stream>>>(prompts_flat, (const int64_t*)off_dev, toks, k, new_tokens, out);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
 int ats_export_beams(BeamSet b, int k, int max_new, int32_t* out_tokens, float* out_scores, hipStream_t st, bool sort_desc) {
   export_beams_kernel<<<1, 64, 0, st>>>(b, k, max_new, out_tokens, out_scores, sort_desc ? 1 : 0);
   ATS_LAUNCH_CHECK();
@@ -805,6 +926,16 @@ int ats_accept(const int32_t* target_flat, const float* target_score, int k, con
 extern "C" int atspeed_lse_rows(const float* logits, int32_t n_rows, int32_t vocab, int32_t ld, float* lse, void* stream) {
   ATS_REQUIRE(logits && lse && vocab > 0 && ld >= vocab, ATSPEED_ERR_INVALID, "lse: bad arguments");
   return ats_lse_rows(logits, n_rows, vocab, ld, lse, (hipStream_t)stream);
+}
+
+extern "C" int atspeed_log_softmax_rows(const float* logits, int32_t ld, const float* lse, int32_t n_rows, int32_t vocab, float* out, int32_t ld_out,
+                                        void* stream) {
+  ATS_REQUIRE(logits && lse && out && vocab > 0 && ld >= vocab && ld_out >= vocab && n_rows >= 0 && n_rows <= 65535, ATSPEED_ERR_INVALID,
+              "log_softmax_rows: bad arguments");
+  if (n_rows == 0) return ATSPEED_OK;
+  log_softmax_rows_kernel<<<dim3((vocab + 255) / 256, n_rows), 256, 0, (hipStream_t)stream>>>(logits, ld, lse, vocab, out, ld_out);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
 }
 
 extern "C" int atspeed_accept(const int32_t* target_flat, const float* target_score, int32_t k, const int32_t* draft_flat,
@@ -829,6 +960,33 @@ extern "C" int atspeed_beam_expand_prune(const float* logits, int32_t ld, const 
   a.k = k;
   a.dst.score = out_score; a.dst.parent = out_parent; a.dst.tok = out_token; a.dst.node = out_node; a.dst.flat = out_flat;
   a.dst.seq = nullptr;
+  a.emit = 0; a.mail = nullptr; a.vis_words = 0;
+  ATS_REQUIRE(fsm->dev.n_nodes > 0, ATSPEED_ERR_INVALID, "beam_expand_prune: a mask-free automaton needs atspeed_beam_expand_prune_free");
+  return ats_beam_step(a, (hipStream_t)stream);
+}
+
+extern "C" int atspeed_row_topk(const float* scores, int32_t n_rows, int32_t vocab, int32_t ld, int32_t k, int32_t* out_tokens, void* stream) {
+  ATS_REQUIRE(scores && out_tokens && vocab > 0 && ld >= vocab && n_rows >= 0, ATSPEED_ERR_INVALID, "row_topk: bad arguments");
+  return ats_row_topk(scores, n_rows, vocab, ld, k, out_tokens, (hipStream_t)stream);
+}
+
+extern "C" int atspeed_beam_expand_prune_free(const float* logits, int32_t ld, const float* lse, const float* beam_score, int32_t n_rows,
+                                              int32_t vocab, int32_t k, int32_t* row_cand_ws, float* out_score, int32_t* out_parent,
+                                              int32_t* out_token, int32_t* out_flat, void* stream) {
+  ATS_REQUIRE(logits && lse && beam_score && row_cand_ws && out_score && out_parent && out_token && out_flat, ATSPEED_ERR_INVALID,
+              "beam_expand_prune_free: null argument");
+  ATS_REQUIRE(vocab > 0 && ld >= vocab && (int64_t)MAXB * vocab < (int64_t)0x7fffffff, ATSPEED_ERR_INVALID, "beam_expand_prune_free: bad vocabulary");
+  ATS_TRY(ats_row_topk(logits, n_rows, vocab, ld, k, row_cand_ws, (hipStream_t)stream));
+  BeamStepArgs a{};
+  a.src.score = const_cast<float*>(beam_score);
+  a.src.node = nullptr; a.src.seq = nullptr;
+  a.n_src = n_rows; a.gen_len = 0;
+  a.logits = logits; a.ld = ld; a.lse = lse;
+  a.fsm = FsmDev{nullptr, nullptr, nullptr, 0, 0, vocab, 0, -1};
+  a.k = k;
+  a.dst.score = out_score; a.dst.parent = out_parent; a.dst.tok = out_token; a.dst.node = nullptr; a.dst.flat = out_flat;
+  a.dst.seq = nullptr;
+  a.row_cand = row_cand_ws; a.n_row_cand = k;
   a.emit = 0; a.mail = nullptr; a.vis_words = 0;
   return ats_beam_step(a, (hipStream_t)stream);
 }

@@ -51,6 +51,10 @@ class Trie:
         self.bos_token_id = bos_token_id
 
     # -- lookup -----------------------------------------------------------------
+    def _chained(self) -> bool:
+        """the reference tests `if append_trie` (generation_trie.py:54,67): an appended trie with len() == 0 is falsy there"""
+        return self.append_trie is not None and len(self.append_trie) != 0
+
     def _descend(self, prefix: Sequence[int]) -> Tuple[Optional[Dict], int]:
         level = self.trie_dict
         for depth, token in enumerate(prefix):
@@ -63,12 +67,13 @@ class Trie:
     def get(self, prefix_sequence: Sequence[int]) -> List[int]:
         prefix = [int(t) for t in prefix_sequence]
         level, depth = self._descend(prefix)
+        chained = self._chained()
         if level is None:
-            if self.append_trie is not None:
+            if chained:
                 return self.append_trie.get(prefix[depth:])
             return []
         children = list(level)
-        if self.append_trie is not None and self.bos_token_id in children:
+        if chained and self.bos_token_id in children:
             children.remove(self.bos_token_id)
             children.extend(self.append_trie.trie_dict)
         return children
@@ -112,9 +117,11 @@ class Trie:
     def flatten(self, root_prefix: Sequence[int] = ()) -> "ConstraintFSM":
         """CSR automaton of the subtree below `root_prefix` (breadth-first node ids, children sorted by token id), built by
         the native `atspeed_trie_flatten` (include/atspeed_hip.h: the C-ABI counterpart of `Trie.__init__` / `_add_to_trie`,
-        reference `code/generation_trie.py:8-14,40-44`).  Chained tries (`append`) are not flattened."""
-        if self.append_trie is not None:
-            raise NotImplementedError("flatten() of a chained Trie (append) is not supported")
+        reference `code/generation_trie.py:8-14,40-44`).  A chained trie (`append`, `:19-21,55-57,67-68`) becomes ONE automaton
+        over the nodes of every trie of the chain (`_flatten_chain`); `start` is then the node `root_prefix` leads to."""
+        if self._chained():
+            fsm = self._flatten_chain()
+            return ConstraintFSM(fsm.row_ptr, fsm.tok, fsm.nxt, fsm.walk(0, [int(t) for t in root_prefix]), levels=fsm.levels)
         import ctypes as C
         from . import _lib
         root, _ = self._descend([int(t) for t in root_prefix])
@@ -135,6 +142,45 @@ class Trie:
                                             nxt.ctypes.data, C.byref(n_nodes), C.byref(n_edges)))
         return ConstraintFSM(row_ptr, tok[: n_edges.value], nxt[: n_edges.value], 0)
 
+    def _flatten_chain(self) -> "ConstraintFSM":
+        """The reference's chained lookup (`_get_from_trie`, generation_trie.py:46-70) as one automaton.  Walking a sentence through
+        trie A: while the tokens are A's, stay in A; the first token A does not have hands the REST of the sentence (that token
+        included) to the appended trie B, from B's root, for good (`:66-68`).  Where the walk ends inside A, the allowed set is the
+        node's children with `bos_token_id` replaced by B's root tokens (`:52-58`).  So: nodes = A's nodes then B's (B flattened the
+        same way, its own chain included); an A node that has the bos child allows (children - {bos}) + B's root tokens, the latter
+        leading to B's first-level nodes (a token both have stays A's: A is asked first).  `levels` keeps every trie's own automaton for
+        walking arbitrary prompt tokens, which need not be allowed ones."""
+        chain, t = [], self
+        while t is not None:
+            chain.append(t)
+            t = t.append_trie if t._chained() else None
+        raws = []
+        for tr in chain:
+            plain = Trie.load_from_dict(tr.trie_dict)        # the same nodes without the chain
+            raws.append(plain.flatten())
+        offs = np.concatenate([[0], np.cumsum([r.n_nodes for r in raws])]).astype(np.int64)
+        row_ptr, tok, nxt = [0], [], []
+        for li, (tr, raw) in enumerate(zip(chain, raws)):
+            nxt_raw = raws[li + 1] if li + 1 < len(raws) else None
+            b_tok = nxt_raw.allowed(0) if nxt_raw is not None else None
+            b_nxt = (nxt_raw.nxt[nxt_raw.row_ptr[0]: nxt_raw.row_ptr[1]] + offs[li + 1]) if nxt_raw is not None else None
+            for n in range(raw.n_nodes):
+                lo, hi = int(raw.row_ptr[n]), int(raw.row_ptr[n + 1])
+                a_tok, a_nxt = raw.tok[lo:hi], raw.nxt[lo:hi].astype(np.int64) + offs[li]
+                if nxt_raw is not None and tr.bos_token_id in a_tok:
+                    keep = a_tok != tr.bos_token_id
+                    a_tok, a_nxt = a_tok[keep], a_nxt[keep]
+                    new = ~np.isin(b_tok, a_tok)
+                    m_tok = np.concatenate([a_tok, b_tok[new]])
+                    m_nxt = np.concatenate([a_nxt, b_nxt[new]])
+                    order = np.argsort(m_tok, kind="stable")
+                    a_tok, a_nxt = m_tok[order], m_nxt[order]
+                tok += a_tok.tolist()
+                nxt += a_nxt.tolist()
+                row_ptr.append(len(tok))
+        return ConstraintFSM(np.asarray(row_ptr, np.int32), np.asarray(tok, np.int32), np.asarray(nxt, np.int32), 0,
+                             levels=[(int(o), r) for o, r in zip(offs[:-1], raws)])
+
 
 @dataclass
 class ConstraintFSM:
@@ -143,6 +189,11 @@ class ConstraintFSM:
     tok: np.ndarray       # int32 [n_edges]
     nxt: np.ndarray       # int32 [n_edges]
     start: int = 0
+    free: bool = False    # no mask at all (prefix_allowed_tokens_fn=None): the arrays are empty, every token is a candidate
+    levels: Optional[list] = None    # chained tries: [(node offset, that trie's own automaton)] for walking arbitrary tokens
+    # (min_item_token, eos_token) of the post-top-k id filter; None = the reference's hard-coded (32000, 2) (code/beamSD.py:80-86);
+    # min_item_token <= 0 keeps every pick (atspeed_fsm_set_id_filter)
+    id_filter: Optional[Tuple[int, int]] = None
 
     @property
     def n_nodes(self) -> int:
@@ -161,6 +212,28 @@ class ConstraintFSM:
         if j >= hi or self.tok[j] != token:
             raise KeyError((node, token))
         return int(self.nxt[j])
+
+    def walk(self, node: int, tokens: Sequence[int]) -> int:
+        """The node a sentence leads to, as the reference's `Trie.get` walks it (tokens need not be allowed ones).  Plain automaton:
+        `step` per token (KeyError = the reference returns []).  Chained tries: inside trie i of the chain use its OWN children (the
+        bos child included); the first token it does not have restarts at the root of trie i + 1 with that token."""
+        if not self.levels:
+            for t in tokens:
+                node = self.step(node, int(t))
+            return node
+        li = max(i for i, (off, _) in enumerate(self.levels) if off <= node)
+        local = node - self.levels[li][0]
+        for t in tokens:
+            while True:
+                try:
+                    local = self.levels[li][1].step(local, int(t))
+                    break
+                except KeyError:
+                    li += 1
+                    local = 0
+                    if li >= len(self.levels):
+                        raise
+        return self.levels[li][0] + local
 
     def validate(self, vocab_size: int) -> None:
         assert self.row_ptr[0] == 0 and np.all(np.diff(self.row_ptr) >= 0)
@@ -195,9 +268,10 @@ class PositionSetConstraint:
     `code/data.py:96-102`: scan from the end for the separator, index by distance.
     """
 
-    def __init__(self, allowed_tokens: Dict[int, Iterable[int]], sep: Sequence[int]):
+    def __init__(self, allowed_tokens: Dict[int, Iterable[int]], sep: Sequence[int], id_filter: Optional[Tuple[int, int]] = None):
         self.allowed_tokens = {int(i): list(v) for i, v in allowed_tokens.items()}
         self.sep = [int(s) for s in sep]
+        self.id_filter = id_filter                    # see ConstraintFSM.id_filter
         self._fsm: Optional[ConstraintFSM] = None     # CSR arrays are prompt-independent; only `start` varies
 
     def __call__(self, batch_id, sentence) -> Optional[List[int]]:
@@ -224,17 +298,18 @@ class PositionSetConstraint:
         f = self._fsm
         if i0 >= f.n_nodes:
             raise KeyError(i0)         # reference: allowed_tokens[i] KeyError past the last position
-        return ConstraintFSM(f.row_ptr, f.tok, f.nxt, i0)
+        return ConstraintFSM(f.row_ptr, f.tok, f.nxt, i0, id_filter=self.id_filter)
 
 
 class SuffixTrieConstraint:
     """Strict item trie keyed on `[bos] + tokens generated after "Response:"`
     (reference `code/generate_teacher_data.py:174-188`)."""
 
-    def __init__(self, trie: Trie, sep: Sequence[int], bos_token_id: int = 1):
+    def __init__(self, trie: Trie, sep: Sequence[int], bos_token_id: int = 1, id_filter: Optional[Tuple[int, int]] = None):
         self.trie = trie
         self.sep = [int(s) for s in sep]
         self.bos_token_id = int(bos_token_id)
+        self.id_filter = id_filter
         self._fsm: Optional[ConstraintFSM] = None
 
     def _suffix(self, s: List[int]) -> List[int]:
@@ -251,18 +326,17 @@ class SuffixTrieConstraint:
         if self._fsm is None:
             self._fsm = self.trie.flatten([self.bos_token_id])
         fsm = self._fsm
-        node = 0
-        for t in self._suffix([int(x) for x in prompt]):
-            node = fsm.step(node, t)
-        return ConstraintFSM(fsm.row_ptr, fsm.tok, fsm.nxt, node)
+        node = fsm.walk(fsm.start, self._suffix([int(x) for x in prompt]))
+        return ConstraintFSM(fsm.row_ptr, fsm.tok, fsm.nxt, node, levels=fsm.levels, id_filter=self.id_filter)
 
 
 class WholeSentenceTrieConstraint:
     """`prefix_allowed_tokens_fn(trie)` of the reference: the ENTIRE sentence, prompt
     included, is looked up in the trie (`code/generation_trie.py:92-98`)."""
 
-    def __init__(self, trie: Trie):
+    def __init__(self, trie: Trie, id_filter: Optional[Tuple[int, int]] = None):
         self.trie = trie
+        self.id_filter = id_filter
         self._fsm: Optional[ConstraintFSM] = None
 
     def __call__(self, batch_id, sentence) -> List[int]:
@@ -272,13 +346,20 @@ class WholeSentenceTrieConstraint:
         if self._fsm is None:
             self._fsm = self.trie.flatten()
         fsm = self._fsm
-        node = 0
         try:
-            for t in prompt:
-                node = fsm.step(node, int(t))
+            node = fsm.walk(fsm.start, [int(t) for t in prompt])
         except KeyError:
             raise ValueError("`prefix_allowed_tokens_fn` returned an empty list for batch ID 0.") from None
-        return ConstraintFSM(fsm.row_ptr, fsm.tok, fsm.nxt, node)
+        return ConstraintFSM(fsm.row_ptr, fsm.tok, fsm.nxt, node, levels=fsm.levels, id_filter=self.id_filter)
+
+
+_FREE = ConstraintFSM(np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32), 0, free=True)
+
+
+def free_constraint() -> ConstraintFSM:
+    """The automaton of a call without a mask (`prefix_allowed_tokens_fn=None`, no logits processor): every token is a candidate and
+    the reference's post-top-k id filter is off (`code/beamSD.py:80`).  One shared object, so a batch of users shares it."""
+    return _FREE
 
 
 def prefix_allowed_tokens_fn(candidate_trie: Trie) -> WholeSentenceTrieConstraint:

@@ -8,11 +8,21 @@ arithmetic still runs in libatspeed_hip — forwards (`atspeed_llama_forward`), 
 (`atspeed_lse_rows`), mask + expand + top-K (`atspeed_beam_expand_prune` over a per-step automaton whose node r
 holds row r's allowed list) and the acceptance test (`atspeed_accept`); only the mask lists and the small beam
 tables cross PCIe, with one synchronisation per step like the reference.  One user at a time.
+
+Extra logits processors (`BSSD(..., logits_processor=LogitsProcessorList([...]))`, beamSD.py:469-478) are torch callables
+`(input_ids [n, len], scores [n, V]) -> scores`, so a step with processors hands them the log-softmax rows as a device tensor
+(`atspeed_log_softmax_rows`) -- the mask first, as HF's PrefixConstrainedLogitsProcessor does it (scores + (-inf outside the allowed
+list)), then the caller's processors in order (HF appends custom processors after its own) -- and the library expands the rows they
+return (`atspeed_beam_expand_prune_free`: row-wise top-k, then the K best (row, token) pairs; -inf entries are never picked).
+The reference's post-top-k id filter runs whenever the processor list is non-empty (beamSD.py:80), mask or not.
+Stage times (`draft/target/verify_time_cost`, the CSV columns inference.py:183-187 reads) are wall clock with a device
+synchronisation at the end of each stage, as the reference's Timer measures them (beamSD.py:12-37).
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import Callable, Dict, List, Sequence
+import time
+from typing import Callable, Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -110,13 +120,56 @@ def _expand_prune(model: HipLlama, logits, lse, row_ids: Sequence[int], beam_sco
     return s[keep], p[keep].astype(np.int64), t[keep].astype(np.int64), f[keep].astype(np.int64)
 
 
-def _one_step(model: HipLlama, inp: _Inputs, k: int, beam_scores: np.ndarray, beam_seq: np.ndarray, fn: Callable) -> Dict:
+def _expand_processed(model: HipLlama, logits, lse, row_ids: Sequence[int], beam_scores: np.ndarray, seqs: np.ndarray,
+                      fn: Optional[Callable], procs: Sequence[Callable], k: int):
+    """The expand of a step WITH extra logits processors (beamSD.py:58-78): log-softmax rows -> mask -> processors -> + beam scores ->
+    top-k.  Returns host arrays like `_expand_prune`."""
+    lib = _lib.load()
+    dev = model.device
+    V, ld = model.dims.vocab_size, model.logits_ld
+    n = len(row_ids)
+    with torch.cuda.device(dev):
+        st = _lib.stream_ptr(dev)
+        rows = torch.as_tensor(list(row_ids), dtype=torch.int64, device=dev)
+        lg = logits.view(-1, ld)[rows].contiguous()
+        ls = lse[rows].contiguous()
+        scores = torch.empty(n, V, dtype=torch.float32, device=dev)
+        _lib.check(lib.atspeed_log_softmax_rows(lg.data_ptr(), ld, ls.data_ptr(), n, V, scores.data_ptr(), V, st))
+        ids = torch.from_numpy(np.ascontiguousarray(seqs)).to(dev)
+        if fn is not None:                              # transformers PrefixConstrainedLogitsProcessor.__call__: scores + mask
+            mask = torch.full_like(scores, float("-inf"))
+            for r, al in enumerate(_allowed_lists(fn, seqs)):
+                mask[r, torch.as_tensor(al, dtype=torch.long, device=dev)] = 0
+            scores = scores + mask
+        for proc in procs:
+            scores = proc(ids, scores)
+        scores = scores.to(torch.float32).contiguous()
+        bs = torch.from_numpy(np.asarray(beam_scores, np.float32)).to(dev)
+        zero = torch.zeros(n, dtype=torch.float32, device=dev)
+        ws = torch.empty(n * _lib.MAX_BEAMS, dtype=torch.int32, device=dev)
+        o_s = torch.empty(k, dtype=torch.float32, device=dev)
+        o_p, o_t, o_f = (torch.empty(k, dtype=torch.int32, device=dev) for _ in range(3))
+        _lib.check(lib.atspeed_beam_expand_prune_free(scores.data_ptr(), V, zero.data_ptr(), bs.data_ptr(), n, V, k, ws.data_ptr(),
+                                                      o_s.data_ptr(), o_p.data_ptr(), o_t.data_ptr(), o_f.data_ptr(), st))
+        s, p, t, f = (x.cpu().numpy() for x in (o_s, o_p, o_t, o_f))
+    keep = f >= 0
+    return s[keep], p[keep].astype(np.int64), t[keep].astype(np.int64), f[keep].astype(np.int64)
+
+
+def _expand(model, logits, lse, row_ids, beam_scores, seqs, fn, procs, k):
+    if procs:
+        return _expand_processed(model, logits, lse, row_ids, beam_scores, seqs, fn, procs, k)
+    return _expand_prune(model, logits, lse, row_ids, beam_scores, _allowed_lists(fn, seqs), k)
+
+
+def _one_step(model: HipLlama, inp: _Inputs, k: int, beam_scores: np.ndarray, beam_seq: np.ndarray, fn: Optional[Callable],
+              procs: Sequence[Callable] = ()) -> Dict:
     """one_step_beam_search (beamSD.py:40-106)."""
     n = len(beam_scores)
     logits, lse = _forward(model, inp, n)
     seqs = beam_seq[:1] if (n == 1 and k != 1) else beam_seq                       # :61-64
-    s, p, t, f = _expand_prune(model, logits, lse, range(n), beam_scores, _allowed_lists(fn, seqs), k)
-    keep = (t >= 32000) | (t == 2)                                                  # :80-86 (hard-coded Llama vocab / EOS)
+    s, p, t, f = _expand(model, logits, lse, range(n), beam_scores, seqs, fn, procs, k)
+    keep = (t >= 32000) | (t == 2)                                                  # :80-86 (hard-coded Llama vocab / EOS; any processor switches it on)
     s, p, t, f = s[keep], p[keep], t[keep], f[keep]
     m = len(t)
     S = inp.vis.shape[1]
@@ -130,20 +183,37 @@ def _causal(ids: np.ndarray) -> _Inputs:
     return _Inputs(ids, np.arange(n), np.arange(n), np.tril(np.ones((n, n), bool)))
 
 
-def target_generate_host_mask(model: HipLlama, prompt: np.ndarray, max_new_tokens: int, fn: Callable) -> Dict:
+def target_generate_host_mask(model: HipLlama, prompt: np.ndarray, max_new_tokens: int, fn: Optional[Callable],
+                              procs: Sequence[Callable] = ()) -> Dict:
     k = int(model.generation_config.num_beams)
     inp = _causal(prompt)
     scores = np.zeros(1, np.float32)
     seq = np.repeat(prompt[None, :], k, axis=0)
     for _ in range(max_new_tokens):                                                 # beamSD.py:579-588
-        o = _one_step(model, inp, k, scores, seq, fn)
+        o = _one_step(model, inp, k, scores, seq, fn, procs)
         inp, scores, seq = o["next"], o["scores"], o["seq"]
     return dict(beam_sequence=seq, beam_scores=scores)
 
 
-def bssd_host_mask(target: HipLlama, draft: HipLlama, prompt: np.ndarray, gamma: int, max_new_tokens: int, fn: Callable) -> Dict:
-    """BSSD (beamSD.py:458-542) with the mask function on the host."""
+class _Stage:
+    """wall clock of a stage with a device synchronisation at its end (the reference's Timer, beamSD.py:12-37)"""
+
+    def __init__(self, acc: Dict[str, float], key: str, dev):
+        self.acc, self.key, self.dev = acc, key, dev
+
+    def __enter__(self):
+        self.t0 = time.time()
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize(self.dev)
+        self.acc[self.key] += time.time() - self.t0
+
+
+def bssd_host_mask(target: HipLlama, draft: HipLlama, prompt: np.ndarray, gamma: int, max_new_tokens: int, fn: Optional[Callable],
+                   procs: Sequence[Callable] = ()) -> Dict:
+    """BSSD (beamSD.py:458-542) with the mask function / logits processors on the host."""
     lib = _lib.load()
+    cost = {"draft_time_cost": 0.0, "target_time_cost": 0.0, "verify_time_cost": 0.0}
     k, dk = int(target.generation_config.num_beams), int(draft.generation_config.num_beams)
     V = target.dims.vocab_size
     cur_len, max_len = len(prompt), len(prompt) + max_new_tokens
@@ -153,26 +223,29 @@ def bssd_host_mask(target: HipLlama, draft: HipLlama, prompt: np.ndarray, gamma:
     accept_steps: List[int] = []
     while cur_len < max_len:
         dl = min(gamma, max_len - cur_len - 1)                                      # :504
-        if dl == 0:                                                                 # :505-509
-            o = _one_step(target, tin, k, scores, seq, fn)
+        if dl == 0:                                                                 # :505-509 (in no stage's sum: the reference breaks before :523-525)
+            o = _one_step(target, tin, k, scores, seq, fn, procs)
             seq, scores = o["seq"], o["scores"]
             break
         # ---- draft (:108-179)
         steps, inp, d_scores, d_seq = [], din, scores, seq
         step_len, step_seq = [len(scores)], [seq]
-        for _ in range(dl):
-            o = _one_step(draft, inp, dk, d_scores, d_seq, fn)
-            inp, d_scores, d_seq = o["next"], o["scores"], o["seq"]
-            steps.append(o)
-            step_len.append(len(d_scores))
-            step_seq.append(d_seq)
+        with _Stage(cost, "draft_time_cost", draft.device):
+            for _ in range(dl):
+                o = _one_step(draft, inp, dk, d_scores, d_seq, fn, procs)
+                inp, d_scores, d_seq = o["next"], o["scores"], o["seq"]
+                steps.append(o)
+                step_len.append(len(d_scores))
+                step_seq.append(d_seq)
         # ---- target: one forward over round inputs ++ every draft block (:190-232)
         blocks = [tin] + [o["next"] for o in steps]
         width = max(b.vis.shape[1] for b in blocks)
         packed = _Inputs(np.concatenate([b.ids for b in blocks]), np.concatenate([b.pos for b in blocks]),
                          np.concatenate([b.slots for b in blocks]), np.concatenate([_pad(b.vis, width) for b in blocks], axis=0))
         n_rows = sum(step_len)
-        logits, lse = _forward(target, packed, n_rows)
+        with _Stage(cost, "target_time_cost", target.device):
+            logits, lse = _forward(target, packed, n_rows)
+        t_verify = time.time()
         # ---- verify (:242-456, greedy)
         n0 = len(tin.ids)
         nm, lo, hi = 0, 0, step_len[0]
@@ -189,7 +262,7 @@ def bssd_host_mask(target: HipLlama, draft: HipLlama, prompt: np.ndarray, gamma:
                 v_scores = v_scores[hit4]
             if i == 0 and len(rows) == 1 and k != 1:
                 seqs = seqs[:1]
-            s, p, t, f = _expand_prune(target, logits, lse, rows, v_scores, _allowed_lists(fn, seqs), k)
+            s, p, t, f = _expand(target, logits, lse, rows, v_scores, seqs, fn, procs, k)
             v_scores = s
             parents = hit[p] if i > 0 else p
             flat = parents * V + t
@@ -229,6 +302,8 @@ def bssd_host_mask(target: HipLlama, draft: HipLlama, prompt: np.ndarray, gamma:
                           np.concatenate((last.slots, tin.slots)), np.concatenate((_pad(last.vis, base + m), vis), axis=0))
         cur_len += nm + 1
         accept_steps.append(nm)
+        torch.cuda.synchronize(target.device)
+        cost["verify_time_cost"] += time.time() - t_verify
     n_run, total = len(accept_steps), sum(accept_steps)
     return dict(beam_sequence=seq, beam_scores=scores, n_run=n_run, total_accept_steps=total, total_accept_tokens=total * k,
-                ave_accept_tokens=total * k / n_run if n_run else 0.0, accept_steps=accept_steps)
+                ave_accept_tokens=total * k / n_run if n_run else 0.0, accept_steps=accept_steps, **cost)

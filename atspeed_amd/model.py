@@ -34,11 +34,43 @@ def _interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     return out
 
 
+COMPUTE_DTYPES = (torch.float32, torch.bfloat16)
+
+
+def _weight_tensors(packed: Dict):
+    for k in ("embed", "final_norm", "lm_head"):
+        yield k, packed[k]
+    for l, lw in enumerate(packed["layers"]):
+        for k, t in lw.items():
+            yield f"layers.{l}.{k}", t
+
+
+def engine_dtype_for(checkpoint_dtype: torch.dtype) -> torch.dtype:
+    """The arithmetic type a checkpoint of `checkpoint_dtype` runs in.  fp32 -> fp32 (exact-fp32 MFMA, the parity mode), bf16 -> bf16,
+    and fp16 -> bf16: the reference loads both models with `torch_dtype=torch.float16` (code/inference.py:75-100); gfx950's fast MFMA path
+    here is bf16 with fp32 accumulation, so fp16 weights are converted BY VALUE (through fp32; every fp16 value is inside bf16's range,
+    its 11-bit significand is rounded to 8 bits).  Pass `dtype=torch.float32` to keep every fp16 bit."""
+    if checkpoint_dtype in (torch.float32, torch.float64):
+        return torch.float32
+    if checkpoint_dtype in (torch.bfloat16, torch.float16):
+        return torch.bfloat16
+    raise TypeError(f"no engine dtype for a {checkpoint_dtype} checkpoint (quantised checkpoints must be dequantised first)")
+
+
 class HipLlama:
     def __init__(self, dims: synth.LlamaDims, packed: Dict, dtype: torch.dtype, device: torch.device,
                  max_slots: int = 512, max_tokens: int = 512, max_logit_rows: int = 384, num_beams: int = 1):
         if device.type != "cuda":
             raise RuntimeError("HipLlama needs a HIP device; atspeed_amd has no CPU path")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if dtype not in COMPUTE_DTYPES:
+            # the library reads weights as ATSPEED_F32 or ATSPEED_BF16 bits; anything else (fp16!) would be silently reinterpreted
+            raise TypeError(f"HipLlama computes in torch.bfloat16 or torch.float32, not {dtype}: convert the checkpoint "
+                            "(HipLlama.from_hf / from_state_dict do, by value) instead of passing its storage dtype")
+        for name, t in _weight_tensors(packed):
+            if t.dtype != dtype or t.device != device:
+                raise TypeError(f"HipLlama: weight {name} is {t.dtype} on {t.device}, the model was declared {dtype} on {device}")
         self.dims = dims
         self._packed = packed          # keeps the weight tensors alive
         self._dtype = dtype
@@ -130,8 +162,12 @@ class HipLlama:
     @classmethod
     def from_state_dict(cls, dims: synth.LlamaDims, state_dict: Dict, dtype: torch.dtype = torch.float32,
                         device="cuda", **kw) -> "HipLlama":
-        """HF-named tensors (numpy or torch, any float dtype) -> packed device weights."""
+        """HF-named tensors (numpy or torch, any float dtype: values are converted through fp32, never reinterpreted) -> device weights
+        in `dtype`, which must be torch.float32 or torch.bfloat16."""
         device = torch.device(device)
+        if dtype not in COMPUTE_DTYPES:
+            raise TypeError(f"HipLlama.from_state_dict: dtype must be torch.bfloat16 or torch.float32, not {dtype} "
+                            "(an fp16 checkpoint is converted by value: see engine_dtype_for)")
         sd = {}
         for k, v in state_dict.items():
             t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v.detach()
@@ -140,21 +176,38 @@ class HipLlama:
 
     @classmethod
     def from_hf(cls, hf_model, dtype: Optional[torch.dtype] = None, device="cuda", **kw) -> "HipLlama":
-        """Adapter for an HF `LlamaForCausalLM` (the object the reference loads, inference.py:75-100)."""
+        """Adapter for an HF `LlamaForCausalLM` (the object the reference loads, inference.py:75-100).  `dtype=None` picks the engine
+        dtype from the checkpoint's (`engine_dtype_for`: fp32 -> fp32, bf16 -> bf16, fp16 -> bf16 by value -- the reference's
+        `torch_dtype=torch.float16` models run in bf16 here, `.dtype` says so); `dtype=torch.float32` keeps every bit of an fp16 / bf16
+        checkpoint and computes in fp32.  Anything the kernels do not implement raises instead of approximating."""
         c = hf_model.config
-        dims = synth.LlamaDims(c.vocab_size, c.hidden_size, c.num_hidden_layers, c.num_attention_heads,
-                               c.intermediate_size, float(getattr(c, "rope_theta", 10000.0)), float(c.rms_norm_eps))
-        if getattr(c, "num_key_value_heads", c.num_attention_heads) != c.num_attention_heads:
+        rp = getattr(c, "rope_parameters", None) or {}
+        theta = getattr(c, "rope_theta", None) or (rp.get("rope_theta") if isinstance(rp, dict) else None) or 10000.0
+        scaling = getattr(c, "rope_scaling", None) or rp          # transformers 4.41: None or {"type": ...}; 5.x: always a dict with rope_type
+        if isinstance(scaling, dict) and (scaling.get("rope_type") or scaling.get("type") or "default") != "default":
+            raise NotImplementedError(f"rope scaling {scaling} is not on this path (Llama-68M / Llama-7B use plain RoPE)")
+        if getattr(c, "num_key_value_heads", None) not in (None, c.num_attention_heads):
             raise NotImplementedError("grouped-query attention is not on this path (Llama-68M / Llama-7B are MHA)")
+        if getattr(c, "attention_bias", False) or getattr(c, "mlp_bias", False):
+            raise NotImplementedError("projection biases are not on this path (Llama has none)")
+        if getattr(c, "head_dim", None) not in (None, c.hidden_size // c.num_attention_heads):
+            raise NotImplementedError("head_dim != hidden_size / num_attention_heads is not on this path")
+        dims = synth.LlamaDims(c.vocab_size, c.hidden_size, c.num_hidden_layers, c.num_attention_heads,
+                               c.intermediate_size, float(theta), float(c.rms_norm_eps))
         sd = {k: v for k, v in hf_model.state_dict().items() if "rotary" not in k}
-        m = cls.from_state_dict(dims, sd, dtype or hf_model.dtype, device, **kw)
+        if "lm_head.weight" not in sd:                       # tie_word_embeddings
+            sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
+        m = cls.from_state_dict(dims, sd, engine_dtype_for(hf_model.dtype) if dtype is None else dtype, device, **kw)
         m.generation_config.num_beams = getattr(hf_model.generation_config, "num_beams", 1)
+        m.generation_config.do_sample = bool(getattr(hf_model.generation_config, "do_sample", False))
+        temp = getattr(hf_model.generation_config, "temperature", None)
+        m.generation_config.temperature = 1.0 if temp is None else float(temp)
         return m
 
     @classmethod
     def from_synthetic(cls, dims: synth.LlamaDims, seed: int, std: float = 0.02, head_std: Optional[float] = None,
                        norm_jitter: float = 0.1, dtype: torch.dtype = torch.bfloat16, device="cuda",
-                       resid_scale: float = 1.0, align_to: Optional["HipLlama"] = None, **kw) -> "HipLlama":
+                       resid_scale: float = 1.0, align_to: Optional["HipLlama"] = None, round_to_bf16: bool = False, **kw) -> "HipLlama":
         """Weights generated ON THE DEVICE by the same hash recipe as `synth.synthetic_state_dict`
         (bit-identical values), so 7B-sized models need no host generation or PCIe transfer.
 
@@ -162,10 +215,15 @@ class HipLlama:
         o_proj / down_proj weights scaled by `resid_scale` << 1 a model is close to its own bigram table
         head(norm(embed[tok])); `align_to=draft` copies the draft's embedding / final norm / head into the first
         `draft.hidden` coordinates of this (wider) model, so both models rank next tokens almost alike while every
-        kernel still runs on dense weights of the full shapes."""
+        kernel still runs on dense weights of the full shapes.
+
+        `round_to_bf16` (fp32 models): every weight is rounded to the nearest bf16 value, i.e. the fp32 engine holds EXACTLY the weights
+        of the bf16 model of the same seed -- the judge of tests/replay.py and bench.py's fp32 accepted-length comparison."""
         device = torch.device(device)
         lib = _lib.load()
         head_std = std if head_std is None else head_std
+        if dtype not in COMPUTE_DTYPES:
+            raise TypeError(f"HipLlama.from_synthetic: dtype must be torch.bfloat16 or torch.float32, not {dtype}")
         code = _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16
         sd: Dict[str, torch.Tensor] = {}
         with torch.cuda.device(device):
@@ -191,6 +249,9 @@ class HipLlama:
                 sd["lm_head.weight"][:, :hd] = (align_to._unpack_rows(src["lm_head"], dims.vocab_size) if align_to.weights_packed else src["lm_head"])
                 # RMS over `hidden` coordinates of which `hd` carry the signal: rescale so norm(x)[:hd] matches the draft's
                 sd["model.norm.weight"][:hd] = (src["final_norm"].float() * (hd / dims.hidden) ** 0.5).to(dtype)
+            if round_to_bf16 and dtype == torch.float32:
+                for t in sd.values():
+                    t.copy_(t.to(torch.bfloat16))
             packed = cls._pack(sd, dims)
             del sd
         return cls(dims, packed, dtype, device, **kw)

@@ -13,16 +13,24 @@ verify rounds), prompts already resident in HBM; `value` = users * K beams / wal
 Users are independent, so N GPUs shard the user list (weak scaling: --steps batches per GPU)
 and exchange only one all-gather of counters at the end.
 
-Extra objects on the JSON line:
+Extra objects on the JSON line (N = 1; all driver-clocked, all bounded so the default run stays within minutes):
   roofline     — the dominant kernel (the target forward's gate_up projection GEMM), hipEvent-bracketed on its
                  launch stream: algorithmic flops / launch time vs the 2.5 PF dense bf16 MFMA peak when users are
-                 batched (HBM bytes vs 8 TB/s with --streams 1); verify_scan: the verify step's scan vs 8 TB/s.
+                 batched; verify_scan: the verify step's scan vs 8 TB/s.
+  configs      — BASELINE configs 3 and 5 as sub-passes with their own items/s, ms_per_step and dominant-kernel roofline:
+                 games_256 / games_256_trie (Games V=33014, 256 users per lock-step batch, position-set mask / strict item
+                 trie) and fp8 (e4m3 W8A8 target projections, roofline against 5 PF, accepted-length drift vs bf16).
+  aligned_weight_brackets — the same users and kernels with draft / target weights that agree (accept length 3 and ~1.1), each
+                 with the fp32 ENGINE's accepted length on the same weights and >= 32 users next to the bf16 engine's.
+  latency_curve — items/s and ms to the last result at 1 / 4 / 16 / 64 / 256 users per lock-step batch.
+  single_user_stream — the reference's one-user-at-a-time loop (HBM-bound projections).
   cpu_baseline — the oracle (oracle/beamsd_ref.py, torch-CPU fp32) timed on the host cores on a
                  bounded sample of the same workload with the same weights (rank 0, N=1 only).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -58,43 +66,64 @@ def parse():
     ap.add_argument("--new-tokens", type=int, default=4)
     ap.add_argument("--seed", type=int, default=2025)
     ap.add_argument("--streams", type=int, default=256, help="users decoded in lock step per GPU (one batched forward per draft step / verification); 1 = the reference's one-user-at-a-time loop")
-    ap.add_argument("--target-fp8", action="store_true", help="BASELINE config 5: fp8 (e4m3 W8A8) target projections in the batched forwards")
+    ap.add_argument("--target-fp8", action="store_true", help="BASELINE config 5 as the HEADLINE pass: fp8 (e4m3 W8A8) target projections in the batched forwards")
     ap.add_argument("--single-stream-users", type=int, default=6, help="extra untimed-for-value pass: users decoded one at a time (the reference's loop)")
     ap.add_argument("--aligned-resid-scale", type=str, default="3e-6,3e-5",
                     help="extra brackets (SURVEY.md 8d 'oracle-draft'): same shapes and kernels, draft/target weights aligned through a "
                          "shared bigram table with the layers' residual contributions scaled by each factor of this comma list "
                          "(3e-6: every draft step accepted, 3e-5: about one step per verification); empty string skips the pass")
-    ap.add_argument("--dataset", choices=("beauty", "games"), default="beauty", help="vocabulary / prompt-length shape (games = BASELINE config 3)")
+    ap.add_argument("--aligned-fp32-users", type=int, default=32, help="users per aligned bracket the fp32 ENGINE also decodes (accepted length next to the bf16 engine's)")
+    ap.add_argument("--dataset", choices=("beauty", "games"), default="beauty", help="vocabulary / prompt-length shape of the headline pass (games = BASELINE config 3)")
     ap.add_argument("--mask", choices=("position", "trie"), default="position",
                     help="position = the per-position allowed sets inference.py installs; trie = strict item trie on the generated suffix")
     ap.add_argument("--do-sample", action="store_true", help="sampling-mode beam-SD (generation_config.do_sample) instead of the greedy headline")
     ap.add_argument("--temperature", type=float, default=1.0)
     ap.add_argument("--cpu-baseline-users", type=int, default=1)
-    ap.add_argument("--aligned-oracle-users", type=int, default=1, help="users per aligned-weight bracket that the CPU oracle also decodes (accepted length next to the GPU's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sub-steps", type=int, default=2, help="timed batches of each sub-pass (configs 3 / 5, aligned brackets); independent of --steps so the line stays bounded")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / config 5 sub-passes")
+    ap.add_argument("--no-latency-curve", action="store_true")
     return ap.parse_args()
 
 
-TRAFFIC_FILE = os.path.join("profiles", "pmc_traffic.json")
+# ------------------------------------------------------------------------------------------------ roofline.traffic provenance
+TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+KERNEL_SOURCES = ("gemm.hip", "common.h", "internal.h")
 
 
-def traffic_from_profiles(kind: str):
-    """(HBM bytes per launch, provenance) from the committed PMC summary, if present.  The counters need their own rocprofv3 --pmc
-    passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), so this number is NOT measured by the run that prints it: the line
-    carries `traffic_source` next to it."""
-    p = os.path.join(ROOT, TRAFFIC_FILE)
+def kernel_sha(root: str = ROOT) -> str:
+    """Identity of the GEMM kernels' source: sha256 over gemm.hip + the headers it includes (first 16 hex digits)."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(root, "atspeed_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def traffic_from_profiles(kind: str, path: str = None, sha: str = None):
+    """(HBM bytes per launch, provenance) from the committed PMC summary.  The counters need their own rocprofv3 --pmc passes (FETCH_SIZE
+    and WRITE_SIZE do not fit one pass), so this number is NOT measured by the run that prints it: the line carries `traffic_source`, and
+    a summary recorded for OTHER kernel sources than the ones in this tree (`kernel_sha`) is refused -- the number would be stale."""
+    p = path or os.path.join(ROOT, TRAFFIC_FILE)
     if not os.path.exists(p):
         return None, None
     try:
         with open(p) as f:
             d = json.load(f)
-        v = d.get(kind, {}).get("hbm_bytes_per_launch")
-        src = f"{TRAFFIC_FILE} (offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this workload; not measured in this run)"
-        return v, (src if v is not None else None)
     except Exception:
         return None, None
+    v = d.get(kind, {}).get("hbm_bytes_per_launch")
+    if v is None:
+        return None, None
+    have, want = d.get("kernel_sha"), (sha or kernel_sha())
+    rel = os.path.relpath(p, ROOT)
+    if have != want:
+        return None, f"{rel} refused: recorded for kernel sources {have}, this tree has {want} (re-run tools/profile_round.sh)"
+    return v, (f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload at commit {d.get('commit', '?')}, avg M "
+               f"{d.get(kind, {}).get('avg_m', '?')}, same kernel sources {have}; collected offline, not in this run)")
 
 
+# ------------------------------------------------------------------------------------------------ CPU oracle leg
 def cpu_baseline(target, draft, prompts, fn, args, n_users=None):
     """Oracle (CPU restatement of the reference) on the same weights/prompts; bounded sample.  Returns (object, oracle outputs, oracle models)."""
     from oracle import beamsd_ref as R
@@ -141,9 +170,9 @@ def oracle_scores_of(ref_model, prompt, seqs):
 
 
 def disagreement_report(gpu_out, ref_out, P, ref_target, prompt):
-    """Where the bf16 engine's ranking of a user differs from the fp32 oracle's: per rank, the oracle's own score of both items.
-    If the gaps are within the bf16 noise (|gpu score - oracle score of the same item|) the disagreements are near-ties of nearly
-    flat random-init logits, not errors -- this prints the evidence instead of asserting it in a comment."""
+    """Where the bf16 engine's ranking of a user differs from the fp32 oracle's: per rank, the oracle's own score of both items.  The
+    ASSERTED form of this statement is tests/test_decisions_gpu.py (every decision of 64 users replayed by the fp32 engine, margin-gated);
+    this is the same evidence for the headline user, next to the timing."""
     g_items = [tuple(x) for x in gpu_out["beam_sequence"][:, P:].cpu().tolist()]
     r_items = [tuple(x) for x in ref_out["beam_sequence"][:, P:].tolist()]
     g_scores = [float(x) for x in gpu_out["beam_scores"].cpu().tolist()]
@@ -158,10 +187,12 @@ def disagreement_report(gpu_out, ref_out, P, ref_target, prompt):
                  gap=r_scores[i] - sc[g_items[i]], bf16_noise_on_gpu_item=abs(g_scores[i] - sc[g_items[i]])) for i in ranks]
     rep.update(per_rank=rows, max_gap=max(abs(r["gap"]) for r in rows), max_bf16_noise=max(r["bf16_noise_on_gpu_item"] for r in rows),
                oracle_kth_score_margin=(r_scores[-2] - r_scores[-1]) if len(r_scores) > 1 else None,
+               asserted_by="tests/test_decisions_gpu.py (64 users, every top-K / top-DK decision judged by the fp32 engine; clear margins identical)",
                note="gap = how much worse (by the fp32 oracle's own arithmetic) the item the bf16 engine put at this rank is than the oracle's item there")
     return rep
 
 
+# ------------------------------------------------------------------------------------------------ launch plumbing
 def launcher_command(n_gpus: int, argv, port: int = 0):
     """The torch.distributed.run command line that starts `n_gpus` ranks of this script (one process per GPU, RCCL rendezvous on
     127.0.0.1).  What `python bench.py --gpus N` runs when it was not started under torchrun itself."""
@@ -181,6 +212,111 @@ def resolve_world(args, env=os.environ):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start exactly --gpus ranks "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus} ...)")
     return ("run", int(env["RANK"]), int(env.get("LOCAL_RANK", "0")), world)
+
+
+def per_rank_report(per_rank, beam: int):
+    """Straggler visibility of an N > 1 line: what every rank decoded and how long it took (the job's time is the slowest rank's)."""
+    return [dict(rank=i, n_users=c.n_users, n_run=c.n_run, accept_steps=c.accept_steps, elapsed_ms=c.elapsed_ns * 1e-6,
+                 items_per_s=(c.n_users * beam / (c.elapsed_ns * 1e-9)) if c.elapsed_ns else 0.0) for i, c in enumerate(per_rank)]
+
+
+# ------------------------------------------------------------------------------------------------ workload pieces
+def make_mask(vocab, kind: str):
+    if kind == "trie":
+        from atspeed_amd.generation_trie import SuffixTrieConstraint, Trie
+        return SuffixTrieConstraint(Trie([[1] + [int(t) for t in it] + [2] for it in synth.synthetic_items(vocab)]), synth.RESPONSE_SEP, 1)
+    return PositionSetConstraint(vocab.allowed_tokens(), synth.RESPONSE_SEP)
+
+
+def make_prompts(n, first, seed, dataset, dev):
+    plens = synth.prompt_lengths(first + n, seed, mean_hist=7.33 if dataset == "beauty" else 5.98)   # SURVEY.md 8d
+    prompts = [synth.synthetic_prompt(int(plens[first + u]), synth.tensor_seed(seed, f"user{first + u}")) for u in range(n)]
+    return prompts, [{"input_ids": torch.from_numpy(p)[None].to(dev)} for p in prompts]   # resident in HBM before timing
+
+
+def run_users(target, draft, dprompts, lo, hi, streams, fn, args):
+    """users [lo, hi) in lock-step batches of `streams` (1 = plain per-user BSSD calls, the reference's loop)"""
+    res = []
+    if streams <= 1:
+        for u in range(lo, hi):
+            res.append(BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn))
+        return res
+    for g in range(lo, hi, streams):
+        res += BSSD_batch(target, draft, dprompts[g:min(hi, g + streams)], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
+    return res
+
+
+def gemm_roofline(target, prof, prof_big, fp8: bool, measured, streams: int, with_traffic: bool):
+    """Roofline object of the GEMM kind with the largest total time.  One user at a time (M ~ 100-230 tokens) a launch is a single pass
+    over the weights: HBM-bound.  With lock-step batching M = tokens of all users (thousands): arithmetic intensity is far above the ridge
+    (2.5 PF / 8 TB/s = 312 flop/B) and the bound is the MFMA peak of the arithmetic type."""
+    kind = max(prof, key=lambda k: prof[k]["ms"])
+    one_kernel = prof_big[kind]["count"] > 0          # launches of >= 1024 tokens: exactly the 256x256 ring kernel
+    pk = prof_big[kind] if one_kernel else prof[kind]
+    N, K = target.gemm_shape(kind)
+    avg_m = pk["rows"] / max(1, pk["count"])
+    n_out = N // 2 if kind == "gate_up" else N
+    out_b = 4 if kind == "lm_head" else 2
+    f8 = fp8 and kind != "lm_head"
+    in_b = 1 if f8 else 2                             # operand bytes: e4m3 or bf16
+    alg_bytes = N * K * in_b + avg_m * K * in_b + avg_m * n_out * out_b
+    alg_flops = 2.0 * avg_m * N * K
+    avg_ms = pk["ms"] / max(1, pk["count"])
+    gemm_ms_total = sum(v["ms"] for v in prof.values())
+    intensity = alg_flops / alg_bytes
+    if intensity >= MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+        achieved = alg_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        bound, peak, unit = "mfma", (MFMA_FP8_PEAK_TFLOPS if f8 else MFMA_PEAK_TFLOPS), "TFLOP/s"
+    else:
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        bound, peak, unit = "hbm", HBM_PEAK_GBS, "GB/s"
+    # qkv: 5 = RoPE + KV scatter in the epilogue (head_dim 128 targets), as the engine's counter says
+    epi = {"qkv": 5 if target.rope_fused_launches() > 0 else 0, "o_proj": 2, "gate_up": 3, "down": 2, "lm_head": 1}[kind]
+    ring = (f"gemm_ring_mx_kernel<{epi}, 8>" if (f8 and os.environ.get("ATSPEED_FP8_MX", "1") != "0")
+            else f"gemm_ring_kernel<{4 if kind == 'lm_head' else epi}, 8, {'true' if f8 else 'false'}, false, 4>")
+    kname = (f"{ring} [{kind}] N={N} K={K} avg_M={avg_m:.0f} (launches of >= 1024 tokens)"
+             if one_kernel else f"projection GEMM [{kind}] N={N} K={K} avg_M={avg_m:.0f} (all launches)")
+    # PMC traffic was collected on the bf16 headline workload: it says nothing about the fp8 kernels or other batch shapes
+    traffic, traffic_source = traffic_from_profiles(kind) if (with_traffic and one_kernel and not fp8 and streams == 256) else (None, None)
+    m_peak = None
+    if measured:
+        m_peak = (measured["mfma_bf16_tflops"] if not f8 else None) if bound == "mfma" else measured["hbm_read_gbs"]
+    return dict(bound=bound, kernel=kname, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
+                peak_measured=m_peak, frac_of_measured=(achieved / m_peak) if m_peak else None,
+                traffic=traffic, traffic_source=traffic_source, traffic_over_algorithmic=(traffic / alg_bytes) if traffic else None,
+                avg_launch_us=avg_ms * 1e3, launches=pk["count"],
+                algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=alg_flops, arithmetic_intensity=intensity,
+                gemm_ms_share={k: v["ms"] / gemm_ms_total for k, v in prof.items()} if gemm_ms_total else {},
+                all_gemms_tflops=(sum(2.0 * v["rows"] * target.gemm_shape(k)[0] * target.gemm_shape(k)[1] for k, v in prof.items())
+                                  / (gemm_ms_total * 1e-3) / 1e12) if gemm_ms_total else 0.0)
+
+
+def timed_pass(target, draft, dprompts, n_warm_batches, n_batches, streams, fn, args, dev, profile=True):
+    """`n_warm_batches` untimed then `n_batches` timed lock-step batches of `streams` users from `dprompts`.  -> dict(outs, elapsed, prof, prof_big)"""
+    ups = max(1, streams)
+    n_warm, n_timed = n_warm_batches * ups, n_batches * ups
+    assert n_warm + n_timed <= len(dprompts)
+    run_users(target, draft, dprompts, 0, n_warm, streams, fn, args)
+    if streams > 1 and n_warm == 0:                  # create every decoder / grow the batch buffers outside the timed region
+        BSSD_batch(target, draft, dprompts[:streams], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
+    if profile:
+        target.profile(1)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    outs = run_users(target, draft, dprompts, n_warm, n_warm + n_timed, streams, fn, args)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    prof_big = target.profile_big() if profile else None
+    prof = target.profile(0) if profile else None
+    return dict(outs=outs, elapsed=elapsed, prof=prof, prof_big=prof_big, n_timed=n_timed)
+
+
+def pass_summary(r, args, streams):
+    outs, n = r["outs"], r["n_timed"]
+    runs = sum(o["n_run"] for o in outs)
+    return dict(items_per_s=n * args.beam / r["elapsed"], ms_per_step=1e3 * r["elapsed"] / max(1, n // max(1, streams)), users=n,
+                mean_accept_len=sum(o["total_accept_steps"] for o in outs) / max(1, runs),
+                target_forwards_per_user=sum(o["n_target_forwards"] for o in outs) / n, n_run_per_user=runs / n)
 
 
 def main():
@@ -208,43 +344,33 @@ def main():
     tdims = synth.llama_7b(V, args.target_layers)
     ddims = synth.llama_68m(V)
     kw = dict(max_slots=512, max_tokens=512, max_logit_rows=384, device=dev)
-    target = HipLlama.from_synthetic(tdims, args.seed, std=0.02, head_std=0.02, dtype=torch.bfloat16, num_beams=args.beam, **kw)
-    draft = HipLlama.from_synthetic(ddims, args.seed + 1, std=0.02, head_std=0.02, dtype=torch.bfloat16, num_beams=args.draft_beam, **kw)
+
+    def build_pair(tdims_, ddims_, dtype=torch.bfloat16, resid_scale=None, **extra):
+        rs = 1.0 if resid_scale is None else resid_scale
+        k2 = dict(kw, **extra)
+        d = HipLlama.from_synthetic(ddims_, args.seed + 1, std=0.02, head_std=0.02, dtype=dtype, num_beams=args.draft_beam, resid_scale=rs, **k2)
+        t = HipLlama.from_synthetic(tdims_, args.seed, std=0.02, head_std=0.02, dtype=dtype, num_beams=args.beam, resid_scale=rs,
+                                    align_to=(d if resid_scale is not None else None), **k2)
+        if args.do_sample:
+            for m in (t, d):
+                m.generation_config.do_sample = True
+                m.generation_config.temperature = args.temperature
+        return t, d
+
+    target, draft = build_pair(tdims, ddims)
     if args.target_fp8:
         target.enable_fp8()
     if args.do_sample:
-        for m in (target, draft):
-            m.generation_config.do_sample = True
-            m.generation_config.temperature = args.temperature
         torch.manual_seed(args.seed)
-    if args.mask == "trie":
-        from atspeed_amd.generation_trie import SuffixTrieConstraint, Trie
-        fn = SuffixTrieConstraint(Trie([[1] + [int(t) for t in it] + [2] for it in synth.synthetic_items(vocab)]), synth.RESPONSE_SEP, 1)
-    else:
-        fn = PositionSetConstraint(vocab.allowed_tokens(), synth.RESPONSE_SEP)
+    fn = make_mask(vocab, args.mask)
 
     # a STEP is one lock-step batch: `--streams` users decoded together (one pass of the hot path over one batch of inputs)
     ups = max(1, args.streams)
     n_warm, n_timed = args.warmup * ups, args.steps * ups
     n_local = n_warm + n_timed
-    first = rank * n_local                                   # contiguous user shard per rank
-    plens = synth.prompt_lengths(world * n_local, args.seed, mean_hist=7.33 if args.dataset == "beauty" else 5.98)
-    prompts = [synth.synthetic_prompt(int(plens[first + u]), synth.tensor_seed(args.seed, f"user{first + u}")) for u in range(n_local)]
-    dprompts = [{"input_ids": torch.from_numpy(p)[None].to(dev)} for p in prompts]   # resident in HBM before timing
+    prompts, dprompts = make_prompts(n_local, rank * n_local, args.seed, args.dataset, dev)   # contiguous user shard per rank
 
-    def run_users(lo, hi):
-        """users [lo, hi): groups of --streams interleaved lanes (1 = plain per-user BSSD calls)"""
-        res = []
-        if args.streams <= 1:
-            for u in range(lo, hi):
-                res.append(BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn))
-            return res
-        for g in range(lo, hi, args.streams):
-            res += BSSD_batch(target, draft, dprompts[g:min(hi, g + args.streams)], args.gamma, args.new_tokens,
-                              prefix_allowed_tokens_fn=fn)
-        return res
-
-    run_users(0, n_warm)
+    run_users(target, draft, dprompts, 0, n_warm, args.streams, fn, args)
     if args.streams > 1:                         # create every decoder / grow the batch buffers outside the timed region
         BSSD_batch(target, draft, dprompts[:args.streams], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
     target.profile(1)
@@ -256,7 +382,7 @@ def main():
     stage = np.zeros(3)
     n_tf = n_df = 0
     outs = []
-    for o in run_users(n_warm, n_local):
+    for o in run_users(target, draft, dprompts, n_warm, n_local, args.streams, fn, args):
         n_run += o["n_run"]; acc += o["total_accept_steps"]
         stage += (o["draft_time_cost"], o["target_time_cost"], o["verify_time_cost"])
         n_tf += o["n_target_forwards"]; n_df += o["n_draft_forwards"]
@@ -267,13 +393,50 @@ def main():
     elapsed = time.perf_counter() - t0
     prof_big = target.profile_big()
     prof = target.profile(0)
+    solo = world == 1                 # auxiliary passes belong to the N = 1 line only
+    sub_steps = max(1, min(args.sub_steps, args.steps))
+    sub_warm = 1 if (args.warmup + args.steps) > sub_steps else 0       # sub-passes reuse the main pass's users: one warm batch if there is room
+
+    # ---- measured peaks of THIS box (SURVEY.md 8d): register-only bf16 MFMA loop on random operands, read-only HBM stream over 2 GiB
+    measured = None
+    if rank == 0:
+        import ctypes as C
+        from atspeed_amd import _lib
+        lib, tf, gbs = _lib.load(), C.c_double(), C.c_double()
+        buf = torch.empty(2 << 30, dtype=torch.uint8, device=dev).fill_(1)
+        scratch = torch.empty(4 << 20, dtype=torch.uint8, device=dev)
+        _lib.check(lib.atspeed_probe_mfma_bf16(4000, scratch.data_ptr(), scratch.numel(), _lib.stream_ptr(dev), C.byref(tf)))
+        _lib.check(lib.atspeed_probe_hbm_read(buf.data_ptr(), buf.numel(), 8, scratch.data_ptr(), _lib.stream_ptr(dev), C.byref(gbs)))
+        measured = dict(mfma_bf16_tflops=tf.value, hbm_read_gbs=gbs.value,
+                        how="atspeed_probe_mfma_bf16 (16x16x32, random operands, 8 waves/CU) and atspeed_probe_hbm_read (2 GiB, 8 passes, best of 2 access shapes x 5 grids)")
+        del buf, scratch
+
+    # ---- latency curve: where lock-step batching overtakes per-user calls (items/s and ms until the LAST user of the batch has its result)
+    curve = None
+    if solo and not args.no_latency_curve and args.streams > 1:
+        curve = []
+        for s in (1, 4, 16, 64, 256):
+            if s > args.streams or s > n_timed:
+                continue
+            grp = dprompts[n_warm: n_warm + s]
+            call = (lambda: [BSSD(target, draft, grp[0], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)]) if s == 1 else \
+                   (lambda: BSSD_batch(target, draft, grp, args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn))
+            call(); call()                                            # recurring shapes settled
+            torch.cuda.synchronize(dev)
+            reps = 3 if s <= 16 else 2
+            tc = time.perf_counter()
+            for _ in range(reps):
+                call()
+            torch.cuda.synchronize(dev)
+            ms = 1e3 * (time.perf_counter() - tc) / reps
+            curve.append(dict(users_per_batch=s, ms_to_last_result=ms, items_per_s=s * args.beam / (ms * 1e-3), ms_per_user=ms / s))
 
     # ---- the reference's own regime, for the record (not part of `value`): a few users strictly one at a time.
     # Here every projection is one pass over the weights (M ~ 20-230 tokens): HBM-bound.
     single = None
-    if world == 1 and args.streams > 1 and args.single_stream_users > 0:      # auxiliary passes belong to the N=1 line only
+    if solo and args.streams > 1 and args.single_stream_users > 0:
         n1 = min(args.single_stream_users, n_timed)
-        for u in range(n_warm, n_warm + min(3, n1)):       # warm-up: recurring forward shapes get their hipGraphs
+        for u in range(n_warm, n_warm + min(3, n1)):       # warm-up
             BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
@@ -281,7 +444,7 @@ def main():
             BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
         torch.cuda.synchronize(dev)
         dt1 = time.perf_counter() - t1
-        target.profile(1)                                           # GEMM brackets from a second, untimed pass (profiling bypasses the graphs)
+        target.profile(1)                                           # GEMM brackets from a second, untimed pass
         for u in range(n_warm, n_warm + min(3, n1)):
             BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
         torch.cuda.synchronize(dev)
@@ -291,58 +454,88 @@ def main():
         m1 = p1[k1]["rows"] / max(1, p1[k1]["count"])
         b1 = N1 * K1 * 2 + m1 * K1 * 2 + m1 * (N1 // 2 if k1 == "gate_up" else N1) * (4 if k1 == "lm_head" else 2)
         us1 = 1e3 * p1[k1]["ms"] / max(1, p1[k1]["count"])
+        # the whole forward against the stream of its weights: target forwards per user x W_t bytes / time
+        tf_user = sum(o["n_target_forwards"] for o in outs[:n1]) / n1
         single = dict(users=n1, items_per_s=n1 * args.beam / dt1, ms_per_user=1e3 * dt1 / n1,
-                      roofline=dict(bound="hbm", kernel=f"small-M projection [{k1}] N={N1} K={K1} avg_M={m1:.0f} (split-K ring GEMM + slab reduce)",
+                      weights_stream_gbs=tf_user * tdims.n_params_streamed() * 2 / (dt1 / n1) / 1e9,
+                      weights_stream_frac_of_hbm_peak=tf_user * tdims.n_params_streamed() * 2 / (dt1 / n1) / 1e9 / HBM_PEAK_GBS,
+                      roofline=dict(bound="hbm", kernel=f"small-M projection [{k1}] N={N1} K={K1} avg_M={m1:.0f}",
                                     achieved=b1 / (us1 * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                                    frac=b1 / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, avg_launch_us=us1))
+                                    frac=b1 / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, avg_launch_us=us1,
+                                    per_kind_us={k: 1e3 * v["ms"] / max(1, v["count"]) for k, v in p1.items()}))
 
-    # ---- high-acceptance bracket: identical shapes / kernels / users, weights aligned so the draft's beams are mostly
-    # the target's (the natural bracket above accepts ~0 steps because the random weights are unrelated).
-    aligned = None
+    # ---- high-acceptance brackets: identical shapes / kernels / users, weights aligned so the draft's beams are mostly the target's
+    # (the natural bracket above accepts ~0 steps because the random weights are unrelated).  Next to each: the fp32 ENGINE (bit-exact
+    # against the CPU oracle at these dims, tests/test_fulldims_gpu.py) on the same weight values and users -- the "reference's" accepted length.
+    aligned, fp8_drift = None, None
     scales = [float(x) for x in args.aligned_resid_scale.split(",") if x.strip()]
-    if world == 1 and scales:
-        release_decoders(target, draft)                # the main pass's per-user KV arenas: room for the second model pair
+    if solo and scales:
+        release_decoders(target, draft)                # the main pass's per-user KV arenas: room for the other model pairs
         aligned = []
-        grp = max(1, args.streams)
         for rs in scales:
-            draft_a = HipLlama.from_synthetic(ddims, args.seed + 1, std=0.02, head_std=0.02, dtype=torch.bfloat16, num_beams=args.draft_beam,
-                                              resid_scale=rs, **kw)
-            target_a = HipLlama.from_synthetic(tdims, args.seed, std=0.02, head_std=0.02, dtype=torch.bfloat16, num_beams=args.beam,
-                                               resid_scale=rs, align_to=draft_a, **kw)
+            target_a, draft_a = build_pair(tdims, ddims, resid_scale=rs)
             if args.target_fp8:
                 target_a.enable_fp8()
-            if args.do_sample:
-                for m in (target_a, draft_a):
-                    m.generation_config.do_sample = True
-                    m.generation_config.temperature = args.temperature
-
-            def run_aligned(lo, hi):
-                res = []
-                for g in range(lo, hi, grp):
-                    res += BSSD_batch(target_a, draft_a, dprompts[g:min(hi, g + grp)], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
-                return res
-            run_aligned(0, min(n_local, max(n_warm, grp)))
-            torch.cuda.synchronize(dev)
-            ta = time.perf_counter()
-            ro = run_aligned(n_warm, n_local)
-            torch.cuda.synchronize(dev)
-            dta = time.perf_counter() - ta
-            br = dict(resid_scale=rs, items_per_s=n_timed * args.beam / dta, ms_per_user=1e3 * dta / n_timed,
-                      mean_accept_len=sum(o["total_accept_steps"] for o in ro) / max(1, sum(o["n_run"] for o in ro)),
-                      n_run_per_user=sum(o["n_run"] for o in ro) / n_timed,
-                      target_forwards_per_user=sum(o["n_target_forwards"] for o in ro) / n_timed)
-            if rank == 0 and not args.no_cpu_baseline and not args.do_sample and args.aligned_oracle_users > 0:
-                # the accepted length of the CPU oracle (fp32) on EXACTLY these aligned weights and users, next to the engine's (bf16):
-                # the non-zero data points behind "mean accepted length >= the reference's"
-                cb_a, ref_a, _models = cpu_baseline(target_a, draft_a, prompts[n_warm:], fn, args, n_users=args.aligned_oracle_users)
-                na = len(ref_a)
-                del _models
-                br["oracle"] = dict(users=na, mean_accept_len=cb_a["mean_accept_len"], accept_steps=[[r["n_matches"] for r in o["rounds"]] for o in ref_a],
-                                    gpu_mean_accept_len_same_users=sum(o["total_accept_steps"] for o in ro[:na]) / max(1, sum(o["n_run"] for o in ro[:na])),
-                                    gpu_accept_steps_same_users=[o["accept_steps"] for o in ro[:na]], items_per_s=cb_a["value"], sample=cb_a["sample"])
+            r = timed_pass(target_a, draft_a, dprompts, sub_warm, sub_steps, args.streams, fn, args, dev, profile=False)
+            br = dict(resid_scale=rs, **pass_summary(r, args, ups))
+            nf = min(args.aligned_fp32_users, r["n_timed"])
+            if nf > 0 and not args.do_sample:
+                t32, d32 = build_pair(tdims, ddims, dtype=torch.float32, resid_scale=rs, round_to_bf16=True, max_logit_rows=448)
+                tf0 = time.perf_counter()
+                fo = [BSSD(t32, d32, dprompts[sub_warm * ups + u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn) for u in range(nf)]
+                torch.cuda.synchronize(dev)
+                go = r["outs"][:nf]
+                br["fp32_engine"] = dict(
+                    users=nf, mean_accept_len=sum(o["total_accept_steps"] for o in fo) / max(1, sum(o["n_run"] for o in fo)),
+                    bf16_mean_accept_len_same_users=sum(o["total_accept_steps"] for o in go) / max(1, sum(o["n_run"] for o in go)),
+                    users_with_equal_accept_steps=sum(1 for a, b in zip(fo, go) if a["accept_steps"] == b["accept_steps"]),
+                    users_with_equal_item_sets=sum(1 for a, b, p in zip(fo, go, prompts[sub_warm * ups:]) if
+                                                   {tuple(x) for x in a["beam_sequence"][:, len(p):].tolist()} == {tuple(x) for x in b["beam_sequence"][:, len(p):].tolist()}),
+                    seconds=time.perf_counter() - tf0,
+                    what="the fp32 engine (exact-fp32 MFMA, one user at a time) on the same bf16-valued weights and users; it equals the CPU oracle bit for bit at these dims")
+                release_decoders(t32, d32)
+                del t32, d32
+            if rs == max(scales) and not args.target_fp8 and not args.do_sample and not args.no_configs:
+                # config 5's accepted-length drift: the SAME aligned pair and users with the target's projections in fp8
+                target_a.enable_fp8()
+                r8 = timed_pass(target_a, draft_a, dprompts, sub_warm, sub_steps, args.streams, fn, args, dev, profile=False)
+                s8 = pass_summary(r8, args, ups)
+                fp8_drift = dict(resid_scale=rs, users=r8["n_timed"], bf16_mean_accept_len=br["mean_accept_len"], fp8_mean_accept_len=s8["mean_accept_len"],
+                                 drift_steps=s8["mean_accept_len"] - br["mean_accept_len"], fp8_items_per_s=s8["items_per_s"])
             aligned.append(br)
             release_decoders(target_a, draft_a)
-            del target_a, draft_a, run_aligned
+            del target_a, draft_a
+
+    # ---- BASELINE configs 3 and 5 as bounded sub-passes of the same line (driver-clocked)
+    configs = None
+    if solo and not args.no_configs and not args.do_sample and args.streams > 1:
+        configs = {}
+        if args.dataset == "beauty" and not args.target_fp8:
+            gv = synth.GAMES
+            tg_, dg_ = build_pair(synth.llama_7b(gv.vocab_size, args.target_layers), synth.llama_68m(gv.vocab_size))
+            _, gprompts = make_prompts((1 + sub_steps) * ups, 0, args.seed, "games", dev)
+            for name, mk in (("games_256", "position"), ("games_256_trie", "trie")):
+                gfn = make_mask(gv, mk)
+                r = timed_pass(tg_, dg_, gprompts, 1, sub_steps, args.streams, gfn, args, dev)
+                configs[name] = dict(workload=f"Games V={gv.vocab_size}, Llama-68M / Llama-7B({args.target_layers}L), K={args.beam}, DK={args.draft_beam}, {args.streams} users per "
+                                              f"lock-step batch, {'position-set mask' if mk == 'position' else 'strict item trie (17 332 items)'}, bf16",
+                                     steps=sub_steps, **pass_summary(r, args, ups),
+                                     roofline=gemm_roofline(tg_, r["prof"], r["prof_big"], False, measured, args.streams, False))
+            release_decoders(tg_, dg_)
+            del tg_, dg_
+        if not args.target_fp8:
+            release_decoders(target, draft)
+            target.enable_fp8()                        # from here on the headline target runs its batched projections in fp8
+            target.fp8_counters(reset=True)
+            r = timed_pass(target, draft, dprompts, sub_warm, sub_steps, args.streams, fn, args, dev)
+            cnt = target.fp8_counters()
+            configs["fp8"] = dict(workload=f"{args.dataset.capitalize()} V={V}, Llama-7B({args.target_layers}L) target verify in fp8 (e4m3 W8A8 projections on the block-scaled MFMA, "
+                                           f"bf16 elsewhere), K={args.beam}, {args.streams} users per lock-step batch",
+                                  steps=sub_steps, dtype="fp8-e4m3 (W8A8 target projections, bf16 elsewhere)", **pass_summary(r, args, ups),
+                                  projection_launches={k: v for k, v in cnt.items()},
+                                  roofline=gemm_roofline(target, r["prof"], r["prof_big"], True, measured, args.streams, False),
+                                  accepted_length_drift_vs_bf16=fp8_drift,
+                                  parity="unpinned against the reference (its 8-bit target is bitsandbytes LLM.int8, absent offline); pinned to the build's W8A8 oracle, tests/test_fp8_gpu.py")
 
     # ---- the verify step's scan (full-vocabulary log-sum-exp over the packed logit rows of one lock-step round, the HBM-bound
     # kernel of beamSD.py:285): rows = users x (1 + 3*DK) at V fp32 logits, timed alone with events on its launch stream
@@ -370,7 +563,7 @@ def main():
                     where="standalone launch of atspeed_lse_rows on a synthetic buffer of one verification round's shape: the kernel the one-user path "
                           "and the C-ABI keep.  The lock-step decode loop no longer runs it (see in_situ)")
         del lg, lse
-        # in situ: since round 2 the batched forwards take the normaliser out of the lm_head GEMM's epilogue and write only the logit tiles that
+        # in situ: the batched forwards take the normaliser out of the lm_head GEMM's epilogue and write only the logit tiles that
         # hold a token of the constraint automaton, so the verify step's former HBM-bound pass (write + re-read of every logit) is gone
         lm = prof["lm_head"]
         tiles_all = (V + 255) // 256
@@ -382,22 +575,8 @@ def main():
                                bytes_written_per_launch=avg_rows * (tiles_kept * 256 * 4 + tiles_all * 8),
                                bytes_avoided_per_launch=avg_rows * ((tiles_all - tiles_kept) * 256 * 4 + V * 4),
                                note="avoided = logit tiles never written + the LSE pass's re-read of every logit (what lse_rows_kernel streamed)")
-
-    # ---- measured peaks of THIS box (SURVEY.md 8d): register-only bf16 MFMA loop on random operands, read-only HBM stream over 2 GiB
-    measured = None
-    if rank == 0:
-        import ctypes as C
-        from atspeed_amd import _lib
-        lib, tf, gbs = _lib.load(), C.c_double(), C.c_double()
-        buf = torch.empty(2 << 30, dtype=torch.uint8, device=dev).fill_(1)
-        scratch = torch.empty(4 << 20, dtype=torch.uint8, device=dev)
-        _lib.check(lib.atspeed_probe_mfma_bf16(4000, scratch.data_ptr(), scratch.numel(), _lib.stream_ptr(dev), C.byref(tf)))
-        _lib.check(lib.atspeed_probe_hbm_read(buf.data_ptr(), buf.numel(), 8, scratch.data_ptr(), _lib.stream_ptr(dev), C.byref(gbs)))
-        measured = dict(mfma_bf16_tflops=tf.value, hbm_read_gbs=gbs.value,
-                        how="atspeed_probe_mfma_bf16 (16x16x32, random operands, 8 waves/CU) and atspeed_probe_hbm_read (2 GiB, 8 passes, best of 2 access shapes x 5 grids)")
-        del buf, scratch
-        if scan is not None:
-            scan["peak_measured"], scan["frac_of_measured"] = gbs.value, scan["achieved"] / gbs.value
+        if measured:
+            scan["peak_measured"], scan["frac_of_measured"] = measured["hbm_read_gbs"], scan["achieved"] / measured["hbm_read_gbs"]
 
     per_rank = all_gather_counters(Counters(n_timed, n_run, acc, int(elapsed * 1e9)), dev)   # the path's single collective
     if rank != 0:
@@ -408,49 +587,8 @@ def main():
     users, t_max, value, mean_accept = agg["users"], agg["elapsed_s"], agg["items_per_s"], agg["mean_accept_len"]
     total_runs = sum(c.n_run for c in per_rank)
 
-    # ---- roofline of the dominant GEMM kind.  One user at a time (M ~ 100-230 tokens) the launch is a single pass over
-    # the weights: HBM-bound.  With lock-step batching M = tokens of all users (thousands): arithmetic intensity is far
-    # above the ridge (2.5 PF / 8 TB/s = 312 flop/B) and the bound is the bf16 MFMA peak.
-    kind = max(prof, key=lambda k: prof[k]["ms"])
-    one_kernel = prof_big[kind]["count"] > 0          # launches of >= 1024 tokens: exactly the 256x256 ring kernel
-    pk = prof_big[kind] if one_kernel else prof[kind]
-    N, K = target.gemm_shape(kind)
-    avg_m = pk["rows"] / max(1, pk["count"])
-    n_out = N // 2 if kind == "gate_up" else N
-    out_b = 4 if kind == "lm_head" else 2
-    in_b = 1 if (args.target_fp8 and kind != "lm_head") else 2        # operand bytes: e4m3 or bf16
-    alg_bytes = N * K * in_b + avg_m * K * in_b + avg_m * n_out * out_b
-    alg_flops = 2.0 * avg_m * N * K
-    avg_ms = pk["ms"] / max(1, pk["count"])
-    gemm_ms_total = sum(v["ms"] for v in prof.values())
-    intensity = alg_flops / alg_bytes
-    if intensity >= MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
-        achieved = alg_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        # the dense MFMA peak of the arithmetic type (guide: ~2.5 PF bf16, ~5 PF fp8 through the block-scaled MFMA forms)
-        bound, peak, unit = "mfma", (MFMA_FP8_PEAK_TFLOPS if (args.target_fp8 and kind != "lm_head") else MFMA_PEAK_TFLOPS), "TFLOP/s"
-    else:
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        bound, peak, unit = "hbm", HBM_PEAK_GBS, "GB/s"
-    # qkv: 5 = RoPE + KV scatter in the epilogue (head_dim 128 targets), as the engine's counter says
-    epi = {"qkv": 5 if target.rope_fused_launches() > 0 else 0, "o_proj": 2, "gate_up": 3, "down": 2, "lm_head": 1}[kind]
-    ring = (f"gemm_ring_mx_kernel<{epi}, 8>" if (args.target_fp8 and kind != "lm_head" and os.environ.get("ATSPEED_FP8_MX", "1") != "0")
-            else f"gemm_ring_kernel<{4 if kind == 'lm_head' else epi}, 8, {'true' if (args.target_fp8 and kind != 'lm_head') else 'false'}, false, 4>")
-    kname = (f"{ring} [{kind}] N={N} K={K} avg_M={avg_m:.0f} (launches of >= 1024 tokens)"
-             if one_kernel else f"projection GEMM [{kind}] N={N} K={K} avg_M={avg_m:.0f} (all launches)")
-    # PMC traffic was collected on the bf16 headline workload: it says nothing about the fp8 kernels or other batch shapes
-    traffic, traffic_source = traffic_from_profiles(kind) if (one_kernel and not args.target_fp8 and args.streams == 256) else (None, None)
-    roofline = dict(bound=bound, kernel=kname,
-                    achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
-                    peak_measured=(measured["mfma_bf16_tflops"] if bound == "mfma" else measured["hbm_read_gbs"]) if measured else None,
-                    frac_of_measured=(achieved / (measured["mfma_bf16_tflops"] if bound == "mfma" else measured["hbm_read_gbs"])) if measured else None,
-                    traffic=traffic, traffic_source=traffic_source, avg_launch_us=avg_ms * 1e3, launches=pk["count"],
-                    algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=alg_flops,
-                    arithmetic_intensity=intensity,
-                    target_forward=dict(avg_ms_per_user=1e3 * stage[1] / max(1, n_tf),
-                                        weight_bytes=tdims.n_params_streamed() * 2,
-                                        gemm_ms_share={k: v["ms"] / gemm_ms_total for k, v in prof.items()} if gemm_ms_total else {},
-                                        all_gemms_tflops=(sum(2.0 * v["rows"] * target.gemm_shape(k)[0] * target.gemm_shape(k)[1] for k, v in prof.items())
-                                                          / (gemm_ms_total * 1e-3) / 1e12) if gemm_ms_total else 0.0))
+    roofline = gemm_roofline(target, prof, prof_big, args.target_fp8, measured, args.streams, True)
+    roofline["target_forward"] = dict(avg_ms_per_user=1e3 * stage[1] / max(1, n_tf), weight_bytes=tdims.n_params_streamed() * 2)
 
     line = {
         "metric": "recommended items/sec (K=20 beams per user), mean accepted length alongside",
@@ -463,25 +601,29 @@ def main():
                    "users_per_step": ups, "users_per_gpu": n_timed, "streams": args.streams,
                    "mean_prompt_len": float(np.mean([len(p) for p in prompts[n_warm:]])),
                    "parallelism": f"user-shard x{world}",
-                   "operand_layout": "packed (row pairs per 128-byte line)" if getattr(target, "weights_packed", False) else "row-major"},
+                   "operand_layout": "packed (row pairs per 128-byte line)" if getattr(target, "weights_packed", False) else "row-major",
+                   "kernel_sha": kernel_sha()},
         "mean_accept_len": mean_accept,
         "accept_note": "unrelated random draft/target weights accept ~0 draft steps: worst-case bracket (3 verify rounds + 1 final step = 4 target forwards per user)",
         "per_user": {"n_run": total_runs / users, "target_forwards": n_tf / n_timed, "draft_forwards": n_df / n_timed,
                      "draft_ms": 1e3 * stage[0] / n_timed, "target_ms": 1e3 * stage[1] / n_timed, "verify_ms": 1e3 * stage[2] / n_timed},
+        "per_rank": per_rank_report(per_rank, args.beam),
         "roofline": roofline,
         "measured_peaks": measured,
         "verify_scan": scan,
+        "configs": configs,                   # BASELINE configs 3 (Games, 256 users) and 5 (fp8 verify), bounded sub-passes
+        "latency_curve": curve,
         "single_user_stream": single,
         "aligned_weight_brackets": aligned,   # same users, shapes and kernels as `value`; only the weights' agreement differs
     }
     if args.do_sample:
         line["decoding"] = f"sampling (temperature {args.temperature})"
     if world == 1 and not args.no_cpu_baseline and not args.do_sample:
+        # (after the fp8 sub-pass the headline target also carries fp8 copies; its bf16 weights, which export_state_dict reads, are untouched)
         cb, ref_outs, (ref_t, _ref_d) = cpu_baseline(target, draft, prompts[n_warm:], fn, args)
         line["cpu_baseline"] = cb
-        # next to the timing: the bf16 engine's items vs the fp32 oracle's on identical weights.  NOT the parity test (tests/test_fulldims_gpu.py
-        # runs the fp32 engine at these dims against the oracle bit for bit): here every rank at which bf16 and fp32 disagree is scored by the
-        # oracle itself, so that "near-ties of flat random-init logits" is a measured statement
+        # next to the timing: the bf16 engine's items vs the fp32 oracle's on identical weights, every rank at which they disagree scored
+        # by the oracle itself (the asserted form over 64 users is tests/test_decisions_gpu.py)
         P0 = len(prompts[n_warm])
         rep = disagreement_report(outs[0], ref_outs[0], P0, ref_t, prompts[n_warm])
         line["cpu_baseline"]["top_k_overlap_with_gpu_bf16"] = rep["top_k_overlap"]

@@ -35,7 +35,8 @@ typedef enum atspeed_status {
   ATSPEED_ERR_HIP = -2,          /* a HIP runtime call failed                          */
   ATSPEED_ERR_CAPACITY = -3,     /* prompt/beam/slot count exceeds the handle's limits */
   ATSPEED_ERR_CONSTRAINT = -4,   /* a beam reached a node with no allowed token (HF raises ValueError there) */
-  ATSPEED_ERR_NO_DEVICE = -5
+  ATSPEED_ERR_NO_DEVICE = -5,
+  ATSPEED_ERR_FILTERED = -6      /* every beam of a step fell to the post-top-k id filter of beamSD.py:80-86 (the reference then dies on a shape mismatch) */
 } atspeed_status;
 
 typedef enum atspeed_dtype { ATSPEED_F32 = 0, ATSPEED_BF16 = 1 } atspeed_dtype;
@@ -67,6 +68,15 @@ typedef struct atspeed_fsm atspeed_fsm;
 int atspeed_fsm_create(const int32_t* row_ptr, const int32_t* tok, const int32_t* nxt,
                        int32_t n_nodes, int32_t n_edges, int32_t vocab_size, atspeed_fsm** out);
 void atspeed_fsm_destroy(atspeed_fsm* fsm);
+/* The "automaton" of a call WITHOUT a mask: BSSD(..., logits_processor=None, prefix_allowed_tokens_fn=None) is legal in the reference
+ * (beamSD.py:460-481: both optional; with an empty processor list :60-64 is the identity and the id filter :80-86 is skipped).  Every
+ * token of the vocabulary is then a candidate of every beam; the decoder first reduces each logit row to its k best tokens
+ * (atspeed_row_topk) and expands those.  Greedy mode only. */
+int atspeed_fsm_create_free(int32_t vocab_size, atspeed_fsm** out);
+/* one_step_beam_search drops, AFTER the top-k, every pick whose token is `< 32000 and != 2` (beamSD.py:80-86, hard-coded for the
+ * Llama-2 vocabulary + item codes).  An automaton is created with those two numbers; other vocabularies set their own here
+ * (min_item_token <= 0: keep every pick).  If a step loses ALL its beams to the filter the generate call returns ATSPEED_ERR_FILTERED. */
+int atspeed_fsm_set_id_filter(atspeed_fsm* fsm, int32_t min_item_token, int32_t eos_token);
 /* host-side flattening of token sequences into the CSR above (breadth-first node ids,
  * children ascending): native counterpart of Trie.__init__/_add_to_trie
  * (generation_trie.py:8-14,40-44).  Two-call protocol: pass NULL outputs to get the sizes. */
@@ -185,6 +195,11 @@ int atspeed_lmhead_lse(const void* x_dev, const void* w_dev, float* logits_dev, 
 int atspeed_lse_rows(const float* logits_dev, int32_t n_rows, int32_t vocab, int32_t ld,
                      float* lse_out_dev, void* stream);
 
+/* out[r][c] = logits[r][c] - lse[r] for c < vocab: the log-softmax rows (beamSD.py:58) as a tensor, for callers that must hand them to
+ * host-side logits processors (beamSD.py:62-64 with a non-empty LogitsProcessorList); the decoder itself never materialises them. */
+int atspeed_log_softmax_rows(const float* logits_dev, int32_t ld, const float* lse_dev, int32_t n_rows, int32_t vocab, float* out_dev,
+                             int32_t ld_out, void* stream);
+
 /* Fused constraint mask + beam expand + prune (beamSD.py:60-87):
  *   cand(r, t) = logits[r][t] - lse[r] + beam_score[r]   for t allowed at node[r]
  *   top-k by (score desc, flat id r*vocab+t asc)  ->  out_*[0..k)
@@ -196,6 +211,15 @@ int atspeed_beam_expand_prune(const float* logits_dev, int32_t ld, const float* 
                               const atspeed_fsm* fsm, int32_t k,
                               float* out_score_dev, int32_t* out_parent_dev, int32_t* out_token_dev,
                               int32_t* out_node_dev, int32_t* out_flat_dev, void* stream);
+
+/* The same without a mask (beamSD.py:58,69-78 with an empty processor list; also the expand of rows that a host-side logits
+ * processor has already rewritten: pass lse = 0): candidates are ALL `vocab` columns of each row; -inf entries are never picked.
+ * atspeed_row_topk: out_tokens[r][ATSPEED_MAX_BEAMS] = the k best columns of row r (value desc, column asc; -1 = fewer finite ones) --
+ * the k best (row, token) pairs lie among them.  row_cand_ws_dev: n_rows * ATSPEED_MAX_BEAMS int32 of scratch. */
+int atspeed_row_topk(const float* scores_dev, int32_t n_rows, int32_t vocab, int32_t ld, int32_t k, int32_t* out_tokens_dev, void* stream);
+int atspeed_beam_expand_prune_free(const float* logits_dev, int32_t ld, const float* lse_dev, const float* beam_score_dev, int32_t n_rows,
+                                   int32_t vocab, int32_t k, int32_t* row_cand_ws_dev, float* out_score_dev, int32_t* out_parent_dev,
+                                   int32_t* out_token_dev, int32_t* out_flat_dev, void* stream);
 
 /* Top-K-aligned acceptance test (beamSD.py:371-380): accept iff every target id is among
  * the draft ids.  hit[r] = r-th smallest draft position that was hit, score_by_hit[r] = the
@@ -259,10 +283,29 @@ int atspeed_target_generate_batch(atspeed_decoder** decoders, int32_t n, const i
                                   int32_t max_new_tokens, int32_t k, int32_t* const* out_tokens_dev,
                                   float* const* out_scores_dev, atspeed_gen_stats* stats_host /* [n] */, void* stream);
 
+/* Result tensors of a whole batch in one launch (the reference builds `beam_sequence` per beam per step with torch.cat,
+ * beamSD.py:87,383): user u's [k][P_u + new_tokens] int64 rows = its prompt followed by the generated suffix of beam j, written at
+ * out_dev + k * (prompt_off[u] + u * new_tokens).  prompts_flat_dev: the prompts one after the other (int32); prompt_off_host[n + 1]:
+ * their offsets (HOST array); toks_dev [n][k][new_tokens] int32 (the out_tokens of atspeed_bssd_generate_batch laid out contiguously). */
+int atspeed_assemble_sequences(const int32_t* prompts_flat_dev, const int64_t* prompt_off_host, const int32_t* toks_dev, int32_t n, int32_t k,
+                               int32_t new_tokens, int64_t* out_dev, void* stream);
+
 /* per-round trace of the last atspeed_bssd_generate call (host memory, for parity tests):
  * for round r, step i: the draft's flat ids (dk entries, -1 = not a beam).  Returns the
  * number of ints written. */
 int atspeed_decoder_trace(atspeed_decoder* d, int32_t* rounds_out, int32_t cap);
+
+/* Decision trace (parity tests at batch sizes the per-round trace above skips; greedy mode; no reference counterpart -- the reference
+ * keeps these as Python locals of verify(), beamSD.py:277-380).  level 1: after every round of the bssd calls made with this decoder
+ * the beam blocks and the verify walk's picks are copied to the host (about 60 KB per user and round); level 0 (default): off.
+ * atspeed_decoder_decisions returns the number of int32 words of the last call's trace and copies up to cap_words of them.  One
+ * record per round: header {kind (0 verify round, 1 final single step), nb, dl, n_matches, tokens generated before the round, k, dk,
+ * n_blocks}; n_blocks beam-set images of 5 * 64 + 64 * 16 words each {score bits[64], node[64], parent[64], tok[64], flat[64],
+ * seq[64][16]} -- kind 0: the round's beams, draft blocks 1..dl, the new round beams; kind 1: the step's parents, its result --; for
+ * kind 0 then (ATSPEED_MAX_GAMMA + 1) * 3 * 64 words: the target's picks of verify step i as {score bits[64], parent[64] (index into
+ * block i), token[64] (-1 = no pick)}, valid for steps 0..n_matches. */
+int atspeed_decoder_set_trace(atspeed_decoder* d, int32_t level);
+int64_t atspeed_decoder_decisions(atspeed_decoder* d, int32_t* out, int64_t cap_words);
 
 /* ------------------------------------------------------------------ low-level ops (tests, benches)
  * C[M,N] = A[M,K] * W[N,K]^T on MFMA; epilogue: 0 store (dtype), 1 fp32 store, 2 residual add into

@@ -70,7 +70,7 @@ def constrain(seqs: torch.Tensor, logp: torch.Tensor, fn: Callable) -> torch.Ten
 
 
 def expand_and_prune(logits: torch.Tensor, beam_scores: torch.Tensor, beam_seq: torch.Tensor,
-                     beam_size: int, fn: Optional[Callable], drop_disallowed: bool = True):
+                     beam_size: int, fn: Optional[Callable], drop_disallowed: bool = True, procs=()):
     """beamSD.py:57-86 given the logits rows: log-softmax over the FULL vocab, mask,
     add beam scores, flatten, top-k, split into (parent, token), drop disallowed picks."""
     n, V = logits.shape
@@ -80,6 +80,10 @@ def expand_and_prune(logits: torch.Tensor, beam_scores: torch.Tensor, beam_seq: 
             logp = constrain(beam_seq[:1], logp, fn)
         else:                                                                     # :64
             logp = constrain(beam_seq, logp, fn)
+    # extra logits processors (beamSD.py:469-478: HF appends the caller's LogitsProcessorList after its own prefix processor)
+    for proc in procs:
+        rows = beam_seq[:1] if (n == 1 and beam_size != 1) else beam_seq          # :61-62: K copies in, row 0 out
+        logp = proc(rows, logp)
     flat = (logp + beam_scores.to(torch.float32)[:, None]).reshape(-1)            # :69-70
     scores, idx = topk_desc_stable(flat, beam_size)                               # :76
     if MARGINS is not None:
@@ -88,7 +92,7 @@ def expand_and_prune(logits: torch.Tensor, beam_scores: torch.Tensor, beam_seq: 
         if len(top) > 1:
             MARGINS.append(float((top[:-1] - top[1:]).min()))
     parents, toks = idx // V, idx % V                                             # :77-78
-    if fn is not None and drop_disallowed:                                        # :80-86 (one_step only)
+    if (fn is not None or len(procs) != 0) and drop_disallowed:                   # :80-86 (one_step only; `len(logits_processor) != 0`)
         keep = (toks >= LLAMA_VOCAB) | (toks == EOS_ID)
         # fewer than beam_size finite candidates: WHICH -inf entries torch.topk returns is
         # unspecified (they are ties); the reference keeps those whose token id happens to
@@ -99,11 +103,11 @@ def expand_and_prune(logits: torch.Tensor, beam_scores: torch.Tensor, beam_seq: 
 
 
 def one_step(model: RefLlama, inp: StepInputs, beam_size: int, beam_scores: torch.Tensor,
-             beam_seq: torch.Tensor, fn: Optional[Callable]) -> Dict:
+             beam_seq: torch.Tensor, fn: Optional[Callable], procs=()) -> Dict:
     """beamSD.py:40-106."""
     n = len(beam_scores)
     logits = model.forward(inp.ids, inp.pos, inp.slots, inp.vis, n_logit_rows=n)  # :52,57
-    idx, scores, parents, toks = expand_and_prune(logits, beam_scores, beam_seq, beam_size, fn)
+    idx, scores, parents, toks = expand_and_prune(logits, beam_scores, beam_seq, beam_size, fn, procs=procs)
     m = len(toks)
     new_seq = torch.cat((beam_seq[parents], toks[:, None]), dim=-1)               # :87
     S = inp.vis.shape[1]
@@ -116,12 +120,12 @@ def one_step(model: RefLlama, inp: StepInputs, beam_size: int, beam_scores: torc
 
 
 def draft_beam_search(model: RefLlama, inp: StepInputs, draft_len: int, beam_size: int,
-                      beam_scores: torch.Tensor, beam_seq: torch.Tensor, fn) -> Dict:
+                      beam_scores: torch.Tensor, beam_seq: torch.Tensor, fn, procs=()) -> Dict:
     """beamSD.py:108-179."""
     out = {"step_len": [len(beam_scores)], "step_seq_tokens": [], "step_beam_sequence": [beam_seq],
            "step_beam_indices": [], "step_beam_tokens": [], "step_inputs": [], "step_scores": []}
     for _ in range(draft_len):                                                    # :136
-        o = one_step(model, inp, beam_size, beam_scores, beam_seq, fn)
+        o = one_step(model, inp, beam_size, beam_scores, beam_seq, fn, procs)
         inp, beam_scores, beam_seq = o["next_inputs"], o["beam_scores"], o["beam_sequence"]
         out["step_len"].append(len(beam_scores))
         out["step_beam_sequence"].append(beam_seq)
@@ -148,7 +152,7 @@ def target_beam_search(model: RefLlama, inp: StepInputs, draft: Dict) -> Dict:
 
 
 def verify(tin: StepInputs, draft: Dict, target: Dict, beam_size: int,
-           beam_scores: torch.Tensor, beam_seq: torch.Tensor, fn) -> Dict:
+           beam_scores: torch.Tensor, beam_seq: torch.Tensor, fn, procs=()) -> Dict:
     """beamSD.py:242-456, greedy branch."""
     draft_len = len(draft["step_beam_indices"])
     step_len = draft["step_len"]
@@ -172,7 +176,7 @@ def verify(tin: StepInputs, draft: Dict, target: Dict, beam_size: int,
         # round 1, i == 0: one logit row masked with the prompt (:287-288); expand_and_prune
         # takes row 0 of seqs (= the round's beam_sequence, K copies of the prompt) for it
         idx, beam_scores, parents, toks = expand_and_prune(rows, beam_scores, seqs, beam_size, fn,
-                                                           drop_disallowed=False)
+                                                           drop_disallowed=False, procs=procs)
         if i > 0:                                                                 # :326-328
             parents = hit[parents]
             idx = parents * V + toks
@@ -220,8 +224,9 @@ def _causal_inputs(ids: torch.Tensor) -> StepInputs:
 
 @torch.no_grad()
 def BSSD(target: RefLlama, draft: RefLlama, input_ids, gamma: int, max_new_tokens: int,
-         beam_size: int, draft_beam_size: int, fn: Optional[Callable] = None) -> Dict:
-    """beamSD.py:458-542.  `input_ids` is the [P] prompt (the reference reads batch row 0)."""
+         beam_size: int, draft_beam_size: int, fn: Optional[Callable] = None, procs=()) -> Dict:
+    """beamSD.py:458-542.  `input_ids` is the [P] prompt (the reference reads batch row 0).  `fn` None = no mask; `procs` = extra logits
+    processors `(input_ids [n, len], scores [n, V]) -> scores` (the LogitsProcessorList argument, :465,469-478)."""
     ids = torch.as_tensor(np.asarray(input_ids), dtype=torch.long).reshape(-1)
     cur_len = len(ids)
     max_len = cur_len + max_new_tokens
@@ -233,12 +238,12 @@ def BSSD(target: RefLlama, draft: RefLlama, input_ids, gamma: int, max_new_token
     while cur_len < max_len:                                                      # :503
         draft_len = min(gamma, max_len - cur_len - 1)                             # :504
         if draft_len == 0:                                                        # :505-509
-            o = one_step(target, tin, beam_size, beam_scores, beam_seq, fn)
+            o = one_step(target, tin, beam_size, beam_scores, beam_seq, fn, procs)
             beam_seq, beam_scores = o["beam_sequence"], o["beam_scores"]
             break
-        d = draft_beam_search(draft, din, draft_len, draft_beam_size, beam_scores, beam_seq, fn)   # :511
+        d = draft_beam_search(draft, din, draft_len, draft_beam_size, beam_scores, beam_seq, fn, procs)   # :511
         t = target_beam_search(target, tin, d)                                                     # :513
-        v = verify(tin, d, t, beam_size, beam_scores, beam_seq, fn)                                # :515
+        v = verify(tin, d, t, beam_size, beam_scores, beam_seq, fn, procs)                         # :515
         rounds.append({"draft_len": draft_len, "n_matches": v["n_matches"], "step_len": list(d["step_len"]),
                        "draft_ids": [x.tolist() for x in d["step_seq_tokens"]],
                        "draft_scores": [x.tolist() for x in d["step_scores"]],
@@ -257,7 +262,7 @@ def BSSD(target: RefLlama, draft: RefLlama, input_ids, gamma: int, max_new_token
 
 @torch.no_grad()
 def target_generate(model: RefLlama, input_ids, max_new_tokens: int, beam_size: int,
-                    fn: Optional[Callable] = None) -> Dict:
+                    fn: Optional[Callable] = None, procs=()) -> Dict:
     """beamSD.py:544-595: plain constrained beam search on the target."""
     ids = torch.as_tensor(np.asarray(input_ids), dtype=torch.long).reshape(-1)
     inp = _causal_inputs(ids)
@@ -265,7 +270,7 @@ def target_generate(model: RefLlama, input_ids, max_new_tokens: int, beam_size: 
     beam_seq = ids[None, :].repeat(beam_size, 1)
     steps = []
     for _ in range(max_new_tokens):                                               # :579-588
-        o = one_step(model, inp, beam_size, beam_scores, beam_seq, fn)
+        o = one_step(model, inp, beam_size, beam_scores, beam_seq, fn, procs)
         inp, beam_scores, beam_seq = o["next_inputs"], o["beam_scores"], o["beam_sequence"]
         steps.append({"ids": o["seq_tokens"].tolist(), "scores": beam_scores.tolist()})
     return {"beam_sequence": beam_seq, "beam_scores": beam_scores, "steps": steps}

@@ -6,7 +6,7 @@ from __future__ import annotations
 import numpy as np
 
 from atspeed_amd import synth
-from atspeed_amd.generation_trie import PositionSetConstraint, SuffixTrieConstraint, Trie
+from atspeed_amd.generation_trie import PositionSetConstraint, SuffixTrieConstraint, Trie, prefix_allowed_tokens_fn
 
 TINY_T = dict(hidden=128, n_layers=2, n_heads=4, ffn=352)
 TINY_D = dict(hidden=96, n_layers=2, n_heads=3, ffn=256)      # draft with its own shape (68M-like: few wide heads)
@@ -42,7 +42,57 @@ CASES = [
     _c("k6_dk12_new7_gamma3_s9", sigma=0.1, gamma=3, max_new_tokens=7, mask="pos7", K=6, DK=12, seed=9),
     _c("k8_dk16_trie", sigma=0.05, K=8, DK=16, mask="trie"),  # strict suffix trie (teacher-data style)
     _c("k20_dk40_trie", sigma=0.1, mask="trie"),
+    # round 3: the optional arguments of BSSD (beamSD.py:460-481) and chained tries (generation_trie.py:19-21,55-57,67-68)
+    _c("k5_dk10_nomask", sigma=0.02, K=5, DK=10, mask="none"),          # prefix_allowed_tokens_fn=None: every token a candidate, no id filter
+    _c("k20_dk40_nomask", sigma=0.05, mask="none"),
+    _c("k8_dk16_chain", sigma=0.05, K=8, DK=16, mask="chain"),           # whole-sentence trie A with an appended trie B taking over after 2 codes
+    _c("k8_dk16_proc", sigma=0.05, K=8, DK=16, procs="bias"),            # mask + an extra logits processor
+    _c("k5_dk10_proc_nomask", sigma=0.05, K=5, DK=10, mask="none", procs="bias+favor"),   # processors only: the id filter is on (beamSD.py:80)
 ]
+
+HANDOVER = 0        # bos_token_id of the chained-trie case: a token no prompt and no item holds
+
+
+class HashBias:
+    """An extra logits processor for the fixtures: scores + b, b a fixed hash-PRNG vector over the vocabulary (any torch device)."""
+
+    def __init__(self, vocab: int, seed: int, std: float = 1.5):
+        import torch
+        self.b = torch.from_numpy(synth.hash_normal(vocab, synth.tensor_seed(seed, "proc.bias"), std))
+
+    def __call__(self, input_ids, scores):
+        return scores + self.b.to(scores.device)
+
+
+class Favor:
+    """scores + boost for tokens >= lo: keeps an unmasked search inside the item codes, where the reference's id filter lets beams live."""
+
+    def __init__(self, lo: int, boost: float):
+        self.lo, self.boost = lo, boost
+
+    def __call__(self, input_ids, scores):
+        out = scores.clone()
+        out[:, self.lo:] += self.boost
+        return out
+
+
+def build_processors(case, vocab_size: int):
+    kind = case.get("procs")
+    if not kind:
+        return []
+    procs = [HashBias(vocab_size, case["seed"])]
+    if "favor" in kind:
+        procs.append(Favor(synth.LLAMA_VOCAB, 40.0))
+    return procs
+
+
+def chain_sequences(prompt, items):
+    """(sequences of trie A, sequences of trie B): A = prompt ++ first two codes ++ HANDOVER, B = last two codes ++ eos"""
+    pre = [int(t) for t in prompt]
+    a = [pre + [int(it[0]), int(it[1]), HANDOVER] for it in items]
+    b = [[int(it[2]), int(it[3]), synth.EOS_ID] for it in items]
+    return a, b
+
 
 
 def build_case_inputs(case):
@@ -71,10 +121,15 @@ def build_case_inputs(case):
     elif case["mask"] == "trie":
         trie = Trie([[synth.BOS_ID] + [int(t) for t in it] + [synth.EOS_ID] for it in items])
         fn = SuffixTrieConstraint(trie, synth.RESPONSE_SEP, synth.BOS_ID)
+    elif case["mask"] == "chain":
+        a, b = chain_sequences(prompt, items)
+        ta = Trie(a)
+        ta.append(Trie(b), HANDOVER)
+        fn = prefix_allowed_tokens_fn(ta)
     else:
         fn = None
     return dict(target_dims=tdims, target_sd=tsd, draft_dims=ddims, draft_sd=dsd, prompt=prompt, fn=fn,
-                items=items, vocab=vocab)
+                items=items, vocab=vocab, procs=build_processors(case, V))
 
 
 def _trie_seqs(n, seed):

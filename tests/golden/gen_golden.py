@@ -39,7 +39,7 @@ from transformers import LlamaConfig, LlamaForCausalLM   # noqa: E402
 from transformers.cache_utils import DynamicCache        # noqa: E402
 
 from atspeed_amd import synth                            # noqa: E402
-from tests.golden.cases import CASES, TRIE_CASES, build_case_inputs   # noqa: E402
+from tests.golden.cases import CASES, HANDOVER, TRIE_CASES, build_case_inputs, chain_sequences   # noqa: E402
 
 
 class HFAdapter:
@@ -83,6 +83,13 @@ def run_case(case) -> dict:
     target = HFAdapter(ci["target_dims"], ci["target_sd"], case["K"])
     draft = HFAdapter(ci["draft_dims"], ci["draft_sd"], case["DK"])
     fn = ci["fn"]
+    if case["mask"] == "chain":          # the reference's OWN chained Trie and mask factory (generation_trie.py:19-21,92-98)
+        a, b = chain_sequences(ci["prompt"], ci["items"])
+        ta = ref_trie.Trie(a)
+        ta.append(ref_trie.Trie(b), HANDOVER)
+        fn = ref_trie.prefix_allowed_tokens_fn(ta)
+    from transformers import LogitsProcessorList
+    procs = LogitsProcessorList(ci["procs"]) if ci["procs"] else None
     inputs = {"input_ids": torch.from_numpy(ci["prompt"])[None, :]}
 
     rounds = []
@@ -104,7 +111,7 @@ def run_case(case) -> dict:
     ref_beamsd.verify, ref_beamsd.draft_beam_search = verify_wrap, draft_wrap
     ref_error = None
     try:
-        out = ref_beamsd.BSSD(target, draft, inputs, case["gamma"], case["max_new_tokens"],
+        out = ref_beamsd.BSSD(target, draft, inputs, case["gamma"], case["max_new_tokens"], logits_processor=procs,
                               prefix_allowed_tokens_fn=fn)
     except RuntimeError as e:
         # known reference defect (DESIGN.md "reference quirks"): after a NON-first round with
@@ -113,7 +120,7 @@ def run_case(case) -> dict:
         ref_error = str(e)
     finally:
         ref_beamsd.verify, ref_beamsd.draft_beam_search = orig_verify, orig_draft
-    tg = ref_beamsd.target_generate(target, inputs, case["max_new_tokens"], prefix_allowed_tokens_fn=fn)
+    tg = ref_beamsd.target_generate(target, inputs, case["max_new_tokens"], logits_processor=procs, prefix_allowed_tokens_fn=fn)
 
     P = len(ci["prompt"])
     if ref_error is not None:
@@ -164,6 +171,20 @@ def run_trie_case(tc) -> dict:
 
 def main():
     outs = []
+    only = set(sys.argv[1:])                 # `gen_golden.py name ...`: (re)generate these cases only and merge them into the stored file
+    if only:
+        with open(os.path.join(HERE, "bssd_golden.json")) as f:
+            old = {c["name"]: c for c in json.load(f)}
+        for case in CASES:
+            if case["name"] in only:
+                old[case["name"]] = run_case(case)
+                r = old[case["name"]]
+                print(f"{case['name']:28s} " + (f"n_run={r['n_run']} accept={r['total_accept_steps']} rounds={[x['n_matches'] for x in r['rounds']]} "
+                                                  f"bssd==tg:{r['bssd_tokens'] == r['tg_tokens']} min_gap={r['min_gap_final']:.2e}"
+                                                  if "reference_error" not in r else "REFERENCE RAISED " + r["reference_error"][:90]))
+        with open(os.path.join(HERE, "bssd_golden.json"), "w") as f:
+            json.dump([old[c["name"]] for c in CASES if c["name"] in old], f)
+        return
     for case in CASES:
         r = run_case(case)
         if "reference_error" in r:

@@ -39,10 +39,29 @@ def test_launcher_command_is_the_drivers_torchrun_line():
     assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]             # the children see the same flags (incl. --gpus)
 
 
-def test_traffic_carries_its_provenance():
-    v, src = bench.traffic_from_profiles("gate_up")
-    assert v is not None and v > 0 and "profiles/pmc_traffic.json" in src and "not measured in this run" in src
-    assert bench.traffic_from_profiles("no_such_kernel") == (None, None)
+def test_traffic_carries_its_provenance_and_refuses_stale_kernels(tmp_path):
+    """`roofline.traffic` comes from offline PMC passes: the line must say so, and a summary recorded for other GEMM sources than this
+    tree's (kernel_sha = sha256 of gemm.hip + its headers) must be refused, not quoted."""
+    import json
+    sha = bench.kernel_sha()
+    assert len(sha) == 16 and sha == bench.kernel_sha()
+    good = tmp_path / "t.json"
+    good.write_text(json.dumps({"kernel_sha": sha, "commit": "abc1234", "gate_up": {"hbm_bytes_per_launch": 5.0e9, "avg_m": 25911}}))
+    v, src = bench.traffic_from_profiles("gate_up", path=str(good))
+    assert v == 5.0e9 and "not in this run" in src and "abc1234" in src and sha in src
+    assert bench.traffic_from_profiles("no_such_kernel", path=str(good)) == (None, None)
+    stale = tmp_path / "s.json"
+    stale.write_text(json.dumps({"kernel_sha": "0" * 16, "commit": "old", "gate_up": {"hbm_bytes_per_launch": 7.6e9}}))
+    v, src = bench.traffic_from_profiles("gate_up", path=str(stale))
+    assert v is None and "refused" in src and sha in src
+    assert bench.traffic_from_profiles("gate_up", path=str(tmp_path / "missing.json")) == (None, None)
+
+
+def test_per_rank_report_shows_stragglers():
+    from atspeed_amd.dist import Counters
+    rep = bench.per_rank_report([Counters(512, 1536, 0, int(2.0e9)), Counters(512, 1500, 30, int(2.5e9))], beam=20)
+    assert [r["rank"] for r in rep] == [0, 1] and rep[1]["elapsed_ms"] == pytest.approx(2500.0)
+    assert rep[0]["items_per_s"] == pytest.approx(512 * 20 / 2.0) and rep[1]["n_users"] == 512 and rep[1]["accept_steps"] == 30
 
 
 def test_oracle_scores_of_reproduces_the_oracles_own_beam_scores():

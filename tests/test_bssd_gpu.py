@@ -86,12 +86,13 @@ def test_bssd_and_target_generate_equal_reference(case, bssd_golden):
     tgt, drf = _models(ci, case)
     P = len(ci["prompt"])
     inputs = {"input_ids": torch.from_numpy(ci["prompt"])[None, :].cuda()}
-    tg = target_generate(tgt, inputs, case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"])
+    procs = ci["procs"] or None          # extra logits processors (the LogitsProcessorList argument of beamSD.py:465,549)
+    tg = target_generate(tgt, inputs, case["max_new_tokens"], logits_processor=procs, prefix_allowed_tokens_fn=ci["fn"])
     assert tg["beam_sequence"].shape == (case["K"], P + case["max_new_tokens"]) and tg["beam_sequence"].dtype == torch.int64
     assert (tg["beam_sequence"][:, :P].cpu() == torch.from_numpy(ci["prompt"])[None]).all()
     assert tg["beam_sequence"][:, P:].cpu().tolist() == gold["tg_tokens"]
     np.testing.assert_allclose(tg["beam_scores"].cpu().numpy(), gold["tg_scores"], atol=SCORE_TOL, rtol=0)
-    out = BSSD(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"])
+    out = BSSD(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], logits_processor=procs, prefix_allowed_tokens_fn=ci["fn"])
     for key in ("beam_sequence", "beam_scores", "n_run", "total_accept_steps", "total_accept_tokens", "ave_accept_tokens",
                 "draft_time_cost", "target_time_cost", "verify_time_cost", "time_cost"):
         assert key in out                                                 # keys consumed at inference.py:179-187
@@ -106,6 +107,10 @@ def test_bssd_and_target_generate_equal_reference(case, bssd_golden):
     assert out["total_accept_steps"] == gold["total_accept_steps"]
     assert out["total_accept_tokens"] == gold["total_accept_tokens"]
     assert out["ave_accept_tokens"] == pytest.approx(gold["ave_accept_tokens"])
+    if procs:                            # host path (Python callables per step): real stage times, no device trace
+        assert out["accept_steps"] == [r["n_matches"] for r in gold["rounds"]]
+        assert out["draft_time_cost"] > 0 and out["target_time_cost"] > 0 and out["verify_time_cost"] > 0
+        return
     tr = last_trace(tgt, drf)
     assert [r["n_matches"] for r in tr] == [r["n_matches"] for r in gold["rounds"]]
     assert [r["draft_len"] for r in tr] == [r["draft_len"] for r in gold["rounds"]]
@@ -213,18 +218,34 @@ def test_api_errors():
     ci = build_case_inputs(CASES[0])
     tgt, drf = _models(ci, CASES[0])
     inputs = {"input_ids": torch.from_numpy(ci["prompt"])[None, :].cuda()}
-    with pytest.raises(NotImplementedError):
-        BSSD(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=None)
     with pytest.raises(TypeError):       # separator absent: the reference's fn returns None -> TypeError in HF
         BSSD(tgt, drf, {"input_ids": torch.tensor([[1, 5, 6, 7]]).cuda()}, 4, 4, prefix_allowed_tokens_fn=ci["fn"])
     tgt.generation_config.do_sample = True        # sampling needs a compilable constraint (the draws happen on the device)
     with pytest.raises(NotImplementedError):
         BSSD(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=lambda b, s: ci["fn"](b, s))
+    with pytest.raises(atspeed_amd._lib.AtSpeedError):        # mask-free search is greedy only
+        BSSD(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=None)
+    with pytest.raises(NotImplementedError):                  # ... and so are host-side logits processors
+        BSSD(tgt, drf, inputs, 4, 4, logits_processor=[lambda ids, sc: sc], prefix_allowed_tokens_fn=ci["fn"])
     tgt.generation_config.temperature = 0.0
     with pytest.raises(atspeed_amd._lib.AtSpeedError):
         BSSD(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=ci["fn"])
     tgt.generation_config.temperature = 1.0
     tgt.generation_config.do_sample = False
+    # the reference's post-top-k id filter (beamSD.py:80-86) is hard-coded for item tokens >= 32000: an automaton over ordinary tokens
+    # loses every beam to it (the reference then dies on a shape mismatch); here the call says so, and the thresholds
+    # can be set per automaton
+    low = atspeed_amd.PositionSetConstraint({0: [5, 6, 7, 8, 9], 1: [10, 11, 12], 2: [2]}, synth.RESPONSE_SEP)
+    tgt.generation_config.num_beams, keep = 3, tgt.generation_config.num_beams
+    try:
+        with pytest.raises(atspeed_amd._lib.AtSpeedError) as ei:
+            target_generate(tgt, inputs, 2, prefix_allowed_tokens_fn=low)
+        assert ei.value.status == atspeed_amd._lib.ERR_FILTERED
+        low2 = atspeed_amd.PositionSetConstraint({0: [5, 6, 7, 8, 9], 1: [10, 11, 12], 2: [2]}, synth.RESPONSE_SEP, id_filter=(0, 2))
+        o = target_generate(tgt, inputs, 2, prefix_allowed_tokens_fn=low2)
+        assert o["n_valid"] == 3 and set(o["beam_sequence"][:, -2].cpu().tolist()) <= {5, 6, 7, 8, 9}
+    finally:
+        tgt.generation_config.num_beams = keep
     # position-set mask exhausted (5th generated token after EOS): HF raises ValueError on the empty list
     with pytest.raises((ValueError, KeyError)):
         target_generate(tgt, inputs, 6, prefix_allowed_tokens_fn=ci["fn"])
@@ -300,6 +321,9 @@ def test_arbitrary_python_mask_callable(name, bssd_golden):
     assert (out["n_run"], out["total_accept_steps"]) == (gold["n_run"], gold["total_accept_steps"])
     assert out["accept_steps"] == [r["n_matches"] for r in gold["rounds"]]
     assert calls and set(calls) == {0} and nv > 0
+    # the CSV columns inference.py:183-187 reads: wall-clock stage times as the reference's Timer measures them, not zeros
+    assert out["draft_time_cost"] > 0 and out["target_time_cost"] > 0 and out["verify_time_cost"] > 0
+    assert out["draft_time_cost"] + out["target_time_cost"] + out["verify_time_cost"] <= out["time_cost"]
 
 
 def test_python_mask_callable_errors():

@@ -13,6 +13,14 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 def test_no_register_moves_or_spills_between_the_ring_kernels_asm_mfmas(tmp_path):
     import scan_mfma_loops
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # `make` runs this scan on the ISA of the very compile that produced gemm.o (atspeed_amd/csrc/Makefile) and fails the build on a finding;
+    # when that by-product is there and current, check it rather than compiling again
+    built = os.path.join(ROOT, "atspeed_amd", "csrc", ".isa", "gemm-hip-amdgcn-amd-amdhsa-gfx950.s")
+    src = os.path.join(ROOT, "atspeed_amd", "csrc", "gemm.hip")
+    if os.path.exists(built) and os.path.getmtime(built) >= os.path.getmtime(src):
+        findings, kernels = scan_mfma_loops.scan(built, verbose=False)
+        assert kernels >= 20 and findings == 0, (kernels, findings)
+        return
     out = tmp_path / "gemm.s"
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out),
                     os.path.join(ROOT, "atspeed_amd", "csrc", "gemm.hip")], check=True, cwd=os.path.join(ROOT, "atspeed_amd", "csrc"),

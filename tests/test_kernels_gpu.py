@@ -428,7 +428,8 @@ def test_gemm_fp8(lib, m, n, k, epi):
     np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=tol, rtol=0)
 
 
-@pytest.mark.parametrize("rows,vocab,hidden", [(700, 32859, 512), (1300, 33014, 256), (2100, 5000, 768), (90, 32859, 256)])
+# 70001: more than 256 tiles of 256 columns (a 128k-token target would have 500): the tile mask is sized by the vocabulary
+@pytest.mark.parametrize("rows,vocab,hidden", [(700, 32859, 512), (1300, 33014, 256), (2100, 5000, 768), (90, 32859, 256), (300, 70001, 256)])
 def test_lmhead_lse_fused_epilogue(lib, rows, vocab, hidden):
     """lm_head + full-vocabulary normaliser in one kernel (beamSD.py:58,285): lse equals logsumexp of the fp32 product over ALL columns
     (tail tile of a vocabulary that is no multiple of 256 included), the logit tiles of the automaton's tokens are the plain GEMM's bit for
@@ -444,7 +445,7 @@ def test_lmhead_lse_fused_epilogue(lib, rows, vocab, hidden):
     _lib.check(lib.atspeed_gemm(x.data_ptr(), w.data_ptr(), plain.data_ptr(), rows, vocab, hidden, hidden, ld, _lib.ATSPEED_BF16, _lib.EPI_F32,
                                 ws.data_ptr(), ws.numel(), _st()))
     # automaton over a few token ids: tiles {0, last two full ones, tail}
-    toks = sorted({2, 300 % vocab, vocab - 600, vocab - 300, vocab - 1})
+    toks = sorted({2, 300 % vocab, vocab - 600, vocab - 300, vocab - 1} | ({65536 + 5, 66000} if vocab > 66000 else set()))
     row_ptr = np.array([0, len(toks), len(toks)], np.int32); tok = np.array(toks, np.int32); nxt = np.ones(len(toks), np.int32)
     fsm = C.c_void_p()
     _lib.check(lib.atspeed_fsm_create(row_ptr.ctypes.data, tok.ctypes.data, nxt.ctypes.data, 2, len(toks), vocab, C.byref(fsm)))
@@ -566,3 +567,74 @@ def test_measured_peak_probes_are_plausible(lib):
     assert 2000.0 < gbs.value < 8200.0, gbs.value
     with pytest.raises(_lib.AtSpeedError):
         _lib.check(lib.atspeed_probe_mfma_bf16(10, scratch.data_ptr(), 1024, _lib.stream_ptr(), C.byref(tf)))
+
+
+# ------------------------------------------------------------------ mask-free search (prefix_allowed_tokens_fn=None) and host-side processors
+@pytest.mark.parametrize("rows,vocab,k", [(1, 32859, 20), (40, 32859, 40), (20, 33014, 20), (64, 70001, 64), (7, 300, 5), (3, 16384 + 5, 1)])
+def test_row_topk_and_free_expand_equal_torch(lib, rows, vocab, k):
+    """`atspeed_row_topk`: the k best columns of every row, (value desc, column asc), -inf never; `atspeed_beam_expand_prune_free`: the k
+    best (row, token) pairs of log-softmax + beam score over ALL columns (beamSD.py:58,69-78 with an empty processor list) -- against
+    torch's stable sort.  Vocabularies above one 16384-column chunk, above 65536, a dead beam, rows with -inf entries."""
+    ld = (vocab + 63) // 64 * 64
+    logits = _rand((rows, vocab), 300 + rows, 3.0)
+    logits[0, : min(vocab, 50)] = float("-inf")                      # masked entries (what a logits processor leaves behind)
+    if rows > 2:
+        logits[2, 5:] = float("-inf")                                # fewer finite entries than k
+    lg = torch.full((rows, ld), 7.0)
+    lg[:, :vocab] = logits
+    lg = lg.cuda()
+    out = torch.empty(rows, _lib.MAX_BEAMS, dtype=torch.int32, device="cuda")
+    _lib.check(lib.atspeed_row_topk(lg.data_ptr(), rows, vocab, ld, k, out.data_ptr(), _st()))
+    got = out.cpu()
+    for r in range(rows):
+        srt = torch.sort(logits[r], descending=True, stable=True)
+        want = [int(i) for v, i in zip(srt.values[:k], srt.indices[:k]) if v > float("-inf")]
+        assert got[r, : len(want)].tolist() == want, r
+        assert bool((got[r, len(want):] == -1).all())
+    beam = -torch.rand(rows, generator=torch.Generator().manual_seed(rows)) * 5
+    if rows > 3:
+        beam[3] = float("-inf")                                      # a dead beam is never expanded
+    lse = torch.logsumexp(logits.double(), -1).float()
+    flat = ((logits - lse[:, None]) + beam[:, None]).reshape(-1)
+    vals, idx = R.topk_desc_stable(flat, k)
+    keep = vals > float("-inf")
+    vals, idx = vals[keep], idx[keep]
+    ws = torch.empty(rows * _lib.MAX_BEAMS, dtype=torch.int32, device="cuda")
+    o_s = torch.empty(k, dtype=torch.float32, device="cuda")
+    o_p, o_t, o_f = (torch.empty(k, dtype=torch.int32, device="cuda") for _ in range(3))
+    _lib.check(lib.atspeed_beam_expand_prune_free(lg.data_ptr(), ld, lse.cuda().data_ptr(), beam.cuda().data_ptr(), rows, vocab, k, ws.data_ptr(),
+                                                  o_s.data_ptr(), o_p.data_ptr(), o_t.data_ptr(), o_f.data_ptr(), _st()))
+    f = o_f.cpu()
+    n = int((f >= 0).sum())
+    assert n == len(idx) and bool((f[n:] == -1).all())
+    assert f[:n].tolist() == idx.tolist()                            # flat ids, in order
+    assert o_p.cpu()[:n].tolist() == (idx // vocab).tolist() and o_t.cpu()[:n].tolist() == (idx % vocab).tolist()
+    np.testing.assert_allclose(o_s.cpu()[:n].numpy(), vals.numpy(), atol=1e-5, rtol=0)
+
+
+def test_log_softmax_rows_and_assemble_sequences(lib):
+    rows, vocab = 37, 32859
+    ld = (vocab + 63) // 64 * 64
+    lg = _rand((rows, ld), 17, 2.0).cuda()
+    lse = torch.empty(rows, dtype=torch.float32, device="cuda")
+    _lib.check(lib.atspeed_lse_rows(lg.data_ptr(), rows, vocab, ld, lse.data_ptr(), _st()))
+    out = torch.empty(rows, vocab, dtype=torch.float32, device="cuda")
+    _lib.check(lib.atspeed_log_softmax_rows(lg.data_ptr(), ld, lse.data_ptr(), rows, vocab, out.data_ptr(), vocab, _st()))
+    assert torch.equal(out, lg[:, :vocab] - lse[:, None])
+    np.testing.assert_allclose(out.cpu().numpy(), torch.log_softmax(lg[:, :vocab].double().cpu(), -1).numpy(), atol=2e-5, rtol=0)
+    # beam_sequence tensors of a batch in one launch: prompt ++ suffix per beam, ragged prompts
+    n, k, L = 9, 20, 4
+    g = torch.Generator().manual_seed(3)
+    lens = [int(x) for x in torch.randint(1, 200, (n,), generator=g)]
+    prompts = [torch.randint(0, 32000, (p,), generator=g, dtype=torch.int32) for p in lens]
+    toks = torch.randint(32000, 32859, (n, k, L), generator=g, dtype=torch.int32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    flat = torch.cat(prompts).cuda()
+    res = torch.full((k * (int(off[-1]) + n * L),), -1, dtype=torch.int64, device="cuda")
+    _lib.check(lib.atspeed_assemble_sequences(flat.data_ptr(), off.ctypes.data, toks.cuda().data_ptr(), n, k, L, res.data_ptr(), _st()))
+    res = res.cpu()
+    for u in range(n):
+        o0 = k * (int(off[u]) + u * L)
+        got = res[o0: o0 + k * (lens[u] + L)].view(k, lens[u] + L)
+        want = torch.cat((prompts[u].long()[None].expand(k, -1), toks[u].long()), 1)
+        assert torch.equal(got, want), u

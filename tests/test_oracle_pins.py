@@ -20,8 +20,8 @@ def test_oracle_bssd_equals_reference(case, bssd_golden):
     tgt = RefLlama(ci["target_dims"], ci["target_sd"])
     drf = RefLlama(ci["draft_dims"], ci["draft_sd"])
     P = len(ci["prompt"])
-    out = R.BSSD(tgt, drf, ci["prompt"], case["gamma"], case["max_new_tokens"], case["K"], case["DK"], ci["fn"])
-    tg = R.target_generate(tgt, ci["prompt"], case["max_new_tokens"], case["K"], ci["fn"])
+    out = R.BSSD(tgt, drf, ci["prompt"], case["gamma"], case["max_new_tokens"], case["K"], case["DK"], ci["fn"], procs=ci["procs"])
+    tg = R.target_generate(tgt, ci["prompt"], case["max_new_tokens"], case["K"], ci["fn"], procs=ci["procs"])
     assert tg["beam_sequence"][:, P:].tolist() == gold["tg_tokens"]
     np.testing.assert_allclose(tg["beam_scores"].numpy(), gold["tg_scores"], atol=SCORE_TOL, rtol=0)
     # losslessness of the greedy branch: identical to plain beam search

@@ -113,8 +113,59 @@ def test_native_trie_flatten_equals_python_flattening():
         t = Trie(seqs)
         for pre in ((), (1,), (1, 2), (9, 9)):
             assert _same_csr(t.flatten(pre), ref_flatten(RefTrie(seqs).trie_dict, pre)), (len(seqs), pre)
-    with pytest.raises(NotImplementedError):
-        t = Trie([[1, 2]]); t.append(Trie([[3]]), 1); t.flatten()
+
+
+def _chain_cases():
+    it = synth.synthetic_items(synth.CodeVocab("t", (5, 7, 6, 4), 80), 3)
+    a = [[1] + [int(x) for x in r[:2]] + [9] for r in it]               # two code levels, then the hand-over token 9
+    b = [[int(x) for x in r[2:]] + [2] for r in it]
+    c = [[7, 8], [7, 5, 6]]
+    return [(a, 9, b, None, None), (a, 9, b, 2, c), ([[1, 2, 3], [1, 4]], 3, [[5, 6], [2, 7]], None, None)]
+
+
+def test_chained_trie_flattens_to_one_automaton_that_answers_like_get(trie_golden):
+    """`Trie.append` (generation_trie.py:19-21,55-57,67-68) on the device path: the chain becomes ONE CSR automaton.  For every
+    sentence -- all prefixes of every trie's sequences, concatenations across the hand-over, sentences that miss -- the automaton's
+    node after `walk` allows exactly what the oracle's `RefTrie.get` returns (as a set: the reference's list may hold a token twice),
+    and allowed tokens lead where the longer sentence leads.  The reference's own answers (golden `gets_appended`) are checked too."""
+    for a, bos_a, b, bos_b, c in _chain_cases():
+        t, rt = Trie(a), RefTrie(a)
+        tb, rtb = Trie(b), RefTrie(b)
+        if c is not None:
+            tb.append(Trie(c), bos_b); rtb.append(RefTrie(c), bos_b)
+        t.append(tb, bos_a); rt.append(rtb, bos_a)
+        fsm = t.flatten()
+        fsm.validate(1 << 20)
+        sentences = {()}
+        for seqs in (a, b, c or []):
+            for sq in seqs:
+                for j in range(len(sq) + 1):
+                    sentences.add(tuple(sq[:j]))
+        for sa in a[:20]:                                                # across the hand-over: A's prefix without the bos token, then B
+            for sb in b[:20]:
+                for j in range(len(sb) + 1):
+                    sentences.add(tuple(sa[:-1]) + tuple(sb[:j]))
+        sentences |= {(424242,), (1, 424242), tuple(a[0][:2]) + (424242,)}
+        for sq in sorted(sentences):
+            want = sorted(set(rt.get(list(sq))))
+            assert sorted(set(t.get(list(sq)))) == want
+            try:
+                node = fsm.walk(0, sq)
+            except KeyError:
+                assert want == [], sq
+                continue
+            assert fsm.allowed(node).tolist() == want, sq
+            for tok in want[:3]:                                         # consistency of the edges: step == walk of the longer sentence
+                assert fsm.step(node, tok) == fsm.walk(0, sq + (tok,))
+    tc = next(c for c in TRIE_CASES if c.get("append"))
+    t = Trie(tc["sequences"]); t.append(Trie(tc["append"]["sequences"]), tc["append"]["bos"])
+    fsm = t.flatten()
+    for q, exp in trie_golden[tc["name"]]["gets_appended"]:
+        try:
+            got = fsm.allowed(fsm.walk(0, q)).tolist()
+        except KeyError:
+            got = []
+        assert got == sorted(set(exp)), q
 
 
 @pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/data"), reason="reference data files are only in the build container")
