@@ -72,7 +72,7 @@ def parse():
                     help="extra brackets (SURVEY.md 8d 'oracle-draft'): same shapes and kernels, draft/target weights aligned through a "
                          "shared bigram table with the layers' residual contributions scaled by each factor of this comma list "
                          "(3e-6: every draft step accepted, 3e-5: about one step per verification); empty string skips the pass")
-    ap.add_argument("--aligned-fp32-users", type=int, default=32, help="users per aligned bracket the fp32 ENGINE also decodes (accepted length next to the bf16 engine's)")
+    ap.add_argument("--aligned-fp32-users", type=int, default=64, help="users per aligned bracket the fp32 ENGINE also decodes (accepted length next to the bf16 engine's)")
     ap.add_argument("--dataset", choices=("beauty", "games"), default="beauty", help="vocabulary / prompt-length shape of the headline pass (games = BASELINE config 3)")
     ap.add_argument("--mask", choices=("position", "trie"), default="position",
                     help="position = the per-position allowed sets inference.py installs; trie = strict item trie on the generated suffix")

@@ -37,15 +37,21 @@ def _fp8_applies(m, n, k):                        # gemm.hip: ats_gemm_fp8_appli
 
 
 PROJ_SHAPES = ((3 * H, H), (H, H), (2 * F, H), (H, F))
+# config 5 at its real width: the Llama-7B layer (hidden 4096, ffn 11008, 32 heads x 128: K = 4096 and K = 11008 projections, the fused
+# qkv + RoPE epilogue of the fp8 ring kernel), a few layers deep so that the CPU W8A8 oracle finishes in seconds
+H7, F7, HEADS7 = 4096, 11008, 32
 
 
-def _target(dtype=torch.bfloat16, V=synth.BEAUTY.vocab_size, **kw):
-    dims = synth.LlamaDims(V, H, LAYERS, HEADS, F)
-    return dims, HipLlama.from_synthetic(dims, 31, std=0.03, head_std=0.2, dtype=dtype, max_slots=512, max_tokens=512, max_logit_rows=448, **kw)
+def _target(dtype=torch.bfloat16, V=synth.BEAUTY.vocab_size, width="small", layers=LAYERS, **kw):
+    dims = synth.LlamaDims(V, H, layers, HEADS, F) if width == "small" else synth.LlamaDims(V, H7, layers, HEADS7, F7)
+    return dims, HipLlama.from_synthetic(dims, 31, std=0.03 if width == "small" else 0.02, head_std=0.2 if width == "small" else 0.05, dtype=dtype,
+                                         max_slots=512, max_tokens=512, max_logit_rows=448, **kw)
 
 
-def test_fp8_forward_logits_match_the_w8a8_oracle():
-    dims, m = _target()
+@pytest.mark.parametrize("width,layers", [("small", LAYERS), ("llama7b", 3)], ids=["hidden2048", "llama7b_width"])
+def test_fp8_forward_logits_match_the_w8a8_oracle(width, layers):
+    dims, m = _target(width=width, layers=layers)
+    LAYERS_ = layers
     sd = m.export_state_dict()                                    # the bf16 weight values the device holds (and quantises)
     ref8, ref32 = RefLlama(dims, sd, max_slots=512, w8a8=True), RefLlama(dims, sd, max_slots=512)
     m.enable_fp8()
@@ -60,12 +66,16 @@ def test_fp8_forward_logits_match_the_w8a8_oracle():
         pos = torch.arange(T, dtype=torch.int32)
         seqs.append((ids, pos, pos.clone(), vis_bits_from_bool(vis, 512), T, 6))
         host.append((ids, pos, pos, vis))
-    assert all(_fp8_applies(3200, n, k) for n, k in PROJ_SHAPES)
+    shapes = PROJ_SHAPES if width == "small" else ((3 * H7, H7), (H7, H7), (2 * F7, H7), (H7, F7))
+    assert all(_fp8_applies(3200, n, k) for n, k in shapes)
     m.fp8_counters(reset=True)
+    m.rope_fused_launches(reset=True)
     outs = m.forward_raw_batch(seqs)
     torch.cuda.synchronize()
     cnt = m.fp8_counters()
-    assert all(c["fp8"] == LAYERS and c["other"] == 0 for c in cnt.values()), cnt
+    assert all(c["fp8"] == LAYERS_ and c["other"] == 0 for c in cnt.values()), cnt
+    if width == "llama7b":
+        assert m.rope_fused_launches() == LAYERS_                 # head_dim 128: RoPE + the KV scatter ride in the fp8 qkv projection's epilogue
     worst = []
     for i in (0, 13, 31):
         want8 = ref8.forward(*host[i], n_logit_rows=6)
@@ -119,20 +129,24 @@ def test_fp8_bssd_runs_every_projection_in_fp8_in_every_round_and_matches_the_w8
     release_decoders(tgt, drf)
 
 
-def test_fp8_accept_length_drift_on_an_aligned_pair():
+@pytest.mark.parametrize("width", ["small", "llama7b"], ids=["hidden2048", "llama7b_width"])
+def test_fp8_accept_length_drift_on_an_aligned_pair(width):
     """Accepted length of the fp8 target against the bf16 target on weights where acceptance is non-trivial (draft and target share a
     bigram table, residual branches scaled: HipLlama.from_synthetic(align_to=...)): the drift config 5 reports, with a bound.  The
-    residual scale is the first of a short list at which the bf16 pair accepts a mixed number of steps."""
-    U, P = 144, 64
+    residual scale is the first of a short list at which the bf16 pair accepts a mixed number of steps.  llama7b_width: a full-width
+    (hidden 4096 / ffn 11008, 4 layers) target against the Llama-68M-shaped draft, i.e. bench.py's aligned pair with fewer layers."""
+    U, P = (144, 64) if width == "small" else (64, 64)
     V = synth.BEAUTY.vocab_size
     fn = atspeed_amd.PositionSetConstraint(synth.BEAUTY.allowed_tokens(), synth.RESPONSE_SEP)
     kw = dict(dtype=torch.bfloat16, max_slots=512, max_tokens=512, max_logit_rows=448)
     inputs = [{"input_ids": torch.from_numpy(synth.synthetic_prompt(P, 900 + u))[None].cuda()} for u in range(U)]
     mean_acc = lambda outs: sum(o["total_accept_steps"] for o in outs) / max(1, sum(o["n_run"] for o in outs))
     seen = {}
-    for rs in (3e-4, 5e-4, 1e-3):
-        drf = HipLlama.from_synthetic(synth.LlamaDims(V, 256, 2, 4, 704), 32, std=0.02, head_std=0.02, num_beams=40, resid_scale=rs, **kw)
-        tgt = HipLlama.from_synthetic(synth.LlamaDims(V, H, LAYERS, HEADS, F), 31, std=0.02, head_std=0.02, num_beams=20, resid_scale=rs, align_to=drf, **kw)
+    ddims = synth.LlamaDims(V, 256, 2, 4, 704) if width == "small" else synth.llama_68m(V)
+    tdims = synth.LlamaDims(V, H, LAYERS, HEADS, F) if width == "small" else synth.llama_7b(V, 4)
+    for rs in ((3e-4, 5e-4, 1e-3) if width == "small" else (3e-5, 1e-4, 3e-4, 1e-3)):
+        drf = HipLlama.from_synthetic(ddims, 32, std=0.02, head_std=0.02, num_beams=40, resid_scale=rs, **kw)
+        tgt = HipLlama.from_synthetic(tdims, 31, std=0.02, head_std=0.02, num_beams=20, resid_scale=rs, align_to=drf, **kw)
         a_bf = mean_acc(BSSD_batch(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=fn))
         seen[rs] = [a_bf]
         if 0.2 < a_bf < 2.8:

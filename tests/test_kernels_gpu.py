@@ -397,7 +397,9 @@ def test_rmsnorm_quant_fp8_equals_norm_then_quant(lib, hidden):
 
 
 @pytest.mark.parametrize("m,n,k,epi", [(1024, 2304, 768, 0), (640, 12288, 512, 0), (1300, 1024, 1280, 2), (900, 2752, 512, 3), (1543, 1000, 256, 1),
-                                      (4200, 8192, 256, 0), (8300, 4096, 512, 2), (4200, 8448, 256, 3), (4480, 3072, 1024, 0)])      # more than two tiles per CU
+                                      (4200, 8192, 256, 0), (8300, 4096, 512, 2), (4200, 8448, 256, 3), (4480, 3072, 1024, 0),      # more than two tiles per CU
+                                      # the Llama-7B projections at their real K (config 5): qkv, o_proj, gate_up, down
+                                      (1100, 12288, 4096, 0), (1100, 4096, 4096, 2), (700, 22016, 4096, 3), (1100, 4096, 11008, 2)])
 def test_gemm_fp8(lib, m, n, k, epi):
     x = _rand((m, k), 51, 1.5).to(torch.bfloat16).cuda()
     w = _rand((n, k), 52, 0.05).to(torch.bfloat16).cuda()
@@ -533,7 +535,8 @@ def test_gemm_packed_equals_row_major_bit_for_bit(lib, m, n, k, epi):
         assert torch.equal(c1[:, :n], c0[:, :n])
 
 
-@pytest.mark.parametrize("m,n,k,epi", [(1024, 2304, 768, 0), (1300, 1024, 1280, 2), (900, 2752, 512, 3), (4200, 8448, 256, 3), (8300, 4096, 512, 2), (4480, 3072, 1024, 0)])
+@pytest.mark.parametrize("m,n,k,epi", [(1024, 2304, 768, 0), (1300, 1024, 1280, 2), (900, 2752, 512, 3), (4200, 8448, 256, 3), (8300, 4096, 512, 2), (4480, 3072, 1024, 0),
+                                      (1100, 12288, 4096, 0), (700, 22016, 4096, 3), (1100, 4096, 11008, 2)])      # Llama-7B shapes: K = 4096 and K = 11008
 def test_gemm_fp8_packed_equals_row_major_bit_for_bit(lib, m, n, k, epi):
     x = _rand((m, k), 51, 1.5).to(torch.bfloat16).cuda()
     w = _rand((n, k), 52, 0.05).to(torch.bfloat16).cuda()
@@ -602,8 +605,10 @@ def test_row_topk_and_free_expand_equal_torch(lib, rows, vocab, k):
     ws = torch.empty(rows * _lib.MAX_BEAMS, dtype=torch.int32, device="cuda")
     o_s = torch.empty(k, dtype=torch.float32, device="cuda")
     o_p, o_t, o_f = (torch.empty(k, dtype=torch.int32, device="cuda") for _ in range(3))
-    _lib.check(lib.atspeed_beam_expand_prune_free(lg.data_ptr(), ld, lse.cuda().data_ptr(), beam.cuda().data_ptr(), rows, vocab, k, ws.data_ptr(),
+    lse_d, beam_d = lse.cuda(), beam.cuda()                         # named: a temporary's memory is gone before the kernel runs
+    _lib.check(lib.atspeed_beam_expand_prune_free(lg.data_ptr(), ld, lse_d.data_ptr(), beam_d.data_ptr(), rows, vocab, k, ws.data_ptr(),
                                                   o_s.data_ptr(), o_p.data_ptr(), o_t.data_ptr(), o_f.data_ptr(), _st()))
+    torch.cuda.synchronize()
     f = o_f.cpu()
     n = int((f >= 0).sum())
     assert n == len(idx) and bool((f[n:] == -1).all())
