@@ -88,11 +88,11 @@ def parse():
 
 # ------------------------------------------------------------------------------------------------ roofline.traffic provenance
 TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
-KERNEL_SOURCES = ("gemm.hip", "common.h", "internal.h")
+KERNEL_SOURCES = ("gemm.hip", "common.h")          # the GEMM kernels and the device helpers they use (internal.h holds only host-side declarations for them)
 
 
 def kernel_sha(root: str = ROOT) -> str:
-    """Identity of the GEMM kernels' source: sha256 over gemm.hip + the headers it includes (first 16 hex digits)."""
+    """Identity of the GEMM kernels' source: sha256 over gemm.hip + common.h (first 16 hex digits)."""
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
         with open(os.path.join(root, "atspeed_amd", "csrc", f), "rb") as fh:
