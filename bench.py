@@ -411,9 +411,22 @@ def main():
                         how="atspeed_probe_mfma_bf16 (16x16x32, random operands, 8 waves/CU) and atspeed_probe_hbm_read (2 GiB, 8 passes, best of 2 access shapes x 5 grids)")
         del buf, scratch
 
+    sub_errors = {}
+
+    def guarded(name, fn_):
+        """an auxiliary pass must never cost the headline: its failure is recorded on the line (`sub_pass_errors`) and the run goes on"""
+        try:
+            return fn_()
+        except Exception as e:                                        # noqa: BLE001
+            sub_errors[name] = f"{type(e).__name__}: {e}"[:400]
+            try:
+                torch.cuda.synchronize(dev)
+            except Exception:                                         # noqa: BLE001
+                pass
+            return None
+
     # ---- latency curve: where lock-step batching overtakes per-user calls (items/s and ms until the LAST user of the batch has its result)
-    curve = None
-    if solo and not args.no_latency_curve and args.streams > 1:
+    def latency_curve_pass():
         curve = []
         for s in (1, 4, 16, 64, 256):
             if s > args.streams or s > n_timed:
@@ -430,11 +443,13 @@ def main():
             torch.cuda.synchronize(dev)
             ms = 1e3 * (time.perf_counter() - tc) / reps
             curve.append(dict(users_per_batch=s, ms_to_last_result=ms, items_per_s=s * args.beam / (ms * 1e-3), ms_per_user=ms / s))
+        return curve
+
+    curve = guarded("latency_curve", latency_curve_pass) if (solo and not args.no_latency_curve and args.streams > 1) else None
 
     # ---- the reference's own regime, for the record (not part of `value`): a few users strictly one at a time.
     # Here every projection is one pass over the weights (M ~ 20-230 tokens): HBM-bound.
-    single = None
-    if solo and args.streams > 1 and args.single_stream_users > 0:
+    def single_user_pass():
         n1 = min(args.single_stream_users, n_timed)
         for u in range(n_warm, n_warm + min(3, n1)):       # warm-up
             BSSD(target, draft, dprompts[u], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
@@ -463,13 +478,17 @@ def main():
                                     achieved=b1 / (us1 * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                     frac=b1 / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, avg_launch_us=us1,
                                     per_kind_us={k: 1e3 * v["ms"] / max(1, v["count"]) for k, v in p1.items()}))
+        return single
+
+    single = guarded("single_user_pass", single_user_pass) if (solo and args.streams > 1 and args.single_stream_users > 0) else None
 
     # ---- high-acceptance brackets: identical shapes / kernels / users, weights aligned so the draft's beams are mostly the target's
     # (the natural bracket above accepts ~0 steps because the random weights are unrelated).  Next to each: the fp32 ENGINE (bit-exact
     # against the CPU oracle at these dims, tests/test_fulldims_gpu.py) on the same weight values and users -- the "reference's" accepted length.
-    aligned, fp8_drift = None, None
     scales = [float(x) for x in args.aligned_resid_scale.split(",") if x.strip()]
-    if solo and scales:
+
+    def aligned_pass():
+        fp8_drift = None
         release_decoders(target, draft)                # the main pass's per-user KV arenas: room for the other model pairs
         aligned = []
         for rs in scales:
@@ -505,10 +524,12 @@ def main():
             aligned.append(br)
             release_decoders(target_a, draft_a)
             del target_a, draft_a
+        return aligned, fp8_drift
+
+    aligned, fp8_drift = (guarded("aligned_weight_brackets", aligned_pass) or (None, None)) if (solo and scales) else (None, None)
 
     # ---- BASELINE configs 3 and 5 as bounded sub-passes of the same line (driver-clocked)
-    configs = None
-    if solo and not args.no_configs and not args.do_sample and args.streams > 1:
+    def configs_pass():
         configs = {}
         if args.dataset == "beauty" and not args.target_fp8:
             gv = synth.GAMES
@@ -536,11 +557,13 @@ def main():
                                   roofline=gemm_roofline(target, r["prof"], r["prof_big"], True, measured, args.streams, False),
                                   accepted_length_drift_vs_bf16=fp8_drift,
                                   parity="unpinned against the reference (its 8-bit target is bitsandbytes LLM.int8, absent offline); pinned to the build's W8A8 oracle, tests/test_fp8_gpu.py")
+        return configs
+
+    configs = guarded("configs", configs_pass) if (solo and not args.no_configs and not args.do_sample and args.streams > 1) else None
 
     # ---- the verify step's scan (full-vocabulary log-sum-exp over the packed logit rows of one lock-step round, the HBM-bound
     # kernel of beamSD.py:285): rows = users x (1 + 3*DK) at V fp32 logits, timed alone with events on its launch stream
-    scan = None
-    if rank == 0:
+    def scan_pass():
         from atspeed_amd import _lib
         lib = _lib.load()
         rows = max(1, args.streams) * (1 + (args.new_tokens - 1) * args.draft_beam)
@@ -577,6 +600,9 @@ def main():
                                note="avoided = logit tiles never written + the LSE pass's re-read of every logit (what lse_rows_kernel streamed)")
         if measured:
             scan["peak_measured"], scan["frac_of_measured"] = measured["hbm_read_gbs"], scan["achieved"] / measured["hbm_read_gbs"]
+        return scan
+
+    scan = guarded("verify_scan", scan_pass) if rank == 0 else None
 
     per_rank = all_gather_counters(Counters(n_timed, n_run, acc, int(elapsed * 1e9)), dev)   # the path's single collective
     if rank != 0:
@@ -615,24 +641,25 @@ def main():
         "latency_curve": curve,
         "single_user_stream": single,
         "aligned_weight_brackets": aligned,   # same users, shapes and kernels as `value`; only the weights' agreement differs
+        "sub_pass_errors": sub_errors or None,   # an auxiliary pass that raised (the headline above does not depend on any of them)
     }
     if args.do_sample:
         line["decoding"] = f"sampling (temperature {args.temperature})"
-    if world == 1 and not args.no_cpu_baseline and not args.do_sample:
+    def cpu_pass():
         # (after the fp8 sub-pass the headline target also carries fp8 copies; its bf16 weights, which export_state_dict reads, are untouched)
         cb, ref_outs, (ref_t, _ref_d) = cpu_baseline(target, draft, prompts[n_warm:], fn, args)
-        line["cpu_baseline"] = cb
         # next to the timing: the bf16 engine's items vs the fp32 oracle's on identical weights, every rank at which they disagree scored
         # by the oracle itself (the asserted form over 64 users is tests/test_decisions_gpu.py)
         P0 = len(prompts[n_warm])
         rep = disagreement_report(outs[0], ref_outs[0], P0, ref_t, prompts[n_warm])
-        line["cpu_baseline"]["top_k_overlap_with_gpu_bf16"] = rep["top_k_overlap"]
-        line["cpu_baseline"]["bf16_vs_fp32_disagreements"] = rep
-        line["cpu_baseline"]["gpu_accept_len_same_users"] = float(sum(o["total_accept_steps"] for o in outs[:len(ref_outs)])) / max(
+        cb["top_k_overlap_with_gpu_bf16"] = rep["top_k_overlap"]
+        cb["bf16_vs_fp32_disagreements"] = rep
+        cb["gpu_accept_len_same_users"] = float(sum(o["total_accept_steps"] for o in outs[:len(ref_outs)])) / max(
             1, sum(o["n_run"] for o in outs[:len(ref_outs)]))
-        del ref_t, _ref_d
-    else:
-        line["cpu_baseline"] = None
+        return cb
+
+    line["cpu_baseline"] = guarded("cpu_baseline", cpu_pass) if (world == 1 and not args.no_cpu_baseline and not args.do_sample) else None
+    line["sub_pass_errors"] = sub_errors or None
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -70,17 +70,23 @@ class TreeJudge:
         return s
 
 
-def _judge_one(base: torch.Tensor, rows: List[int], logp: torch.Tensor, allowed: torch.Tensor, chosen: List[Tuple[int, int, float]], n: int):
-    """One decision, raw.  base [n_par] fp32 parent scores, rows = the parents' logp rows, allowed = candidate token ids of the step;
+def _judge_one(base: torch.Tensor, rows: List[int], logp: torch.Tensor, allowed: List[torch.Tensor], chosen: List[Tuple[int, int, float]], n: int):
+    """One decision, raw.  base [n_par] fp32 parent scores, rows = the parents' logp rows, allowed[p] = candidate token ids of parent p
+    (ascending; one shared tensor per depth for the position mask, the trie's children per parent for the strict trie);
     chosen = (parent index, token, bf16 engine's score) of the items the bf16 engine picked; n = beams kept.
     -> dict(flat = fp32 score of every candidate (CPU), idx = candidates the bf16 engine chose, err = its score minus the fp32 score)"""
-    sc = base[:, None] + logp[rows][:, allowed]                       # [n_par, m] fp32 score of every candidate
-    m = allowed.numel()
-    flat = sc.reshape(-1).cpu()
-    tok_index = {int(t): i for i, t in enumerate(allowed.tolist())}
-    idx = torch.tensor([p * m + tok_index[t] for p, t, _ in chosen], dtype=torch.long)
+    parts, par, tok, off = [], [], [], [0]
+    for p_i, (r, al) in enumerate(zip(rows, allowed)):
+        parts.append(base[p_i] + logp[r][al])
+        par.append(torch.full((al.numel(),), p_i, dtype=torch.long))
+        tok.append(al.cpu())
+        off.append(off[-1] + al.numel())
+    flat = torch.cat(parts).cpu() if parts else torch.zeros(0)
+    cand_par, cand_tok = (torch.cat(par), torch.cat(tok)) if parts else (torch.zeros(0, dtype=torch.long),) * 2
+    pos = [{int(t): j for j, t in enumerate(al.tolist())} for al in allowed]
+    idx = torch.tensor([off[p] + pos[p][t] for p, t, _ in chosen], dtype=torch.long)
     b_scores = torch.tensor([b for _, _, b in chosen], dtype=torch.float32)
-    return dict(flat=flat, idx=idx, err=b_scores - flat[idx], n=n, m=m, allowed=allowed.cpu())
+    return dict(flat=flat, idx=idx, err=b_scores - flat[idx], n=n, cand_par=cand_par, cand_tok=cand_tok)
 
 
 def evaluate(reports: List[dict]):
@@ -93,8 +99,11 @@ def evaluate(reports: List[dict]):
         if r["err"].numel():
             eps[r["key"]] = max(eps.get(r["key"], 0.0), float(r["err"].abs().max()))
     for r in reports:
-        flat, idx, n, m, allowed = r["flat"], r["idx"], r["n"], r["m"], r["allowed"]
-        n_eff = min(n, flat.numel())
+        flat, idx, n, cpar, ctok = r["flat"], r["idx"], r["n"], r["cand_par"], r["cand_tok"]
+        n_eff = min(n, int((flat > float("-inf")).sum()))
+        if n_eff == 0:
+            r.update(noise=0.0, own_noise=0.0, bound=0.0, gap=float("inf"), n_in=0, n_clear=0, n_same=0, all_clear=True, violations=[])
+            continue
         top = torch.topk(flat, min(n_eff + 1, flat.numel())).values
         s_n = float(top[n_eff - 1])
         s_n1 = float(top[n_eff]) if top.numel() > n_eff else float("-inf")
@@ -107,9 +116,9 @@ def evaluate(reports: List[dict]):
         viol_b = chosen_mask & ~in_f & ((s_n - flat) > bound)             # clearly not among the n best, but the bf16 engine kept it
         clear_in = in_f & ((flat - s_n1) > bound)
         b_min = float((flat[idx] + r["err"]).min()) if idx.numel() else float("nan")
-        viol = [dict(kind="dropped", parent=int(i) // m, tok=int(allowed[int(i) % m]), score=float(flat[i]), boundary=s_n1, bound=bound,
+        viol = [dict(kind="dropped", parent=int(cpar[i]), tok=int(ctok[i]), score=float(flat[i]), boundary=s_n1, bound=bound,
                      implied_error=b_min - float(flat[i])) for i in torch.nonzero(viol_a).flatten().tolist()]
-        viol += [dict(kind="kept", parent=int(i) // m, tok=int(allowed[int(i) % m]), score=float(flat[i]), boundary=s_n, bound=bound)
+        viol += [dict(kind="kept", parent=int(cpar[i]), tok=int(ctok[i]), score=float(flat[i]), boundary=s_n, bound=bound)
                  for i in torch.nonzero(viol_b).flatten().tolist()]
         r.update(noise=noise, own_noise=float(r["err"].abs().max()) if r["err"].numel() else 0.0, bound=bound, gap=s_n - s_n1,
                  n_in=int(in_f.sum()), n_clear=int(clear_in.sum()), n_same=int((in_f & chosen_mask).sum()),
@@ -117,10 +126,11 @@ def evaluate(reports: List[dict]):
     return eps
 
 
-def judge_user(prompt: np.ndarray, rounds: List[dict], jt: TreeJudge, jd: TreeJudge, allowed_by_depth: Dict[int, torch.Tensor]):
+def judge_user(prompt: np.ndarray, rounds: List[dict], jt: TreeJudge, jd: TreeJudge, allowed_of):
     """Replay one user's decision trace.  -> list of raw decision reports (dicts of _judge_one + `what`, `key`; thresholds are applied
     by `evaluate` over the whole batch) and the consistency of the
-    acceptance tests (beamSD.py:371-380: step accepted iff every target pick is among the draft's candidates)."""
+    acceptance tests (beamSD.py:371-380: step accepted iff every target pick is among the draft's candidates).
+    `allowed_of(generated suffix as a tuple)` -> device LongTensor of the tokens the mask allows next, ascending."""
     reports = []
     accept_ok = True
     for rd in rounds:
@@ -133,7 +143,7 @@ def judge_user(prompt: np.ndarray, rounds: List[dict], jt: TreeJudge, jd: TreeJu
             # parent indices of the result block index the parents block's slots: map slot -> position among the valid rows
             slot_pos = {s: i for i, s in enumerate(rd["parents"]["index"])}
             chosen = [(slot_pos[p], t, b) for p, t, b in chosen]
-            r = _judge_one(base, [row[tuple(s)] for s in par], logp, allowed_by_depth[rd["gen0"]], chosen, rd["k"])
+            r = _judge_one(base, [row[tuple(s)] for s in par], logp, [allowed_of(tuple(s)) for s in par], chosen, rd["k"])
             r["what"], r["key"] = f"final step at depth {rd['gen0']}", ("target", rd["gen0"])
             reports.append(r)
             continue
@@ -151,7 +161,7 @@ def judge_user(prompt: np.ndarray, rounds: List[dict], jt: TreeJudge, jd: TreeJu
             blk = rd["draft"][i]
             chosen = [(par_slot[blk["parent"][j]], blk["tok"][j], blk["score"][j]) for j in range(len(blk["tok"]))]
             base = torch.tensor(par_score, dtype=torch.float32, device=dev)
-            r = _judge_one(base, [rowD[tuple(s)] for s in par_seq], logpD, allowed_by_depth[gen0 + i], chosen, dk)
+            r = _judge_one(base, [rowD[tuple(s)] for s in par_seq], logpD, [allowed_of(tuple(s)) for s in par_seq], chosen, dk)
             r["what"], r["key"] = f"draft step {i} at depth {gen0 + i}", ("draft", gen0 + i)
             reports.append(r)
             nxt_score = [par_score[p] + float(logpD[rowD[tuple(par_seq[p])], t]) for p, t, _ in chosen]
@@ -170,7 +180,7 @@ def judge_user(prompt: np.ndarray, rounds: List[dict], jt: TreeJudge, jd: TreeJu
                 pos_of = {s: prev_pos[q] for s, q in blk_seq.items() if q in prev_pos}
             chosen = [(pos_of[pk["parent"][j]], pk["tok"][j], pk["score"][j]) for j in range(len(pk["tok"]))]
             base = torch.tensor(par_score, dtype=torch.float32, device=dev)
-            r = _judge_one(base, [rowT[tuple(s)] for s in par_seq], logpT, allowed_by_depth[gen0 + i], chosen, k)
+            r = _judge_one(base, [rowT[tuple(s)] for s in par_seq], logpT, [allowed_of(tuple(s)) for s in par_seq], chosen, k)
             r["what"], r["key"] = f"verify step {i} at depth {gen0 + i}", ("target", gen0 + i)
             reports.append(r)
             # acceptance as the reference defines it, on the bf16 engine's own sets

@@ -32,14 +32,13 @@ ACCEPT_EPS = 0.05       # (iii)
 # non-vacuity floors, set from the measured values printed by the test (MI355X, seeds below): share of the fp32 judge's top-n memberships
 # that are clear, and users whose every decision is clear
 # measured: clear 0.177 / 0.842 / 0.951, identical 0.932 / 0.988 / 0.996, noise level of the deepest target step 0.63 / 0.03 / 0.009
-MIN_CLEAR_SHARE = {None: 0.10, 3e-5: 0.70, 3e-6: 0.85}
-MIN_SAME_SHARE = {None: 0.88, 3e-5: 0.97, 3e-6: 0.99}
-MIN_SAME_USERS = {None: 0, 3e-5: 0, 3e-6: 24}        # users whose every decision equals the judge's (measured 0 / 0 / 40+)
+MIN_CLEAR_SHARE = {None: 0.10, 3e-5: 0.70, 3e-6: 0.85, "games_trie": 0.10}
+MIN_SAME_SHARE = {None: 0.88, 3e-5: 0.97, 3e-6: 0.99, "games_trie": 0.88}
+MIN_SAME_USERS = {None: 0, 3e-5: 0, 3e-6: 24, "games_trie": 0}        # users whose every decision equals the judge's (measured 0 / 0 / 40+)
 
 
-def _pairs(resid_scale):
+def _pairs(resid_scale, V=synth.BEAUTY.vocab_size):
     """bench.py's model pair in bf16 and, with the same weight VALUES, in fp32"""
-    V = synth.BEAUTY.vocab_size
     tdims, ddims = synth.llama_7b(V, 32), synth.llama_68m(V)
     kw = dict(max_slots=512, max_tokens=512, device=torch.device("cuda", 0))
     rs = 1.0 if resid_scale is None else resid_scale
@@ -52,13 +51,29 @@ def _pairs(resid_scale):
     return out
 
 
-@pytest.mark.parametrize("resid_scale", [None, 3e-5, 3e-6], ids=["unrelated_weights", "aligned_3e-5", "aligned_3e-6"])
+@pytest.mark.parametrize("resid_scale", [None, 3e-5, 3e-6, "games_trie"], ids=["unrelated_weights", "aligned_3e-5", "aligned_3e-6", "games_strict_trie"])
 def test_bf16_lockstep_decisions_equal_fp32_engine_where_margins_clear(resid_scale):
-    (tb, db), (tf, df) = _pairs(resid_scale)
+    case = resid_scale                                      # key of the floors above
+    games = resid_scale == "games_trie"                     # BASELINE config 3's mask at the full dims: Games vocabulary, strict item trie
+    vocab = synth.GAMES if games else synth.BEAUTY
+    resid_scale = None if games else resid_scale
+    (tb, db), (tf, df) = _pairs(resid_scale, vocab.vocab_size)
     dev = tb.device
-    fn = atspeed_amd.PositionSetConstraint(synth.BEAUTY.allowed_tokens(), synth.RESPONSE_SEP)
-    allowed = {d: torch.tensor(t, dtype=torch.long, device=dev) for d, t in synth.BEAUTY.allowed_tokens().items()}
-    plens = synth.prompt_lengths(N_USERS, 2025)
+    if games:
+        from atspeed_amd.generation_trie import SuffixTrieConstraint, Trie
+        trie = Trie([[1] + [int(t) for t in it] + [2] for it in synth.synthetic_items(vocab)])
+        fn = SuffixTrieConstraint(trie, synth.RESPONSE_SEP, 1)
+        cache = {}
+
+        def allowed_of(seq):                                # the trie's children of [bos] + generated suffix (generate_teacher_data.py:174-188)
+            if seq not in cache:
+                cache[seq] = torch.tensor(sorted(trie.get([1] + list(seq))), dtype=torch.long, device=dev)
+            return cache[seq]
+    else:
+        fn = atspeed_amd.PositionSetConstraint(vocab.allowed_tokens(), synth.RESPONSE_SEP)
+        by_depth = {d: torch.tensor(t, dtype=torch.long, device=dev) for d, t in vocab.allowed_tokens().items()}
+        allowed_of = lambda seq: by_depth[len(seq)]
+    plens = synth.prompt_lengths(N_USERS, 2025, mean_hist=5.98 if games else 7.33)
     prompts = [synth.synthetic_prompt(int(plens[u]), synth.tensor_seed(2025, f"user{u}")) for u in range(N_USERS)]
     inputs = [{"input_ids": torch.from_numpy(p)[None].to(dev)} for p in prompts]
 
@@ -76,7 +91,7 @@ def test_bf16_lockstep_decisions_equal_fp32_engine_where_margins_clear(resid_sca
     for u in range(N_USERS):
         rounds = last_decisions(tb, db, lane=u)
         assert [r["n_matches"] for r in rounds if r["kind"] == "verify"] == outs[u]["accept_steps"]
-        reports, accept_ok = judge_user(prompts[u], rounds, jt, jd, allowed)
+        reports, accept_ok = judge_user(prompts[u], rounds, jt, jd, allowed_of)
         assert accept_ok, f"user {u}: traced acceptance inconsistent with the traced sets"
         per_user.append(reports)
     eps = evaluate([r for reports in per_user for r in reports])
@@ -90,16 +105,16 @@ def test_bf16_lockstep_decisions_equal_fp32_engine_where_margins_clear(resid_sca
         if all(r["n_same"] == r["n_in"] for r in reports):
             same_users.append(u)
     noises = [r["own_noise"] for reports in per_user for r in reports]
-    print(f"[{resid_scale}] noise level per (model, depth):", {f"{k[0]}@{k[1]}": round(v, 4) for k, v in sorted(eps.items())})
+    print(f"[{case}] noise level per (model, depth):", {f"{k[0]}@{k[1]}": round(v, 4) for k, v in sorted(eps.items())})
     share = n_clear / max(1, n_in)
-    print(f"[{resid_scale}] {N_USERS} users, {n_dec} decisions, {n_in} top-n memberships: {n_same} identical ({n_same / n_in:.3f}), "
+    print(f"[{case}] {N_USERS} users, {n_dec} decisions, {n_in} top-n memberships: {n_same} identical ({n_same / n_in:.3f}), "
           f"{n_clear} clear ({share:.3f}); bf16 score noise median {np.median(noises):.4f} max {max(noises):.4f}; "
           f"users with every decision clear: {len(all_clear_users)}, with every decision equal to the judge's: {len(same_users)}; "
           f"violations: {len(violations)}")
     assert not violations, violations[:5]                                                    # (i)
-    assert share >= MIN_CLEAR_SHARE[resid_scale], f"only {share:.3f} of the memberships are clear: the assertion above would be vacuous"
-    assert n_same / n_in >= MIN_SAME_SHARE[resid_scale]
-    assert len(same_users) >= MIN_SAME_USERS[resid_scale]
+    assert share >= MIN_CLEAR_SHARE[case], f"only {share:.3f} of the memberships are clear: the assertion above would be vacuous"
+    assert n_same / n_in >= MIN_SAME_SHARE[case]
+    assert len(same_users) >= MIN_SAME_USERS[case]
 
     # (ii) + (iii): the fp32 engine decoding freely
     f_acc = f_runs = b_acc = b_runs = 0
@@ -112,6 +127,6 @@ def test_bf16_lockstep_decisions_equal_fp32_engine_where_margins_clear(resid_sca
             assert sorted(map(tuple, outs[u]["beam_sequence"][:, P:].cpu().tolist())) == sorted(map(tuple, fo["beam_sequence"][:, P:].cpu().tolist())), u
             assert (outs[u]["n_run"], outs[u]["accept_steps"]) == (fo["n_run"], fo["accept_steps"]), u
     b_mean, f_mean = b_acc / max(1, b_runs), f_acc / max(1, f_runs)
-    print(f"[{resid_scale}] mean accepted length: bf16 lock-step {b_mean:.4f} ({b_acc}/{b_runs}), fp32 engine {f_mean:.4f} ({f_acc}/{f_runs})")
+    print(f"[{case}] mean accepted length: bf16 lock-step {b_mean:.4f} ({b_acc}/{b_runs}), fp32 engine {f_mean:.4f} ({f_acc}/{f_runs})")
     assert b_mean >= f_mean - ACCEPT_EPS                                                     # (iii)
     release_decoders(tb, db, tf, df)
