@@ -332,11 +332,16 @@ def main():
         raise SystemExit(subprocess.run(launcher_command(args.gpus, sys.argv[1:])).returncode)
     _, rank, local_rank, world = mode
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    # rehearsal switches (NOT for measurements): ATSPEED_BENCH_BACKEND=gloo + ATSPEED_BENCH_SHARE_GPU=1 let two ranks run the N > 1 code
+    # path on a ONE-GPU box (both on cuda:0, counters gathered over gloo) -- RCCL itself refuses two ranks on one device
+    backend = os.environ.get("ATSPEED_BENCH_BACKEND", "nccl")
+    share_gpu = os.environ.get("ATSPEED_BENCH_SHARE_GPU", "0") == "1"
+    dev_index = 0 if (world == 1 or share_gpu) else local_rank
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")       # RCCL over xGMI
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group(backend)      # "nccl" = RCCL over xGMI
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     vocab = synth.BEAUTY if args.dataset == "beauty" else synth.GAMES
@@ -604,7 +609,7 @@ def main():
 
     scan = guarded("verify_scan", scan_pass) if rank == 0 else None
 
-    per_rank = all_gather_counters(Counters(n_timed, n_run, acc, int(elapsed * 1e9)), dev)   # the path's single collective
+    per_rank = all_gather_counters(Counters(n_timed, n_run, acc, int(elapsed * 1e9)), dev if backend == "nccl" else "cpu")   # the path's single collective
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -626,7 +631,7 @@ def main():
                                f"{'position-set mask' if args.mask == 'position' else 'strict item trie'}",
                    "users_per_step": ups, "users_per_gpu": n_timed, "streams": args.streams,
                    "mean_prompt_len": float(np.mean([len(p) for p in prompts[n_warm:]])),
-                   "parallelism": f"user-shard x{world}",
+                   "parallelism": f"user-shard x{world}" + ("" if backend == "nccl" and not share_gpu else f" (REHEARSAL: backend {backend}, ranks share one GPU: {share_gpu})"),
                    "operand_layout": "packed (row pairs per 128-byte line)" if getattr(target, "weights_packed", False) else "row-major",
                    "kernel_sha": kernel_sha()},
         "mean_accept_len": mean_accept,
