@@ -34,7 +34,7 @@ ACCEPT_EPS = 0.05       # (iii)
 # measured: clear 0.177 / 0.842 / 0.951, identical 0.932 / 0.988 / 0.996, noise level of the deepest target step 0.63 / 0.03 / 0.009
 MIN_CLEAR_SHARE = {None: 0.10, 3e-5: 0.70, 3e-6: 0.85, "games_trie": 0.10}
 MIN_SAME_SHARE = {None: 0.88, 3e-5: 0.97, 3e-6: 0.99, "games_trie": 0.88}
-MIN_SAME_USERS = {None: 0, 3e-5: 0, 3e-6: 24, "games_trie": 0}        # users whose every decision equals the judge's (measured 0 / 0 / 40+)
+MIN_SAME_USERS = {None: 0, 3e-5: 0, 3e-6: 16, "games_trie": 0}        # users whose every decision equals the judge's (measured 0 / 0 / 40+)
 
 
 def _pairs(resid_scale, V=synth.BEAUTY.vocab_size):
