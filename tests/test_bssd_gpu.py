@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 import atspeed_amd
 from atspeed_amd import synth
-from atspeed_amd.beamSD import BSSD, last_trace, target_generate
+from atspeed_amd.beamSD import BSSD, last_trace, release_decoders, target_generate
 from atspeed_amd.model import HipLlama, vis_bits_from_bool
 from oracle import beamsd_ref as R
 from oracle.llama_ref import RefLlama
@@ -145,13 +145,16 @@ def test_bssd_bf16_is_lossless_against_own_target_generate():
         assert len({tuple(x) for x in ta} & {tuple(x) for x in tb}) >= 18
 
 
-def test_bssd_batch_equals_sequential_calls(bssd_golden):
+@pytest.mark.parametrize("name", ["k20_dk40_sigma01_s7", "k20_dk40_nomask", "k8_dk16_chain"])
+def test_bssd_batch_equals_sequential_calls(name, bssd_golden):
     """Interleaved multi-user decoding (one stream per user) must give exactly the per-user results."""
     from atspeed_amd.beamSD import BSSD_batch
-    case = [c for c in CASES if c["name"] == "k20_dk40_sigma01_s7"][0]
+    case = [c for c in CASES if c["name"] == name][0]       # position mask, no mask at all (row top-k + free expand), chained whole-sentence trie
     ci = build_case_inputs(case)
     tgt, drf = _models(ci, case)
     users = [synth.synthetic_prompt(18 + 5 * u, 900 + u) for u in range(5)]
+    if case["mask"] == "chain":                              # the whole-sentence trie only knows its own prompt
+        users = [ci["prompt"]] * 5
     users[2] = ci["prompt"]                                  # one user is the golden case itself
     inputs = [{"input_ids": torch.from_numpy(p)[None].cuda()} for p in users]
     seq = [BSSD(tgt, drf, inp, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"]) for inp in inputs]
@@ -212,6 +215,47 @@ def test_games_strict_trie_many_users_batch():
         assert len({tuple(t) for t in toks}) == len(toks), "duplicate items in one user's beams"
         sc = bat[u]["beam_scores"][: bat[u]["n_valid"]].cpu().numpy()
         assert np.all(np.diff(sc) <= 1e-6), "beams must be sorted by score"
+
+
+def test_mask_free_search_many_users_batch_bf16():
+    """`prefix_allowed_tokens_fn=None` at batch scale on the bf16 engine: 48 users in lock step (ring GEMMs, the lm_head's fused normaliser
+    with EVERY logit tile stored, `row_topk_kernel` over all logit rows of a round) against the same engine one user at a time (small-M
+    kernels, plain lm_head + streaming LSE): same n_run / accept_steps, item sets equal up to bf16 near-ties (scores agree to bf16 noise), and
+    two users in fp32 against the oracle bit for bit."""
+    from atspeed_amd.beamSD import BSSD_batch
+    V = synth.GAMES.vocab_size
+    tdims = synth.LlamaDims(V, 256, 2, 4, 704)
+    ddims = synth.LlamaDims(V, 128, 2, 2, 352)
+    tsd = synth.synthetic_state_dict(tdims, 21, std=0.05, head_std=0.3)
+    dsd = synth.perturbed_state_dict(synth.synthetic_state_dict(ddims, 22, std=0.05, head_std=0.3), 23, 0.0)
+    kw = dict(max_slots=512, max_tokens=512, max_logit_rows=448)
+    n_users = 48
+    prompts = [synth.synthetic_prompt(20 + (7 * u) % 40, 6000 + u) for u in range(n_users)]
+    inputs = [{"input_ids": torch.from_numpy(p)[None].cuda()} for p in prompts]
+    for dtype in (torch.float32, torch.bfloat16):
+        tgt = HipLlama.from_state_dict(tdims, tsd, dtype, num_beams=20, **kw)
+        drf = HipLlama.from_state_dict(ddims, dsd, dtype, num_beams=40, **kw)
+        bat = BSSD_batch(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=None)
+        assert len(bat) == n_users and all(o["n_valid"] == 20 for o in bat)
+        for u in (0, 7, 23, 47):
+            one = BSSD(tgt, drf, inputs[u], 4, 4, prefix_allowed_tokens_fn=None)
+            P = len(prompts[u])
+            a = {tuple(x) for x in one["beam_sequence"][:, P:].cpu().tolist()}
+            b = {tuple(x) for x in bat[u]["beam_sequence"][:, P:].cpu().tolist()}
+            if dtype == torch.float32:
+                assert torch.equal(one["beam_sequence"], bat[u]["beam_sequence"])
+                assert (one["n_run"], one["accept_steps"]) == (bat[u]["n_run"], bat[u]["accept_steps"])
+            else:
+                assert len(a & b) >= 17, (u, len(a & b))
+                np.testing.assert_allclose(np.sort(one["beam_scores"].cpu().numpy()), np.sort(bat[u]["beam_scores"].cpu().numpy()), atol=0.15, rtol=0)
+        if dtype == torch.float32:
+            for u in (3, 31):
+                ref = R.BSSD(RefLlama(tdims, tsd), RefLlama(ddims, dsd), prompts[u], 4, 4, 20, 40, None)
+                P = len(prompts[u])
+                assert bat[u]["beam_sequence"][:, P:].cpu().tolist() == ref["beam_sequence"][:, P:].tolist()
+                assert (bat[u]["n_run"], bat[u]["total_accept_steps"]) == (ref["n_run"], ref["total_accept_steps"])
+                np.testing.assert_allclose(bat[u]["beam_scores"].cpu().numpy(), ref["beam_scores"].numpy(), atol=SCORE_TOL, rtol=0)
+        release_decoders(tgt, drf)
 
 
 def test_api_errors():
