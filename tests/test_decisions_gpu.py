@@ -14,6 +14,9 @@ whose fp32 margin exceeds the engine's own noise is identical.  tests/replay.py 
         ties the replay to a free decode);
   (iii) on the two aligned-weight brackets of bench.py the mean accepted length of the bf16 engine over the batch is >= the fp32
         engine's - 0.05 steps ("mean accepted length >= the reference's").
+Two more cases run the same replay on BASELINE config 3's mask (Games vocabulary, strict item trie: the candidates of a decision are the
+trie's children of each parent) and on config 5 (the target's projections in fp8: the judge stays the fp32 engine, so the quantisation
+error is part of the measured noise the margins are held against).
 """
 import numpy as np
 import pytest
@@ -32,9 +35,9 @@ ACCEPT_EPS = 0.05       # (iii)
 # non-vacuity floors, set from the measured values printed by the test (MI355X, seeds below): share of the fp32 judge's top-n memberships
 # that are clear, and users whose every decision is clear
 # measured: clear 0.177 / 0.842 / 0.951, identical 0.932 / 0.988 / 0.996, noise level of the deepest target step 0.63 / 0.03 / 0.009
-MIN_CLEAR_SHARE = {None: 0.10, 3e-5: 0.70, 3e-6: 0.85, "games_trie": 0.10}
-MIN_SAME_SHARE = {None: 0.88, 3e-5: 0.97, 3e-6: 0.99, "games_trie": 0.88}
-MIN_SAME_USERS = {None: 0, 3e-5: 0, 3e-6: 16, "games_trie": 0}        # users whose every decision equals the judge's (measured 0 / 0 / 40+)
+MIN_CLEAR_SHARE = {None: 0.10, 3e-5: 0.70, 3e-6: 0.85, "games_trie": 0.10, "fp8_3e-5": 0.60}
+MIN_SAME_SHARE = {None: 0.88, 3e-5: 0.97, 3e-6: 0.99, "games_trie": 0.88, "fp8_3e-5": 0.96}
+MIN_SAME_USERS = {None: 0, 3e-5: 0, 3e-6: 16, "games_trie": 0, "fp8_3e-5": 0}        # users whose every decision equals the judge's (measured 0 / 0 / 40+)
 
 
 def _pairs(resid_scale, V=synth.BEAUTY.vocab_size):
@@ -51,12 +54,14 @@ def _pairs(resid_scale, V=synth.BEAUTY.vocab_size):
     return out
 
 
-@pytest.mark.parametrize("resid_scale", [None, 3e-5, 3e-6, "games_trie"], ids=["unrelated_weights", "aligned_3e-5", "aligned_3e-6", "games_strict_trie"])
+@pytest.mark.parametrize("resid_scale", [None, 3e-5, 3e-6, "games_trie", "fp8_3e-5"],
+                         ids=["unrelated_weights", "aligned_3e-5", "aligned_3e-6", "games_strict_trie", "fp8_target_aligned_3e-5"])
 def test_bf16_lockstep_decisions_equal_fp32_engine_where_margins_clear(resid_scale):
     case = resid_scale                                      # key of the floors above
     games = resid_scale == "games_trie"                     # BASELINE config 3's mask at the full dims: Games vocabulary, strict item trie
-    vocab = synth.GAMES if games else synth.BEAUTY
-    resid_scale = None if games else resid_scale
+    fp8 = resid_scale == "fp8_3e-5"                         # BASELINE config 5: the target's batched projections in fp8 (W8A8 e4m3); the judge stays fp32:
+    vocab = synth.GAMES if games else synth.BEAUTY          # the quantisation error is then part of the measured noise the margins are held against
+    resid_scale = None if games else (3e-5 if fp8 else resid_scale)
     (tb, db), (tf, df) = _pairs(resid_scale, vocab.vocab_size)
     dev = tb.device
     if games:
@@ -77,6 +82,9 @@ def test_bf16_lockstep_decisions_equal_fp32_engine_where_margins_clear(resid_sca
     prompts = [synth.synthetic_prompt(int(plens[u]), synth.tensor_seed(2025, f"user{u}")) for u in range(N_USERS)]
     inputs = [{"input_ids": torch.from_numpy(p)[None].to(dev)} for p in prompts]
 
+    if fp8:
+        tb.enable_fp8()
+        tb.fp8_counters(reset=True)
     tb.profile(1)
     outs = BSSD_batch(tb, db, inputs, 4, 4, prefix_allowed_tokens_fn=fn, trace_decisions=True)
     torch.cuda.synchronize()
@@ -85,6 +93,9 @@ def test_bf16_lockstep_decisions_equal_fp32_engine_where_margins_clear(resid_sca
     for kind in ("qkv", "o_proj", "gate_up", "down", "lm_head"):
         assert big[kind]["count"] > 0 and 2 * big[kind]["count"] >= allp[kind]["count"], (kind, big[kind], allp[kind])
     assert tb.rope_fused_launches(reset=True) > 0
+    if fp8:
+        cnt = tb.fp8_counters()
+        assert all(c["fp8"] > 0 and c["other"] == 0 for c in cnt.values()), cnt       # every layer projection of every forward ran in fp8
 
     jt, jd = TreeJudge(tf), TreeJudge(df)
     per_user, violations, all_clear_users, same_users = [], [], [], []
