@@ -101,3 +101,48 @@ def test_disagreement_report_scores_both_items_with_the_oracle():
     assert rows[2]["gap"] == pytest.approx(sc[2] - sc[3], abs=2e-5) and rows[3]["gap"] == pytest.approx(sc[3] - sc[2], abs=2e-5)
     assert rows[5]["oracle_score_of_oracle_item"] == pytest.approx(sc[5])
     assert rep["max_gap"] >= abs(rows[2]["gap"])
+
+
+class _FakeTarget:
+    """what gemm_roofline() reads from a HipLlama: projection shapes and the fused-RoPE counter"""
+    dims = synth.llama_7b(synth.BEAUTY.vocab_size, 32)
+
+    def gemm_shape(self, kind):
+        d = self.dims
+        return {"qkv": (3 * d.hidden, d.hidden), "o_proj": (d.hidden, d.hidden), "gate_up": (2 * d.ffn, d.hidden),
+                "down": (d.hidden, d.ffn), "lm_head": (d.vocab_size, d.hidden)}[kind]
+
+    def rope_fused_launches(self):
+        return 5
+
+
+def _prof(ms, count, rows):
+    return dict(ms=ms, count=count, rows=rows)
+
+
+def test_roofline_object_arithmetic(tmp_path, monkeypatch):
+    """`roofline` of the line: achieved = 2 M N K / launch time against the dense MFMA peak of the arithmetic type when the launch is above the
+    ridge, algorithmic bytes / time against 8 TB/s below it; `frac` = achieved / peak; fp8 is priced against 5 PF; traffic only with provenance."""
+    monkeypatch.setattr(bench, "traffic_from_profiles", lambda kind, **kw: (7.5e9, "test provenance") if kind == "gate_up" else (None, None))
+    t = _FakeTarget()
+    M, launches = 26000, 256
+    prof = {"qkv": _prof(400.0, launches, M * launches), "o_proj": _prof(150.0, launches, M * launches), "gate_up": _prof(800.0, launches, M * launches),
+            "down": _prof(380.0, launches, M * launches), "lm_head": _prof(30.0, 8, 19000 * 8)}
+    r = bench.gemm_roofline(t, prof, prof, False, dict(mfma_bf16_tflops=1900.0, hbm_read_gbs=7000.0), 256, True)
+    flops = 2.0 * M * 22016 * 4096
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and "gate_up" in r["kernel"] and "gemm_ring_kernel<3, 8, false" in r["kernel"]
+    assert r["achieved"] == pytest.approx(flops / (800.0 / launches * 1e-3) / 1e12) and r["frac"] == pytest.approx(r["achieved"] / 2500.0)
+    assert r["frac_of_measured"] == pytest.approx(r["achieved"] / 1900.0)
+    assert r["algorithmic_bytes_per_launch"] == pytest.approx(22016 * 4096 * 2 + M * 4096 * 2 + M * 11008 * 2)
+    assert r["traffic"] == 7.5e9 and r["traffic_over_algorithmic"] == pytest.approx(7.5e9 / r["algorithmic_bytes_per_launch"])
+    assert sum(r["gemm_ms_share"].values()) == pytest.approx(1.0)
+    # fp8: operand bytes halve, the peak is the dense fp8 peak, no bf16 measured peak is quoted, traffic (recorded for bf16) is not quoted
+    r8 = bench.gemm_roofline(t, prof, prof, True, dict(mfma_bf16_tflops=1900.0, hbm_read_gbs=7000.0), 256, False)
+    assert r8["peak"] == 5000.0 and "gemm_ring_mx_kernel" in r8["kernel"] and r8["peak_measured"] is None and r8["traffic"] is None
+    assert r8["algorithmic_bytes_per_launch"] == pytest.approx(22016 * 4096 + M * 4096 + M * 11008 * 2)
+    # one user's launches (M ~ 100): below the ridge -> HBM roofline on the algorithmic bytes
+    small = {k: _prof(v["ms"] / 50, launches, 100 * launches) for k, v in prof.items()}
+    zero = {k: _prof(0.0, 0, 0) for k in prof}
+    rs = bench.gemm_roofline(t, small, zero, False, dict(mfma_bf16_tflops=1900.0, hbm_read_gbs=7000.0), 1, True)
+    assert rs["bound"] == "hbm" and rs["unit"] == "GB/s" and rs["peak"] == 8000.0 and rs["traffic"] is None
+    assert rs["achieved"] == pytest.approx(rs["algorithmic_bytes_per_launch"] / (small["gate_up"]["ms"] / launches * 1e-3) / 1e9)
