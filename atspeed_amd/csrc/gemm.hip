@@ -43,6 +43,7 @@ template <> struct GemmTraits<bf16_t> { static constexpr int BK = 64; static con
 template <> struct GemmTraits<float>  { static constexpr int BK = 32; static constexpr int EPC = 4; };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row * kChunks + (chunk ^ (row & 7))) * 16; }
+template <int CH> __device__ __forceinline__ int swz(int row, int chunk) { return (row * CH + (chunk ^ (row & (CH - 1)))) * 16; }
 
 template <typename T, int BM, int BN, int WM, int WN>
 struct TileCfg {
@@ -1371,6 +1372,134 @@ int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char*
   return ATSPEED_OK;
 }
 
+
+// =====================================================================================
+// One user's WIDE projections (qkv, gate_up, lm_head) at 33-128 tokens, without split-K: the weight-streaming regime.
+//
+//   C^T[n][m] = sum_k W[n][k] X[m][k]: a workgroup owns BN weight rows and the WHOLE K for all (<= BM) token rows, so its epilogue
+//   (store / SwiGLU / fp32) applies directly: no fp32 slabs, no reduce launch, one kernel per projection.  Used for gate_up and the
+//   lm_head (wdma_applies); hipBLASLt's kernels for these shapes have the same form (MT128x32x128 / MT96x128x128, one launch).
+//
+// What makes this stream (measured round 3, profiles/r03_one_user_*.txt): a workgroup must keep several k-tiles of loads in flight, or
+// every tile costs a memory round trip (~1.5 us).  Register prefetch cannot do it on this compiler (hipcc drains vmcnt across loop
+// iterations), so the tiles travel by LDS-DMA issued from INLINE ASM -- the compiler does not know these
+// vector-memory operations exist, hence inserts no waits for them -- into a ring of NST stages of (BM + BN) rows x 128 bytes; the wait
+// for "tile kt has landed" is a hand-counted s_waitcnt vmcnt((NST-2) * pieces per wave) followed by s_barrier.  The MFMA work of a stage
+// is ordinary compiler-scheduled code (fragment reads from LDS that is stable between two barriers): at 100 tokens it is a third of the
+// time the stage's bytes need, so nothing has to be interleaved by hand.  LDS image of a stage: X rows then W rows, chunk c of row r at
+// position c ^ (r & 7) (conflict-free for the 16-row fragment reads), applied on the per-lane SOURCE address since the DMA's destination is
+// lane-linear (1 KB piece = 8 rows x 128 bytes, lane l -> row l >> 3, position l & 7).
+template <int BM, int BN, int NST, int EPI>
+__global__ __launch_bounds__(256) void gemm_wdma_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, void* __restrict__ Cv,
+                                                        int M, int N, int K, int ldx, int ldc, int pk) {
+  constexpr int RB = 128, STAGE = (BM + BN) * RB;
+  constexpr int NPIECE = (BM + BN) / 8, NP = NPIECE / 4;               // 1 KB pieces per stage; per wave
+  constexpr int NI = BN / 2 / 16, MI = BM / 2 / 16;                    // wave tile (2 x 2 waves): BN/2 weight rows x BM/2 token rows
+  static_assert(NPIECE % 4 == 0 && (NST - 2) * NP <= 63, "pieces per wave / vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wm = wave & 1, lq = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * BN;
+  const int n_kt = K / 64;                                             // launcher: K % 64 == 0, n_kt >= NST - 1
+  const unsigned lbase = lds_addr(smem);
+
+  // this wave's pieces: piece index p = wave * NP + j covers LDS rows 8p .. 8p+7 of a stage (rows < BM: X, then W)
+  unsigned voff[NP];
+  int m0p[NP];
+  bool is_w[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int piece = wave * NP + j, row = piece * 8 + (lane >> 3), pos = lane & 7, c = pos ^ (row & 7);
+    const bool w = row >= BM;                                          // uniform per piece (BM % 8 == 0)
+    const int gr = w ? min(n0 + row - BM, N - 1) : min(row, M - 1);
+    const unsigned ld = w ? (unsigned)K : (unsigned)ldx;
+    voff[j] = pk ? (unsigned)(gr >> 1) * (ld * 4u) + (gr & 1) * 64 + (unsigned)(c >> 2) * 128 + (c & 3) * 16 : (unsigned)gr * (ld * 2u) + c * 16;
+    m0p[j] = __builtin_amdgcn_readfirstlane((int)lbase + piece * 1024);
+    is_w[j] = __builtin_amdgcn_readfirstlane(piece * 8 >= BM ? 1 : 0) != 0;
+  }
+  const unsigned long long wb = (unsigned long long)W, xb = (unsigned long long)X;
+  const unsigned long long kstep = pk ? 256 : 128;                     // bytes from one 64-k tile of a row to the next
+  auto issue = [&](int kt) {
+    const int so = (kt % NST) * STAGE;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) ATS_DMA16(voff[j], (is_w[j] ? wb : xb) + (unsigned long long)kt * kstep, m0p[j] + so);
+  };
+
+  f32x4_t acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t) issue(t);
+  for (int kt = 0; kt < n_kt; ++kt) {
+    if (kt + NST - 2 < n_kt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NP) : "memory");   // tiles kt+1 .. kt+NST-2 may still fly
+    else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");                            // everyone's pieces of tile kt; and stage (kt-1) % NST is read out
+    if (kt + NST - 1 < n_kt) issue(kt + NST - 1);
+    const unsigned char* sx = smem + (kt % NST) * STAGE + (wm * (BM / 2)) * RB;
+    const unsigned char* sw = smem + (kt % NST) * STAGE + BM * RB + (wn * (BN / 2)) * RB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {                                   // two k-steps of 32 per 128-byte row
+      s16x8_t wf[NI], xf[MI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const s16x8_t*>(sw + swz<8>(i * 16 + lq, ks * 4 + g));
+#pragma unroll
+      for (int j = 0; j < MI; ++j) xf[j] = *reinterpret_cast<const s16x8_t*>(sx + swz<8>(j * 16 + lq, ks * 4 + g));
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[i]), __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // epilogue: acc[i][j][r] = C[m][n] with m = wm*BM/2 + j*16 + lq (token row), n = n0 + wn*BN/2 + i*16 + g*4 + r (weight row): a lane
+  // holds four adjacent output columns of one token row
+  const int nw = n0 + wn * (BN / 2);
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int gm = wm * (BM / 2) + j * 16 + lq;
+    if (gm >= M) continue;
+    if constexpr (EPI == EPI_SWIGLU) {                                 // gate rows 32b .. 32b+15, up rows 32b+16 .. 32b+31: tiles (2q, 2q+1)
+      bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
+#pragma unroll
+      for (int q = 0; q < NI / 2; ++q) {
+        const int gn = nw + q * 32 + g * 4;                            // gate row of r = 0
+        if (gn + 16 >= N) continue;                                    // N % 32 == 0: the whole (gate, up) group is inside N or not at all
+        uint32_t o[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t gp = f2bf_pk(acc[2 * q][j][2 * h], acc[2 * q][j][2 * h + 1]), up = f2bf_pk(acc[2 * q + 1][j][2 * h], acc[2 * q + 1][j][2 * h + 1]);
+          o[h] = f2bf_pk(ats_silu<false>(bf_lo(gp)) * bf_lo(up), ats_silu<false>(bf_hi(gp)) * bf_hi(up));
+        }
+        *reinterpret_cast<uint2*>(C + ats_opnd_idx<2>(pk, gm, (nw >> 1) + q * 16 + g * 4, ldc)) = make_uint2(o[0], o[1]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int gn = nw + i * 16 + g * 4;
+        if (gn >= N) continue;
+        if constexpr (EPI == EPI_F32) {
+          float* C = reinterpret_cast<float*>(Cv) + (size_t)gm * ldc + gn;
+          if (gn + 3 < N && (ldc & 3) == 0) *reinterpret_cast<float4*>(C) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          else
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[i][j][r];
+        } else {
+          static_assert(EPI == EPI_STORE || EPI == EPI_SWIGLU || EPI == EPI_F32, "store / fp32 / SwiGLU");
+          bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
+          if (gn + 3 < N && (ldc & 3) == 0) *reinterpret_cast<uint2*>(C) = make_uint2(f2bf_pk(acc[i][j][0], acc[i][j][1]), f2bf_pk(acc[i][j][2], acc[i][j][3]));
+          else
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = f2bf(acc[i][j][r]);
+        }
+      }
+    }
+  }
+}
+
 struct Plan { int bm; int bn; int splits; int k_per_split; };
 
 static int env_int(const char* name, int dflt) {
@@ -1501,9 +1630,60 @@ int launch_cfg(const T* a, const T* w, void* c, int m, int n, int k, int lda, in
   return ATSPEED_OK;
 }
 
+
+// dispatch of gemm_wdma_kernel: bf16, 33-256 tokens, K % 64 == 0, and an N that gives 150-256 workgroups of 192 or 128 weight rows (one per
+// CU, the deepest ring that fits): gate_up (22016 = 172 x 128) and the lm_head (32859 = 172 x 192).  Measured in the engine's form (packed
+// operands, tools/yardstick_engine_like.py, us per launch at 60 / 100 / 121 tokens): gate_up 48.3 / 53.2 / 56.2 -> 44.8 / 47.8 / 50.0, lm_head
+// 75.9 / 85.5 / 89.6 -> 64.1 / 70.4 / 73.1 (4.2 TB/s at 60 tokens).  NOT the qkv projection (12288 rows: 96 tiles of 128 leave 160 CUs idle,
+// 35-42 us; 192 tiles of 64 give 27.7 / 32.6 against 30.9 / 35.4, but the split-K form hands its slabs to the RoPE kernel, which the
+// bf16 store + separate RoPE pass of this form gives back: 22.71 vs 22.65 ms per user) and not N = 4096 (split-K + fused reduce / norm).
+static bool wdma_applies(int m, int n, int k, int lda, int epilogue) {
+  static const int on = env_int("ATSPEED_GEMM_WDMA", 1);
+  static const int min_m = env_int("ATSPEED_GEMM_WDMA_MIN_M", 33);
+  static const int max_m = env_int("ATSPEED_GEMM_WDMA_MAX_M", 256);
+  if (!on || m < min_m || m > max_m || k % 64 != 0 || k < 512 || (lda % 8) != 0) return false;
+  const int t192 = (n + 191) / 192, t128 = (n + 127) / 128;
+  const bool ok128 = t128 >= 150 && t128 <= 256, ok192 = t192 >= 150 && t192 <= 256;
+  if (!(ok128 || (ok192 && m <= 128))) return false;                  // 129-256 rows: 128-row tiles only
+  return epilogue == EPI_STORE || epilogue == EPI_F32 || (epilogue == EPI_SWIGLU && n % 32 == 0);
+}
+template <int BM, int BN, int NST, int EPI>
+int launch_wdma_cfg(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, int lda, int ldc, hipStream_t st, int pk) {
+  auto kern = gemm_wdma_kernel<BM, BN, NST, EPI>;
+  constexpr int lds = NST * (BM + BN) * 128;
+  static thread_local AtsPerDeviceFlag attr_flag;
+  bool& attr_done = attr_flag.cur();
+  if (!attr_done) {
+    ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN), dim3(256), lds, st, a, w, c, m, n, k, lda, ldc, pk);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+template <int EPI>
+int launch_wdma(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, int lda, int ldc, hipStream_t st, int pk) {
+  const int t192 = (n + 191) / 192, t128 = (n + 127) / 128;
+  const bool ok128 = t128 >= 150 && t128 <= 256;
+  // tile width: 128 weight rows when that gives 150-256 workgroups, else 192 (the lm_head: 257 tiles of 128 would spill one into a second round)
+  if (m <= 64) {
+    if (ok128) return launch_wdma_cfg<64, 128, 6, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);           // 24 KB x 6
+    return launch_wdma_cfg<64, 192, 4, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);                      // 32 KB x 4
+  }
+  if (m <= 128) {
+    if (ok128) return launch_wdma_cfg<128, 128, 4, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);          // 32 KB x 4
+    return launch_wdma_cfg<128, 192, 3, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);                     // 40 KB x 3
+  }
+  (void)t192;
+  return launch_wdma_cfg<256, 128, 3, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);                       // 129-256 tokens: 48 KB x 3 (the X rows are two thirds of a stage)
+}
+
 template <typename T, int EPI>
 int launch_epi(const T* a, const T* w, void* c, int m, int n, int k, int lda, int ldc, float* partial, size_t ws_bytes,
                hipStream_t st, FusedNorm* fn, int pk) {
+  if constexpr (sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_F32 || EPI == EPI_SWIGLU)) {
+    if (wdma_applies(m, n, k, lda, EPI)) return launch_wdma<EPI>(a, w, c, m, n, k, lda, ldc, st, pk);
+  }
   if constexpr (sizeof(T) == 2) {
     const int rs = ring_split_count(m, n, k);
     if (rs >= 1 && (lda % 8) == 0 && (size_t)rs * m * n * sizeof(float) <= ws_bytes && (EPI != EPI_SWIGLU || n % 32 == 0))
@@ -1556,6 +1736,7 @@ int ats_gemm_partials(const void* a, const void* w, int m, int n, int k, int lda
                       hipStream_t st, int* splits_out, int pk) {
   *splits_out = 0;
   if (dtype != ATSPEED_BF16 || m <= 0 || big_kernel_applies(m, n, k, lda, n, dtype, EPI_STORE)) return ATSPEED_OK;
+  if (wdma_applies(m, n, k, lda, EPI_STORE)) return ATSPEED_OK;        // the no-split kernel writes bf16 qkv itself: the caller runs ats_gemm + the plain RoPE pass
   const int rs = ring_split_count(m, n, k);
   if (rs < 1 || (lda % 8) != 0 || (n % 4) != 0 || ((uintptr_t)workspace & 15) != 0 || (size_t)rs * m * n * sizeof(float) > workspace_bytes) return ATSPEED_OK;
   ATS_REQUIRE(a && w && workspace, ATSPEED_ERR_INVALID, "gemm: null operand");

@@ -98,7 +98,7 @@ def test_gemm_store_and_f32(lib, m, n, k, dtype):
 
 
 @pytest.mark.parametrize("m,n,k", [(7, 256, 128), (40, 768, 768), (228, 4096, 11008), (228, 4096, 4096), (1100, 768, 1024), (2000, 500, 256), (100, 8192, 512), (6400, 4096, 512), (8300, 4096, 512), (4500, 8192, 256), (6400, 4104, 512),
-                                   (50, 8192, 1024), (128, 12288, 768), (129, 8200, 384), (256, 8192, 256)])      # one user's wide projections: the no-split weight-streaming tiles (64 / 128 / 256 token rows)
+                                   (50, 8192, 1024), (128, 12288, 768), (129, 8200, 384), (256, 8192, 256), (100, 22016, 512), (60, 32859, 576), (250, 22016, 1024)])      # one user's wide projections: the no-split weight-streaming tiles (64 / 128 / 256 token rows)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_residual(lib, m, n, k, dtype):
     a = _rand((m, k), 3).to(dtype).cuda()
@@ -110,7 +110,7 @@ def test_gemm_residual(lib, m, n, k, dtype):
     np.testing.assert_allclose(c.double().cpu().numpy(), ref.numpy(), atol=tol, rtol=0)
 
 
-@pytest.mark.parametrize("m,ffn,k", [(3, 32, 64), (40, 352, 128), (228, 11008, 4096), (20, 3072, 768), (1300, 1376, 512), (800, 496, 256), (300, 4224, 256), (4200, 4224, 256), (4200, 4240, 256), (60, 4224, 256), (110, 11008, 4096)])
+@pytest.mark.parametrize("m,ffn,k", [(3, 32, 64), (40, 352, 128), (228, 11008, 4096), (20, 3072, 768), (1300, 1376, 512), (800, 496, 256), (300, 4224, 256), (4200, 4224, 256), (4200, 4240, 256), (60, 4224, 256), (110, 11008, 4096), (40, 11008, 512), (256, 11008, 1024)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_swiglu(lib, m, ffn, k, dtype):
     from atspeed_amd.model import _interleave_gate_up
@@ -511,7 +511,7 @@ def test_pack_rows_layout_and_round_trip(lib):
         _lib.check(lib.atspeed_pack_rows(x.data_ptr(), lib_out.data_ptr(), 4, 80, _st()))
 
 
-@pytest.mark.parametrize("m,n,k,epi", [(20, 768, 256, 0), (100, 12288, 512, 0), (228, 4096, 4096, 2), (228, 22016, 512, 3), (121, 32859, 256, 1), (50, 12288, 512, 0), (50, 8448, 256, 3),
+@pytest.mark.parametrize("m,n,k,epi", [(20, 768, 256, 0), (100, 12288, 512, 0), (228, 4096, 4096, 2), (228, 22016, 512, 3), (121, 32859, 256, 1), (50, 12288, 512, 0), (50, 8448, 256, 3), (121, 32859, 512, 1), (110, 22016, 512, 3), (64, 8448, 1024, 3), (128, 8192, 4096, 0), (33, 16384, 576, 0), (225, 22016, 512, 3), (256, 12288, 1024, 0), (129, 32859, 512, 1), (64, 22016, 1024, 3), (40, 32859, 576, 1), (100, 22016, 512, 0), (200, 22000, 512, 0), (128, 28672, 512, 1),
                                       (1300, 1024, 1280, 2), (900, 2752, 512, 3), (4200, 8192, 256, 0), (1543, 1001, 256, 1), (777, 4096, 11008, 2)])
 def test_gemm_packed_equals_row_major_bit_for_bit(lib, m, n, k, epi):
     """Every bf16 GEMM path (LDS-tiled, its split-K + reduce, the split-K ring, the 256-wide ring) on packed operands: the same products
