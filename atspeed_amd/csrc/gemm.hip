@@ -1389,9 +1389,11 @@ int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char*
 // time the stage's bytes need, so nothing has to be interleaved by hand.  LDS image of a stage: X rows then W rows, chunk c of row r at
 // position c ^ (r & 7) (conflict-free for the 16-row fragment reads), applied on the per-lane SOURCE address since the DMA's destination is
 // lane-linear (1 KB piece = 8 rows x 128 bytes, lane l -> row l >> 3, position l & 7).
-template <int BM, int BN, int NST, int EPI>
+// SPLIT: the grid's y dimension divides K (64-k tiles z * n / splits .. (z+1) * n / splits); part z stores its fp32 partial sums to slab z of
+// Cv ([z][M][N]) and the caller's reduce kernel finishes the job (qkv: the RoPE kernel sums the slabs; down: reduce + residual + RMSNorm).
+template <int BM, int BN, int NST, int EPI, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_wdma_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, void* __restrict__ Cv,
-                                                        int M, int N, int K, int ldx, int ldc, int pk) {
+                                                        int M, int N, int K, int ldx, int ldc, int pk, int n_split) {
   constexpr int RB = 128, STAGE = (BM + BN) * RB;
   constexpr int NPIECE = (BM + BN) / 8, NP = NPIECE / 4;               // 1 KB pieces per stage; per wave
   constexpr int NI = BN / 2 / 16, MI = BM / 2 / 16;                    // wave tile (2 x 2 waves): BN/2 weight rows x BM/2 token rows
@@ -1400,7 +1402,12 @@ __global__ __launch_bounds__(256) void gemm_wdma_kernel(const bf16_t* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wm = wave & 1, lq = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * BN;
-  const int n_kt = K / 64;                                             // launcher: K % 64 == 0, n_kt >= NST - 1
+  int kt0 = 0, n_kt = K / 64;                                          // launcher: K % 64 == 0; this part's tiles are kt0 .. kt0 + n_kt - 1
+  if constexpr (SPLIT) {
+    const int all = n_kt, z = blockIdx.y;
+    kt0 = (int)((long long)z * all / n_split);
+    n_kt = (int)((long long)(z + 1) * all / n_split) - kt0;
+  }
   const unsigned lbase = lds_addr(smem);
 
   // this wave's pieces: piece index p = wave * NP + j covers LDS rows 8p .. 8p+7 of a stage (rows < BM: X, then W)
@@ -1419,10 +1426,10 @@ __global__ __launch_bounds__(256) void gemm_wdma_kernel(const bf16_t* __restrict
   }
   const unsigned long long wb = (unsigned long long)W, xb = (unsigned long long)X;
   const unsigned long long kstep = pk ? 256 : 128;                     // bytes from one 64-k tile of a row to the next
-  auto issue = [&](int kt) {
+  auto issue = [&](int kt) {                                           // kt: tile index inside this part
     const int so = (kt % NST) * STAGE;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) ATS_DMA16(voff[j], (is_w[j] ? wb : xb) + (unsigned long long)kt * kstep, m0p[j] + so);
+    for (int j = 0; j < NP; ++j) ATS_DMA16(voff[j], (is_w[j] ? wb : xb) + (unsigned long long)(kt0 + kt) * kstep, m0p[j] + so);
   };
 
   f32x4_t acc[NI][MI];
@@ -1432,7 +1439,7 @@ __global__ __launch_bounds__(256) void gemm_wdma_kernel(const bf16_t* __restrict
     for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-  for (int t = 0; t < NST - 1; ++t) issue(t);
+  for (int t = 0; t < NST - 1; ++t) if (t < n_kt) issue(t);           // (a part shorter than the ring only ever waits vmcnt(0) below)
   for (int kt = 0; kt < n_kt; ++kt) {
     if (kt + NST - 2 < n_kt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NP) : "memory");   // tiles kt+1 .. kt+NST-2 may still fly
     else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1458,6 +1465,25 @@ __global__ __launch_bounds__(256) void gemm_wdma_kernel(const bf16_t* __restrict
   // epilogue: acc[i][j][r] = C[m][n] with m = wm*BM/2 + j*16 + lq (token row), n = n0 + wn*BN/2 + i*16 + g*4 + r (weight row): a lane
   // holds four adjacent output columns of one token row
   const int nw = n0 + wn * (BN / 2);
+  if constexpr (SPLIT) {
+    float* P = reinterpret_cast<float*>(Cv) + (size_t)blockIdx.y * M * N;
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int gm = wm * (BM / 2) + j * 16 + lq;
+      if (gm >= M) continue;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int gn = nw + i * 16 + g * 4;
+        if (gn >= N) continue;
+        float* C = P + (size_t)gm * N + gn;
+        if (gn + 3 < N && (N & 3) == 0) *reinterpret_cast<float4*>(C) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[i][j][r];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
     const int gm = wm * (BM / 2) + j * 16 + lq;
@@ -1657,9 +1683,40 @@ int launch_wdma_cfg(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int
     ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN), dim3(256), lds, st, a, w, c, m, n, k, lda, ldc, pk);
+  hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN), dim3(256), lds, st, a, w, c, m, n, k, lda, ldc, pk, 1);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
+}
+// split-K form: projections whose N gives too few 128-row tiles (qkv: 96, down: 32) take tiles x splits = 150-256 workgroups, every part at
+// least 16 k-tiles long (o_proj, K = 4096 over 32 tiles, would need 8 parts of 8 tiles: all prologue, it keeps the LDS-tiled kernel)
+static int wdma_split_count(int m, int n, int k, int lda) {
+  static const int on = env_int("ATSPEED_GEMM_WDMA_SPLIT", 1);
+  static const int on_all = env_int("ATSPEED_GEMM_WDMA", 1);
+  static const int min_m = env_int("ATSPEED_GEMM_WDMA_MIN_M", 33);
+  if (!on || !on_all || m < min_m || m > 256 || k % 64 != 0 || (lda % 8) != 0 || n < 2048) return 0;
+  const int t128 = (n + 127) / 128, n_kt = k / 64;
+  if (t128 >= 150) return 0;                                           // wide enough for the no-split form (or too wide for one round)
+  const int s = std::min(256 / t128, n_kt / 16);
+  return (s >= 2 && t128 * s >= 150) ? s : 0;
+}
+template <int BM, int NST>
+int launch_wdma_split_cfg(const bf16_t* a, const bf16_t* w, float* partial, int m, int n, int k, int lda, int splits, hipStream_t st, int pk) {
+  auto kern = gemm_wdma_kernel<BM, 128, NST, EPI_F32, true>;
+  constexpr int lds = NST * (BM + 128) * 128;
+  static thread_local AtsPerDeviceFlag attr_flag;
+  bool& attr_done = attr_flag.cur();
+  if (!attr_done) {
+    ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((n + 127) / 128, splits), dim3(256), lds, st, a, w, (void*)partial, m, n, k, lda, n, pk, splits);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+static int launch_wdma_split(const bf16_t* a, const bf16_t* w, float* partial, int m, int n, int k, int lda, int splits, hipStream_t st, int pk) {
+  if (m <= 64)  return launch_wdma_split_cfg<64, 6>(a, w, partial, m, n, k, lda, splits, st, pk);
+  if (m <= 128) return launch_wdma_split_cfg<128, 4>(a, w, partial, m, n, k, lda, splits, st, pk);
+  return launch_wdma_split_cfg<256, 3>(a, w, partial, m, n, k, lda, splits, st, pk);
 }
 template <int EPI>
 int launch_wdma(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, int lda, int ldc, hipStream_t st, int pk) {
@@ -1671,7 +1728,7 @@ int launch_wdma(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, 
     return launch_wdma_cfg<64, 192, 4, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);                      // 32 KB x 4
   }
   if (m <= 128) {
-    if (ok128) return launch_wdma_cfg<128, 128, 4, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);          // 32 KB x 4
+    if (ok128) return launch_wdma_cfg<128, 128, 4, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);          // 32 KB x 4 (x 5 = all 160 KB: no faster)
     return launch_wdma_cfg<128, 192, 3, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);                     // 40 KB x 3
   }
   (void)t192;
@@ -1683,6 +1740,13 @@ int launch_epi(const T* a, const T* w, void* c, int m, int n, int k, int lda, in
                hipStream_t st, FusedNorm* fn, int pk) {
   if constexpr (sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_F32 || EPI == EPI_SWIGLU)) {
     if (wdma_applies(m, n, k, lda, EPI)) return launch_wdma<EPI>(a, w, c, m, n, k, lda, ldc, st, pk);
+  }
+  if constexpr (sizeof(T) == 2) {
+    const int s = wdma_split_count(m, n, k, lda);
+    if (s >= 2 && (size_t)s * m * n * sizeof(float) <= ws_bytes && ((uintptr_t)partial & 15) == 0 && (EPI != EPI_SWIGLU || n % 32 == 0)) {
+      ATS_TRY(launch_wdma_split(a, w, partial, m, n, k, lda, s, st, pk));
+      return reduce_splits<bf16_t, EPI>(partial, c, m, n, ldc, s, st, fn, pk);
+    }
   }
   if constexpr (sizeof(T) == 2) {
     const int rs = ring_split_count(m, n, k);
@@ -1724,6 +1788,7 @@ size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype) {
   Plan p = dtype == ATSPEED_BF16 ? make_plan<bf16_t>(m, n, k) : make_plan<float>(m, n, k);
   size_t b = p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
   if (dtype == ATSPEED_BF16) b = std::max(b, (size_t)ring_split_count(m, n, k) * m * n * sizeof(float));
+  if (dtype == ATSPEED_BF16) b = std::max(b, (size_t)wdma_split_count(m, n, k, k) * m * n * sizeof(float));
   return b;
 }
 
@@ -1737,6 +1802,16 @@ int ats_gemm_partials(const void* a, const void* w, int m, int n, int k, int lda
   *splits_out = 0;
   if (dtype != ATSPEED_BF16 || m <= 0 || big_kernel_applies(m, n, k, lda, n, dtype, EPI_STORE)) return ATSPEED_OK;
   if (wdma_applies(m, n, k, lda, EPI_STORE)) return ATSPEED_OK;        // the no-split kernel writes bf16 qkv itself: the caller runs ats_gemm + the plain RoPE pass
+  {
+    const int s = wdma_split_count(m, n, k, lda);
+    if (s >= 2 && (n % 4) == 0 && ((uintptr_t)workspace & 15) == 0 && (size_t)s * m * n * sizeof(float) <= workspace_bytes) {
+      ATS_REQUIRE(a && w && workspace, ATSPEED_ERR_INVALID, "gemm: null operand");
+      ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "gemm: operands must be 16-byte aligned");
+      ATS_TRY(launch_wdma_split((const bf16_t*)a, (const bf16_t*)w, (float*)workspace, m, n, k, lda, s, st, pk));
+      *splits_out = s;
+      return ATSPEED_OK;
+    }
+  }
   const int rs = ring_split_count(m, n, k);
   if (rs < 1 || (lda % 8) != 0 || (n % 4) != 0 || ((uintptr_t)workspace & 15) != 0 || (size_t)rs * m * n * sizeof(float) > workspace_bytes) return ATSPEED_OK;
   ATS_REQUIRE(a && w && workspace, ATSPEED_ERR_INVALID, "gemm: null operand");

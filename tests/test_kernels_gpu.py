@@ -98,7 +98,7 @@ def test_gemm_store_and_f32(lib, m, n, k, dtype):
 
 
 @pytest.mark.parametrize("m,n,k", [(7, 256, 128), (40, 768, 768), (228, 4096, 11008), (228, 4096, 4096), (1100, 768, 1024), (2000, 500, 256), (100, 8192, 512), (6400, 4096, 512), (8300, 4096, 512), (4500, 8192, 256), (6400, 4104, 512),
-                                   (50, 8192, 1024), (128, 12288, 768), (129, 8200, 384), (256, 8192, 256), (100, 22016, 512), (60, 32859, 576), (250, 22016, 1024)])      # one user's wide projections: the no-split weight-streaming tiles (64 / 128 / 256 token rows)
+                                   (50, 8192, 1024), (128, 12288, 768), (129, 8200, 384), (256, 8192, 256), (100, 22016, 512), (60, 32859, 576), (250, 22016, 1024), (100, 12288, 4096), (60, 4096, 11008), (225, 4096, 11008), (128, 12288, 2048)])      # ... and the split-K form of the weight-streaming kernel (qkv, down)      # one user's wide projections: the no-split weight-streaming tiles (64 / 128 / 256 token rows)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_residual(lib, m, n, k, dtype):
     a = _rand((m, k), 3).to(dtype).cuda()

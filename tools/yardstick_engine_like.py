@@ -19,12 +19,13 @@ def timeit(fs, iters=40):
     for i in range(iters): fs[i % len(fs)]()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / iters
-for name, n, k, epi in (("qkv", 12288, 4096, _lib.EPI_STORE), ("gate_up", 22016, 4096, _lib.EPI_SWIGLU), ("lm_head", 32859, 4096, _lib.EPI_F32)):
+for name, n, k, epi in (("qkv", 12288, 4096, _lib.EPI_STORE), ("o_proj", 4096, 4096, _lib.EPI_RESID), ("gate_up", 22016, 4096, _lib.EPI_SWIGLU), ("down", 4096, 11008, _lib.EPI_RESID),
+                        ("lm_head", 32859, 4096, _lib.EPI_F32)):
     wl = [pack((torch.randn(n, k, device="cuda") * 0.02).to(torch.bfloat16)) for _ in range(6)]     # rotate weights: no cache-resident W
     for m in (20, 60, 100, 121, 225):
         a = pack(torch.randn(m, k, device="cuda").to(torch.bfloat16))
-        ldc = {_lib.EPI_STORE: n, _lib.EPI_SWIGLU: n // 2, _lib.EPI_F32: (n + 63) // 64 * 64}[epi]
-        c = torch.empty((m + 1) // 2 * 2, ldc, dtype=torch.float32 if epi == _lib.EPI_F32 else torch.bfloat16, device="cuda")
+        ldc = {_lib.EPI_STORE: n, _lib.EPI_RESID: n, _lib.EPI_SWIGLU: n // 2, _lib.EPI_F32: (n + 63) // 64 * 64}[epi]
+        c = torch.zeros((m + 1) // 2 * 2, ldc, dtype=torch.float32 if epi == _lib.EPI_F32 else torch.bfloat16, device="cuda")
         t = timeit([(lambda w=w: _lib.check(lib.atspeed_gemm_packed(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, ldc, epi, ws.data_ptr(), ws.numel(), st))) for w in wl])
         print(f"{name:8s} M={m:4d}  {t:7.1f} us {n * k * 2 / t / 1e3:6.0f} GB/s", flush=True)
     del wl
