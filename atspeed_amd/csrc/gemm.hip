@@ -1687,8 +1687,7 @@ int launch_wdma_cfg(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
-// split-K form: projections whose N gives too few 128-row tiles (qkv: 96, down: 32) take tiles x splits = 150-256 workgroups, every part at
-// least 16 k-tiles long (o_proj, K = 4096 over 32 tiles, would need 8 parts of 8 tiles: all prologue, it keeps the LDS-tiled kernel)
+// split-K form: projections whose N gives too few 128-row tiles (qkv: 96, o_proj and down: 32) take tiles x splits = 150-256 workgroups
 static int wdma_split_count(int m, int n, int k, int lda) {
   static const int on = env_int("ATSPEED_GEMM_WDMA_SPLIT", 1);
   static const int on_all = env_int("ATSPEED_GEMM_WDMA", 1);
@@ -1696,7 +1695,11 @@ static int wdma_split_count(int m, int n, int k, int lda) {
   if (!on || !on_all || m < min_m || m > 256 || k % 64 != 0 || (lda % 8) != 0 || n < 2048) return 0;
   const int t128 = (n + 127) / 128, n_kt = k / 64;
   if (t128 >= 150) return 0;                                           // wide enough for the no-split form (or too wide for one round)
-  const int s = std::min(256 / t128, n_kt / 16);
+  // k-tiles per part at least: 8 up to 128 tokens (o_proj, K = 4096: 8 parts of 8 tiles, 15.8 / 18.8 -> 13.5 / 16.0 us at 60 / 100 tokens), 16 above
+  // (at 225 tokens the 8 x 8 form lost: 24.4 vs 23.7 us)
+  static const int min_tiles_env = env_int("ATSPEED_GEMM_WDMA_MIN_TILES", 0);
+  const int min_tiles = min_tiles_env > 0 ? min_tiles_env : (m <= 128 ? 8 : 16);
+  const int s = std::min(256 / t128, n_kt / min_tiles);
   return (s >= 2 && t128 * s >= 150) ? s : 0;
 }
 template <int BM, int NST>
