@@ -1429,7 +1429,11 @@ __global__ __launch_bounds__(256) void gemm_wdma_kernel(const bf16_t* __restrict
   auto issue = [&](int kt) {                                           // kt: tile index inside this part
     const int so = (kt % NST) * STAGE;
 #pragma unroll
+#if defined(ATS_WDMA_ABLATE) && ATS_WDMA_ABLATE >= 3                   // tuning build: the X pieces re-read tile 0 (same pipe, no L2 traffic to speak of)
+    for (int j = 0; j < NP; ++j) ATS_DMA16(voff[j], is_w[j] ? wb + (unsigned long long)(kt0 + kt) * kstep : xb, m0p[j] + so);
+#else
     for (int j = 0; j < NP; ++j) ATS_DMA16(voff[j], (is_w[j] ? wb : xb) + (unsigned long long)(kt0 + kt) * kstep, m0p[j] + so);
+#endif
   };
 
   f32x4_t acc[NI][MI];
@@ -1447,6 +1451,7 @@ __global__ __launch_bounds__(256) void gemm_wdma_kernel(const bf16_t* __restrict
     if (kt + NST - 1 < n_kt) issue(kt + NST - 1);
     const unsigned char* sx = smem + (kt % NST) * STAGE + (wm * (BM / 2)) * RB;
     const unsigned char* sw = smem + (kt % NST) * STAGE + BM * RB + (wn * (BN / 2)) * RB;
+#if !defined(ATS_WDMA_ABLATE) || ATS_WDMA_ABLATE < 2                   // tuning builds (make ablate_wdma): 1 = no MFMAs, 2 = no fragment reads either
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {                                   // two k-steps of 32 per 128-byte row
       s16x8_t wf[NI], xf[MI];
@@ -1454,12 +1459,22 @@ __global__ __launch_bounds__(256) void gemm_wdma_kernel(const bf16_t* __restrict
       for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const s16x8_t*>(sw + swz<8>(i * 16 + lq, ks * 4 + g));
 #pragma unroll
       for (int j = 0; j < MI; ++j) xf[j] = *reinterpret_cast<const s16x8_t*>(sx + swz<8>(j * 16 + lq, ks * 4 + g));
+#if defined(ATS_WDMA_ABLATE)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[i]));
+#pragma unroll
+      for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(xf[j]));
+#else
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < MI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[i]), __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
+#endif
     }
+#else
+    (void)sx; (void)sw;
+#endif
   }
 
   // epilogue: acc[i][j][r] = C[m][n] with m = wm*BM/2 + j*16 + lq (token row), n = n0 + wn*BN/2 + i*16 + g*4 + r (weight row): a lane
@@ -1592,6 +1607,10 @@ int reduce_splits(const float* partial, void* c, int m, int n, int ldc, int spli
 
 // One user's tokens through the ring kernel: tiles x splits <= 256 workgroups (one per CU: the ring takes 96-128 KB of LDS).
 // 257-512 tokens (the first verification of a long prompt) take two 256-row token tiles per weight tile.
+// The LDS-DMA kernels address an operand as a 64-bit scalar base + a 32-bit per-lane byte offset that holds the row: an operand of 4 GB or
+// more (rows x row bytes) does not fit and takes the LDS-tiled kernel (64-bit pointers) instead
+static bool dma_offsets_fit(long long rows, long long ld_elems, int esz) { return (rows + 1) * ld_elems * esz <= 0xffffffffll; }
+
 static int ring_split_count(int m, int n, int k) {
   static const int on = env_int("ATSPEED_GEMM_RING_SPLIT", 1);
   static const int min_m = env_int("ATSPEED_GEMM_RING_SPLIT_MIN_M", 33);
@@ -1600,7 +1619,7 @@ static int ring_split_count(int m, int n, int k) {
   // 33-256 tokens, loses on N = 4096 where 16 slabs of partials outweigh the weight stream
   static const int min_n = env_int("ATSPEED_GEMM_RING_SPLIT_MIN_N", 8192);
   static const int max_s = env_int("ATSPEED_GEMM_RING_SPLIT_MAX_SPLITS", 256);
-  if (!on || m < min_m || m > max_m || k % 128 != 0 || k < 256 || n < min_n) return 0;
+  if (!on || m < min_m || m > max_m || k % 128 != 0 || k < 256 || n < min_n || !dma_offsets_fit(n, k, 2)) return 0;
   const int tiles = ((n + 255) / 256) * ((m + 255) / 256), units = k / 128;
   int s = 256 / tiles;
   if (s > units) s = units;
@@ -1667,7 +1686,7 @@ static bool wdma_applies(int m, int n, int k, int lda, int epilogue) {
   static const int on = env_int("ATSPEED_GEMM_WDMA", 1);
   static const int min_m = env_int("ATSPEED_GEMM_WDMA_MIN_M", 33);
   static const int max_m = env_int("ATSPEED_GEMM_WDMA_MAX_M", 256);
-  if (!on || m < min_m || m > max_m || k % 64 != 0 || k < 512 || (lda % 8) != 0) return false;
+  if (!on || m < min_m || m > max_m || k % 64 != 0 || k < 512 || (lda % 8) != 0 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return false;
   const int t192 = (n + 191) / 192, t128 = (n + 127) / 128;
   const bool ok128 = t128 >= 150 && t128 <= 256, ok192 = t192 >= 150 && t192 <= 256;
   if (!(ok128 || (ok192 && m <= 128))) return false;                  // 129-256 rows: 128-row tiles only
@@ -1692,7 +1711,7 @@ static int wdma_split_count(int m, int n, int k, int lda) {
   static const int on = env_int("ATSPEED_GEMM_WDMA_SPLIT", 1);
   static const int on_all = env_int("ATSPEED_GEMM_WDMA", 1);
   static const int min_m = env_int("ATSPEED_GEMM_WDMA_MIN_M", 33);
-  if (!on || !on_all || m < min_m || m > 256 || k % 64 != 0 || (lda % 8) != 0 || n < 2048) return 0;
+  if (!on || !on_all || m < min_m || m > 256 || k % 64 != 0 || (lda % 8) != 0 || n < 2048 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return 0;
   const int t128 = (n + 127) / 128, n_kt = k / 64;
   if (t128 >= 150) return 0;                                           // wide enough for the no-split form (or too wide for one round)
   // k-tiles per part at least: 8 up to 128 tokens (o_proj, K = 4096: 8 parts of 8 tiles, 15.8 / 18.8 -> 13.5 / 16.0 us at 60 / 100 tokens), 16 above
@@ -1893,7 +1912,7 @@ static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype,
   // from 257 tokens (two token tiles): measured against the split-K mode at 300-500 tokens, gate_up 115-138 -> 96-108 us, qkv 80 -> 75 us
   static const int big_min_m = env_int("ATSPEED_GEMM_BIG_MIN_M", 257);
   static const int min_fill = env_int("ATSPEED_GEMM_BIG_MIN_FILL", 60);   // crossover measured at ~50-60 % (o_proj, down, qkv, gate_up at 512-1920 tokens)
-  if (dtype != ATSPEED_BF16 || m < big_min_m || k % 128 != 0 || (lda % 8) != 0) return false;
+  if (dtype != ATSPEED_BF16 || m < big_min_m || k % 128 != 0 || (lda % 8) != 0 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return false;
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
   const int tn = (n + 255) / 256;
   return big_fill_pct(tn * ((m + 255) / 256)) >= min_fill || big_fill_pct(tn * ((m + 127) / 128)) >= min_fill;
@@ -1929,6 +1948,7 @@ int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* s
                  int epilogue, hipStream_t st, int pk) {
   ATS_REQUIRE(xq && sx && wq && sw && c, ATSPEED_ERR_INVALID, "gemm_fp8: null argument");
   ATS_REQUIRE(m >= 1 && n >= 1 && k % 256 == 0, ATSPEED_ERR_INVALID, "gemm_fp8: K=%d must be a multiple of 256", k);
+  ATS_REQUIRE(dma_offsets_fit(n, k, 1) && dma_offsets_fit(m, k, 1), ATSPEED_ERR_CAPACITY, "gemm_fp8: an operand of %d x %d or %d x %d bytes exceeds the kernel's 32-bit row offsets", n, k, m, k);
   ATS_REQUIRE(epilogue != EPI_SWIGLU || ((ldc & 3) == 0 && n % 32 == 0), ATSPEED_ERR_INVALID, "gemm_fp8: SwiGLU needs N %% 32 == 0 and ldc %% 4 == 0");
   const unsigned char* X = (const unsigned char*)xq; const unsigned char* Wq = (const unsigned char*)wq;
   switch (epilogue) {

@@ -976,6 +976,8 @@ extern "C" int atspeed_beam_expand_prune_free(const float* logits, int32_t ld, c
   ATS_REQUIRE(logits && lse && beam_score && row_cand_ws && out_score && out_parent && out_token && out_flat, ATSPEED_ERR_INVALID,
               "beam_expand_prune_free: null argument");
   ATS_REQUIRE(vocab > 0 && ld >= vocab && (int64_t)MAXB * vocab < (int64_t)0x7fffffff, ATSPEED_ERR_INVALID, "beam_expand_prune_free: bad vocabulary");
+  ATS_REQUIRE(n_rows >= 1 && n_rows <= MAXB && k >= 1 && k <= MAXB, ATSPEED_ERR_CAPACITY, "beam_expand_prune_free: rows=%d / k=%d out of [1,%d] (row_cand_ws holds rows x %d ids)",
+              n_rows, k, MAXB, MAXB);
   ATS_TRY(ats_row_topk(logits, n_rows, vocab, ld, k, row_cand_ws, (hipStream_t)stream));
   BeamStepArgs a{};
   a.src.score = const_cast<float*>(beam_score);
