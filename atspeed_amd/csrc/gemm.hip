@@ -1391,16 +1391,19 @@ int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char*
 // lane-linear (1 KB piece = 8 rows x 128 bytes, lane l -> row l >> 3, position l & 7).
 // SPLIT: the grid's y dimension divides K (64-k tiles z * n / splits .. (z+1) * n / splits); part z stores its fp32 partial sums to slab z of
 // Cv ([z][M][N]) and the caller's reduce kernel finishes the job (qkv: the RoPE kernel sums the slabs; down: reduce + residual + RMSNorm).
-template <int BM, int BN, int NST, int EPI, bool SPLIT = false>
-__global__ __launch_bounds__(256) void gemm_wdma_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, void* __restrict__ Cv,
-                                                        int M, int N, int K, int ldx, int ldc, int pk, int n_split) {
-  constexpr int RB = 128, STAGE = (BM + BN) * RB;
-  constexpr int NPIECE = (BM + BN) / 8, NP = NPIECE / 4;               // 1 KB pieces per stage; per wave
-  constexpr int NI = BN / 2 / 16, MI = BM / 2 / 16;                    // wave tile (2 x 2 waves): BN/2 weight rows x BM/2 token rows
-  static_assert(NPIECE % 4 == 0 && (NST - 2) * NP <= 63, "pieces per wave / vmcnt range");
+// WM: waves along the token rows (2 x WM waves per workgroup).  2 x 2 up to 128 tokens, where the MFMAs are free (ablation builds,
+// profiles/r03_one_user_stream_ceiling.txt); 2 x 4 for the 256-row tile, whose 64 MFMAs per k-tile and wave at one wave per SIMD showed
+// (73.8 us against 60 without them at 225 tokens): two waves per SIMD overlap one's fragment reads with the other's MFMAs.
+template <int BM, int BN, int NST, int EPI, bool SPLIT = false, int WM = 2>
+__global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, void* __restrict__ Cv,
+                                                             int M, int N, int K, int ldx, int ldc, int pk, int n_split) {
+  constexpr int RB = 128, STAGE = (BM + BN) * RB, NWAVE = 2 * WM;
+  constexpr int NPIECE = (BM + BN) / 8, NP = NPIECE / NWAVE;           // 1 KB pieces per stage; per wave
+  constexpr int NI = BN / 2 / 16, MI = BM / WM / 16;                   // wave tile (2 x WM waves): BN/2 weight rows x BM/WM token rows
+  static_assert(NPIECE % NWAVE == 0 && (NST - 2) * NP <= 63 && BM % (16 * WM) == 0, "pieces per wave / vmcnt range");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave >> 1, wm = wave & 1, lq = lane & 15, g = lane >> 4;
+  const int wn = wave / WM, wm = wave % WM, lq = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * BN;
   int kt0 = 0, n_kt = K / 64;                                          // launcher: K % 64 == 0; this part's tiles are kt0 .. kt0 + n_kt - 1
   if constexpr (SPLIT) {
@@ -1449,7 +1452,7 @@ __global__ __launch_bounds__(256) void gemm_wdma_kernel(const bf16_t* __restrict
     else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");                            // everyone's pieces of tile kt; and stage (kt-1) % NST is read out
     if (kt + NST - 1 < n_kt) issue(kt + NST - 1);
-    const unsigned char* sx = smem + (kt % NST) * STAGE + (wm * (BM / 2)) * RB;
+    const unsigned char* sx = smem + (kt % NST) * STAGE + (wm * (BM / WM)) * RB;
     const unsigned char* sw = smem + (kt % NST) * STAGE + BM * RB + (wn * (BN / 2)) * RB;
 #if !defined(ATS_WDMA_ABLATE) || ATS_WDMA_ABLATE < 2                   // tuning builds (make ablate_wdma): 1 = no MFMAs, 2 = no fragment reads either
 #pragma unroll
@@ -1477,14 +1480,14 @@ __global__ __launch_bounds__(256) void gemm_wdma_kernel(const bf16_t* __restrict
 #endif
   }
 
-  // epilogue: acc[i][j][r] = C[m][n] with m = wm*BM/2 + j*16 + lq (token row), n = n0 + wn*BN/2 + i*16 + g*4 + r (weight row): a lane
+  // epilogue: acc[i][j][r] = C[m][n] with m = wm*BM/WM + j*16 + lq (token row), n = n0 + wn*BN/2 + i*16 + g*4 + r (weight row): a lane
   // holds four adjacent output columns of one token row
   const int nw = n0 + wn * (BN / 2);
   if constexpr (SPLIT) {
     float* P = reinterpret_cast<float*>(Cv) + (size_t)blockIdx.y * M * N;
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-      const int gm = wm * (BM / 2) + j * 16 + lq;
+      const int gm = wm * (BM / WM) + j * 16 + lq;
       if (gm >= M) continue;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -1501,7 +1504,7 @@ __global__ __launch_bounds__(256) void gemm_wdma_kernel(const bf16_t* __restrict
   }
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
-    const int gm = wm * (BM / 2) + j * 16 + lq;
+    const int gm = wm * (BM / WM) + j * 16 + lq;
     if (gm >= M) continue;
     if constexpr (EPI == EPI_SWIGLU) {                                 // gate rows 32b .. 32b+15, up rows 32b+16 .. 32b+31: tiles (2q, 2q+1)
       bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
@@ -1692,9 +1695,9 @@ static bool wdma_applies(int m, int n, int k, int lda, int epilogue) {
   if (!(ok128 || (ok192 && m <= 128))) return false;                  // 129-256 rows: 128-row tiles only
   return epilogue == EPI_STORE || epilogue == EPI_F32 || (epilogue == EPI_SWIGLU && n % 32 == 0);
 }
-template <int BM, int BN, int NST, int EPI>
+template <int BM, int BN, int NST, int EPI, int WM = 2>
 int launch_wdma_cfg(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, int lda, int ldc, hipStream_t st, int pk) {
-  auto kern = gemm_wdma_kernel<BM, BN, NST, EPI>;
+  auto kern = gemm_wdma_kernel<BM, BN, NST, EPI, false, WM>;
   constexpr int lds = NST * (BM + BN) * 128;
   static thread_local AtsPerDeviceFlag attr_flag;
   bool& attr_done = attr_flag.cur();
@@ -1702,7 +1705,7 @@ int launch_wdma_cfg(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int
     ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN), dim3(256), lds, st, a, w, c, m, n, k, lda, ldc, pk, 1);
+  hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN), dim3(128 * WM), lds, st, a, w, c, m, n, k, lda, ldc, pk, 1);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -1721,9 +1724,9 @@ static int wdma_split_count(int m, int n, int k, int lda) {
   const int s = std::min(256 / t128, n_kt / min_tiles);
   return (s >= 2 && t128 * s >= 150) ? s : 0;
 }
-template <int BM, int NST>
+template <int BM, int NST, int WM = 2>
 int launch_wdma_split_cfg(const bf16_t* a, const bf16_t* w, float* partial, int m, int n, int k, int lda, int splits, hipStream_t st, int pk) {
-  auto kern = gemm_wdma_kernel<BM, 128, NST, EPI_F32, true>;
+  auto kern = gemm_wdma_kernel<BM, 128, NST, EPI_F32, true, WM>;
   constexpr int lds = NST * (BM + 128) * 128;
   static thread_local AtsPerDeviceFlag attr_flag;
   bool& attr_done = attr_flag.cur();
@@ -1731,13 +1734,15 @@ int launch_wdma_split_cfg(const bf16_t* a, const bf16_t* w, float* partial, int 
     ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((n + 127) / 128, splits), dim3(256), lds, st, a, w, (void*)partial, m, n, k, lda, n, pk, splits);
+  hipLaunchKernelGGL(kern, dim3((n + 127) / 128, splits), dim3(128 * WM), lds, st, a, w, (void*)partial, m, n, k, lda, n, pk, splits);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
 static int launch_wdma_split(const bf16_t* a, const bf16_t* w, float* partial, int m, int n, int k, int lda, int splits, hipStream_t st, int pk) {
   if (m <= 64)  return launch_wdma_split_cfg<64, 6>(a, w, partial, m, n, k, lda, splits, st, pk);
   if (m <= 128) return launch_wdma_split_cfg<128, 4>(a, w, partial, m, n, k, lda, splits, st, pk);
+  static const int wm4 = env_int("ATSPEED_GEMM_WDMA_WM4", 1);
+  if (wm4) return launch_wdma_split_cfg<256, 3, 4>(a, w, partial, m, n, k, lda, splits, st, pk);
   return launch_wdma_split_cfg<256, 3>(a, w, partial, m, n, k, lda, splits, st, pk);
 }
 template <int EPI>
@@ -1754,7 +1759,9 @@ int launch_wdma(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, 
     return launch_wdma_cfg<128, 192, 3, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);                     // 40 KB x 3
   }
   (void)t192;
-  return launch_wdma_cfg<256, 128, 3, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);                       // 129-256 tokens: 48 KB x 3 (the X rows are two thirds of a stage)
+  static const int wm4 = env_int("ATSPEED_GEMM_WDMA_WM4", 1);
+  if (wm4) return launch_wdma_cfg<256, 128, 3, EPI, 4>(a, w, c, m, n, k, lda, ldc, st, pk);           // 129-256 tokens: 48 KB x 3 (the X rows are two thirds of a stage), 8 waves
+  return launch_wdma_cfg<256, 128, 3, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);
 }
 
 template <typename T, int EPI>

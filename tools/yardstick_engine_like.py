@@ -22,7 +22,7 @@ def timeit(fs, iters=40):
 for name, n, k, epi in (("qkv", 12288, 4096, _lib.EPI_STORE), ("o_proj", 4096, 4096, _lib.EPI_RESID), ("gate_up", 22016, 4096, _lib.EPI_SWIGLU), ("down", 4096, 11008, _lib.EPI_RESID),
                         ("lm_head", 32859, 4096, _lib.EPI_F32)):
     wl = [pack((torch.randn(n, k, device="cuda") * 0.02).to(torch.bfloat16)) for _ in range(6)]     # rotate weights: no cache-resident W
-    for m in (20, 60, 100, 121, 225):
+    for m in [int(x) for x in os.environ.get("YARD_M", "20,60,100,121,225").split(",")]:
         a = pack(torch.randn(m, k, device="cuda").to(torch.bfloat16))
         ldc = {_lib.EPI_STORE: n, _lib.EPI_RESID: n, _lib.EPI_SWIGLU: n // 2, _lib.EPI_F32: (n + 63) // 64 * 64}[epi]
         c = torch.zeros((m + 1) // 2 * 2, ldc, dtype=torch.float32 if epi == _lib.EPI_F32 else torch.bfloat16, device="cuda")
