@@ -62,6 +62,7 @@ SIGNATURES = {
     "atspeed_llama_fp8_counters": (C.c_int, [_P, _P, _P, _I]),
     "atspeed_llama_rope_fused_launches": (C.c_int64, [_P, _I]),
     "atspeed_quant_rows_fp8": (C.c_int, [_P, _I, _I, _P, _P, _P]),
+    "atspeed_quant_rows_fp8_packed": (C.c_int, [_P, _I, _I, _P, _P, _P]),
     "atspeed_gemm_fp8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "atspeed_llama_profile": (C.c_int, [_P, _I, _P, _P, _P]),
     "atspeed_llama_profile_big": (C.c_int, [_P, _P, _P, _P]),

@@ -521,10 +521,70 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
   }
 }
 
+// The same for PACKED operands, one workgroup per ROW PAIR: the two rows share every 128-byte line of the bf16 input (64 bytes each), so a
+// workgroup per row fetches each line twice (through two L2s, the neighbours of a pair landing on different XCDs) -- 2.9 TB/s of algorithmic
+// bytes in the fp8 step's profile.  Here a thread owns 16-byte chunk (tid & 7) of line (tid >> 3) + 32 i: chunks 0-3 are the even row's, 4-7 the
+// odd row's, so its row is fixed; the pair stays in registers between the maximum and the conversion (read once), and 16 consecutive threads
+// fill one whole 128-byte line of the packed e4m3 output.  Bit-identical to quant_rows_fp8_kernel.
+template <int NC>
+__global__ __launch_bounds__(256) void quant_row_pairs_fp8_kernel(const bf16_t* __restrict__ x, int rows, int cols, unsigned char* __restrict__ q,
+                                                                  float* __restrict__ scale) {
+  __shared__ float red[2][4];
+  const int n_lines = cols >> 5;                                   // 128-byte lines of the pair: 32 bf16 of each row per line
+  const uint4* xp = reinterpret_cast<const uint4*>(x) + (size_t)blockIdx.x * n_lines * 8;
+  const int sub = threadIdx.x & 7, odd = sub >> 2, l0 = threadIdx.x >> 3;
+  uint4 v[NC];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int line = l0 + 32 * i;
+    v[i] = line < n_lines ? xp[(size_t)line * 8 + sub] : make_uint4(0, 0, 0, 0);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(bf2f(e[j])));
+  }
+  const float m0 = wave_max_f32(odd ? 0.f : amax), m1 = wave_max_f32(odd ? amax : 0.f);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m0; red[1][threadIdx.x >> 6] = m1; }
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[odd][0], red[odd][1]), fmaxf(red[odd][2], red[odd][3]));
+  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / sc;
+  const int row = 2 * blockIdx.x + odd;
+  if ((threadIdx.x & 3) == 0 && l0 == 0 && row < rows) scale[row] = sc;      // threads 0 and 4
+  // packed e4m3: line L' of the pair holds columns 64 L' .. 64 L' + 63 of each row (64 bytes each); input line L = columns 32 L .. 32 L + 31
+  unsigned char* qp = q + (size_t)blockIdx.x * (size_t)cols * 2;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int line = l0 + 32 * i;
+    if (line < n_lines) {
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&v[i]);
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(bf2f(e[j]) * inv, -448.f), 448.f);
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+      const int col = line * 32 + (sub & 3) * 8;                   // first of this chunk's 8 columns
+      *reinterpret_cast<uint2*>(qp + (size_t)(col >> 6) * 128 + odd * 64 + (col & 63)) = make_uint2((unsigned)lo, (unsigned)hi);
+    }
+  }
+}
+
 int ats_quant_rows_fp8(const void* x, int rows, int cols, int ld, void* q, float* scale, hipStream_t st, int pk) {
   if (rows <= 0) return ATSPEED_OK;
   ATS_REQUIRE(cols % 8 == 0 && ld % 8 == 0, ATSPEED_ERR_INVALID, "quant_fp8: cols=%d / ld=%d must be multiples of 8", cols, ld);
   ATS_REQUIRE(!pk || (cols % 64 == 0 && ld == cols), ATSPEED_ERR_INVALID, "quant_fp8: packed operands need cols %% 64 == 0 and ld == cols");
+  static const bool pairs_off = getenv("ATSPEED_QUANT_PAIRS") && atoi(getenv("ATSPEED_QUANT_PAIRS")) == 0;
+  if (pk && !pairs_off && cols <= 12 * 1024) {                     // a pair of up to 12288 columns in registers (12 x 16 bytes per thread)
+    const int n_pairs = (rows + 1) / 2, nc = ((cols >> 5) + 31) / 32;     // the pad row of an odd count is allocated (operands hold an even number of rows)
+    if (nc <= 4)       quant_row_pairs_fp8_kernel<4><<<n_pairs, 256, 0, st>>>((const bf16_t*)x, rows, cols, (unsigned char*)q, scale);
+    else if (nc <= 8)  quant_row_pairs_fp8_kernel<8><<<n_pairs, 256, 0, st>>>((const bf16_t*)x, rows, cols, (unsigned char*)q, scale);
+    else               quant_row_pairs_fp8_kernel<12><<<n_pairs, 256, 0, st>>>((const bf16_t*)x, rows, cols, (unsigned char*)q, scale);
+    ATS_LAUNCH_CHECK();
+    return ATSPEED_OK;
+  }
   quant_rows_fp8_kernel<<<rows, 256, 0, st>>>((const bf16_t*)x, cols, ld, (unsigned char*)q, scale, pk);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
@@ -533,6 +593,11 @@ int ats_quant_rows_fp8(const void* x, int rows, int cols, int ld, void* q, float
 extern "C" int atspeed_quant_rows_fp8(const void* x, int32_t rows, int32_t cols, void* q, float* scale, void* stream) {
   ATS_REQUIRE(x && q && scale, ATSPEED_ERR_INVALID, "quant_fp8: null argument");
   return ats_quant_rows_fp8(x, rows, cols, cols, q, scale, (hipStream_t)stream, 0);
+}
+
+extern "C" int atspeed_quant_rows_fp8_packed(const void* x, int32_t rows, int32_t cols, void* q, float* scale, void* stream) {
+  ATS_REQUIRE(x && q && scale, ATSPEED_ERR_INVALID, "quant_fp8: null argument");
+  return ats_quant_rows_fp8(x, rows, cols, cols, q, scale, (hipStream_t)stream, 1);
 }
 
 

@@ -322,6 +322,10 @@ int atspeed_gemm_fp8_packed(const void* xq_dev, const float* sx_dev, const void*
                             int32_t n, int32_t k, int32_t ldc, int32_t epilogue, void* stream);
 /* per-row e4m3 quantisation q = e4m3(x / scale[r]), scale[r] = max|x[r]| / 448, and the W8A8 GEMM over such operands */
 int atspeed_quant_rows_fp8(const void* x_bf16_dev, int32_t rows, int32_t cols, void* q_dev, float* scale_dev, void* stream);
+/* the same on operands in the packed layout (x through atspeed_pack_rows with row_bytes = 2 cols, q comes out as atspeed_pack_rows with
+ * row_bytes = cols would lay it out; cols % 64 == 0; both buffers hold an even number of rows): what the engine runs between a bf16
+ * producer (attention, SwiGLU) and the fp8 projection that consumes it -- one workgroup per row PAIR, whole 128-byte lines in and out */
+int atspeed_quant_rows_fp8_packed(const void* x_bf16_packed_dev, int32_t rows, int32_t cols, void* q_packed_dev, float* scale_dev, void* stream);
 int atspeed_gemm_fp8(const void* xq_dev, const float* sx_dev, const void* wq_dev, const float* sw_dev, void* c_dev, int32_t m,
                      int32_t n, int32_t k, int32_t ldc, int32_t epilogue, void* stream);
 int atspeed_rmsnorm(const void* x_dev, const void* w_dev, void* y_dev, int32_t rows, int32_t hidden,

@@ -357,6 +357,28 @@ def _fp8_to_float(q_u8: torch.Tensor) -> torch.Tensor:
     return q_u8.cpu().view(torch.float8_e4m3fn).to(torch.float32)
 
 
+@pytest.mark.parametrize("rows,cols", [(37, 1152), (64, 4096), (51, 11008), (6, 64), (9, 12352)])
+def test_quant_rows_fp8_packed_equals_the_row_major_kernel_bit_for_bit(lib, rows, cols):
+    """the row-pair kernel of the packed layout (whole 128-byte lines, a pair in registers; 12352 columns: the one-row fallback) against
+    atspeed_quant_rows_fp8 on the same values; odd row counts leave the pad row of the last pair alone"""
+    x = (_rand((rows, cols), 43, 3.0) * torch.linspace(0.01, 30, rows)[:, None]).to(torch.bfloat16).cuda()
+    x[min(5, rows - 1)] = 0
+    q0 = torch.empty(rows, cols, dtype=torch.uint8, device="cuda")
+    s0 = torch.empty(rows, dtype=torch.float32, device="cuda")
+    _lib.check(lib.atspeed_quant_rows_fp8(x.data_ptr(), rows, cols, q0.data_ptr(), s0.data_ptr(), _st()))
+    re = (rows + 1) // 2 * 2
+    xp = torch.zeros(re, cols, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.atspeed_pack_rows(x.data_ptr(), xp.data_ptr(), rows, cols * 2, _st()))
+    qp = torch.full((re, cols), 0xAB, dtype=torch.uint8, device="cuda")
+    s1 = torch.full((rows + 1,), -7.0, dtype=torch.float32, device="cuda")
+    _lib.check(lib.atspeed_quant_rows_fp8_packed(xp.data_ptr(), rows, cols, qp.data_ptr(), s1.data_ptr(), _st()))
+    q1 = torch.empty(rows, cols, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.atspeed_unpack_rows(qp.data_ptr(), q1.data_ptr(), rows, cols, _st()))
+    torch.cuda.synchronize()
+    assert torch.equal(q0, q1)
+    assert torch.equal(s0, s1[:rows]) and float(s1[rows]) == -7.0            # no scale written for the pad row
+
+
 def test_quant_rows_fp8(lib):
     rows, cols = 37, 1152
     x = (_rand((rows, cols), 41, 3.0) * torch.linspace(0.01, 30, rows)[:, None]).to(torch.bfloat16).cuda()
