@@ -419,6 +419,15 @@ def test_rmsnorm_quant_fp8_equals_norm_then_quant(lib, hidden):
     assert torch.equal(q, q3) and torch.equal(sc, sc3)
 
 
+def test_gemm_fp8_refuses_an_operand_beyond_the_kernels_32_bit_row_offsets(lib):
+    """the LDS-DMA kernels address an operand as a 64-bit base + a 32-bit per-lane byte offset: an operand of 4 GB or more is refused
+    (ATSPEED_ERR_CAPACITY) before anything is launched -- the pointers here are never dereferenced"""
+    x = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    s = torch.zeros(64, dtype=torch.float32, device="cuda")
+    rc = lib.atspeed_gemm_fp8(x.data_ptr(), s.data_ptr(), x.data_ptr(), s.data_ptr(), x.data_ptr(), 512, 70000, 65536, 70000, 0, _st())
+    assert rc == _lib.ERR_CAPACITY and b"32-bit" in lib.atspeed_last_error()
+
+
 @pytest.mark.parametrize("m,n,k,epi", [(1024, 2304, 768, 0), (640, 12288, 512, 0), (1300, 1024, 1280, 2), (900, 2752, 512, 3), (1543, 1000, 256, 1),
                                       (4200, 8192, 256, 0), (8300, 4096, 512, 2), (4200, 8448, 256, 3), (4480, 3072, 1024, 0),      # more than two tiles per CU
                                       # the Llama-7B projections at their real K (config 5): qkv, o_proj, gate_up, down
