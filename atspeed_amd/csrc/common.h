@@ -140,15 +140,28 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// maximum of a 64-bit key over the wave, returned wave-uniform.  Data-parallel-primitive moves instead of ds_bpermute shuffles (a block top-K
+// runs this once per extracted key: 12 LDS round trips per call were most of a one-user beam step's 85 us): row_shr 1/2/4/8 leave a 16-lane
+// row's maximum in its lane 15 (max is idempotent, an invalid source lane keeps the own value), row_bcast15 / row_bcast31 carry it to
+// lane 63, one readlane pair makes it uniform.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long ats_dpp_max_u64(unsigned long long v) {
+  const int lo = (int)(unsigned)(v & 0xffffffffull), hi = (int)(unsigned)(v >> 32);
+  const unsigned wlo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+  const unsigned whi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  const unsigned long long w = ((unsigned long long)whi << 32) | wlo;
+  return w > v ? w : v;
+}
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), o, 64);
-    unsigned hi = __shfl_xor((unsigned)(v >> 32), o, 64);
-    unsigned long long w = ((unsigned long long)hi << 32) | lo;
-    v = w > v ? w : v;
-  }
-  return v;
+  v = ats_dpp_max_u64<0x111, 0xf>(v);        // row_shr:1
+  v = ats_dpp_max_u64<0x112, 0xf>(v);        // row_shr:2
+  v = ats_dpp_max_u64<0x114, 0xf>(v);        // row_shr:4
+  v = ats_dpp_max_u64<0x118, 0xf>(v);        // row_shr:8   -> lane 15 of every row: the row's maximum
+  v = ats_dpp_max_u64<0x142, 0xa>(v);        // row_bcast15 into rows 1 and 3
+  v = ats_dpp_max_u64<0x143, 0xc>(v);        // row_bcast31 into rows 2 and 3 -> lane 63: the wave's maximum
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 // monotone float <-> uint32 map: a > b  <=>  ford(a) > ford(b)   (-inf -> 0x007fffff)

@@ -86,20 +86,22 @@ __global__ __launch_bounds__(NT) void lse_rows_kernel(const float* __restrict__ 
 struct TopkShared {
   unsigned long long wtop[kScanWaves][MAXB];
   unsigned long long sel[MAXB];
+  unsigned long long bound;                      // block_topk: lower bound of the k-th largest key after the lead rounds
 };
 
+// rounds j0 .. j1-1 of wave-argmax: the owner lane retires its key, out[j] = the j-th largest key of this wave.  Stops early -- zero-filling
+// out[j .. k) -- when the wave has nothing left or its best remaining key is below `floor_key`; returns true when it stopped.
 template <int NK>
-__device__ __forceinline__ unsigned long long wave_topk_rounds(unsigned long long (&keys)[NK], int k,
-                                                               unsigned long long* out, int lane) {
-  // k rounds of wave-argmax; the owner lane retires its key. returns nothing useful.
-  for (int j = 0; j < k; ++j) {
+__device__ __forceinline__ bool wave_topk_rounds(unsigned long long (&keys)[NK], int j0, int j1, int k, unsigned long long floor_key,
+                                                 unsigned long long* out, int lane) {
+  for (int j = j0; j < j1; ++j) {
     unsigned long long m = 0;
 #pragma unroll
     for (int c = 0; c < NK; ++c) m = keys[c] > m ? keys[c] : m;
-    unsigned long long M = wave_max_u64(m);
-    if (M == 0) {                                   // wave-uniform: nothing left
+    const unsigned long long M = wave_max_u64(m);
+    if (M == 0 || M < floor_key) {                  // wave-uniform: nothing left that can be among the block's k best
       for (int jj = j + lane; jj < k; jj += 64) out[jj] = 0;
-      break;
+      return true;
     }
     if (m == M) {
 #pragma unroll
@@ -107,14 +109,42 @@ __device__ __forceinline__ unsigned long long wave_topk_rounds(unsigned long lon
     }
     if (lane == 0) out[j] = M;
   }
-  return 0;
+  return false;
 }
 
-// every thread passes its NK candidate keys; afterwards sh.sel[0..k) holds the k largest, descending
+// every thread passes its NK candidate keys (distinct, 0 = none); afterwards sh.sel[0..k) holds the k largest, descending.
+// Two phases: every wave extracts its kTopkLead best keys; the k-th largest of those 16 x kTopkLead keys is a lower bound of the block's k-th
+// largest key, so a wave goes on only while its best remaining key reaches that bound -- 16 x 4 + about k wave-rounds instead of 16 x k
+// (the 16 waves of a workgroup share four SIMDs: at k = 40 the full rounds were 50 of the 85 us of one user's beam step).  The selected set
+// and its order are the same: every key at or above the bound is extracted by its wave, and the merge takes the k best of their union.
+constexpr int kTopkLead = 4;
+static_assert(kScanWaves * kTopkLead <= 64, "the bound is computed by one wave, one lead key per lane");
 template <int NK>
 __device__ void block_topk(unsigned long long (&keys)[NK], int k, TopkShared& sh) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  wave_topk_rounds<NK>(keys, k, sh.wtop[wave], lane);
+  const int lead = k < kTopkLead ? k : kTopkLead;
+  const bool done = wave_topk_rounds<NK>(keys, 0, lead, k, 0ull, sh.wtop[wave], lane);
+  __syncthreads();
+  if (wave == 0) {
+    const unsigned long long x = lane < kScanWaves * lead ? sh.wtop[lane / lead][lane % lead] : 0ull;
+    const unsigned xlo = (unsigned)(x & 0xffffffffull), xhi = (unsigned)(x >> 32);
+    int rank = 0;                                    // lead keys above mine
+#pragma unroll
+    for (int l = 0; l < 64; ++l) {
+      const unsigned long long y = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)xhi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)xlo, l);
+      rank += y > x ? 1 : 0;
+    }
+    // the lead key with k - 1 keys above it (fewer than k lead keys: no such lane, or only lanes holding 0 -> no bound)
+    const unsigned long long hit = __ballot(rank == k - 1);
+    unsigned long long bound = 0;
+    if (hit) {
+      const int src = __ffsll((long long)hit) - 1;
+      bound = ((unsigned long long)(unsigned)__shfl((int)xhi, src, 64) << 32) | (unsigned)__shfl((int)xlo, src, 64);
+    }
+    if (lane == 0) sh.bound = bound;
+  }
+  __syncthreads();
+  if (!done) wave_topk_rounds<NK>(keys, lead, k, k, sh.bound, sh.wtop[wave], lane);
   __syncthreads();
   if (wave == 0) {
     unsigned long long k2[kScanWaves];
@@ -123,7 +153,7 @@ __device__ void block_topk(unsigned long long (&keys)[NK], int k, TopkShared& sh
       int e = lane + 64 * c;                         // < 16*64
       k2[c] = (e < kScanWaves * k) ? sh.wtop[e / k][e % k] : 0ull;
     }
-    wave_topk_rounds<kScanWaves>(k2, k, sh.sel, lane);
+    wave_topk_rounds<kScanWaves>(k2, 0, k, k, 0ull, sh.sel, lane);
   }
   __syncthreads();
 }
@@ -147,6 +177,8 @@ struct ExpandShared {
   int lrow[MAXB];       // row index inside the logits buffer
   float bscore[MAXB];
   float lse[MAXB];
+  int rp[MAXB];         // first edge of the row's node (fsm.row_ptr[node]) and its number of children
+  int deg[MAXB];
   int status;
   float red_m[kScanWaves], red_s[kScanWaves];   // block reductions of the sampling paths
   float red_out;
@@ -159,13 +191,21 @@ __device__ void expand_and_select(ExpandShared& sh, int n_rows, const float* __r
                                   const int32_t* __restrict__ row_cand = nullptr, int n_row_cand = 0) {
   const int tid = threadIdx.x;
   const bool free_mode = fsm.n_nodes == 0;            // no mask (prefix_allowed_tokens_fn = None): a row's candidates = its row_cand list
-  if (tid < n_rows) sh.lse[tid] = lse[sh.lrow[tid]];
+  if (tid < n_rows) {
+    // every row fetches its own edge range (one thread walking 40 rows paid 40 dependent global round trips: 35 of the 87 us a step of ONE
+    // user took); the range's start stays in LDS for the candidates below
+    sh.lse[tid] = lse[sh.lrow[tid]];
+    const int nd = sh.node[tid];
+    const int e0 = free_mode ? 0 : fsm.row_ptr[nd];
+    sh.rp[tid] = e0;
+    sh.deg[tid] = free_mode ? n_row_cand : fsm.row_ptr[nd + 1] - e0;
+  }
+  __syncthreads();
   if (tid == 0) {
     int tot = 0;
     for (int r = 0; r < n_rows; ++r) {
       sh.off[r] = tot;
-      int nd = sh.node[r];
-      int deg = free_mode ? n_row_cand : fsm.row_ptr[nd + 1] - fsm.row_ptr[nd];
+      const int deg = sh.deg[r];
       bool live = sh.bscore[r] > -INFINITY;
       if (live && deg == 0) sh.status = ATSPEED_ERR_CONSTRAINT;   // HF: "returned an empty list" ValueError
       tot += live ? deg : 0;
@@ -184,7 +224,7 @@ __device__ void expand_and_select(ExpandShared& sh, int n_rows, const float* __r
       int lo = 0, hi = n_rows;                        // last r with off[r] <= c
       while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (sh.off[mid] <= c) lo = mid; else hi = mid; }
       int r = lo;
-      int tok = free_mode ? row_cand[(size_t)sh.lrow[r] * MAXB + (c - sh.off[r])] : fsm.tok[fsm.row_ptr[sh.node[r]] + (c - sh.off[r])];
+      int tok = free_mode ? row_cand[(size_t)sh.lrow[r] * MAXB + (c - sh.off[r])] : fsm.tok[sh.rp[r] + (c - sh.off[r])];
       if (tok >= 0) {
         float sc = (logits[(size_t)sh.lrow[r] * ld + tok] - sh.lse[r]) + sh.bscore[r];
         uint32_t o = ford(sc);
@@ -255,13 +295,18 @@ struct CandRegs { int flat[kCPT]; float sc[kCPT]; };
 __device__ void expand_candidates(ExpandShared& sh, int n_rows, const float* __restrict__ logits, int ld,
                                   const float* __restrict__ lse, const FsmDev& fsm, float temperature, CandRegs& cr) {
   const int tid = threadIdx.x;
-  if (tid < n_rows) sh.lse[tid] = lse[sh.lrow[tid]];
+  if (tid < n_rows) {                                 // as in expand_and_select: every row fetches its own edge range
+    sh.lse[tid] = lse[sh.lrow[tid]];
+    const int nd = sh.node[tid], e0 = fsm.row_ptr[nd];
+    sh.rp[tid] = e0;
+    sh.deg[tid] = fsm.row_ptr[nd + 1] - e0;
+  }
+  __syncthreads();
   if (tid == 0) {
     int tot = 0;
     for (int r = 0; r < n_rows; ++r) {
       sh.off[r] = tot;
-      int nd = sh.node[r];
-      int deg = fsm.row_ptr[nd + 1] - fsm.row_ptr[nd];
+      const int deg = sh.deg[r];
       bool live = sh.bscore[r] > -INFINITY;
       if (live && deg == 0) sh.status = ATSPEED_ERR_CONSTRAINT;
       tot += live ? deg : 0;
@@ -279,7 +324,7 @@ __device__ void expand_candidates(ExpandShared& sh, int n_rows, const float* __r
       int lo = 0, hi = n_rows;
       while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (sh.off[mid] <= c) lo = mid; else hi = mid; }
       int r = lo;
-      int tok = fsm.tok[fsm.row_ptr[sh.node[r]] + (c - sh.off[r])];
+      int tok = fsm.tok[sh.rp[r] + (c - sh.off[r])];
       cr.sc[i] = (logits[(size_t)sh.lrow[r] * ld + tok] - sh.lse[r]) / temperature + sh.bscore[r];
       cr.flat[i] = sh.brow[r] * fsm.vocab + tok;
     }

@@ -26,8 +26,11 @@ for s, e, k in ev:
 tot_busy = sum(v[0] for v in busy.values())
 print(f"span {span / 1e6:.2f} ms; kernels busy {tot_busy / 1e6:.2f} ms ({100 * tot_busy / span:.1f} %); gaps < 200 us {gaps / 1e6:.2f} ms ({100 * gaps / span:.1f} %); "
       f"long idle (host sync) {big / 1e6:.2f} ms ({100 * big / span:.1f} %); {len(ev)} launches")
-for k, (ns, c) in sorted(busy.items(), key=lambda kv: -kv[1][0])[:18]:
-    print(f"  {k:70s} {c:6d} x {ns / c / 1e3:8.1f} us = {ns / 1e6:8.2f} ms ({100 * ns / span:5.1f} %)")
+durs = collections.defaultdict(list)
+for s_, e_, k_ in ev: durs[k_.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]].append((e_ - s_) / 1e3)
+for k, (ns, c) in sorted(busy.items(), key=lambda kv: -kv[1][0])[:24]:
+    d = sorted(durs[k])
+    print(f"  {k:70s} {c:6d} x {ns / c / 1e3:8.1f} us = {ns / 1e6:8.2f} ms ({100 * ns / span:5.1f} %)  min {d[0]:.1f} med {d[len(d) // 2]:.1f} max {d[-1]:.1f}")
 print("gap histogram (us bucket: count):", " ".join(f"{b}:{c}" for b, c in sorted(gap_hist.items())))
 if n_long:
     print(f"{len(longs)} idle intervals > 200 us; the longest (ms idle, at ms of the window, after kernel -> before kernel):")
