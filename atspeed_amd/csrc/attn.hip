@@ -119,19 +119,37 @@ __device__ __forceinline__ void tr_read_2pairs(u32x2_t& a0, u32x2_t& b0, u32x2_t
       : "memory");
 }
 
+// K / V tiles HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers).  A DMA instruction fills 64 consecutive 16-byte LDS
+// positions, so a swizzle or a row padding of the LDS image is applied on the source side: lane i of instruction j fetches whatever
+// belongs at position 64 j + i.
+#define ATS_ATTN_DMA16(voff, sbase, m0v) \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory")
+
 // ---------------------------------------------------------------------------- MFMA kernel (bf16)
 // blockIdx.x walks the 64-row query tiles of all segments (tile -> segment through the table's qtile arrays)
-template <int DH, int NW>   // NW waves per workgroup = 16*NW query rows per tile
+// NSTG = 0: K / V tiles staged through registers into one static LDS tile, the next tile's loads in flight during a tile's products (two
+// barriers per tile).  NSTG >= 3 (one user's forwards: up to 256 workgroups, one per CU): a RING of NSTG tiles filled by LDS-DMA, NSTG - 1
+// tiles in flight -- with 2-5 tiles of K/V per user the whole cache is on its way before the first product, where the register form exposed
+// a memory round trip per tile (2.1 us per tile against 0.6 us of work: tools/su_trace.sh) -- hand-counted vmcnt, one barrier per tile.
+// Nothing the compiler knows to be a vector-memory load may sit in that loop (its waits would drain the ring: the counter is in order), so
+// the visibility words of the tile's rows are copied to LDS first and the query fragments are forced to arrive before the first DMA.
+template <int DH, int NW, int NSTG = 0>   // NW waves per workgroup = 16*NW query rows per tile
 __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* __restrict__ q, int ldq, const SegTable* __restrict__ tab,
                                                              size_t layer_off, int vis_words,
                                                              bf16_t* __restrict__ out, int ldo, int pk,
                                                              int n_heads, float scale) {
   constexpr int KCH = DH / 8;                 // 16-byte chunks per K row
   constexpr int VROW = DH * 2 + 32;           // V tile row stride in bytes: 8 rows x 32 B of a transposed read cover all 64 banks
+  constexpr int VCH = VROW / 16;              // 16-byte positions per V row (the last two are padding)
   constexpr int DT = DH / 16;                 // output d-tiles
   constexpr int KS = DH / 32;                 // k-steps of the QK product
-  __shared__ __attribute__((aligned(16))) unsigned char ks_lds[64 * DH * 2];
-  __shared__ __attribute__((aligned(16))) unsigned char vs_lds[64 * VROW];   // V tile row-major; consumed column-wise by ds_read_b64_tr_b16
+  constexpr int KBYTES = 64 * DH * 2, TILE = KBYTES + 64 * VROW;
+  constexpr bool RING = NSTG >= 3;
+  __shared__ __attribute__((aligned(16))) unsigned char ks_static[RING ? 16 : 64 * DH * 2];
+  __shared__ __attribute__((aligned(16))) unsigned char vs_static[RING ? 16 : 64 * VROW];   // V tile row-major; consumed column-wise by ds_read_b64_tr_b16
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring_smem[];                   // RING: [NSTG][K tile | V tile][16 NW rows x n_tiles visibility words]
+  unsigned char* ks_lds = ks_static;
+  unsigned char* vs_lds = vs_static;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, lq = lane & 15;
   // 1-D grid over (head, query tile).  Workgroup L runs on XCD L % 8: give every XCD a contiguous range of work items, heads
@@ -154,11 +172,14 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
   const uint64_t* vis_row = sg.vis + (size_t)lrow * vis_words;
 
   s16x8_t qf[KS];
+  auto load_q = [&]() {
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    if (qok) qf[ks] = *reinterpret_cast<const s16x8_t*>(q + (size_t)qrow * ldq + h * DH + ks * 32 + g * 8);
-    else qf[ks] = s16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-  }
+    for (int ks = 0; ks < KS; ++ks) {
+      if (qok) qf[ks] = *reinterpret_cast<const s16x8_t*>(q + (size_t)qrow * ldq + h * DH + ks * 32 + g * 8);
+      else qf[ks] = s16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  };
+  if constexpr (NSTG < 3) load_q();            // (the ring form starts its K/V tiles first and fetches the queries behind them)
   f32x4_t o[DT];
 #pragma unroll
   for (int d = 0; d < DT; ++d) o[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -166,7 +187,7 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
 
   const int n_tiles = (n_slots + 63) >> 6;
   // K/V of tile kt+1 travel to registers while tile kt is being multiplied (one tile of global-load latency hidden)
-  constexpr int NLD = (64 * KCH + 64 * NW - 1) / (64 * NW);
+  constexpr int NLD = RING ? 1 : (64 * KCH + 64 * NW - 1) / (64 * NW);
   uint4 kreg[NLD], vreg[NLD];
   auto load_tile = [&](int kt) {
 #pragma unroll
@@ -182,8 +203,59 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
       }
     }
   };
-  load_tile(0);
+  // RING: the same LDS image by DMA.  NI instructions per tile (K: KCH, V: VCH), dealt round-robin to the waves; rows past n_slots (last
+  // tile) are fetched from the last valid row: finite values, masked out by the visibility word
+  constexpr int NI = KCH + VCH;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int lds0 = RING ? __builtin_amdgcn_readfirstlane((int)lds_off(ring_smem)) : 0;
+  const unsigned long long kbase = (unsigned long long)kc + (size_t)h * DH * 2, vbase = (unsigned long long)vc + (size_t)h * DH * 2;
+  auto dma_tile = [&](int kt, int buf) {
+#pragma unroll
+    for (int j0 = 0; j0 < NI; j0 += NW) {
+      const int j = j0 + wave_u;                       // wave-uniform (SGPR): the DMA's M0 and branch are scalar
+      if (j < KCH) {
+        const int P = j * 64 + lane, r = P / KCH, cs = P % KCH;
+        const int key = min(kt * 64 + r, n_slots - 1);
+        const unsigned voff = (unsigned)key * (unsigned)(hidden * 2) + ((cs ^ (r & 7)) * 16);
+        ATS_ATTN_DMA16(voff, kbase, lds0 + buf * TILE + j * 1024);
+      } else if (j < NI) {
+        const int P = (j - KCH) * 64 + lane, r = P / VCH, c = P % VCH;
+        const int key = min(kt * 64 + r, n_slots - 1);
+        const unsigned voff = (unsigned)key * (unsigned)(hidden * 2) + (c < KCH ? c * 16 : 0);
+        ATS_ATTN_DMA16(voff, vbase, lds0 + buf * TILE + KBYTES + (j - KCH) * 1024);
+      }
+    }
+  };
+  uint64_t* vis_lds = reinterpret_cast<uint64_t*>(ring_smem + (RING ? NSTG : 0) * TILE) + (size_t)(wave * 16 + lq) * n_tiles;   // this lane's row
+  if constexpr (RING) {
+    // the first NSTG - 1 tiles leave before anything else is fetched; queries and visibility words travel behind them and everything is
+    // awaited once (one memory round trip instead of three in a row), so that no load the compiler knows of is pending inside the ring
+#pragma unroll
+    for (int t = 0; t < NSTG - 1; ++t) if (t < n_tiles) dma_tile(t, t);
+    load_q();
+    for (int w = g; w < n_tiles; w += 4) vis_lds[w] = qok ? vis_row[w] : 0ull;     // the 4 lanes of a row share its words
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    load_tile(0);
+  }
   for (int kt = 0; kt < n_tiles; ++kt) {
+    uint64_t word;
+    if constexpr (RING) {
+      // tile kt has landed: all but the pieces of the NSTG - 2 younger tiles (this wave issues (NI - wave + NW - 1) / NW pieces per tile)
+      if (kt + NSTG - 2 < n_tiles) {
+        if (wave_u < NI % NW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * ((NI + NW - 1) / NW)) : "memory");
+        else                  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (NI / NW)) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();                                 // everyone's pieces of tile kt; and tile kt - 1 is fully consumed
+      if (kt + NSTG - 1 < n_tiles) dma_tile(kt + NSTG - 1, (kt + NSTG - 1) % NSTG);
+      ks_lds = ring_smem + (kt % NSTG) * TILE;
+      vs_lds = ks_lds + KBYTES;
+      word = vis_lds[kt];
+    } else {
     __syncthreads();                                   // previous tile fully consumed
     // ---- stage K (swizzled rows) and V (row-major, padded rows)
 #pragma unroll
@@ -197,7 +269,8 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
     }
     __syncthreads();
     if (kt + 1 < n_tiles) load_tile(kt + 1);
-    uint64_t word = qok ? vis_row[kt] : 0ull;
+    word = qok ? vis_row[kt] : 0ull;
+    }
     if (kt == n_tiles - 1 && (n_slots & 63)) word &= (~0ull) >> (64 - (n_slots & 63));
     if (__ballot(word != 0ull) == 0ull) continue;      // this wave's 16 rows see nothing here (wave-uniform)
 
@@ -292,9 +365,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 // K / V tiles travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers) into a double buffer, tile kt+1 while
 // tile kt is multiplied; ONE barrier per tile.  A DMA instruction fills 64 consecutive 16-byte LDS positions, so the K swizzle and
 // the V row padding are applied on the source side: lane i of instruction j fetches whatever belongs at position 64 j + i.
-#define ATS_ATTN_DMA16(voff, sbase, m0v) \
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory")
-
 template <int DH, int NW>   // NW waves per workgroup = 32*NW query rows per tile
 __global__ __launch_bounds__(64 * NW, 2) void tree_attn32_kernel(const bf16_t* __restrict__ q, int ldq, const SegTable* __restrict__ tab,
                                                                  size_t layer_off, int vis_words, bf16_t* __restrict__ out, int ldo, int pk,
@@ -492,6 +562,33 @@ int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const Seg
 #undef ATS_ATTN32
       ATS_LAUNCH_CHECK();
       return ATSPEED_OK;
+    }
+    // one user's forwards (at most one workgroup per CU): the DMA-ring form, the whole K/V of a user in flight before the first product
+    static const int ring_on = getenv("ATSPEED_ATTN_RING") ? atoi(getenv("ATSPEED_ATTN_RING")) : 1;
+    static const int ring_max_wgs = getenv("ATSPEED_ATTN_RING_MAX_WGS") ? atoi(getenv("ATSPEED_ATTN_RING_MAX_WGS")) : 256;
+    {
+      const int nw = t.qtile_rows / 16;
+      const size_t tile = (size_t)64 * head_dim * 2 + (size_t)64 * (head_dim * 2 + 32);
+      const size_t ring_lds = 4 * tile + (size_t)16 * nw * vis_words * sizeof(uint64_t);
+      // (not the 256-row tile: 16 waves cap a lane at 128 registers and the compiler's spill traffic would sit in the hand-counted vmcnt window)
+      if (ring_on && nw <= 8 && (int)(t.n_qtiles * n_heads) <= ring_max_wgs && ring_lds <= 160 * 1024 - 64) {
+#define ATS_ATTN_RING(DHV, NWV)                                                                                                \
+  {                                                                                                                            \
+    static thread_local AtsPerDeviceFlag attr_flag;                                                                            \
+    bool& attr_done = attr_flag.cur();                                                                                         \
+    if (!attr_done) {                                                                                                          \
+      ATS_HIP(hipFuncSetAttribute((const void*)tree_attn_mfma_kernel<DHV, NWV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); \
+      attr_done = true;                                                                                                        \
+    }                                                                                                                          \
+    tree_attn_mfma_kernel<DHV, NWV, 4><<<mgrid, 64 * NWV, ring_lds, st>>>((const bf16_t*)q, ldq, dt, layer_off_bytes, vis_words, \
+                                                                          (bf16_t*)out, ldo, pk, n_heads, scale);                  \
+  }
+        if (head_dim == 128) { if (nw == 8) ATS_ATTN_RING(128, 8) else ATS_ATTN_RING(128, 4) }
+        else                 { if (nw == 8) ATS_ATTN_RING(64, 8)  else ATS_ATTN_RING(64, 4) }
+#undef ATS_ATTN_RING
+        ATS_LAUNCH_CHECK();
+        return ATSPEED_OK;
+      }
     }
     if (t.qtile_rows == 256) {
       if (head_dim == 128)

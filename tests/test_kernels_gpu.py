@@ -311,11 +311,12 @@ def test_tree_attention(lib, dtype, heads, dh, T):
 
 @pytest.mark.parametrize("rows_per_wave", [16, 32])
 @pytest.mark.parametrize("qtile", [64, 128, 256])
-@pytest.mark.parametrize("heads,dh,T,S", [(12, 64, 200, 330), (32, 128, 300, 470), (8, 128, 37, 64), (4, 64, 129, 1)])
+@pytest.mark.parametrize("heads,dh,T,S", [(12, 64, 200, 330), (32, 128, 300, 470), (8, 128, 37, 64), (4, 64, 129, 1), (32, 128, 600, 200)])
 def test_tree_attention_every_tiling(lib, heads, dh, T, S, qtile, rows_per_wave):
-    """Both MFMA kernels (16 rows per wave, register-staged tiles; 32 rows per wave, LDS-DMA double buffer) at every query-tile
-    height: ragged last tiles (T, S not multiples of 64), a single-slot cache, rows that see one far slot, rows that see nothing
-    in whole 64-slot tiles."""
+    """The MFMA kernels (16 rows per wave: a four-tile LDS-DMA ring up to 256 workgroups -- one user's forwards --, register-staged tiles
+    above that (the 600-row case) and for the 256-row tile; 32 rows per wave, LDS-DMA double buffer) at every query-tile height: ragged last
+    tiles (T, S not multiples of 64), a single-slot cache (fewer tiles than ring stages), 8 tiles through a 4-stage ring, rows that see
+    one far slot, rows that see nothing in whole 64-slot tiles."""
     from atspeed_amd.model import vis_bits_from_bool
     max_slots = 512
     H = heads * dh
