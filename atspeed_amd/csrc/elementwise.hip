@@ -88,7 +88,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bf16_vec_kernel(const bf16_t* __r
                                                                unsigned char* __restrict__ q, float* __restrict__ scale, int pk) {
   __shared__ float red[4], red2[4];
   const int nchunk = hidden >> 3;
-  const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)blockIdx.x * hidden);
+  // packed output: rows 2i and 2i+1 share every 128-byte line (64 bytes each).  Workgroup L runs on XCD L % 8, so consecutive workgroups
+  // would leave the two halves of a line dirty in two different L2s; inside a group of 16 workgroups the pair goes to the SAME XCD
+  // (workgroups x and x + 8 take rows 2x and 2x + 1) and its lines leave one L2 whole
+  int row = blockIdx.x;
+  if (pk && (row | 15) < (int)gridDim.x && !(pk & 2)) { const int b = row & 15; row = (row & ~15) + (b & 7) * 2 + (b >> 3); }
+  const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)row * hidden);
   const uint4* wr = reinterpret_cast<const uint4*>(w);
   uint4 v[NC];
   float ss = 0.f;
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bf16_vec_kernel(const bf16_t* __r
         oe[j] = f2bf(bf2f(we[j]) * bf2f(f2bf(bf2f(e[j]) * rs)));   // HF casts the normalised value first
         if constexpr (QUANT) amax = fmaxf(amax, fabsf(bf2f(oe[j])));
       }
-      if (y) *reinterpret_cast<uint4*>(y + ats_opnd_idx<2>(pk, blockIdx.x, (size_t)i * 8, hidden)) = o;   // outputs are GEMM operands: packed when pk
+      if (y) *reinterpret_cast<uint4*>(y + ats_opnd_idx<2>(pk & 1, row, (size_t)i * 8, hidden)) = o;   // outputs are GEMM operands: packed when pk
       v[c] = o;
     }
   }
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bf16_vec_kernel(const bf16_t* __r
     amax = fmaxf(fmaxf(red2[0], red2[1]), fmaxf(red2[2], red2[3]));
     const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
     const float inv = 1.0f / sc;
-    if (threadIdx.x == 0) scale[blockIdx.x] = sc;
+    if (threadIdx.x == 0) scale[row] = sc;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int i = threadIdx.x + c * 256;
@@ -144,10 +149,17 @@ __global__ __launch_bounds__(256) void rmsnorm_bf16_vec_kernel(const bf16_t* __r
         lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
-        *reinterpret_cast<uint2*>(q + ats_opnd_idx<1>(pk, blockIdx.x, (size_t)i * 8, hidden)) = make_uint2((unsigned)lo, (unsigned)hi);
+        *reinterpret_cast<uint2*>(q + ats_opnd_idx<1>(pk & 1, row, (size_t)i * 8, hidden)) = make_uint2((unsigned)lo, (unsigned)hi);
       }
     }
   }
+}
+
+// kernel argument `pk` of rmsnorm_bf16_vec_kernel: bit 0 = packed output, bit 1 = keep the workgroup -> row map linear (A/B switch
+// ATSPEED_RMSNORM_PAIRS=0)
+static int rmsnorm_pk_arg(int pk) {
+  static const bool pairs_off = getenv("ATSPEED_RMSNORM_PAIRS") && atoi(getenv("ATSPEED_RMSNORM_PAIRS")) == 0;
+  return pk ? (pairs_off ? 3 : 1) : 0;
 }
 
 // RMSNorm whose consumer is a W8A8 projection: y (bf16, optional) and the e4m3 row + scale in one pass
@@ -158,9 +170,9 @@ int ats_rmsnorm_quant_fp8(const void* x, const void* w, void* y, void* q, float*
   const bf16_t *xb = (const bf16_t*)x, *wb = (const bf16_t*)w;
   bf16_t* yb = (bf16_t*)y;
   unsigned char* qb = (unsigned char*)q;
-  if (hidden <= 2048)      rmsnorm_bf16_vec_kernel<1, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale, pk);
-  else if (hidden <= 4096) rmsnorm_bf16_vec_kernel<2, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale, pk);
-  else                     rmsnorm_bf16_vec_kernel<4, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale, pk);
+  if (hidden <= 2048)      rmsnorm_bf16_vec_kernel<1, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale, rmsnorm_pk_arg(pk));
+  else if (hidden <= 4096) rmsnorm_bf16_vec_kernel<2, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale, rmsnorm_pk_arg(pk));
+  else                     rmsnorm_bf16_vec_kernel<4, true><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, qb, scale, rmsnorm_pk_arg(pk));
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -173,9 +185,9 @@ int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, flo
   if (vec_ok) {
     const bf16_t *xb = (const bf16_t*)x, *wb = (const bf16_t*)w;
     bf16_t* yb = (bf16_t*)y;
-    if (hidden <= 2048)      rmsnorm_bf16_vec_kernel<1, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr, pk);
-    else if (hidden <= 4096) rmsnorm_bf16_vec_kernel<2, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr, pk);
-    else                     rmsnorm_bf16_vec_kernel<4, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr, pk);
+    if (hidden <= 2048)      rmsnorm_bf16_vec_kernel<1, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr, rmsnorm_pk_arg(pk));
+    else if (hidden <= 4096) rmsnorm_bf16_vec_kernel<2, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr, rmsnorm_pk_arg(pk));
+    else                     rmsnorm_bf16_vec_kernel<4, false><<<rows, 256, 0, st>>>(xb, wb, yb, hidden, eps, nullptr, nullptr, rmsnorm_pk_arg(pk));
     ATS_LAUNCH_CHECK();
     return ATSPEED_OK;
   }
