@@ -259,9 +259,11 @@ def _batch_results(keep, toks: torch.Tensor, scores: torch.Tensor, k: int):
     flat, starts = keep
     n, L = toks.shape[0], toks.shape[2]
     off = np.asarray(starts, dtype=np.int64)
-    out = torch.empty(k * (int(off[-1]) + n * L), dtype=torch.int64, device=toks.device)
-    _lib.check(_lib.load().atspeed_assemble_sequences(flat.data_ptr(), off.ctypes.data, toks.data_ptr(), n, k, L, out.data_ptr(),
-                                                      _lib.stream_ptr(toks.device)))
+    # under the MODEL's device like every other library call: the library stages `off` through the ring of the thread's current device
+    with torch.cuda.device(toks.device):
+        out = torch.empty(k * (int(off[-1]) + n * L), dtype=torch.int64, device=toks.device)
+        _lib.check(_lib.load().atspeed_assemble_sequences(flat.data_ptr(), off.ctypes.data, toks.data_ptr(), n, k, L, out.data_ptr(),
+                                                          _lib.stream_ptr(toks.device)))
     res = []
     for i in range(n):
         o0, P = k * (int(off[i]) + i * L), int(off[i + 1] - off[i])

@@ -122,6 +122,9 @@ __device__ __forceinline__ void tr_read_2pairs(u32x2_t& a0, u32x2_t& b0, u32x2_t
 // K / V tiles HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers).  A DMA instruction fills 64 consecutive 16-byte LDS
 // positions, so a swizzle or a row padding of the LDS image is applied on the source side: lane i of instruction j fetches whatever
 // belongs at position 64 j + i.
+// (m0 is written here without an "m0" clobber on purpose: m0 is a RESERVED register for LLVM's AMDGPU backend -- it never keeps a value
+// live in it across instructions, it re-materialises m0 glued to each of its own m0 readers -- and hipcc rejects the clobber with
+// -Winline-asm "clobber list contains reserved registers ... may lead to undefined behaviour".)
 #define ATS_ATTN_DMA16(voff, sbase, m0v) \
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory")
 

@@ -570,6 +570,9 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 #define ATS_MFMA_BF16(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
 #define ATS_MFMA_BF16_A(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
 #define ATS_MFMA_FP8(c, a, b) asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
+// (m0 is written here without an "m0" clobber on purpose: m0 is a RESERVED register for LLVM's AMDGPU backend -- it never keeps a value
+// live in it across instructions, it re-materialises m0 glued to each of its own m0 readers -- and hipcc rejects the clobber with
+// -Winline-asm "clobber list contains reserved registers ... may lead to undefined behaviour".)
 #define ATS_DMA16(voff, sbase, m0v) \
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory")
 

@@ -20,6 +20,8 @@ def test_no_register_moves_or_spills_between_the_ring_kernels_asm_mfmas(tmp_path
     if os.path.exists(built) and os.path.getmtime(built) >= os.path.getmtime(src):
         findings, kernels = scan_mfma_loops.scan(built, verbose=False)
         assert kernels >= 20 and findings == 0, (kernels, findings)
+        f2, k2 = scan_mfma_loops.scan_dma(built, verbose=False)
+        assert k2 >= 40 and f2 == 0, (k2, f2)
         return
     out = tmp_path / "gemm.s"
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out),
@@ -28,3 +30,19 @@ def test_no_register_moves_or_spills_between_the_ring_kernels_asm_mfmas(tmp_path
     findings, kernels = scan_mfma_loops.scan(str(out), verbose=False)
     assert kernels >= 20, f"only {kernels} ring kernels found in the assembly: the scan is looking at the wrong thing"
     assert findings == 0, "register moves / spills between asm MFMAs: run tools/scan_mfma_loops.py on the assembly for the list"
+    f2, k2 = scan_mfma_loops.scan_dma(str(out), verbose=False)
+    assert k2 >= 40 and f2 == 0, f"{f2} compiler VMEM / scratch instructions inside hand-counted LDS-DMA windows of {k2} kernels"
+
+
+def test_no_compiler_stores_inside_the_attention_kernels_counted_dma_windows(tmp_path):
+    """attn.hip's K / V rings (tree_attn32_kernel, tree_attn_mfma_kernel<.., 4>) wait for LDS-DMA with hand-counted vmcnt: same rule."""
+    import scan_mfma_loops
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    built = os.path.join(ROOT, "atspeed_amd", "csrc", ".isa", "attn-hip-amdgcn-amd-amdhsa-gfx950.s")
+    src = os.path.join(ROOT, "atspeed_amd", "csrc", "attn.hip")
+    if not (os.path.exists(built) and os.path.getmtime(built) >= os.path.getmtime(src)):
+        built = str(tmp_path / "attn.s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", built, src], check=True,
+                       cwd=os.path.join(ROOT, "atspeed_amd", "csrc"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    findings, kernels = scan_mfma_loops.scan_dma(built, verbose=False)
+    assert kernels >= 8 and findings == 0, (kernels, findings)

@@ -56,7 +56,50 @@ def scan(path, verbose=True):
     return findings, kernels
 
 
+def scan_dma(path, verbose=True, want=r'.'):
+    """Second rule, for EVERY kernel that issues LDS-DMA (`global_load_lds_*`) from inline asm and waits for it with hand-counted
+    `s_waitcnt vmcnt(N)` -- the ring GEMMs, gemm_wdma_kernel, the attention rings of attn.hip.  On gfx9 every vector-memory operation counts
+    in vmcnt.  Loads retire in order among themselves, so a load the compiler issues itself only makes a counted wait stricter; STORES (and
+    scratch spills, which are stores + loads) retire out of order with loads, so one of them inside the counted window makes the count
+    wrong: tiles read before they land, silently wrong sums.  Checked per kernel, in layout order:
+      * between the first LDS-DMA and the last MFMA (prologue + main loop; the epilogue's stores come after): no scratch_* instruction, no
+        buffer_ / flat_ / global_ STORE or atomic;
+      * the kernel descriptor's .amdhsa_private_segment_fixed_size is 0 (no scratch at all);
+      * `strict` kernels (the GEMMs, whose loops contain nothing but asm): no compiler VMEM load in that window either.
+    -> (findings, kernels)"""
+    s = open(path).read()
+    priv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r'\.amdhsa_kernel (\S+)\n(?:[^\n]*\n)*?\s+\.amdhsa_private_segment_fixed_size (\d+)', s))
+    findings = kernels = 0
+    for m in re.finditer(r'^(_Z\w+):[^\n]*\n(.*?)s_endpgm', s, re.S | re.M):
+        name, lines = m.group(1), m.group(2).splitlines()
+        dma = [i for i, l in enumerate(lines) if re.match(r'\s+global_load_lds', l)]
+        mf = [i for i, l in enumerate(lines) if re.match(r'\s+v_mfma', l)]
+        if not dma or not mf or not re.search(want, name):
+            continue
+        kernels += 1
+        strict = "gemm_" in name
+        bad = []
+        for i in range(dma[0], mf[-1]):
+            t = lines[i]
+            if re.match(r'\s+scratch_', t) or re.match(r'\s+(buffer|flat|global)_(store|atomic)', t):
+                bad.append((i, t.strip()[:60]))
+            elif strict and re.match(r'\s+(buffer_|flat_|global_(?!load_lds))', t):
+                bad.append((i, t.strip()[:60]))
+        if priv.get(name, 0) != 0:
+            bad.append((-1, f"private_segment_fixed_size {priv[name]}"))
+        short = re.sub(r'^_ZN12_GLOBAL__N_1\d+', '', re.sub(r'EEvPK.*', '', name))
+        if verbose:
+            print(f"{short:44s} {len(dma):4d} LDS-DMA, {len(mf):4d} MFMAs, {len(bad):3d} VMEM / scratch findings in the counted window {bad[:2] if bad else ''}")
+        findings += len(bad)
+    return findings, kernels
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "--dma-only":           # attn.hip: no asm MFMAs, only the counted DMA windows
+        f2, k2 = scan_dma(sys.argv[1])
+        print(f"{k2} LDS-DMA kernels, {f2} findings")
+        sys.exit(1 if f2 or not k2 else 0)
     f, k = scan(sys.argv[1])
-    print(f"{k} ring kernels, {f} findings")
-    sys.exit(1 if f or not k else 0)
+    f2, k2 = scan_dma(sys.argv[1])
+    print(f"{k} ring kernels, {f} findings; {k2} LDS-DMA kernels, {f2} findings")
+    sys.exit(1 if f or f2 or not k or not k2 else 0)
