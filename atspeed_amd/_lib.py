@@ -66,6 +66,7 @@ SIGNATURES = {
     "atspeed_gemm_fp8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "atspeed_llama_profile": (C.c_int, [_P, _I, _P, _P, _P]),
     "atspeed_llama_profile_big": (C.c_int, [_P, _P, _P, _P]),
+    "atspeed_llama_forward_log": (C.c_int32, [_P, _I, _P, _I]),
     "atspeed_llama_logits_ld": (_I, [_P]),
     "atspeed_lse_rows": (C.c_int, [_P, _I, _I, _I, _P, _P]),
     "atspeed_log_softmax_rows": (C.c_int, [_P, _I, _P, _I, _I, _P, _I, _P]),

@@ -239,6 +239,8 @@ struct atspeed_llama {
   // how often each layer projection (0 qkv, 1 o_proj, 2 gate_up, 3 down) ran as an fp8 / as a bf16 (fp32) GEMM (atspeed_llama_fp8_counters)
   long fp8_cnt[4] = {0, 0, 0, 0}, other_cnt[4] = {0, 0, 0, 0};
   long rope_fused_cnt = 0;                       // qkv projections that carried RoPE + the KV scatter in their epilogue (atspeed_llama_rope_fused_launches)
+  bool fwd_log_on = false;                       // (tokens, logit rows) of every forward while on (atspeed_llama_forward_log)
+  std::vector<int32_t> fwd_log;
 };
 constexpr int ATS_PROF_BIG_ROWS = 1024;
 
@@ -415,6 +417,14 @@ extern "C" int atspeed_llama_profile(atspeed_llama* m, int32_t enable, double* m
   return ATSPEED_OK;
 }
 
+extern "C" int32_t atspeed_llama_forward_log(atspeed_llama* m, int32_t enable, int32_t* pairs_out, int32_t max_pairs) {
+  if (!m) return -1;
+  const int32_t n = (int32_t)(m->fwd_log.size() / 2);
+  if (pairs_out) for (int32_t i = 0; i < n && i < max_pairs; ++i) { pairs_out[2 * i] = m->fwd_log[2 * i]; pairs_out[2 * i + 1] = m->fwd_log[2 * i + 1]; }
+  if (enable >= 0) { m->fwd_log_on = enable != 0; if (enable) m->fwd_log.clear(); }
+  return n;
+}
+
 extern "C" int atspeed_llama_profile_big(atspeed_llama* m, double* ms_out, int64_t* count_out, int64_t* rows_out) {
   ATS_REQUIRE(m && ms_out && count_out && rows_out, ATSPEED_ERR_INVALID, "profile_big: null argument");
   prof_harvest(m);
@@ -511,6 +521,7 @@ static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits
     ATS_REQUIRE(t.seg[i].n_logit >= 0 && t.seg[i].n_logit <= t.seg[i].n_tok, ATSPEED_ERR_INVALID, "forward: bad logit row count");
   }
   if (m->prof_on) prof_harvest(m);
+  if (m->fwd_log_on && m->fwd_log.size() < 2 * 4096) { m->fwd_log.push_back(T); m->fwd_log.push_back(t.total_logit); }
   // the table travels through the pinned ring to its fixed device address (stream ordered behind the previous forward)
   ATS_TRY(ats_stage_to(&t, sizeof(t), cx->segtab_dev, st));
   const SegTable* dtab = cx->segtab_dev;

@@ -293,6 +293,14 @@ class HipLlama:
         _lib.check(_lib.load().atspeed_llama_profile_big(self._handle, ms, cnt, rows))
         return {k: dict(ms=ms[i], count=int(cnt[i]), rows=int(rows[i])) for i, k in enumerate(self.GEMM_KINDS)}
 
+    def forward_log(self, enable: int = -1):
+        """[(tokens, logit rows)] of the forwards run since the log was switched on (atspeed_llama_forward_log); enable as there."""
+        lib = _lib.load()
+        n = int(lib.atspeed_llama_forward_log(self._handle, -1, None, 0))
+        buf = (C.c_int32 * max(2 * n, 2))()
+        lib.atspeed_llama_forward_log(self._handle, enable, buf, n)
+        return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n)]
+
     def gemm_shape(self, kind: str):
         """(N, K) of a GEMM kind."""
         d = self.dims

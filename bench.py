@@ -22,7 +22,10 @@ Extra objects on the JSON line (N = 1; all driver-clocked, all bounded so the de
                  trie) and fp8 (e4m3 W8A8 target projections, roofline against 5 PF, accepted-length drift vs bf16).
   aligned_weight_brackets — the same users and kernels with draft / target weights that agree (accept length 3 and ~1.1), each
                  with the fp32 ENGINE's accepted length on the same weights and >= 32 users next to the bf16 engine's.
-  latency_curve — items/s and ms to the last result at 1 / 4 / 16 / 64 / 256 users per lock-step batch.
+  speedup_curve — the reference's own figure of merit (inference.py:179: speedup = target_generate time / BSSD time) on this engine at
+                 1 / 4 / 16 / 64 / 256 users per lock-step batch: items/s and ms to the last result of both decoders, speedup, and per point
+                 the fraction of max(weight stream at 8 TB/s, matrix flops at 2.5 PF) over the forwards the call really ran (engine log);
+                 the aligned brackets carry the same curve at accept length ~1.1 and 3.  latency_curve = its BSSD leg.
   single_user_stream — the reference's one-user-at-a-time loop (HBM-bound projections).
   cpu_baseline — the oracle (oracle/beamsd_ref.py, torch-CPU fp32) timed on the host cores on a
                  bounded sample of the same workload with the same weights (rank 0, N=1 only).
@@ -44,7 +47,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from atspeed_amd import synth                      # noqa: E402
-from atspeed_amd.beamSD import BSSD, BSSD_batch, release_decoders    # noqa: E402
+from atspeed_amd.beamSD import BSSD, BSSD_batch, release_decoders, target_generate, target_generate_batch    # noqa: E402
 from atspeed_amd.dist import Counters, aggregate, all_gather_counters   # noqa: E402
 from atspeed_amd.generation_trie import PositionSetConstraint   # noqa: E402
 from atspeed_amd.model import HipLlama             # noqa: E402
@@ -319,6 +322,71 @@ def pass_summary(r, args, streams):
                 target_forwards_per_user=sum(o["n_target_forwards"] for o in outs) / n, n_run_per_user=runs / n)
 
 
+def forwards_roofline(logs, elapsed_s, bytes_per_weight=2):
+    """A whole decode call against its roofline.  `logs` = [(dims, [(tokens, logit rows), ...])] per model: every forward the call ran, as
+    the engine logged it.  A forward can finish no sooner than max(its weights streamed once at 8 TB/s, its matrix flops at 2.5 PF): one
+    user's forwards (20-230 tokens) sit on the first term, 256 users' on the second, and the band in between is where both matter."""
+    hbm_s = mfma_s = ideal_s = 0.0
+    n_fwd = tokens = 0
+    n_hbm_bound = 0
+    for dims, log in logs:
+        w_layers = dims.n_layers * (4 * dims.hidden * dims.hidden + 3 * dims.hidden * dims.ffn)
+        w_head = dims.hidden * dims.vocab_size
+        for t_, r_ in log:
+            b = (w_layers + w_head) * bytes_per_weight / (HBM_PEAK_GBS * 1e9)
+            f = 2.0 * (w_layers * t_ + w_head * r_) / (MFMA_PEAK_TFLOPS * 1e12)
+            hbm_s += b; mfma_s += f; ideal_s += max(b, f)
+            n_hbm_bound += 1 if b >= f else 0
+            n_fwd += 1; tokens += t_
+    return dict(bound="hbm" if n_hbm_bound * 2 >= n_fwd else "mfma", ideal_ms=1e3 * ideal_s, measured_ms=1e3 * elapsed_s,
+                frac=(ideal_s / elapsed_s) if elapsed_s > 0 else 0.0, forwards=n_fwd, forwards_hbm_bound=n_hbm_bound,
+                tokens_per_forward=(tokens / n_fwd) if n_fwd else 0.0, weight_stream_ms=1e3 * hbm_s, mfma_ms=1e3 * mfma_s,
+                what="sum over the call's forwards (target + draft) of max(weight bytes / 8 TB/s, matrix flops / 2.5 PF dense bf16) over the measured time")
+
+
+def speedup_curve(target, draft, dprompts, first, sizes, fn, args, dev):
+    """The reference's own figure of merit (inference.py:179: speedup = target_generate time / BSSD time, CSV columns :152-156) on THIS engine, per
+    lock-step batch size: BSSD(_batch) and target_generate(_batch) on the same users, same weights, same box, each point with its roofline
+    fraction (forwards_roofline) and the per-kind GEMM launch times of the BSSD call."""
+    curve = []
+    for s in sizes:
+        grp = dprompts[first: first + s]
+        if len(grp) < s:
+            continue
+        if s == 1:
+            bssd = lambda: [BSSD(target, draft, grp[0], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)]
+            tg = lambda: [target_generate(target, grp[0], args.new_tokens, prefix_allowed_tokens_fn=fn)]
+        else:
+            bssd = lambda: BSSD_batch(target, draft, grp, args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
+            tg = lambda: target_generate_batch(target, grp, args.new_tokens, prefix_allowed_tokens_fn=fn)
+        reps = 3 if s <= 16 else 2
+        point = dict(users_per_batch=s)
+        for name, call in (("bssd", bssd), ("target_generate", tg)):
+            call(); call()                                            # decoders created, recurring shapes settled
+            torch.cuda.synchronize(dev)
+            tc = time.perf_counter()
+            for _ in range(reps):
+                outs = call()
+            torch.cuda.synchronize(dev)
+            sec = (time.perf_counter() - tc) / reps
+            # one more, untimed, call with the forward log and the GEMM brackets on (the brackets add events to the stream)
+            target.forward_log(1); draft.forward_log(1); target.profile(1)
+            call()
+            torch.cuda.synchronize(dev)
+            prof = target.profile(0)
+            tlog, dlog = target.forward_log(0), draft.forward_log(0)
+            d = dict(ms_to_last_result=1e3 * sec, ms_per_user=1e3 * sec / s, items_per_s=s * args.beam / sec,
+                     roofline=forwards_roofline([(target.dims, tlog), (draft.dims, dlog)], sec),
+                     target_forwards=len(tlog), target_tokens_per_forward=[t_ for t_, _ in tlog], draft_forwards=len(dlog),
+                     per_kind_us={k: 1e3 * v["ms"] / max(1, v["count"]) for k, v in prof.items()})
+            if name == "bssd":
+                d["mean_accept_len"] = sum(o["total_accept_steps"] for o in outs) / max(1, sum(o["n_run"] for o in outs))
+            point[name] = d
+        point["speedup"] = point["target_generate"]["ms_to_last_result"] / point["bssd"]["ms_to_last_result"]   # inference.py:179
+        curve.append(point)
+    return curve
+
+
 def main():
     args = parse()
     mode = resolve_world(args)
@@ -418,39 +486,41 @@ def main():
 
     sub_errors = {}
 
+    device_dead = []
+
     def guarded(name, fn_):
-        """an auxiliary pass must never cost the headline: its failure is recorded on the line (`sub_pass_errors`) and the run goes on"""
+        """An auxiliary pass must never cost the headline: an ORDINARY failure is recorded on the line (`sub_pass_errors`) and the run goes on.
+        A DEVICE error (the library's ERR_HIP status, a HIP error out of torch, a synchronize that fails) poisons the context: every later GPU
+        pass is skipped, the line is still printed with what was measured before, and the process exits non-zero -- no in-process retry."""
+        if device_dead:
+            sub_errors[name] = f"skipped: device error in {device_dead[0]}"
+            return None
         try:
             return fn_()
         except Exception as e:                                        # noqa: BLE001
             sub_errors[name] = f"{type(e).__name__}: {e}"[:400]
+            from atspeed_amd import _lib as _l
+            hip = (isinstance(e, _l.AtSpeedError) and e.status == _l.ERR_HIP) or "HIP error" in str(e) or "hipError" in str(e)
             try:
                 torch.cuda.synchronize(dev)
             except Exception:                                         # noqa: BLE001
-                pass
+                hip = True
+            if hip:
+                device_dead.append(name)
             return None
 
-    # ---- latency curve: where lock-step batching overtakes per-user calls (items/s and ms until the LAST user of the batch has its result)
-    def latency_curve_pass():
-        curve = []
-        for s in (1, 4, 16, 64, 256):
-            if s > args.streams or s > n_timed:
-                continue
-            grp = dprompts[n_warm: n_warm + s]
-            call = (lambda: [BSSD(target, draft, grp[0], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)]) if s == 1 else \
-                   (lambda: BSSD_batch(target, draft, grp, args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn))
-            call(); call()                                            # recurring shapes settled
-            torch.cuda.synchronize(dev)
-            reps = 3 if s <= 16 else 2
-            tc = time.perf_counter()
-            for _ in range(reps):
-                call()
-            torch.cuda.synchronize(dev)
-            ms = 1e3 * (time.perf_counter() - tc) / reps
-            curve.append(dict(users_per_batch=s, ms_to_last_result=ms, items_per_s=s * args.beam / (ms * 1e-3), ms_per_user=ms / s))
-        return curve
+    # ---- speedup curve (the reference's figure of merit, inference.py:179): BSSD against plain beam search on the same engine, users and
+    # box, by users per lock-step batch, each point with its roofline fraction; `latency_curve` is its BSSD leg (kept under that name)
+    sizes = [s_ for s_ in (1, 4, 16, 64, 256) if s_ <= args.streams and s_ <= n_timed]
 
-    curve = guarded("latency_curve", latency_curve_pass) if (solo and not args.no_latency_curve and args.streams > 1) else None
+    def speedup_pass(t_, d_, first):
+        return speedup_curve(t_, d_, dprompts, first, sizes, fn, args, dev)
+
+    speedup = guarded("speedup_curve", lambda: speedup_pass(target, draft, n_warm)) if (solo and not args.no_latency_curve and args.streams > 1) else None
+    curve = [dict(users_per_batch=p_["users_per_batch"], **{k_: p_["bssd"][k_] for k_ in ("ms_to_last_result", "items_per_s", "ms_per_user")})
+             for p_ in speedup] if speedup else None
+    if speedup:
+        release_decoders(target)                      # the plain-beam-search decoders of the curve (a KV arena per lane)
 
     # ---- the reference's own regime, for the record (not part of `value`): a few users strictly one at a time.
     # Here every projection is one pass over the weights (M ~ 20-230 tokens): HBM-bound.
@@ -502,6 +572,8 @@ def main():
                 target_a.enable_fp8()
             r = timed_pass(target_a, draft_a, dprompts, sub_warm, sub_steps, args.streams, fn, args, dev, profile=False)
             br = dict(resid_scale=rs, **pass_summary(r, args, ups))
+            if not args.no_latency_curve and not args.do_sample:
+                br["speedup_curve"] = speedup_pass(target_a, draft_a, sub_warm * ups)
             nf = min(args.aligned_fp32_users, r["n_timed"])
             if nf > 0 and not args.do_sample:
                 t32, d32 = build_pair(tdims, ddims, dtype=torch.float32, resid_scale=rs, round_to_bf16=True, max_logit_rows=448)
@@ -643,6 +715,7 @@ def main():
         "measured_peaks": measured,
         "verify_scan": scan,
         "configs": configs,                   # BASELINE configs 3 (Games, 256 users) and 5 (fp8 verify), bounded sub-passes
+        "speedup_curve": speedup,             # BSSD vs target_generate on the same engine (inference.py:179), by users per batch, with roofline fractions
         "latency_curve": curve,
         "single_user_stream": single,
         "aligned_weight_brackets": aligned,   # same users, shapes and kernels as `value`; only the weights' agreement differs
@@ -665,7 +738,9 @@ def main():
 
     line["cpu_baseline"] = guarded("cpu_baseline", cpu_pass) if (world == 1 and not args.no_cpu_baseline and not args.do_sample) else None
     line["sub_pass_errors"] = sub_errors or None
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
+    if device_dead:
+        raise SystemExit(f"bench.py: device error in sub-pass {device_dead[0]} (line printed above with sub_pass_errors); exiting non-zero")
     if world > 1:
         dist.destroy_process_group()
 

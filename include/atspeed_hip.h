@@ -155,6 +155,11 @@ int atspeed_llama_profile(atspeed_llama* m, int32_t enable, double* ms_out, int6
  * atspeed_llama_profile call that resets them.  bench.py's roofline uses these so that its average launch time is
  * that of one kernel (gemm_ring_kernel<EPI, 8, false>) and can be checked against the rocprofv3 kernel summary. */
 int atspeed_llama_profile_big(atspeed_llama* m, double* ms_out, int64_t* count_out, int64_t* rows_out);
+/* Token counts of the forwards this model ran since logging was switched on: enable = 1 starts (and clears) the log, 0 stops it, < 0
+ * only reads.  Writes up to `max_pairs` (tokens, logit rows) pairs, oldest first, to pairs_out (may be NULL) and returns how many forwards
+ * the log holds (it keeps the first 4096).  bench.py prices every forward of a decode against max(weight stream, MFMA time) with these:
+ * the packed verification of beamSD.py:203-221 makes the token count of a forward data dependent.  No reference counterpart. */
+int32_t atspeed_llama_forward_log(atspeed_llama* m, int32_t enable, int32_t* pairs_out, int32_t max_pairs);
 /* Measured peaks for the roofline report (nominal peaks are re-measured on the box).  No reference counterpart.
  * atspeed_probe_mfma_bf16: register-only loop of v_mfma_f32_16x16x32_bf16 on random operands, `iters` trips of 32 MFMAs per wave,
  * 8 waves x 1024 workgroups; scratch_dev >= 2 MiB.  atspeed_probe_hbm_read: `reps` read-only passes over buf_dev (use a buffer far

@@ -146,3 +146,19 @@ def test_roofline_object_arithmetic(tmp_path, monkeypatch):
     rs = bench.gemm_roofline(t, small, zero, False, dict(mfma_bf16_tflops=1900.0, hbm_read_gbs=7000.0), 1, True)
     assert rs["bound"] == "hbm" and rs["unit"] == "GB/s" and rs["peak"] == 8000.0 and rs["traffic"] is None
     assert rs["achieved"] == pytest.approx(rs["algorithmic_bytes_per_launch"] / (small["gate_up"]["ms"] / launches * 1e-3) / 1e9)
+
+
+def test_forwards_roofline_prices_each_forward_against_its_own_bound():
+    """One user's forward (100 tokens) is priced by its weight stream, a 256-user forward (58 k tokens) by its matrix flops; the call's
+    ideal time is the sum of the per-forward maxima and `frac` = ideal / measured."""
+    import bench
+    from atspeed_amd import synth
+    d = synth.llama_7b(32859, 32)
+    w_layers = 32 * (4 * 4096 * 4096 + 3 * 4096 * 11008)
+    w_head = 4096 * 32859
+    r = bench.forwards_roofline([(d, [(100, 100), (58000, 30976)])], elapsed_s=1.0)
+    hbm = (w_layers + w_head) * 2 / 8e12
+    mf = 2.0 * (w_layers * 58000 + w_head * 30976) / 2.5e15
+    assert r["forwards"] == 2 and r["forwards_hbm_bound"] == 1
+    assert abs(r["ideal_ms"] - 1e3 * (hbm + mf)) < 1e-6 and abs(r["frac"] - (hbm + mf)) < 1e-9
+    assert 2.0 * (w_layers * 100 + w_head * 100) / 2.5e15 < hbm < mf
