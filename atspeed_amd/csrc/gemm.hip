@@ -34,6 +34,64 @@ static float big_rounds(int tiles) {
 }
 static bool big_use_256_rows(int t256, int t128) { return big_rounds(t256) <= 0.65f * big_rounds(t128); }
 
+// ---- split-K tail of the ring kernel (gemm_ring_kernel<..., SK = true>): plan and cost model, host side.
+// The kernel accepts any even deal of the tail's k-units over G workgroups; the plans made here are the ALIGNED ones, G = R x S: each of the
+// R tail tiles is cut into S equal k-ranges, one workgroup each, one seam per tile.  Unaligned deals (a workgroup finishing one tile and
+// starting the next) were measured first and lost: every part publishes a whole fp32 tile (256 / 128 KB) whatever its share of K, so the
+// seam traffic -- R x S slots written, R x (S - 1) read back -- must stay small against the k-loop it shortens (gate_up at 912 tokens, 88 tail
+// tiles over 256 workgroups in 3-4 parts each: 160 MB of slots next to 200 MB of operands, no gain; down at 2400 tokens 189 -> 293 us).
+// Cost model, fitted to tools/sk_sweep.py on MI355X (profiles/r04_sk_sweep.txt): a tile's time grows with the number of workgroups running
+// beside it (clock, L2, fabric) -- 256 x 256: k x (14.5 + 7.5 c / 256) ns, 256 x 128: k x (7 + 7.5 c / 256) ns for c concurrent workgroups
+// (82 us for a 256-row tile at K = 4096 and 172 tiles, 94 at 240; 42 / 50 / 64 us for a 128-row one at 160 / 192 / 240) -- and a seam costs
+// 22 / 38 / 46 us (256 KB slots) or 14 / 24 / 27 us (128 KB slots) for 2 / 3 / 4 parts: second prologue, dump, ticket, the finisher's reads.
+struct SkPlan { bool on; int n_dp, G, U, TU, parts; };
+static int env_now(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }   // read per call: tools flip these in-process
+static SkPlan sk_plan_s(int tiles, int k, int S) {
+  SkPlan p{false, 0, 0, 0, 0, 1};
+  p.U = k / 128;
+  p.n_dp = tiles / 256 * 256;
+  const int R = tiles - p.n_dp;
+  if (S < 2 || R == 0 || R * S > 256 || p.U < 4 * S) return p;    // >= 4 units (512 k) per part
+  p.TU = R * p.U;
+  p.G = R * S;
+  p.parts = S;
+  p.on = true;
+  return p;
+}
+static float ring_tile_us(int k, bool rows256, int concurrent) {
+  return 1e-3f * (float)k * ((rows256 ? 14.5f : 7.f) + 7.5f * (float)concurrent / 256.f);
+}
+static float sk_cost_us(int tiles, int k, bool rows256, SkPlan* plan_out) {
+  const int mode = env_now("ATSPEED_GEMM_SK", 1);                  // 0: off, 1: cost model, 2-4: that many parts wherever they fit
+  const int full = tiles / 256, R = tiles % 256;
+  const float whole = (float)full * ring_tile_us(k, rows256, 256);
+  if (plan_out) *plan_out = SkPlan{false, 0, 0, 0, 0, 1};
+  if (R == 0) return whole;
+  float best = whole + ring_tile_us(k, rows256, R);               // the partly filled last round as it is
+  if (mode == 0) return best;
+  static const float seam256[5] = {0.f, 0.f, 22.f, 38.f, 46.f}, seam128[5] = {0.f, 0.f, 14.f, 24.f, 27.f};
+  for (int S = 2; S <= 4; ++S) {
+    if (mode >= 2 && S != mode) continue;
+    const SkPlan p = sk_plan_s(tiles, k, S);
+    if (!p.on) continue;
+    const float c = whole + ring_tile_us(k, rows256, p.G) / (float)S + (rows256 ? seam256[S] : seam128[S]);
+    if (c < best || mode >= 2) { best = c; if (plan_out) *plan_out = p; }
+  }
+  return best;
+}
+// tile height and split decision of a ring-kernel launch
+struct BigChoice { bool rows256; SkPlan sk; };
+static BigChoice big_choose(int t256, int t128, int k) {
+  const int force_mt = env_now("ATSPEED_GEMM_FORCE_MT", 0);        // tuning: 8 / 4 = always 256- / 128-row token tiles
+  BigChoice c;
+  SkPlan p256, p128;
+  const float c256 = sk_cost_us(t256, k, true, &p256), c128 = sk_cost_us(t128, k, false, &p128);
+  c.rows256 = force_mt ? force_mt == 8 : c256 <= c128;
+  c.sk = c.rows256 ? p256 : p128;
+  return c;
+}
+static bool sk_any_plan(int tiles, int k) { SkPlan p; sk_cost_us(tiles, k, false, &p); return p.on; }
+
 constexpr int kThreads = 256;
 constexpr int kRowBytes = 128;      // bytes of K per LDS row
 constexpr int kChunks = 8;          // 16-byte chunks per row
@@ -584,13 +642,27 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // LDS-DMA ring (three k-steps = 72-96 KB per CU in flight, no register staging) is what pulls the weight stream.
 // NA = 16-row weight tiles per wave: 4 -> 8 waves (4 x 2) of 64 x (MT2*16); 8 -> 4 waves (2 x 2) of 128 x 128 with the 256
 // accumulator registers in AGPRs: one wave per SIMD and a third fewer LDS fragment bytes per flop (the kernel is power-limited).
-template <int EPI, int MT2, bool FP8, bool SPLITK = false, int NA = 4>
+// SK (stream-K tail, bf16 batched forwards in the 4-64-user band): the tile grid of such a forward is 0.3-3 rounds of 256 workgroups and a
+// tile lasts 50-85 us, so the last, partly filled round costs a whole tile time (gate_up at 912 tokens: 344 tiles = 1.34 rounds, paid as 2).
+// With SK the first n_dp = 256 * floor(tiles / 256) tiles run as before (one workgroup each, whole K, the epilogue of EPI), and the k-steps
+// of the R remaining tiles are dealt EVENLY to G <= 256 more workgroups in units of 128 k: workgroup g takes units [g TU / G, (g + 1) TU / G)
+// of the R x U unit space (U = K / 128 units per tile), i.e. the end of one tile and / or the start of the next.  A tile that ends up in
+// several parts is finished in-launch by the part that arrives LAST (cdna_hip_programming.md, "In-launch split-K reduction", the sc1 form
+// of its hand-off table's first row): every part writes its fp32 accumulators lane-linearly to its slot of the workspace with sc1
+// (write-through) 16-byte stores, every wave drains vmcnt, workgroup barrier, one lane adds to the tile's counter (agent scope); the part
+// whose add returns parts - 1 sums ALL parts in part order -- its own from registers at its place in that order, the others by sc1 loads:
+// the sum does not depend on who arrived last -- and runs the ordinary epilogue.  Nobody waits for anybody: no spin, no co-residency
+// assumption.  Consecutive ranges are given to workgroup ids 8 apart (same XCD under round-robin dispatch: a speed choice only).
+struct SkTail { int n_dp = 0; int G = 0; int U = 0; int TU = 0; float* ws = nullptr; int* cnt = nullptr; };
+
+template <int EPI, int MT2, bool FP8, bool SPLITK = false, int NA = 4, bool SK = false>
 __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const void* __restrict__ X, const void* __restrict__ W,
                                                            const float* __restrict__ sx, const float* __restrict__ sw,
                                                            void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
                                                            int tiles_n, int tiles_m, int GM, int n_split = 1,
                                                            float* __restrict__ lse_part = nullptr, const unsigned char* __restrict__ tile_store = nullptr,
-                                                           int pk = 0, RopeEpi rope = RopeEpi{}) {
+                                                           int pk = 0, RopeEpi rope = RopeEpi{}, SkTail sk = SkTail{}) {
+  static_assert(!(SK && (SPLITK || FP8 || NA != 4)), "the stream-K tail is built for the bf16 eight-wave form");
   // pk: X and W (and the SwiGLU output) are in the packed operand layout -- every 1 KB DMA piece is then eight FULL 128-byte lines
   // (two rows x 64 bytes each) instead of sixteen half lines: 83 against 55 GB/s per CU from L2 (tools/probe/dma_depth.hip)
   constexpr int BT = 256, RB = 64, ESZ = FP8 ? 1 : 2;
@@ -616,7 +688,45 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   const int nwg = tiles_n * tiles_m;
   int bid = blockIdx.x, zpart = 0;
   if constexpr (SPLITK) { zpart = bid / nwg; bid -= zpart * nwg; }
-  {
+  // stream-K tail: this workgroup's range [sk_u, sk_ue) of the tail's k-units, walked tile by tile by the segment loop below
+  int sk_g = 0, sk_u = 0, sk_ue = 0, sk_seg = 0;
+  bool sk_tail = false;
+  if constexpr (SK) {
+    if (bid >= sk.n_dp) {
+      const int j = bid - sk.n_dp;
+      sk_g = (sk.G & 7) ? j : (j & 7) * (sk.G >> 3) + (j >> 3);    // G % 8 == 0: consecutive ranges on ids 8 apart (one XCD)
+      sk_u = (int)((long long)sk_g * sk.TU / sk.G);
+      sk_ue = (int)((long long)(sk_g + 1) * sk.TU / sk.G);
+      sk_tail = true;
+    }
+  }
+  const int wn = wave >> 1, wm = wave & 1;
+  auto swz = [](int row) { return (0xD2 >> (((row >> 2) & 3) * 2)) & 3; };   // f = {2,0,1,3} packed in 0b11010010
+  const unsigned lbase = lds_addr(smem);
+  int m0w[WP], m0x[XP];
+#pragma unroll
+  for (int j = 0; j < WP; ++j) m0w[j] = __builtin_amdgcn_readfirstlane((int)lbase + (wave * WP + j) * 1024);
+#pragma unroll
+  for (int j = 0; j < XP; ++j) m0x[j] = __builtin_amdgcn_readfirstlane((int)lbase + BT * RB + (wave * XP + j) * 1024);
+  bool sk_more;
+  do {                                                             // one pass unless SK: a tail workgroup's range may end one tile and start the next
+  sk_more = false;
+  int sk_tt = 0;                                                   // tail tile of this segment, whole = it covers the tile's whole K
+  bool sk_whole = true;
+  int ks0 = 0, nks = K / BK;                                     // launcher: K % (4 BK) == 0; nks = END of this part's k-steps
+  if constexpr (SK) {
+    if (sk_tail) {
+      sk_tt = sk_u / sk.U;
+      const int k0 = sk_u - sk_tt * sk.U, k1 = min(sk.U, sk_ue - sk_tt * sk.U);
+      ks0 = 4 * k0; nks = 4 * k1;
+      sk_whole = k0 == 0 && k1 == sk.U;
+      sk_u = sk_tt * sk.U + k1;
+      sk_more = sk_u < sk_ue;
+      bid = sk.n_dp + sk_tt;                                       // the tail's tiles are the last positions of the tile order
+    } else {
+      bid = (bid & 7) * (sk.n_dp >> 3) + (bid >> 3);               // n_dp % 256 == 0: XCD x walks positions [x n_dp / 8, (x + 1) n_dp / 8)
+    }
+  } else {
     const int q = nwg / 8, r = nwg % 8, x = bid % 8;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
   }
@@ -624,8 +734,6 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   const int band_rows = min(GM, tiles_m - band * GM);
   const int tn = rem / band_rows, tm = band * GM + rem % band_rows;
   const int n0 = tn * BT, m0 = tm * XR;
-  const int wn = wave >> 1, wm = wave & 1;
-  int ks0 = 0, nks = K / BK;                                     // launcher: K % (4 BK) == 0; nks = END of this part's k-steps
   if constexpr (SPLITK) {
     const int units = nks >> 2;                                  // launcher: n_split <= units
     ks0 = 4 * (int)((long long)zpart * units / n_split);
@@ -633,22 +741,17 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   }
 
   // per-lane DMA source offsets (bytes): piece = 16 rows x 64 B, lane l -> row l>>2, stored position l&3
-  auto swz = [](int row) { return (0xD2 >> (((row >> 2) & 3) * 2)) & 3; };   // f = {2,0,1,3} packed in 0b11010010
   unsigned woff[WP], xoff[XP];
-  int m0w[WP], m0x[XP];
-  const unsigned lbase = lds_addr(smem);
 #pragma unroll
   for (int j = 0; j < WP; ++j) {
     const int row = (wave * WP + j) * 16 + (lane >> 2);          // LDS row; its weight row follows the epilogue's row order (ring_src_row)
     const int gr = min(n0 + (row & ~63) + ring_src_row<ORD>(row & 63), N - 1);
     woff[j] = (pk ? (unsigned)(gr >> 1) * (unsigned)(K * ESZ * 2) + (gr & 1) * 64 : (unsigned)gr * (unsigned)(K * ESZ)) + (((lane & 3) ^ swz(row)) * 16);
-    m0w[j] = __builtin_amdgcn_readfirstlane((int)lbase + (wave * WP + j) * 1024);
   }
 #pragma unroll
   for (int j = 0; j < XP; ++j) {
     const int row = (wave * XP + j) * 16 + (lane >> 2), gr = min(m0 + row, M - 1);
     xoff[j] = (pk ? (unsigned)(gr >> 1) * (unsigned)(ldx * ESZ * 2) + (gr & 1) * 64 : (unsigned)gr * (unsigned)(ldx * ESZ)) + (((lane & 3) ^ swz(row)) * 16);
-    m0x[j] = __builtin_amdgcn_readfirstlane((int)lbase + BT * RB + (wave * XP + j) * 1024);
   }
   const unsigned long long wb = (unsigned long long)W, xb = (unsigned long long)X;
   const unsigned long long kadv = pk ? 2 * RB : RB;               // bytes from one k-step's 64-byte block of a row to the next
@@ -769,6 +872,76 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
 #undef ATS_STAMP
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");               // MFMA results -> VALU reads (the compiler cannot see the asm MFMAs)
 
+  bool sk_epilogue = true;
+  if constexpr (SK) {
+    if (sk_tail && !sk_whole) {
+      // a PART of tail tile sk_tt: publish the accumulators, draw a ticket; the last part to arrive sums all parts and goes on
+      constexpr int NT = NWV * 64, SLOT = NA * MT2 * NT;           // threads, 16-byte items per slot (256 / 128 KB)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sk.ws, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < MT2; ++j) {
+          u32x4_t v;
+          __builtin_memcpy(&v, &acc[i][j], 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, (((sk_g * 2 + sk_seg) * SLOT) + (i * MT2 + j) * NT + tid) * 16, 0, 16);   // aux 16 = sc1
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave, before the barrier the ticket lane joins
+      __syncthreads();                                             // (also: every wave is done with the ring, smem[0..3] is free)
+      const int u_lo = sk_tt * sk.U, u_hi = u_lo + sk.U - 1;       // the part that holds unit u: ceil((u + 1) G / TU) - 1
+      const int g_first = (int)(((long long)(u_lo + 1) * sk.G + sk.TU - 1) / sk.TU) - 1;
+      const int g_last = (int)(((long long)(u_hi + 1) * sk.G + sk.TU - 1) / sk.TU) - 1;
+      const int parts = g_last - g_first + 1;
+      volatile int* flag = reinterpret_cast<volatile int*>(smem);
+      if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(sk.cnt + sk_tt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == parts - 1) __hip_atomic_store(sk.cnt + sk_tt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+        *flag = old;
+      }
+      __syncthreads();
+      sk_epilogue = *flag == parts - 1;
+      if (sk_epilogue) {
+        auto slot_of = [&](int gp) { return (gp * 2 + (((int)((long long)gp * sk.TU / sk.G)) / sk.U == sk_tt ? 0 : 1)) * SLOT; };
+        auto part_load = [&](int slot, int idx) {
+          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (slot + idx * NT + tid) * 16, 0, 16);
+          f32x4_t f;
+          __builtin_memcpy(&f, &v, 16);
+          return f;
+        };
+        // sum in part order, the own part (still in registers) at its place: bit-identical whoever arrived last.  CH loads in flight per
+        // lane and part (the RoPE epilogue's registers leave room for 4: with 8 that instantiation spilled)
+        constexpr int CH = EPI == EPI_QKV_ROPE ? 4 : 8;
+#pragma unroll
+        for (int c0 = 0; c0 < NA * MT2; c0 += CH) {
+          f32x4_t pre[CH];
+#pragma unroll
+          for (int e = 0; e < CH; ++e) pre[e] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          for (int gp = g_first; gp < sk_g; ++gp) {
+            const int so = slot_of(gp);
+            f32x4_t v[CH];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) v[e] = part_load(so, c0 + e);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) pre[e] += v[e];
+          }
+          if (sk_g > g_first) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e) acc[(c0 + e) / MT2][(c0 + e) % MT2] = pre[e] + acc[(c0 + e) / MT2][(c0 + e) % MT2];
+          }
+          for (int gp = sk_g + 1; gp <= g_last; ++gp) {
+            const int so = slot_of(gp);
+            f32x4_t v[CH];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) v[e] = part_load(so, c0 + e);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) acc[(c0 + e) / MT2][(c0 + e) % MT2] += v[e];
+          }
+        }
+      }
+      sk_seg = 1;
+    }
+  }
+  if (sk_epilogue) {
   if constexpr (FP8) {                                             // per-row scales: acc[i][j][r] *= sx[m] * sw[n]
 #pragma unroll
     for (int j = 0; j < MT2; ++j) {
@@ -827,6 +1000,9 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   } else if constexpr (EPI == EPI_QKV_ROPE) qkv_rope_epilogue<NA, MT2>(acc, reinterpret_cast<bf16_t*>(Cv), M, ldc, m0, n0, wave, lane, rope, smem);
   else if constexpr (SPLITK) big_epilogue<EPI_F32, NA, MT2>(acc, reinterpret_cast<float*>(Cv) + (size_t)zpart * M * N, M, N, N, m0, n0, wn, wm, lq, g);
   else                  big_epilogue<EPI, NA, MT2>(acc, Cv, M, N, ldc, m0, n0, wn, wm, lq, g, pk);
+  }
+  if constexpr (SK) { if (sk_more) { sk_seg = 1; __syncthreads(); } }   // the next segment's DMA overwrites LDS an epilogue may still be reading
+  } while (sk_more);
 #ifdef ATS_RING_STAMPS
   // tuning build: sw carries the stamp buffer [workgroup][wave][10] = loop cycles in {issue, lgkmcnt wait, vmcnt wait, barrier}, then
   // the absolute counter at kernel entry, loop start, loop end and after the epilogue's stores have been acknowledged, then the
@@ -1202,21 +1378,57 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* _
   }
 }
 
+// library-owned workspace of the stream-K tail, per device: 256 workgroups x 2 slots x 256 KB of fp32 partials + one arrival counter per
+// tail tile (zeroed here once; the finishing part leaves its counter at zero).  Launches that use it are ordered by the stream; a launch
+// on ANOTHER stream than the last one first waits for that one (event), so callers with several streams stay correct.
+struct SkWorkspace { float* ws = nullptr; int* cnt = nullptr; hipStream_t last = nullptr; hipEvent_t ev = nullptr; bool have_last = false; };
+static int sk_workspace(hipStream_t st, SkWorkspace** out) {
+  static thread_local SkWorkspace per_dev[ATS_MAX_DEVICES];
+  const int d = ats_cur_device();
+  ATS_REQUIRE(d >= 0, ATSPEED_ERR_HIP, "gemm: no current HIP device");
+  SkWorkspace& w = per_dev[d];
+  if (!w.ws) {
+    ATS_HIP(hipMalloc((void**)&w.ws, (size_t)512 * 256 * 1024));
+    ATS_HIP(hipMalloc((void**)&w.cnt, 256 * sizeof(int)));
+    ATS_HIP(hipMemset(w.cnt, 0, 256 * sizeof(int)));
+    ATS_HIP(hipEventCreateWithFlags(&w.ev, hipEventDisableTiming));
+  }
+  if (w.have_last && w.last != st) { ATS_HIP(hipEventRecord(w.ev, w.last)); ATS_HIP(hipStreamWaitEvent(st, w.ev, 0)); }
+  w.last = st; w.have_last = true;
+  *out = &w;
+  return ATSPEED_OK;
+}
+
 template <int EPI>
-int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st, int pk, const RopeEpi& rope = RopeEpi{}) {
+int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st, int pk, const RopeEpi& rope = RopeEpi{},
+               float* lse_part = nullptr, const unsigned char* tile_store = nullptr) {
   static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
-  static const int force_mt = env_int("ATSPEED_GEMM_FORCE_MT", 0);     // tuning: 8 / 4 = always 256- / 128-row token tiles
   const int tiles_n = (n + 255) / 256;
+  constexpr int LDS8 = EPI == EPI_F32_LSE ? 136 * 1024 : 128 * 1024, LDS4 = EPI == EPI_F32_LSE ? 100 * 1024 : 96 * 1024;
   static thread_local AtsPerDeviceFlag attr_flag;
   bool& attr_done = attr_flag.cur();
   if (!attr_done) {
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 8, false, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, 4, false, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
     attr_done = true;
   }
   const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
-  const bool use256 = force_mt ? force_mt == 8 : big_use_256_rows(t256, t128);
+  const BigChoice ch = big_choose(t256, t128, k);
+  const bool use256 = ch.rows256;
   const float* none = nullptr;
+  if (ch.sk.on) {
+    // stream-K tail: n_dp whole tiles + G workgroups that share the k-steps of the remaining ones evenly
+    SkWorkspace* wsp = nullptr;
+    ATS_TRY(sk_workspace(st, &wsp));
+    const SkTail tail{ch.sk.n_dp, ch.sk.G, ch.sk.U, ch.sk.TU, wsp->ws, wsp->cnt};
+    const int grid = ch.sk.n_dp + ch.sk.G;
+    if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false, false, 4, true>), dim3(grid), dim3(512), LDS8, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, lse_part, tile_store, pk, rope, tail);
+    else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false, false, 4, true>), dim3(grid), dim3(512), LDS4, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, lse_part, tile_store, pk, rope, tail);
+    ATS_LAUNCH_CHECK();
+    return ATSPEED_OK;
+  }
 #ifdef ATS_RING_STAMPS
   static const char* stamp_env = getenv("ATSPEED_STAMP_PTR");      // tuning build: device buffer for the in-kernel cycle stamps
   const float* stamps = stamp_env ? (const float*)(uintptr_t)strtoull(stamp_env, nullptr, 16) : nullptr;
@@ -1225,8 +1437,8 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
 #endif
   // (a four-wave form, one wave per SIMD with 128 x 128 per wave and the accumulators in AGPRs, was 3 % slower on every projection and is
   // not instantiated any more: profiles/README.md)
-  if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, none, stamps, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk, rope);
-  else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, (float*)nullptr, (const unsigned char*)nullptr, pk, rope);
+  if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), LDS8, st, (const void*)x, (const void*)w, none, stamps, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, lse_part, tile_store, pk, rope);
+  else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), LDS4, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, lse_part, tile_store, pk, rope);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
@@ -1251,24 +1463,8 @@ __global__ __launch_bounds__(256) void lse_combine_kernel(const float2* __restri
 // lm_head over the batched rows with the normaliser fused into the epilogue (gemm_ring_kernel<EPI_F32_LSE>)
 int launch_big_lse(const bf16_t* x, const bf16_t* w, float* c, int m, int n, int k, int ldx, int ldc, float* part, const unsigned char* tile_store,
                    float* lse, hipStream_t st, int pk) {
-  static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
   const int tiles_n = (n + 255) / 256;
-  static thread_local AtsPerDeviceFlag attr_flag;
-  bool& attr_done = attr_flag.cur();
-  if (!attr_done) {
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI_F32_LSE, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI_F32_LSE, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    attr_done = true;
-  }
-  const int t256 = tiles_n * ((m + 255) / 256), t128 = tiles_n * ((m + 127) / 128);
-  const float* none = nullptr;
-  if (big_use_256_rows(t256, t128))
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32_LSE, 8, false>), dim3(t256), dim3(512), 136 * 1024, st, (const void*)x, (const void*)w, none, none, (void*)c, m, n, k,
-                       ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, part, tile_store, pk);
-  else
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32_LSE, 4, false>), dim3(t128), dim3(512), 100 * 1024, st, (const void*)x, (const void*)w, none, none, (void*)c, m, n, k,
-                       ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, part, tile_store, pk);
-  ATS_LAUNCH_CHECK();
+  ATS_TRY(launch_big<EPI_F32_LSE>(x, w, (void*)c, m, n, k, ldx, ldc, st, pk, RopeEpi{}, part, tile_store));
   lse_combine_kernel<<<(m + 3) / 4, 256, 0, st>>>(reinterpret_cast<const float2*>(part), m, tiles_n, lse);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
@@ -1925,7 +2121,12 @@ static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype,
   if (dtype != ATSPEED_BF16 || m < big_min_m || k % 128 != 0 || (lda % 8) != 0 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return false;
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
   const int tn = (n + 255) / 256;
-  return big_fill_pct(tn * ((m + 255) / 256)) >= min_fill || big_fill_pct(tn * ((m + 127) / 128)) >= min_fill;
+  if (big_fill_pct(tn * ((m + 255) / 256)) >= min_fill || big_fill_pct(tn * ((m + 127) / 128)) >= min_fill) return true;
+  // a thin grid whose k-steps the stream-K tail spreads over the chip: from 64 tiles of 128 rows (at most 4 parts per tile; N = 4096
+  // from ~400 tokens), where it overtakes the LDS-tiled split-K kernel + reduce pass (tools/yardstick_engine_like.py)
+  static const int sk_min_tiles = env_int("ATSPEED_GEMM_SK_MIN_TILES", 64);
+  const int t128 = tn * ((m + 127) / 128);
+  return t128 >= sk_min_tiles && sk_any_plan(t128, k);
 }
 
 int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int k, int lda, int ldh, int dtype,

@@ -464,7 +464,7 @@ def test_gemm_fp8(lib, m, n, k, epi):
 
 
 # 70001: more than 256 tiles of 256 columns (a 128k-token target would have 500): the tile mask is sized by the vocabulary
-@pytest.mark.parametrize("rows,vocab,hidden", [(700, 32859, 512), (1300, 33014, 256), (2100, 5000, 768), (90, 32859, 256), (300, 70001, 256)])
+@pytest.mark.parametrize("rows,vocab,hidden", [(700, 32859, 512), (1300, 33014, 256), (2100, 5000, 768), (90, 32859, 256), (300, 70001, 256), (700, 32859, 2048), (1300, 33014, 1024)])      # the last two: K deep enough for the stream-K tail
 def test_lmhead_lse_fused_epilogue(lib, rows, vocab, hidden):
     """lm_head + full-vocabulary normaliser in one kernel (beamSD.py:58,285): lse equals logsumexp of the fp32 product over ALL columns
     (tail tile of a vocabulary that is no multiple of 256 included), the logit tiles of the automaton's tokens are the plain GEMM's bit for
@@ -676,3 +676,54 @@ def test_log_softmax_rows_and_assemble_sequences(lib):
         got = res[o0: o0 + k * (lens[u] + L)].view(k, lens[u] + L)
         want = torch.cat((prompts[u].long()[None].expand(k, -1), toks[u].long()), 1)
         assert torch.equal(got, want), u
+
+
+# ------------------------------------------------------------------ stream-K tail of the ring GEMM (4-64 users per lock-step batch)
+SK_SHAPES = [(900, 4096, 4096, 2), (900, 4096, 11008, 2), (1800, 12288, 4096, 0), (912, 22016, 4096, 3), (400, 4096, 4096, 2), (912, 12288, 4096, 0),
+             (1600, 22016, 4096, 3), (640, 4096, 11008, 2), (700, 32859, 2048, 1), (3650, 22016, 1024, 3), (330, 12288, 4096, 0), (2500, 4096, 4096, 0)]
+
+
+@pytest.mark.parametrize("m,n,k,epi", SK_SHAPES)
+def test_gemm_stream_k_tail(lib, m, n, k, epi):
+    """Target forwards of 4-64 users (260-4000 tokens): the ring kernel's tile grid is 0.2-3 rounds of 256 workgroups, and the k-steps of the
+    last, partly filled round are dealt evenly over the chip (gemm_ring_kernel<..., SK>): parts of a tile meet through the workspace and the
+    last one to arrive sums them in part order.  Checked on the Llama-7B projection shapes against torch fp32 on the same bf16 values, and:
+    the sum must not depend on which part arrived last (three runs bit-identical), packed operands = row-major operands bit for bit."""
+    a = _rand((m, k), 81, 1.0).to(torch.bfloat16).cuda()
+    w = _rand((n, k), 82, 0.03).to(torch.bfloat16).cuda()
+    ws = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+    if epi == _lib.EPI_SWIGLU:
+        from atspeed_amd.model import _interleave_gate_up
+        w = _interleave_gate_up(w[: n // 2].contiguous(), w[n // 2:].contiguous())
+    base = _rand((m, n), 83).to(torch.bfloat16).cuda() if epi == _lib.EPI_RESID else None
+    if epi == _lib.EPI_F32:
+        ldc = (n + 63) // 64 * 64; mk = lambda: torch.zeros(m, ldc, dtype=torch.float32, device="cuda")
+    elif epi == _lib.EPI_SWIGLU:
+        ldc = n // 2; mk = lambda: torch.zeros((m + 1) // 2 * 2, ldc, dtype=torch.bfloat16, device="cuda")
+    else:
+        ldc = n; mk = lambda: (base.clone() if epi == _lib.EPI_RESID else torch.zeros(m, n, dtype=torch.bfloat16, device="cuda"))
+    outs = []
+    for _ in range(3):
+        c = mk()
+        _lib.check(lib.atspeed_gemm(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, k, ldc, _lib.ATSPEED_BF16, epi, ws.data_ptr(), ws.numel(), _st()))
+        outs.append(c)
+    ap, wp = _pack(lib, a), _pack(lib, w)
+    cp = mk()
+    _lib.check(lib.atspeed_gemm_packed(ap.data_ptr(), wp.data_ptr(), cp.data_ptr(), m, n, k, ldc, epi, ws.data_ptr(), ws.numel(), _st()))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "the stream-K sum depends on the arrival order"
+    prod = a.float() @ w.float().T                                   # torch fp32 on the bf16 values
+    if epi == _lib.EPI_SWIGLU:
+        v = prod.view(m, n // 32, 2, 16)
+        gate, up = v[:, :, 0].reshape(m, n // 2), v[:, :, 1].reshape(m, n // 2)
+        ref = torch.nn.functional.silu(gate.to(torch.bfloat16).float()) * up.to(torch.bfloat16).float()
+        got = outs[0][:m].float()
+        assert torch.equal(_unpack(lib, cp, m), outs[0][:m])
+        tol = 3e-2 * float(ref.abs().max())
+    else:
+        ref = prod + (base.float() if epi == _lib.EPI_RESID else 0.0)
+        got = outs[0][:, :n].float()
+        assert torch.equal(cp[:, :n], outs[0][:, :n])
+        tol = (2e-5 * np.sqrt(k) if epi == _lib.EPI_F32 else 1e-2) * float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    assert err <= tol, (err, tol)

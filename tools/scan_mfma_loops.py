@@ -64,7 +64,8 @@ def scan_dma(path, verbose=True, want=r'.'):
     wrong: tiles read before they land, silently wrong sums.  Checked per kernel, in layout order:
       * between the first LDS-DMA and the last MFMA (prologue + main loop; the epilogue's stores come after): no scratch_* instruction, no
         buffer_ / flat_ / global_ STORE or atomic;
-      * the kernel descriptor's .amdhsa_private_segment_fixed_size is 0 (no scratch at all);
+      * the kernel descriptor's .amdhsa_private_segment_fixed_size is 0, or every spill sits in front of the first LDS-DMA and every reload
+        behind the last MFMA (nothing of it in flight while a count is relied on);
       * `strict` kernels (the GEMMs, whose loops contain nothing but asm): no compiler VMEM load in that window either.
     -> (findings, kernels)"""
     s = open(path).read()
@@ -85,11 +86,19 @@ def scan_dma(path, verbose=True, want=r'.'):
                 bad.append((i, t.strip()[:60]))
             elif strict and re.match(r'\s+(buffer_|flat_|global_(?!load_lds))', t):
                 bad.append((i, t.strip()[:60]))
+        note = ""
         if priv.get(name, 0) != 0:
-            bad.append((-1, f"private_segment_fixed_size {priv[name]}"))
+            # scratch is tolerated only as "spilled before the ring starts, reloaded after its last MFMA" (the stream-K RoPE instantiation keeps a
+            # few epilogue values that way at 256 VGPRs): every scratch store in front of the first LDS-DMA, every reload behind the last MFMA
+            st = [i for i, l in enumerate(lines) if re.match(r'\s+scratch_store', l)]
+            ld = [i for i, l in enumerate(lines) if re.match(r'\s+scratch_load', l)]
+            if (st and max(st) > dma[0]) or (ld and min(ld) < mf[-1]) or not (st or ld):
+                bad.append((-1, f"private_segment_fixed_size {priv[name]} with scratch traffic inside the ring"))
+            else:
+                note = f" (scratch {priv[name]} B: {len(st)} spills before the ring, {len(ld)} reloads after it)"
         short = re.sub(r'^_ZN12_GLOBAL__N_1\d+', '', re.sub(r'EEvPK.*', '', name))
         if verbose:
-            print(f"{short:44s} {len(dma):4d} LDS-DMA, {len(mf):4d} MFMAs, {len(bad):3d} VMEM / scratch findings in the counted window {bad[:2] if bad else ''}")
+            print(f"{short:44s} {len(dma):4d} LDS-DMA, {len(mf):4d} MFMAs, {len(bad):3d} VMEM / scratch findings in the counted window {bad[:2] if bad else ''}{note}")
         findings += len(bad)
     return findings, kernels
 
