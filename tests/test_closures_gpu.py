@@ -3,6 +3,7 @@ sentence, generation_trie.py:92-98), the post-top-k id filter of one_step_beam_s
 config 3 at its stated batch (Games, strict trie, 256 users in lock step), the RCCL collective, and the decoder cache's
 lifetime across a beam-size sweep (inference.py:151)."""
 import gc
+import os
 
 import numpy as np
 import pytest
@@ -275,3 +276,71 @@ def test_rope_and_kv_scatter_in_the_qkv_epilogue_equal_the_separate_pass(n_seq, 
     for k in (0, 1):
         for x, y in zip(res["1"][k], res["0"][k]):
             assert bool(torch.isfinite(x).all()) and torch.equal(x, y), f"forward {k}: max |diff| {float((x - y).abs().max()):.3e} of max |logit| {float(y.abs().max()):.3f}"
+
+
+def test_rccl_two_ranks(tmp_path):
+    """BASELINE config 4's code path with more than one rank on REAL devices: two fresh child processes (one per GPU, started before anything in
+    them touches a card), rank-local BSSD_batch on disjoint user shards, the path's single collective over RCCL; the union of the shards'
+    results equals the one-rank run, every rank sees both ranks' counters.  Skipped on a one-GPU box (RCCL refuses two ranks on one device)."""
+    import json
+    import subprocess
+    import sys
+    from atspeed_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n_users, port = 5, 29671
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+
+    def run(world, tag):
+        out = str(tmp_path / tag)
+        procs = [subprocess.Popen([sys.executable, "-m", "tests.rccl_worker", str(r), str(world), str(port + world), str(n_users), out], cwd=root, env=env)
+                 for r in range(world)]
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        return [json.load(open(f"{out}.{r}.json")) for r in range(world)]
+
+    one = run(1, "one")[0]
+    # the worker's one-rank leg runs on any box: its results are the in-process engine's
+    case = [c for c in CASES if c["name"] == "k5_dk10_indep"][0]
+    ci = build_case_inputs(case)
+    kw = dict(max_slots=512, max_tokens=512, max_logit_rows=448, device="cuda:0")
+    tgt = HipLlama.from_state_dict(ci["target_dims"], ci["target_sd"], torch.float32, num_beams=case["K"], **kw)
+    drf = HipLlama.from_state_dict(ci["draft_dims"], ci["draft_sd"], torch.float32, num_beams=case["DK"], **kw)
+    prompts = [synth.synthetic_prompt(16 + u, 100 + u) for u in range(n_users)]
+    here = BSSD_batch(tgt, drf, [{"input_ids": torch.from_numpy(p)[None].cuda()} for p in prompts], case["gamma"], case["max_new_tokens"],
+                      prefix_allowed_tokens_fn=ci["fn"])
+    assert one["tokens"] == [o["beam_sequence"][:, len(p):].cpu().tolist() for o, p in zip(here, prompts)]
+    assert one["gathered"] == [[n_users, sum(one["n_run"]), sum(sum(a) for a in one["accept"]), 1_000_000]]
+    release_decoders(tgt, drf)
+    if int(_lib.load().atspeed_device_count()) < 2:
+        pytest.skip("one-rank leg passed; the two-rank leg needs two HIP devices (RCCL refuses two ranks on one device)")
+    two = run(2, "two")
+    assert [u for r in two for u in r["users"]] == one["users"] == list(range(n_users))
+    assert [t for r in two for t in r["tokens"]] == one["tokens"]
+    assert [a for r in two for a in r["accept"]] == one["accept"]
+    want = [(len(r["users"]), sum(r["n_run"]), sum(sum(a) for a in r["accept"]), 1_000_000 * (i + 1)) for i, r in enumerate(two)]
+    for r in two:
+        assert [tuple(g) for g in r["gathered"]] == want
+
+
+def test_batch_calls_on_a_model_that_is_not_on_the_current_device():
+    """every library call of BSSD_batch / target_generate_batch (the result assembly included) runs under the MODEL's device, so a
+    model on cuda:1 works while cuda:0 is the thread's current device.  Needs two devices."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    from atspeed_amd.beamSD import target_generate_batch
+    case = [c for c in CASES if c["name"] == "k5_dk10_indep"][0]
+    ci = build_case_inputs(case)
+    outs = {}
+    for d in (0, 1):
+        dev = torch.device("cuda", d)
+        kw = dict(max_slots=512, max_tokens=512, max_logit_rows=448, device=dev)
+        tgt = HipLlama.from_state_dict(ci["target_dims"], ci["target_sd"], torch.float32, num_beams=case["K"], **kw)
+        drf = HipLlama.from_state_dict(ci["draft_dims"], ci["draft_sd"], torch.float32, num_beams=case["DK"], **kw)
+        torch.cuda.set_device(0)                                     # the current device stays 0 for both
+        ins = [{"input_ids": torch.from_numpy(synth.synthetic_prompt(16 + u, 100 + u))[None].to(dev)} for u in range(3)]
+        b = BSSD_batch(tgt, drf, ins, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"])
+        t = target_generate_batch(tgt, ins, case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"])
+        outs[d] = ([o["beam_sequence"].cpu().tolist() for o in b], [o["beam_sequence"].cpu().tolist() for o in t])
+        assert all(o["beam_sequence"].device == dev for o in b + t)
+        release_decoders(tgt, drf)
+    assert outs[0] == outs[1]
