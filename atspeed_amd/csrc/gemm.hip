@@ -385,14 +385,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, void* __
 // No cost in the main loop (fragment reads and swizzle see LDS rows only; rows still come in groups of four, so the packed layout's
 // full 128-byte lines per DMA piece are kept).  Timing-only forms of the store pattern on the Llama-7B projections at 26 k tokens
 // (profiles/README.md): no stores at all +9-12 % (qkv, gate_up; down +4 %), the same bytes fully coalesced +4 %, this form +2.4-2.8 %.
-// 16-byte epilogue store.  -DATS_EPI_NT (tuning build): non-temporal -- the store-only GEMM gains 0.4-2.4 % at 26 k tokens, the bench nothing
-// (4846 / 4842 vs 4835 / 4838 items/s alternating on one box): every output is the next kernel's input.
+// 16-byte epilogue store (a non-temporal form was tried at 26 k tokens: the store-only GEMM gained 0.4-2.4 %, the bench nothing -- every
+// output is the next kernel's input).
 __device__ __forceinline__ void epi_store16(bf16_t* p, const uint4& v) {
-#ifdef ATS_EPI_NT
-  __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(p));
-#else
   *reinterpret_cast<uint4*>(p) = v;
-#endif
 }
 enum { ROWS_IDENTITY = 0, ROWS_LANE16 = 1, ROWS_SWIGLU8 = 2 };
 template <int EPI> constexpr int ring_row_order() {
@@ -680,9 +676,6 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   static_assert(RG >= 1 && DG >= 1, "segment too short for its reads and DMA pieces");
   constexpr int ORD = SPLITK ? ROWS_IDENTITY : ring_row_order<EPI>();   // order of the weight rows in the LDS image (see big_epilogue)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-#ifdef ATS_RING_STAMPS
-  const unsigned long long st_entry = __builtin_readcyclecounter();
-#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, g = lane >> 4;
   const int nwg = tiles_n * tiles_m;
@@ -819,22 +812,12 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
         ATS_MFMA_BF16(acc[i][j], fa[(Q) & 1][i], fb[(Q) & 1][j]);                                        \
       }                                                                                                  \
     }                                                                                                    \
-    ATS_STAMP(0);                                                                                        \
     if (RD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
-    ATS_STAMP(1);                                                                                        \
     if ((VM) >= 0) {                                                                                     \
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VM) < 0 ? 0 : (VM)) : "memory");                         \
-      ATS_STAMP(2);                                                                                      \
-      asm volatile("s_barrier" ::: "memory");                                                            \
-      ATS_STAMP(3);                                                                                      \
-    }                                                                                                    \
+        asm volatile("s_barrier" ::: "memory");                                                            \
+      }                                                                                                    \
   }
-#ifdef ATS_RING_STAMPS   // tuning build only: cycles a wave spends in the MFMA/issue part, the lgkmcnt wait, the vmcnt wait and the barrier
-  unsigned long long st_t[4] = {0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
-#define ATS_STAMP(i) { unsigned long long _n = __builtin_readcyclecounter(); st_t[i] += _n - st_last; st_last = _n; }
-#else
-#define ATS_STAMP(i)
-#endif
 
   // prologue: k-steps 0..3 into stages 0..3; fragments of k-step 0
 #pragma unroll
@@ -849,10 +832,6 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
   asm volatile("s_barrier" ::: "memory");                          // k-step 1 published, stage 0 read by everyone
 
-#ifdef ATS_RING_STAMPS
-  const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz reference: cycles / ticks = the clock the chip holds
-  const unsigned long long st_loop0 = st_last = __builtin_readcyclecounter();
-#endif
   int ks = ks0;
   for (; ks + 4 < nks; ks += 4) {
     ATS_RING_SEGMENT(0, true, true, 2 * NP, ks);
@@ -865,11 +844,6 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   ATS_RING_SEGMENT(2, false, true, -1, ks + 2);
   ATS_RING_SEGMENT(3, false, false, -1, ks + 3);
 #undef ATS_RING_SEGMENT
-#ifdef ATS_RING_STAMPS
-  const unsigned long long st_loop1 = __builtin_readcyclecounter();
-  const unsigned long long st_rt1 = __builtin_amdgcn_s_memrealtime();
-#endif
-#undef ATS_STAMP
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");               // MFMA results -> VALU reads (the compiler cannot see the asm MFMAs)
 
   bool sk_epilogue = true;
@@ -1003,18 +977,6 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
   }
   if constexpr (SK) { if (sk_more) { sk_seg = 1; __syncthreads(); } }   // the next segment's DMA overwrites LDS an epilogue may still be reading
   } while (sk_more);
-#ifdef ATS_RING_STAMPS
-  // tuning build: sw carries the stamp buffer [workgroup][wave][10] = loop cycles in {issue, lgkmcnt wait, vmcnt wait, barrier}, then
-  // the absolute counter at kernel entry, loop start, loop end and after the epilogue's stores have been acknowledged, then the
-  // 100 MHz real-time counter at loop start and end
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0 && (FP8 ? false : sw != nullptr)) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(sw)) + ((size_t)blockIdx.x * NWV + wave) * 10;
-    dbg[0] = st_t[0]; dbg[1] = st_t[1]; dbg[2] = st_t[2]; dbg[3] = st_t[3];
-    dbg[4] = st_entry; dbg[5] = st_loop0; dbg[6] = st_loop1; dbg[7] = __builtin_readcyclecounter();
-    dbg[8] = st_rt0; dbg[9] = st_rt1;
-  }
-#endif
 }
 
 // =====================================================================================
@@ -1031,9 +993,6 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
 // evenly between them.  Register budget as before: 128 accumulators + 96 fragment registers (double buffered).
 typedef unsigned int u32x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
-#ifndef ATS_MX_ABLATE      // tuning builds only (make ablate, tools/mx_ablate.py): 1 = no DMA, 2 = no fragment reads, 3 = no MFMAs in the main loop
-#define ATS_MX_ABLATE 0
-#endif
 #define ATS_MFMA_MX(c, a, b, s) \
   asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(a), "v"(b), "v"(s))
 // accumulators in AGPRs (the one-wave-per-SIMD form: 256 accumulator registers do not fit the 256 architectural VGPRs beside the fragments)
@@ -1324,16 +1283,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* _
       const int idx = i * TB + j;                                                                        \
       _Pragma("unroll") for (int t = 0; t < NIT; ++t) {                                                  \
         if (t * NMF / NIT == idx) {                                                                      \
-          if (t < NR) { if (RD && ATS_MX_ABLATE != 2) read_one(((Q) + 1) & 3, ((Q) + 1) & 1, t); }       \
-          else if (DMA && ATS_MX_ABLATE != 1) dma_piece((Q), (ks) + 4, t - NR);                          \
+          if (t < NR) { if (RD) read_one(((Q) + 1) & 3, ((Q) + 1) & 1, t); }       \
+          else if (DMA) dma_piece((Q), (ks) + 4, t - NR);                          \
         }                                                                                                \
       }                                                                                                  \
-      if (ATS_MX_ABLATE != 3) {                                                                          \
-        if constexpr (NWV == 4)                                                                          \
-          ATS_MFMA_MX_A(acc[i][j], ATS_CAT8(fal[(Q) & 1][i], fah[(Q) & 1][i]), ATS_CAT8(fbl[(Q) & 1][j], fbh[(Q) & 1][j]), unit_scale); \
-        else                                                                                             \
-          ATS_MFMA_MX(acc[i][j], ATS_CAT8(fal[(Q) & 1][i], fah[(Q) & 1][i]), ATS_CAT8(fbl[(Q) & 1][j], fbh[(Q) & 1][j]), unit_scale); \
-      }                                                                                                  \
+      if constexpr (NWV == 4) \
+        ATS_MFMA_MX_A(acc[i][j], ATS_CAT8(fal[(Q) & 1][i], fah[(Q) & 1][i]), ATS_CAT8(fbl[(Q) & 1][j], fbh[(Q) & 1][j]), unit_scale); \
+      else \
+        ATS_MFMA_MX(acc[i][j], ATS_CAT8(fal[(Q) & 1][i], fah[(Q) & 1][i]), ATS_CAT8(fbl[(Q) & 1][j], fbh[(Q) & 1][j]), unit_scale); \
     }                                                                                                    \
     if (RD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
     if ((VM) >= 0) {                                                                                     \
@@ -1429,15 +1386,9 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
     ATS_LAUNCH_CHECK();
     return ATSPEED_OK;
   }
-#ifdef ATS_RING_STAMPS
-  static const char* stamp_env = getenv("ATSPEED_STAMP_PTR");      // tuning build: device buffer for the in-kernel cycle stamps
-  const float* stamps = stamp_env ? (const float*)(uintptr_t)strtoull(stamp_env, nullptr, 16) : nullptr;
-#else
-  const float* stamps = nullptr;
-#endif
   // (a four-wave form, one wave per SIMD with 128 x 128 per wave and the accumulators in AGPRs, was 3 % slower on every projection and is
   // not instantiated any more: profiles/README.md)
-  if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), LDS8, st, (const void*)x, (const void*)w, none, stamps, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, lse_part, tile_store, pk, rope);
+  if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), LDS8, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, lse_part, tile_store, pk, rope);
   else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), LDS4, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, lse_part, tile_store, pk, rope);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
@@ -1631,11 +1582,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const bf16_t* __res
   auto issue = [&](int kt) {                                           // kt: tile index inside this part
     const int so = (kt % NST) * STAGE;
 #pragma unroll
-#if defined(ATS_WDMA_ABLATE) && ATS_WDMA_ABLATE >= 3                   // tuning build: the X pieces re-read tile 0 (same pipe, no L2 traffic to speak of)
-    for (int j = 0; j < NP; ++j) ATS_DMA16(voff[j], is_w[j] ? wb + (unsigned long long)(kt0 + kt) * kstep : xb, m0p[j] + so);
-#else
     for (int j = 0; j < NP; ++j) ATS_DMA16(voff[j], (is_w[j] ? wb : xb) + (unsigned long long)(kt0 + kt) * kstep, m0p[j] + so);
-#endif
   };
 
   f32x4_t acc[NI][MI];
@@ -1653,7 +1600,6 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const bf16_t* __res
     if (kt + NST - 1 < n_kt) issue(kt + NST - 1);
     const unsigned char* sx = smem + (kt % NST) * STAGE + (wm * (BM / WM)) * RB;
     const unsigned char* sw = smem + (kt % NST) * STAGE + BM * RB + (wn * (BN / 2)) * RB;
-#if !defined(ATS_WDMA_ABLATE) || ATS_WDMA_ABLATE < 2                   // tuning builds (make ablate_wdma): 1 = no MFMAs, 2 = no fragment reads either
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {                                   // two k-steps of 32 per 128-byte row
       s16x8_t wf[NI], xf[MI];
@@ -1661,22 +1607,12 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const bf16_t* __res
       for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const s16x8_t*>(sw + swz<8>(i * 16 + lq, ks * 4 + g));
 #pragma unroll
       for (int j = 0; j < MI; ++j) xf[j] = *reinterpret_cast<const s16x8_t*>(sx + swz<8>(j * 16 + lq, ks * 4 + g));
-#if defined(ATS_WDMA_ABLATE)
-#pragma unroll
-      for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[i]));
-#pragma unroll
-      for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(xf[j]));
-#else
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < MI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[i]), __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
-#endif
     }
-#else
-    (void)sx; (void)sw;
-#endif
   }
 
   // epilogue: acc[i][j][r] = C[m][n] with m = wm*BM/WM + j*16 + lq (token row), n = n0 + wn*BN/2 + i*16 + g*4 + r (weight row): a lane
@@ -1840,19 +1776,13 @@ int launch_ring_split(const bf16_t* a, const bf16_t* w, void* c, int m, int n, i
   }
   const int tiles_n = (n + 255) / 256;
   const float* none = nullptr;
-#ifdef ATS_RING_STAMPS
-  static const char* stamp_env = getenv("ATSPEED_STAMP_PTR");
-  const float* stamps = stamp_env ? (const float*)(uintptr_t)strtoull(stamp_env, nullptr, 16) : nullptr;
-#else
-  const float* stamps = nullptr;
-#endif
   const int tiles_m = (m + 255) / 256;
   if (m > 128)
     hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 8, false, true>), dim3(tiles_n * tiles_m * splits), dim3(512), 128 * 1024, st, (const void*)a, (const void*)w,
-                       none, stamps, (void*)partial, m, n, k, lda, n, tiles_n, tiles_m, 1, splits, (float*)nullptr, (const unsigned char*)nullptr, pk);
+                       none, none, (void*)partial, m, n, k, lda, n, tiles_n, tiles_m, 1, splits, (float*)nullptr, (const unsigned char*)nullptr, pk);
   else
     hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 4, false, true>), dim3(tiles_n * splits), dim3(512), 96 * 1024, st, (const void*)a, (const void*)w,
-                       none, stamps, (void*)partial, m, n, k, lda, n, tiles_n, 1, 1, splits, (float*)nullptr, (const unsigned char*)nullptr, pk);
+                       none, none, (void*)partial, m, n, k, lda, n, tiles_n, 1, 1, splits, (float*)nullptr, (const unsigned char*)nullptr, pk);
   ATS_LAUNCH_CHECK();
   if (c == nullptr) return ATSPEED_OK;          // partials only: the caller's next kernel sums the slabs itself (ats_gemm_partials)
   return reduce_splits<bf16_t, EPI>(partial, c, m, n, ldc, splits, st, fn, pk);
