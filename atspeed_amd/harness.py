@@ -255,6 +255,29 @@ class InferenceResult:
                 "mean_accept_len": acc / runs if runs else 0.0}
 
 
+def capacity_for(max_prompt: int, beam: int, draft_beam: int, gamma: int = 4, max_new_tokens: int = 4) -> Dict[str, int]:
+    """KV slots / tokens / logit rows a model pair needs for prompts of up to `max_prompt` tokens (`HipLlama(max_slots=, max_tokens=,
+    max_logit_rows=)`).  The reference truncates prompts at `cutoff_len` = 512 tokens (code/utils.py:119) and grows its KV cache as it goes
+    (beamSD.py:418-429); here the arenas are sized up front: a verification round occupies the prompt, up to gamma draft blocks of DK
+    tokens and the K tokens of every earlier round (engine.hip: base + n0 + dl * DK), its packed forward is prompt + gamma * DK tokens and
+    reads 1 + gamma * DK logit rows.  Never below the library's defaults (512 / 512 / 384), slots in multiples of 64, at most 2048."""
+    dl = max(1, min(gamma, max_new_tokens - 1))
+    slots = max_prompt + dl * draft_beam + max_new_tokens * (draft_beam + beam)
+    slots = max(512, (slots + 63) // 64 * 64)
+    if slots > 2048:
+        raise ValueError(f"a prompt of {max_prompt} tokens needs {slots} KV slots; the library's arenas hold at most 2048")
+    tokens = max(512, (max_prompt + dl * draft_beam + beam + 63) // 64 * 64)
+    rows = max(384, (beam + dl * draft_beam + 63) // 64 * 64)
+    return dict(max_slots=slots, max_tokens=tokens, max_logit_rows=rows)
+
+
+def longest_prompt(data: "SeqRecTestData", L: int = 0, R: Optional[int] = None, tokenizer=None) -> int:
+    """Token count of the longest prompt among users [L, R) (what `capacity_for` sizes the arenas from)."""
+    enc = CodeTokenEncoder(data.index)
+    stop_r = min(len(data), R) if R is not None else len(data)
+    return max((len(encode_prompt(data, u, tokenizer, enc)) for u in data.users[L:stop_r]), default=1)
+
+
 def run_inference(target, draft, data: SeqRecTestData, gamma: int = 4, max_new_tokens: int = 4, L: int = 0, R: Optional[int] = None,
                   users_per_batch: int = 128, prefix_allowed_tokens_fn=None, tokenizer=None, baseline: bool = False,
                   device=None) -> InferenceResult:

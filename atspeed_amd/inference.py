@@ -50,10 +50,13 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
-def load_models(args, vocab_size: int, beam: int, dev):
+def load_models(args, vocab_size: int, beam: int, dev, max_prompt: int = 0):
     from . import synth
+    from .harness import capacity_for
     from .model import HipLlama
-    kw = dict(max_slots=512, max_tokens=512, max_logit_rows=384, device=dev)
+    # KV arenas, token buffers and logit rows sized from the longest prompt of the users this rank decodes (the reference cuts prompts at
+    # cutoff_len = 512 tokens, code/utils.py:119: 512 + 3 x 40 draft tokens no longer fit the library's default 512 slots)
+    kw = dict(capacity_for(max_prompt, beam, args.draft_beam_size, args.gamma, 4), device=dev)
     if args.target_ckpt and args.draft_ckpt:
         from transformers import AutoModelForCausalLM
         tgt = HipLlama.from_hf(AutoModelForCausalLM.from_pretrained(args.target_ckpt, torch_dtype=torch.bfloat16), torch.bfloat16, dev, num_beams=beam, **{k: v for k, v in kw.items() if k != "device"})
@@ -72,7 +75,7 @@ def main(argv=None):
     args = parse(argv)
     from .beamSD import release_decoders
     from .dist import Counters, aggregate, all_gather_counters, shard_range
-    from .harness import SeqRecTestData, reduce_metrics, run_inference
+    from .harness import SeqRecTestData, longest_prompt, reduce_metrics, run_inference
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -95,8 +98,9 @@ def main(argv=None):
     lo, hi = shard_range(stop_r - args.L, rank, world)
     fn = data.strict_trie_fn() if args.strict_trie else data.get_prefix_allowed_tokens_fn()
     summary = []
+    max_prompt = longest_prompt(data, args.L + lo, args.L + hi, tok)
     for beam in ast.literal_eval(args.run_beam_sizes):          # the reference eval()s this flag (inference.py:151); a literal list is all it needs
-        tgt, drf = load_models(args, data.index.vocab_size, beam, dev)
+        tgt, drf = load_models(args, data.index.vocab_size, beam, dev, max_prompt)
         res = run_inference(tgt, drf, data, args.gamma, 4, args.L + lo, args.L + hi, args.users_per_batch, fn, tok, args.baseline, dev)
         c = res.counters()
         per_rank = all_gather_counters(Counters(len(res.rows), int(sum(r["n_run"] for r in res.rows)),

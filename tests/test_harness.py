@@ -237,3 +237,18 @@ def test_real_test_split_statistics():
     assert len(g) == 8696
     ids = encode_prompt(d, d.users[0])
     assert len(ids) == 4 + 5 * len(d.users[0].history) - 1 + 4 + 2 if d.users[0].history else True
+
+
+def test_capacity_for_sizes_the_arenas_from_the_longest_prompt():
+    """`python -m atspeed_amd.inference` sizes max_slots / max_tokens / max_logit_rows from the data (code/utils.py:119 allows 512-token prompts:
+    with 3 x 40 draft tokens they do not fit the library's default 512 slots)."""
+    from atspeed_amd.harness import capacity_for
+    assert capacity_for(108, 20, 40) == dict(max_slots=512, max_tokens=512, max_logit_rows=384)        # the Beauty mean: the defaults
+    c = capacity_for(512, 20, 40)
+    assert c["max_slots"] >= 512 + 3 * 40 + 3 * 20 and c["max_slots"] % 64 == 0 and c["max_slots"] <= 2048
+    assert c["max_tokens"] >= 512 + 3 * 40 and c["max_logit_rows"] >= 1 + 3 * 40
+    assert capacity_for(400, 20, 40)["max_slots"] > 512                                             # the VERDICT's ~390-token threshold
+    assert capacity_for(300, 64, 64, gamma=4, max_new_tokens=7)["max_logit_rows"] >= 64 + 4 * 64
+    import pytest
+    with pytest.raises(ValueError):
+        capacity_for(1900, 20, 40)
