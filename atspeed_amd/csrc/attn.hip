@@ -17,6 +17,8 @@
 #include <type_traits>
 #include <cstdlib>
 
+namespace ATS_NS {
+
 namespace {
 
 constexpr int kMaxSlots = 2048;
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
       for (int ks = 0; ks < KS; ++ks) {
         int r = c * 16 + lq, ch = ks * 4 + g;
         s16x8_t kf = *reinterpret_cast<const s16x8_t*>(ks_lds + (r * KCH + (ch ^ (r & 7))) * 16);
-        s[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ks]), s[c], 0, 0, 0);
+        s[c] = ATS_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ks]), s[c]);
       }
     }
     float mt = -INFINITY;
@@ -335,8 +337,8 @@ __global__ __launch_bounds__(64 * NW) void tree_attn_mfma_kernel(const bf16_t* _
         if (kk == 0) tr_read_2pairs<0 * 16 * VROW + d * 32, 1 * 16 * VROW + d * 32, 0 * 16 * VROW + (d + 1) * 32, 1 * 16 * VROW + (d + 1) * 32>(a0, b0, a1, b1, vaddr);
         else         tr_read_2pairs<2 * 16 * VROW + d * 32, 3 * 16 * VROW + d * 32, 2 * 16 * VROW + (d + 1) * 32, 3 * 16 * VROW + (d + 1) * 32>(a0, b0, a1, b1, vaddr);
         u32x4_t v0 = {a0[0], a0[1], b0[0], b0[1]}, v1 = {a1[0], a1[1], b1[0], b1[1]};
-        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, v0), __builtin_bit_cast(bf16x8_t, pf[kk]), o[d], 0, 0, 0);
-        o[d + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, v1), __builtin_bit_cast(bf16x8_t, pf[kk]), o[d + 1], 0, 0, 0);
+        o[d] = ATS_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, v0), __builtin_bit_cast(bf16x8_t, pf[kk]), o[d]);
+        o[d + 1] = ATS_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, v1), __builtin_bit_cast(bf16x8_t, pf[kk]), o[d + 1]);
       };
       pv_pair(std::integral_constant<int, 0>{}); pv_pair(std::integral_constant<int, 2>{});
       if constexpr (DT == 8) { pv_pair(std::integral_constant<int, 4>{}); pv_pair(std::integral_constant<int, 6>{}); }
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn32_kernel(const bf16_t* _
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         s16x8_t kf = *reinterpret_cast<const s16x8_t*>(ks_lds + kpos(b * 32 + lc, ks * 2 + hi));
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ks]), sc, 0, 0, 0);
+        sc = ATS_MFMA_32x32x16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ks]), sc);
       }
       // softmax in the log2 domain (one v_exp_f32 per score); the VALU work per score is what bounds this kernel, not the MFMAs:
       // masks from a pre-shifted word with compile-time bit positions, hardware bf16 packing, rescale of O only when a maximum moved
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn32_kernel(const bf16_t* _
         const float p0 = __builtin_amdgcn_exp2f(sc[i] - m_sub), p1 = __builtin_amdgcn_exp2f(sc[i + 1] - m_sub);
         psum += p0 + p1;
         unsigned pk;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(p0), "v"(p1));
+        asm(ATS_CVT_PK_NAME " %0, %1, %2" : "=v"(pk) : "v"(p0), "v"(p1));
         pf[i >> 3][(i & 7) >> 1] = pk;
       }
       if (__ballot(m_new != m_run) != 0ull) {          // wave-uniform: some query's maximum moved
@@ -507,8 +509,8 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn32_kernel(const bf16_t* _
           else if (t == 2) tr_read_2pairs<2 * 16 * VROW + d * 64, (2 * 16 + 8) * VROW + d * 64, 2 * 16 * VROW + (d + 1) * 64, (2 * 16 + 8) * VROW + (d + 1) * 64>(a0, b0, a1, b1, vaddr);
           else             tr_read_2pairs<3 * 16 * VROW + d * 64, (3 * 16 + 8) * VROW + d * 64, 3 * 16 * VROW + (d + 1) * 64, (3 * 16 + 8) * VROW + (d + 1) * 64>(a0, b0, a1, b1, vaddr);
           u32x4_t v0 = {a0[0], a0[1], b0[0], b0[1]}, v1 = {a1[0], a1[1], b1[0], b1[1]};
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, v0), __builtin_bit_cast(bf16x8_t, pf[tt]), o[d], 0, 0, 0);
-          o[d + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, v1), __builtin_bit_cast(bf16x8_t, pf[tt]), o[d + 1], 0, 0, 0);
+          o[d] = ATS_MFMA_32x32x16(__builtin_bit_cast(bf16x8_t, v0), __builtin_bit_cast(bf16x8_t, pf[tt]), o[d]);
+          o[d + 1] = ATS_MFMA_32x32x16(__builtin_bit_cast(bf16x8_t, v1), __builtin_bit_cast(bf16x8_t, pf[tt]), o[d + 1]);
         };
         pv_pair(std::integral_constant<int, 0>{});
         if constexpr (DB == 4) pv_pair(std::integral_constant<int, 2>{});
@@ -535,13 +537,13 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn32_kernel(const bf16_t* _
 int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const SegTable* dt, size_t layer_off_bytes, int vis_words,
                             void* out, int ldo, int n_heads, int head_dim, int dtype, hipStream_t st, int rows_per_wave, int pk) {
   if (t.total_tok <= 0) return ATSPEED_OK;
-  ATS_REQUIRE(!pk || (dtype == ATSPEED_BF16 && ldo % 32 == 0), ATSPEED_ERR_INVALID, "attention: packed output needs bf16 and ldo %% 32 == 0");
+  ATS_REQUIRE(!pk || (dtype == ATS_HALF && ldo % 32 == 0), ATSPEED_ERR_INVALID, "attention: packed output needs bf16 and ldo %% 32 == 0");
   ATS_REQUIRE(head_dim % 8 == 0 && head_dim <= 256, ATSPEED_ERR_INVALID, "attention: head_dim %d unsupported", head_dim);
   ATS_REQUIRE(vis_words * 64 <= kMaxSlots, ATSPEED_ERR_CAPACITY, "attention: visibility bitset too wide (%d words)", vis_words);
   for (int i = 0; i < t.n; ++i)
     ATS_REQUIRE(t.seg[i].n_slots <= vis_words * 64, ATSPEED_ERR_CAPACITY, "attention: %d slots exceed the visibility bitset", t.seg[i].n_slots);
   float scale = 1.0f / sqrtf((float)head_dim);
-  if (dtype == ATSPEED_BF16 && (head_dim == 64 || head_dim == 128) && (ldq % 8) == 0 && (ldo % 4) == 0) {
+  if (dtype == ATS_HALF && (head_dim == 64 || head_dim == 128) && (ldq % 8) == 0 && (ldo % 4) == 0) {
     dim3 mgrid(t.n_qtiles * n_heads);
     ATS_REQUIRE(t.qtile_rows == 64 || t.qtile_rows == 128 || t.qtile_rows == 256, ATSPEED_ERR_INVALID, "attention: query tile of %d rows", t.qtile_rows);
     static const int rows32 = getenv("ATSPEED_ATTN32") ? atoi(getenv("ATSPEED_ATTN32")) : 1;
@@ -641,12 +643,15 @@ int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* v
   return ats_tree_attention_segs(q, ldq, t, (const SegTable*)dt, 0, vis_words, out, ldo, n_heads, head_dim, dtype, st, rows_per_wave, 0);
 }
 
+}  // namespace ATS_NS
+
+#ifndef ATS_F16_FLAVOUR          // the C ABI exists once; it picks the flavour by the dtype code
 extern "C" int atspeed_tree_attention(const void* q, int32_t ldq, const void* kcache, const void* vcache,
                                       const uint64_t* vis, int32_t vis_words, void* out, int32_t n_tokens,
                                       int32_t n_slots, int32_t n_heads, int32_t head_dim, int32_t dtype, void* stream) {
   ATS_REQUIRE(q && kcache && vcache && vis && out, ATSPEED_ERR_INVALID, "attention: null argument");
-  return ats_tree_attention(q, ldq, kcache, vcache, vis, vis_words, out, n_heads * head_dim, n_tokens, n_slots, n_heads,
-                            head_dim, dtype, (hipStream_t)stream, 0, 0);
+  return ATS_KD(dtype, ats_tree_attention(q, ldq, kcache, vcache, vis, vis_words, out, n_heads * head_dim, n_tokens, n_slots, n_heads,
+                            head_dim, dtype, (hipStream_t)stream, 0, 0));
 }
 
 extern "C" int atspeed_tree_attention_tiled(const void* q, int32_t ldq, const void* kcache, const void* vcache,
@@ -654,6 +659,7 @@ extern "C" int atspeed_tree_attention_tiled(const void* q, int32_t ldq, const vo
                                             int32_t n_slots, int32_t n_heads, int32_t head_dim, int32_t dtype, int32_t qtile_rows,
                                             int32_t rows_per_wave, void* stream) {
   ATS_REQUIRE(q && kcache && vcache && vis && out, ATSPEED_ERR_INVALID, "attention: null argument");
-  return ats_tree_attention(q, ldq, kcache, vcache, vis, vis_words, out, n_heads * head_dim, n_tokens, n_slots, n_heads,
-                            head_dim, dtype, (hipStream_t)stream, qtile_rows, rows_per_wave);
+  return ATS_KD(dtype, ats_tree_attention(q, ldq, kcache, vcache, vis, vis_words, out, n_heads * head_dim, n_tokens, n_slots, n_heads,
+                            head_dim, dtype, (hipStream_t)stream, qtile_rows, rows_per_wave));
 }
+#endif

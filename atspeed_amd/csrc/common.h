@@ -7,9 +7,34 @@
 
 #include "../../include/atspeed_hip.h"
 
-typedef unsigned short bf16_t;   // raw bf16 bits
-
+// ---------------------------------------------------------------- the 16-bit flavour of a kernel translation unit
+// The engine computes in fp32, bf16 or fp16 (ATSPEED_F16: the type the reference loads both models in, code/inference.py:75-100).  bf16 and
+// fp16 kernels are the SAME source: gemm.hip, attn.hip and elementwise.hip are compiled twice (Makefile), once per flavour, each into its
+// own namespace (ats_bf16 / ats_f16); what differs is confined to this block -- the element conversions, the MFMA instruction of the type
+// (v_mfma_f32_16x16x32_{bf16,f16}, v_mfma_f32_32x32x16_{bf16,f16}) and the packed conversion (v_cvt_pk_{bf16,f16}_f32).  `bf16_t` and the
+// helper names (bf2f, f2bf, f2bf_pk, bf_lo, bf_hi) keep their names in both flavours: "the engine's 16-bit type".  engine.hip picks the
+// namespace by the model's dtype (ATS_K).
+typedef unsigned short bf16_t;   // raw bits of the flavour's 16-bit type
+#ifdef ATS_F16_FLAVOUR
+#define ATS_NS ats_f16
+#define ATS_HALF ATSPEED_F16
+#define ATS_MFMA_16x16x32_NAME "v_mfma_f32_16x16x32_f16"
+#define ATS_CVT_PK_NAME "v_cvt_pk_f16_f32"
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8_t;
+#define ATS_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define ATS_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#else
+#define ATS_NS ats_bf16
+#define ATS_HALF ATSPEED_BF16
+#define ATS_MFMA_16x16x32_NAME "v_mfma_f32_16x16x32_bf16"
+#define ATS_CVT_PK_NAME "v_cvt_pk_bf16_f32"
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+#define ATS_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define ATS_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+// a call of a flavoured internal function, by dtype code: ATS_KD(dt, ats_gemm(...)) -> ats_f16::ats_gemm(...) or ats_bf16::ats_gemm(...)
+// (the bf16 build also holds the fp32 parity kernels)
+#define ATS_KD(dtype, call) ((dtype) == ATSPEED_F16 ? ats_f16::call : ats_bf16::call)
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // 16-byte register value as an SSA vector: HIP's uint4 STRUCT in a register ring ended up in scratch (hipcc 7.2)
@@ -92,12 +117,24 @@ __host__ __device__ inline uint32_t ats_rng_sub(uint32_t seed, int purpose, int 
 #if defined(__HIPCC__)
 __device__ __forceinline__ float ats_u01(uint32_t h) { return ((float)(h >> 9) + 0.5f) * 1.1920928955078125e-07f; }   // (k + 1/2) 2^-23, exact
 __device__ __forceinline__ float ats_gumbel(uint32_t h) { return -logf(-logf(ats_u01(h))); }
+typedef __attribute__((ext_vector_type(2))) float ats_f32x2_t;
+#ifdef ATS_F16_FLAVOUR
+// fp16 flavour: hardware conversions both ways (v_cvt_f32_f16 / v_cvt_f16_f32, round to nearest even; v_cvt_pk_f16_f32 for pairs on gfx950)
+typedef __attribute__((ext_vector_type(2))) _Float16 ats_bf16x2_t;
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
+  ats_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ats_bf16x2_t));
+}
+__device__ __forceinline__ float bf_lo(uint32_t pk) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(pk & 0xffffu)); }
+__device__ __forceinline__ float bf_hi(uint32_t pk) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(pk >> 16)); }
+#else
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round to nearest even in hardware (v_cvt_pk_bf16_f32 on gfx950: the compiler pairs neighbouring conversions); the six-instruction
 // integer form this replaces was a sixth of the ring GEMM's epilogue and most of the attention softmax's VALU work
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 // two values -> one packed register (low half = lo); and the two values back as floats (a bf16 is the high half of its fp32)
-typedef __attribute__((ext_vector_type(2))) float ats_f32x2_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 ats_bf16x2_t;
 __device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
   ats_f32x2_t v = {lo, hi};
@@ -105,6 +142,7 @@ __device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
 }
 __device__ __forceinline__ float bf_lo(uint32_t pk) { return __uint_as_float(pk << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t pk) { return __uint_as_float(pk & 0xffff0000u); }
+#endif
 // SiLU.  bf16 engine (EXACT = false): the quotient through the hardware reciprocal (v_rcp_f32, 1 ulp of fp32 -- far below the bf16 rounding that
 // follows); the correctly rounded fp32 division is a ten-instruction sequence and made the ring GEMM's SwiGLU epilogue VALU-bound (64 outputs per
 // thread).  fp32 engine (parity mode): the exact quotient.

@@ -2,6 +2,8 @@
 // RoPE + KV scatter.  All HBM-bound: 16-byte coalesced accesses, wave64 reductions.
 #include "internal.h"
 
+namespace ATS_NS {
+
 // ---------------------------------------------------------------------------- fill
 __device__ __forceinline__ uint32_t hash_u32(uint32_t idx, uint32_t seed) { return ats_hash_u32(idx, seed); }
 
@@ -20,20 +22,6 @@ __global__ void fill_hash_normal_kernel(T* dst, size_t n, uint32_t seed, float s
   }
 }
 
-extern "C" int atspeed_fill_hash_normal(void* dst, size_t n, uint32_t seed, float scale, float add, int dtype,
-                                        uint64_t offset, void* stream) {
-  ATS_REQUIRE(dst && (dtype == ATSPEED_F32 || dtype == ATSPEED_BF16), ATSPEED_ERR_INVALID, "fill: bad arguments");
-  if (n == 0) return ATSPEED_OK;
-  size_t blocks = (n + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == ATSPEED_F32)
-    fill_hash_normal_kernel<float><<<(unsigned)blocks, 256, 0, st>>>((float*)dst, n, seed, scale, add, offset);
-  else
-    fill_hash_normal_kernel<bf16_t><<<(unsigned)blocks, 256, 0, st>>>((bf16_t*)dst, n, seed, scale, add, offset);
-  ATS_LAUNCH_CHECK();
-  return ATSPEED_OK;
-}
 
 // ---------------------------------------------------------------------------- embed
 // one 16-byte chunk per thread; a token row is hidden*sizeof(T) contiguous bytes
@@ -179,8 +167,8 @@ int ats_rmsnorm_quant_fp8(const void* x, const void* w, void* y, void* q, float*
 
 int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, float eps, int dtype, hipStream_t st, int pk) {
   if (rows <= 0) return ATSPEED_OK;
-  ATS_REQUIRE(!pk || (dtype == ATSPEED_BF16 && hidden % 32 == 0), ATSPEED_ERR_INVALID, "rmsnorm: packed output needs bf16 and hidden %% 32 == 0");
-  const bool vec_ok = dtype == ATSPEED_BF16 && hidden % 8 == 0 && hidden <= 8192 &&
+  ATS_REQUIRE(!pk || (dtype == ATS_HALF && hidden % 32 == 0), ATSPEED_ERR_INVALID, "rmsnorm: packed output needs bf16 and hidden %% 32 == 0");
+  const bool vec_ok = dtype == ATS_HALF && hidden % 8 == 0 && hidden <= 8192 &&
                       (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0;
   if (vec_ok) {
     const bf16_t *xb = (const bf16_t*)x, *wb = (const bf16_t*)w;
@@ -199,17 +187,7 @@ int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, flo
   return ATSPEED_OK;
 }
 
-extern "C" int atspeed_rmsnorm_quant_fp8(const void* x, const void* w, void* y, void* q, float* scale, int32_t rows, int32_t hidden,
-                                         float eps, void* stream) {
-  ATS_REQUIRE(x && w && q && scale && hidden > 0, ATSPEED_ERR_INVALID, "rmsnorm_quant_fp8: bad arguments");
-  return ats_rmsnorm_quant_fp8(x, w, y, q, scale, rows, hidden, eps, (hipStream_t)stream, 0);
-}
 
-extern "C" int atspeed_rmsnorm(const void* x, const void* w, void* y, int32_t rows, int32_t hidden, float eps,
-                               int32_t dtype, void* stream) {
-  ATS_REQUIRE(x && w && y && hidden > 0, ATSPEED_ERR_INVALID, "rmsnorm: bad arguments");
-  return ats_rmsnorm(x, w, y, rows, hidden, eps, dtype, (hipStream_t)stream, 0);
-}
 
 // ---------------------------------------------------------------------------- rope + kv scatter
 // rotate-half convention of HF Llama: pairs (i, i + dh/2); cos/sin tables [max_pos][dh/2] fp32.
@@ -458,7 +436,7 @@ int ats_rope_kv_segs_slabs(const float* qkv_slabs, int splits, void* qkv, const 
 
 int ats_rope_kv_segs(void* qkv, const SegTable& t, const SegTable* dt, const float* cos_tab, const float* sin_tab, size_t layer_off_bytes,
                      int n_heads, int head_dim, int max_pos, int dtype, hipStream_t st) {
-  if (dtype == ATSPEED_BF16 && head_dim % 16 == 0) {
+  if (dtype == ATS_HALF && head_dim % 16 == 0) {
     int totalv = t.total_tok * n_heads * (head_dim / 16);
     if (totalv <= 0) return ATSPEED_OK;
     rope_kv_segs_vec_kernel<<<(totalv + 255) / 256, 256, 0, st>>>((bf16_t*)qkv, dt, cos_tab, sin_tab, layer_off_bytes, n_heads, head_dim, max_pos);
@@ -602,15 +580,7 @@ int ats_quant_rows_fp8(const void* x, int rows, int cols, int ld, void* q, float
   return ATSPEED_OK;
 }
 
-extern "C" int atspeed_quant_rows_fp8(const void* x, int32_t rows, int32_t cols, void* q, float* scale, void* stream) {
-  ATS_REQUIRE(x && q && scale, ATSPEED_ERR_INVALID, "quant_fp8: null argument");
-  return ats_quant_rows_fp8(x, rows, cols, cols, q, scale, (hipStream_t)stream, 0);
-}
 
-extern "C" int atspeed_quant_rows_fp8_packed(const void* x, int32_t rows, int32_t cols, void* q, float* scale, void* stream) {
-  ATS_REQUIRE(x && q && scale, ATSPEED_ERR_INVALID, "quant_fp8: null argument");
-  return ats_quant_rows_fp8(x, rows, cols, cols, q, scale, (hipStream_t)stream, 1);
-}
 
 
 // ---------------------------------------------------------------------------- packed operand layout (common.h: ats_pk_byte)
@@ -637,9 +607,53 @@ int ats_pack_rows(const void* src, void* dst, int rows, int row_bytes, int to_pa
   return ATSPEED_OK;
 }
 
+int ats_fill_hash_normal(void* dst, size_t n, uint32_t seed, float scale, float add, int dtype, uint64_t offset, hipStream_t st) {
+  ATS_REQUIRE(dst && (dtype == ATSPEED_F32 || dtype == ATS_HALF), ATSPEED_ERR_INVALID, "fill: bad arguments");
+  if (n == 0) return ATSPEED_OK;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == ATSPEED_F32)
+    fill_hash_normal_kernel<float><<<(unsigned)blocks, 256, 0, st>>>((float*)dst, n, seed, scale, add, offset);
+  else
+    fill_hash_normal_kernel<bf16_t><<<(unsigned)blocks, 256, 0, st>>>((bf16_t*)dst, n, seed, scale, add, offset);
+  ATS_LAUNCH_CHECK();
+  return ATSPEED_OK;
+}
+
+}  // namespace ATS_NS
+
+#ifndef ATS_F16_FLAVOUR          // the C ABI exists once; it picks the flavour by the dtype code (fp8 entry points: bf16 input)
+extern "C" int atspeed_fill_hash_normal(void* dst, size_t n, uint32_t seed, float scale, float add, int dtype,
+                                        uint64_t offset, void* stream) {
+  return ATS_KD(dtype, ats_fill_hash_normal(dst, n, seed, scale, add, dtype, offset, (hipStream_t)stream));
+}
+
+extern "C" int atspeed_rmsnorm_quant_fp8(const void* x, const void* w, void* y, void* q, float* scale, int32_t rows, int32_t hidden,
+                                         float eps, void* stream) {
+  ATS_REQUIRE(x && w && q && scale && hidden > 0, ATSPEED_ERR_INVALID, "rmsnorm_quant_fp8: bad arguments");
+  return ats_bf16::ats_rmsnorm_quant_fp8(x, w, y, q, scale, rows, hidden, eps, (hipStream_t)stream, 0);
+}
+
+extern "C" int atspeed_rmsnorm(const void* x, const void* w, void* y, int32_t rows, int32_t hidden, float eps,
+                               int32_t dtype, void* stream) {
+  ATS_REQUIRE(x && w && y && hidden > 0, ATSPEED_ERR_INVALID, "rmsnorm: bad arguments");
+  return ATS_KD(dtype, ats_rmsnorm(x, w, y, rows, hidden, eps, dtype, (hipStream_t)stream, 0));
+}
+
+extern "C" int atspeed_quant_rows_fp8(const void* x, int32_t rows, int32_t cols, void* q, float* scale, void* stream) {
+  ATS_REQUIRE(x && q && scale, ATSPEED_ERR_INVALID, "quant_fp8: null argument");
+  return ats_bf16::ats_quant_rows_fp8(x, rows, cols, cols, q, scale, (hipStream_t)stream, 0);
+}
+
+extern "C" int atspeed_quant_rows_fp8_packed(const void* x, int32_t rows, int32_t cols, void* q, float* scale, void* stream) {
+  ATS_REQUIRE(x && q && scale, ATSPEED_ERR_INVALID, "quant_fp8: null argument");
+  return ats_bf16::ats_quant_rows_fp8(x, rows, cols, cols, q, scale, (hipStream_t)stream, 1);
+}
+
 extern "C" int atspeed_pack_rows(const void* src, void* dst, int32_t rows, int32_t row_bytes, void* stream) {
-  return ats_pack_rows(src, dst, rows, row_bytes, 1, (hipStream_t)stream);
+  return ats_bf16::ats_pack_rows(src, dst, rows, row_bytes, 1, (hipStream_t)stream);       // bytes only: no flavour
 }
 extern "C" int atspeed_unpack_rows(const void* src, void* dst, int32_t rows, int32_t row_bytes, void* stream) {
-  return ats_pack_rows(src, dst, rows, row_bytes, 0, (hipStream_t)stream);
+  return ats_bf16::ats_pack_rows(src, dst, rows, row_bytes, 0, (hipStream_t)stream);
 }
+#endif

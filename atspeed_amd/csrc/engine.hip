@@ -275,11 +275,11 @@ struct ProfBracket {
 static size_t gemm_ws_for(const atspeed_llama_config& c, int max_tok, int max_rows) {
   size_t best = 0;
   for (int m = 1; m <= max_tok; ++m) {          // the split-K plan depends on the exact M: take the true maximum
-    best = std::max(best, ats_gemm_workspace_bytes(m, 3 * c.hidden, c.hidden, c.dtype));
-    best = std::max(best, ats_gemm_workspace_bytes(m, c.hidden, c.hidden, c.dtype));
-    best = std::max(best, ats_gemm_workspace_bytes(m, 2 * c.ffn, c.hidden, c.dtype));
-    best = std::max(best, ats_gemm_workspace_bytes(m, c.hidden, c.ffn, c.dtype));
-    if (m <= max_rows) best = std::max(best, ats_gemm_workspace_bytes(m, c.vocab_size, c.hidden, c.dtype));
+    best = std::max(best, ATS_KD(c.dtype, ats_gemm_workspace_bytes(m, 3 * c.hidden, c.hidden, c.dtype)));
+    best = std::max(best, ATS_KD(c.dtype, ats_gemm_workspace_bytes(m, c.hidden, c.hidden, c.dtype)));
+    best = std::max(best, ATS_KD(c.dtype, ats_gemm_workspace_bytes(m, 2 * c.ffn, c.hidden, c.dtype)));
+    best = std::max(best, ATS_KD(c.dtype, ats_gemm_workspace_bytes(m, c.hidden, c.ffn, c.dtype)));
+    if (m <= max_rows) best = std::max(best, ATS_KD(c.dtype, ats_gemm_workspace_bytes(m, c.vocab_size, c.hidden, c.dtype)));
   }
   return best + (1 << 20);
 }
@@ -317,7 +317,7 @@ static int ensure_act(atspeed_llama* m, int tok, int rows) {
   ATS_HIP(hipMalloc((void**)&cx->logits, (size_t)cx->cap_rows * m->logits_ld * sizeof(float)));
   ATS_HIP(hipMalloc((void**)&cx->lse, (size_t)cx->cap_rows * sizeof(float)));
   ATS_HIP(hipMalloc((void**)&cx->row_cand, (size_t)cx->cap_rows * ATSPEED_MAX_BEAMS * sizeof(int32_t)));
-  cx->lse_part_bytes = ats_lmhead_lse_part_bytes(cx->cap_rows, c.vocab_size);
+  cx->lse_part_bytes = ats_bf16::ats_lmhead_lse_part_bytes(cx->cap_rows, c.vocab_size);
   ATS_HIP(hipMalloc((void**)&cx->lse_part, cx->lse_part_bytes));
   ATS_HIP(hipMalloc(&cx->xq, T * (size_t)std::max(c.hidden, c.ffn)));
   ATS_HIP(hipMalloc((void**)&cx->sx, T * sizeof(float)));
@@ -435,12 +435,12 @@ extern "C" int atspeed_llama_profile_big(atspeed_llama* m, double* ms_out, int64
 extern "C" int atspeed_lmhead_lse(const void* x, const void* w, float* logits, float* lse, int32_t rows, int32_t vocab, int32_t hidden, int32_t ld,
                                   const atspeed_fsm* fsm, void* workspace, size_t workspace_bytes, int32_t* fused_out, void* stream) {
   ATS_REQUIRE(x && w && logits && lse && rows >= 0 && vocab > 0 && hidden > 0 && ld >= vocab, ATSPEED_ERR_INVALID, "lmhead_lse: bad arguments");
-  const size_t pb = ats_lmhead_lse_part_bytes(rows, vocab);
+  const size_t pb = ats_bf16::ats_lmhead_lse_part_bytes(rows, vocab);
   const bool have = workspace && workspace_bytes >= pb && ((uintptr_t)workspace & 15) == 0;
   char* rest = have ? (char*)workspace + (pb + 255) / 256 * 256 : (char*)workspace;
   const size_t rest_bytes = have ? (workspace_bytes > (pb + 255) / 256 * 256 ? workspace_bytes - (pb + 255) / 256 * 256 : 0) : workspace_bytes;
   int fused = 0;
-  const int rc = ats_lmhead_lse(x, w, logits, rows, vocab, hidden, hidden, ld, ATSPEED_BF16, fsm ? fsm->d_tile_store : nullptr, have ? (float*)workspace : nullptr,
+  const int rc = ats_bf16::ats_lmhead_lse(x, w, logits, rows, vocab, hidden, hidden, ld, ATSPEED_BF16, fsm ? fsm->d_tile_store : nullptr, have ? (float*)workspace : nullptr,
                                 have ? pb : 0, lse, rest, rest_bytes, (hipStream_t)stream, &fused);
   if (fused_out) *fused_out = fused;
   return rc;
@@ -476,7 +476,7 @@ extern "C" int atspeed_llama_enable_fp8(atspeed_llama* m, void* stream) {
   auto quant = [&](const void* w, int rows, int cols, void** q, float** sc) -> int {     // packed bf16 rows -> packed e4m3 rows (or row-major both)
     ATS_HIP(hipMalloc(q, (size_t)((rows + 1) & ~1) * cols));
     ATS_HIP(hipMalloc((void**)sc, (size_t)rows * sizeof(float)));
-    return ats_quant_rows_fp8(w, rows, cols, cols, *q, *sc, st, m->pk);
+    return ats_bf16::ats_quant_rows_fp8(w, rows, cols, cols, *q, *sc, st, m->pk);
   };
   m->fp8.resize(m->cfg.n_layers);
   for (int l = 0; l < m->cfg.n_layers; ++l) {
@@ -489,15 +489,6 @@ extern "C" int atspeed_llama_enable_fp8(atspeed_llama* m, void* stream) {
   }
   ATS_HIP(hipStreamSynchronize(st));
   return ATSPEED_OK;
-}
-
-// fp8 projection when enabled and the shape is on the batched path: quantise the activations per token, then W8A8 GEMM
-// x == nullptr: cx->xq / cx->sx already hold the quantised activations (written by the fused RMSNorm)
-static int proj_fp8(atspeed_llama* m, const void* x, const void* wq, const float* sw, void* out, int M, int N, int K, int ldc,
-                    int epi, hipStream_t st) {
-  ActCtx* cx = m->act;
-  if (x) ATS_TRY(ats_quant_rows_fp8(x, M, K, K, cx->xq, cx->sx, st, m->pk));
-  return ats_gemm_fp8(cx->xq, cx->sx, wq, sw, out, M, N, K, ldc, epi, st, m->pk);
 }
 
 // One forward over the tokens of every segment (user) of the table.  Logits of each segment's last n_logit rows land
@@ -555,108 +546,18 @@ static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits
   return llama_forward_body(m, t, dtab, logits_out, st, logits_out ? nullptr : tile_store);
 }
 
-// the launches of one forward (also the body of a captured graph: no allocation, no synchronisation, no staging in here)
+namespace fwd_bf16 {
+using namespace ats_bf16;
+#include "engine_forward.inc"
+}
+namespace fwd_f16 {
+using namespace ats_f16;
+#include "engine_forward.inc"
+}
 static int llama_forward_body(atspeed_llama* m, const SegTable& t, const SegTable* dtab, float* logits_out, hipStream_t st,
                               const unsigned char* tile_store) {
-  const atspeed_llama_config& c = m->cfg;
-  ActCtx* cx = m->act;
-  const int T = t.total_tok;
-  const int H = c.hidden, dt = c.dtype, pk = m->pk;
-  ATS_TRY(ats_embed_segs(m->embed, t, dtab, cx->h, H, c.vocab_size, dt, st));
-  // fp8 projections fed by an RMSNorm take their e4m3 rows + scales straight from the norm kernel (no quantisation pass, no bf16 xn)
-  const bool f8_qkv = !m->fp8.empty() && H <= 8192 && ats_gemm_fp8_applies(T, 3 * H, H, 3 * H, EPI_STORE);
-  const bool f8_gu = !m->fp8.empty() && H <= 8192 && ats_gemm_fp8_applies(T, 2 * c.ffn, H, c.ffn, EPI_SWIGLU);
-  bool xq_ready = false;
-  if (f8_qkv) { ATS_TRY(ats_rmsnorm_quant_fp8(cx->h, m->layers[0].input_norm, nullptr, cx->xq, cx->sx, T, H, c.rms_eps, st, pk)); xq_ready = true; }
-  else ATS_TRY(ats_rmsnorm(cx->h, m->layers[0].input_norm, cx->xn, T, H, c.rms_eps, dt, st, pk));
-  // batched bf16 forwards: RoPE and the KV scatter ride in the qkv projection's epilogue (one pass over qkv less per layer)
-  const bool qkv_in_fp8 = !m->fp8.empty() && ats_gemm_fp8_applies(T, 3 * H, H, 3 * H, EPI_STORE);
-  const bool qkv_rope_fused = qkv_in_fp8 ? ats_gemm_fp8_qkv_rope_applies(T, H, m->head_dim) : ats_gemm_qkv_rope_applies(T, H, m->head_dim, dt);
-  if (qkv_rope_fused) ATS_TRY(ats_row_info(t, dtab, cx->rowinfo, c.max_slots, st));
-  for (int l = 0; l < c.n_layers; ++l) {
-    const atspeed_llama_layer_weights& w = m->layers[l];
-    const size_t loff = (size_t)l * m->layer_kv_bytes;
-    // cx->xn holds rmsnorm(h) * input_norm here (from the embed above or the previous layer's fused down_proj epilogue)
-    const bool f8 = !m->fp8.empty();
-    static const bool fuse_qkv_reduce = !(getenv("ATSPEED_FUSE_QKV_REDUCE") && atoi(getenv("ATSPEED_FUSE_QKV_REDUCE")) == 0);
-    int qkv_splits = 0;
-    { ProfBracket pb(m, 0, T, st);
-      if (qkv_in_fp8) {
-        m->fp8_cnt[0]++;
-        if (qkv_rope_fused) {
-          m->rope_fused_cnt++;
-          if (!xq_ready) ATS_TRY(ats_quant_rows_fp8(cx->xn, T, H, H, cx->xq, cx->sx, st, pk));
-          ATS_TRY(ats_gemm_fp8_qkv_rope(cx->xq, cx->sx, m->fp8[l].wqkv, m->fp8[l].sqkv, cx->qkv, T, H,
-                                        RopeEpi{cx->rowinfo, m->cos_tab, m->sin_tab, loff, H}, st, pk));
-        } else ATS_TRY(proj_fp8(m, xq_ready ? nullptr : cx->xn, m->fp8[l].wqkv, m->fp8[l].sqkv, cx->qkv, T, 3 * H, H, 3 * H, EPI_STORE, st));
-      } else if (qkv_rope_fused) {
-        m->other_cnt[0]++; m->rope_fused_cnt++;
-        ATS_TRY(ats_gemm_qkv_rope(cx->xn, w.wqkv, cx->qkv, T, H, RopeEpi{cx->rowinfo, m->cos_tab, m->sin_tab, loff, H}, st, pk));
-      } else {
-        m->other_cnt[0]++;
-        // one user's forward: the projection leaves fp32 split-K slabs and RoPE sums them itself (one launch less per layer)
-        if (fuse_qkv_reduce && m->head_dim % 16 == 0) ATS_TRY(ats_gemm_partials(cx->xn, w.wqkv, T, 3 * H, H, H, dt, cx->ws, cx->ws_bytes, st, &qkv_splits, pk));
-        if (qkv_splits == 0) ATS_TRY(ats_gemm(cx->xn, w.wqkv, cx->qkv, T, 3 * H, H, H, 3 * H, dt, EPI_STORE, cx->ws, cx->ws_bytes, st, pk));
-      } }
-    if (qkv_rope_fused) {}
-    else if (qkv_splits > 0)
-      ATS_TRY(ats_rope_kv_segs_slabs((const float*)cx->ws, qkv_splits, cx->qkv, t, dtab, m->cos_tab, m->sin_tab, loff, c.n_heads, m->head_dim, c.max_slots, st));
-    else
-      ATS_TRY(ats_rope_kv_segs(cx->qkv, t, dtab, m->cos_tab, m->sin_tab, loff, c.n_heads, m->head_dim, c.max_slots, dt, st));
-    ATS_TRY(ats_tree_attention_segs(cx->qkv, 3 * H, t, dtab, loff, m->vis_words, cx->att, H, c.n_heads, m->head_dim, dt, st, 0, pk));
-    { ProfBracket pb(m, 1, T, st);     // h += att Wo^T ; xn = rmsnorm(h) * post_norm
-      if (f8 && ats_gemm_fp8_applies(T, H, H, H, EPI_RESID)) {
-        m->fp8_cnt[1]++;
-        ATS_TRY(proj_fp8(m, cx->att, m->fp8[l].wo, m->fp8[l].so, cx->h, T, H, H, H, EPI_RESID, st));
-        if (f8_gu) { ATS_TRY(ats_rmsnorm_quant_fp8(cx->h, w.post_norm, nullptr, cx->xq, cx->sx, T, H, c.rms_eps, st, pk)); xq_ready = true; }
-        else { ATS_TRY(ats_rmsnorm(cx->h, w.post_norm, cx->xn, T, H, c.rms_eps, dt, st, pk)); xq_ready = false; }
-      } else {
-        m->other_cnt[1]++;
-        ATS_TRY(ats_gemm_resid_norm(cx->att, w.wo, cx->h, T, H, H, H, H, dt, w.post_norm, cx->xn, c.rms_eps, cx->ws, cx->ws_bytes, st, pk));
-        xq_ready = false;
-      } }
-    { ProfBracket pb(m, 2, T, st);
-      if (f8 && ats_gemm_fp8_applies(T, 2 * c.ffn, H, c.ffn, EPI_SWIGLU)) {
-        m->fp8_cnt[2]++;
-        ATS_TRY(proj_fp8(m, xq_ready ? nullptr : cx->xn, m->fp8[l].wgu, m->fp8[l].sgu, cx->act, T, 2 * c.ffn, H, c.ffn, EPI_SWIGLU, st));
-      } else {
-        m->other_cnt[2]++;
-        ATS_TRY(ats_gemm(cx->xn, w.wgu, cx->act, T, 2 * c.ffn, H, H, c.ffn, dt, EPI_SWIGLU, cx->ws, cx->ws_bytes, st, pk));
-      } }
-    { ProfBracket pb(m, 3, T, st);     // h += act Wd^T ; xn = rmsnorm(h) * next layer's input_norm
-      m->fp8_cnt[3] += (f8 && ats_gemm_fp8_applies(T, H, c.ffn, H, EPI_RESID)) ? 1 : 0;
-      m->other_cnt[3] += (f8 && ats_gemm_fp8_applies(T, H, c.ffn, H, EPI_RESID)) ? 0 : 1;
-      if (f8 && ats_gemm_fp8_applies(T, H, c.ffn, H, EPI_RESID)) {
-        ATS_TRY(proj_fp8(m, cx->act, m->fp8[l].wd, m->fp8[l].sd, cx->h, T, H, c.ffn, H, EPI_RESID, st));
-        xq_ready = false;
-        if (l + 1 < c.n_layers) {
-          if (f8_qkv) { ATS_TRY(ats_rmsnorm_quant_fp8(cx->h, m->layers[l + 1].input_norm, nullptr, cx->xq, cx->sx, T, H, c.rms_eps, st, pk)); xq_ready = true; }
-          else ATS_TRY(ats_rmsnorm(cx->h, m->layers[l + 1].input_norm, cx->xn, T, H, c.rms_eps, dt, st, pk));
-        }
-      } else if (l + 1 < c.n_layers) {
-        ATS_TRY(ats_gemm_resid_norm(cx->act, w.wd, cx->h, T, H, c.ffn, c.ffn, H, dt, m->layers[l + 1].input_norm, cx->xn, c.rms_eps,
-                                    cx->ws, cx->ws_bytes, st, pk));
-        xq_ready = false;
-      } else {
-        ATS_TRY(ats_gemm(cx->act, w.wd, cx->h, T, H, c.ffn, c.ffn, H, dt, EPI_RESID, cx->ws, cx->ws_bytes, st, pk));
-      } }
-  }
-  if (t.total_logit > 0) {
-    const int R = t.total_logit;
-    ATS_TRY(ats_gather_logit_rows(cx->h, t, dtab, cx->gath, H, dt, st));
-    ATS_TRY(ats_rmsnorm(cx->gath, m->final_norm, cx->xn, R, H, c.rms_eps, dt, st, pk));
-    float* lo = logits_out ? logits_out : cx->logits;
-    if (tile_store) {      // decoder forwards: logits + full-vocabulary normaliser (beamSD.py:58,285) from ONE kernel where the batch is large enough
-      ProfBracket pb(m, 4, R, st);
-      ATS_TRY(ats_lmhead_lse(cx->xn, m->lm_head, lo, R, c.vocab_size, H, H, m->logits_ld, dt, tile_store, cx->lse_part, cx->lse_part_bytes, cx->lse,
-                             cx->ws, cx->ws_bytes, st, nullptr, pk));
-    } else {
-      { ProfBracket pb(m, 4, R, st);
-        ATS_TRY(ats_gemm(cx->xn, m->lm_head, lo, R, c.vocab_size, H, H, m->logits_ld, dt, EPI_F32, cx->ws, cx->ws_bytes, st, pk)); }
-      ATS_TRY(ats_lse_rows(lo, R, c.vocab_size, m->logits_ld, cx->lse, st));     // beamSD.py:58,285: full-vocab normaliser
-    }
-  }
-  return ATSPEED_OK;
+  return m->cfg.dtype == ATSPEED_F16 ? fwd_f16::llama_forward_body(m, t, dtab, logits_out, st, tile_store)
+                                     : fwd_bf16::llama_forward_body(m, t, dtab, logits_out, st, tile_store);
 }
 
 extern "C" int atspeed_llama_forward(atspeed_llama* m, const int32_t* ids, const int32_t* pos, const int32_t* slots,

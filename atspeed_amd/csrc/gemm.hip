@@ -20,6 +20,8 @@
 
 #include "internal.h"
 
+namespace ATS_NS {
+
 namespace {
 
 static int env_int(const char* name, int dflt);
@@ -222,8 +224,8 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const T* __restrict__ A,
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
-                                                                __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = ATS_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, af[i]),
+                                                                __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j]);
       }
     } else {
 #pragma unroll
@@ -621,8 +623,8 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // tile rows, W-panel-major: the ~32 tiles an XCD runs at once share GM X panels and 8 W panels.
 // Result on MI355X: MFMA pipe 74 % busy at ~1.55 GHz (the chip lowers its clock under this load), 1.15-1.25 PF on the
 // Llama-7B projections at 2-7 k tokens; hipBLASLt's stream-K 256x256x64 kernel reaches 1.05-1.39 PF on the same shapes.
-#define ATS_MFMA_BF16(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
-#define ATS_MFMA_BF16_A(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
+#define ATS_MFMA_BF16(c, a, b) asm volatile(ATS_MFMA_16x16x32_NAME " %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
+#define ATS_MFMA_BF16_A(c, a, b) asm volatile(ATS_MFMA_16x16x32_NAME " %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
 #define ATS_MFMA_FP8(c, a, b) asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
 // (m0 is written here without an "m0" clobber on purpose: m0 is a RESERVED register for LLVM's AMDGPU backend -- it never keeps a value
 // live in it across instructions, it re-materialises m0 glued to each of its own m0 readers -- and hipcc rejects the clobber with
@@ -1611,7 +1613,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const bf16_t* __res
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < MI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[i]), __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = ATS_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, wf[i]), __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j]);
     }
   }
 
@@ -1943,10 +1945,10 @@ int launch_typed(const void* a, const void* w, void* c, int m, int n, int k, int
 }  // namespace
 
 size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype) {
-  Plan p = dtype == ATSPEED_BF16 ? make_plan<bf16_t>(m, n, k) : make_plan<float>(m, n, k);
+  Plan p = dtype == ATS_HALF ? make_plan<bf16_t>(m, n, k) : make_plan<float>(m, n, k);
   size_t b = p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
-  if (dtype == ATSPEED_BF16) b = std::max(b, (size_t)ring_split_count(m, n, k) * m * n * sizeof(float));
-  if (dtype == ATSPEED_BF16) b = std::max(b, (size_t)wdma_split_count(m, n, k, k) * m * n * sizeof(float));
+  if (dtype == ATS_HALF) b = std::max(b, (size_t)ring_split_count(m, n, k) * m * n * sizeof(float));
+  if (dtype == ATS_HALF) b = std::max(b, (size_t)wdma_split_count(m, n, k, k) * m * n * sizeof(float));
   return b;
 }
 
@@ -1958,7 +1960,7 @@ static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype,
 int ats_gemm_partials(const void* a, const void* w, int m, int n, int k, int lda, int dtype, void* workspace, size_t workspace_bytes,
                       hipStream_t st, int* splits_out, int pk) {
   *splits_out = 0;
-  if (dtype != ATSPEED_BF16 || m <= 0 || big_kernel_applies(m, n, k, lda, n, dtype, EPI_STORE)) return ATSPEED_OK;
+  if (dtype != ATS_HALF || m <= 0 || big_kernel_applies(m, n, k, lda, n, dtype, EPI_STORE)) return ATSPEED_OK;
   if (wdma_applies(m, n, k, lda, EPI_STORE)) return ATSPEED_OK;        // the no-split kernel writes bf16 qkv itself: the caller runs ats_gemm + the plain RoPE pass
   {
     const int s = wdma_split_count(m, n, k, lda);
@@ -1984,14 +1986,14 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
   if (m <= 0 || n <= 0) return ATSPEED_OK;
   int epc = dtype == ATSPEED_F32 ? 4 : 8;
   // packed operands (common.h): bf16 only, K and the row strides multiples of one 64-byte k-block, SwiGLU output rows likewise
-  ATS_REQUIRE(!pk || (dtype == ATSPEED_BF16 && k % 32 == 0 && lda == k && (epilogue != EPI_SWIGLU || ldc % 32 == 0)), ATSPEED_ERR_INVALID,
+  ATS_REQUIRE(!pk || (dtype == ATS_HALF && k % 32 == 0 && lda == k && (epilogue != EPI_SWIGLU || ldc % 32 == 0)), ATSPEED_ERR_INVALID,
               "gemm: packed operands need bf16, K %% 32 == 0, lda == K (K=%d lda=%d ldc=%d)", k, lda, ldc);
   ATS_REQUIRE(a && w && c && k > 0, ATSPEED_ERR_INVALID, "gemm: null operand");
   ATS_REQUIRE(k % epc == 0 && lda % epc == 0, ATSPEED_ERR_INVALID, "gemm: K=%d / lda=%d must be multiples of %d", k, lda, epc);
   ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "gemm: operands must be 16-byte aligned");
   ATS_REQUIRE(epilogue != EPI_SWIGLU || n % 32 == 0, ATSPEED_ERR_INVALID, "gemm: SwiGLU needs N %% 32 == 0 (N=%d)", n);
   if (dtype == ATSPEED_F32) return launch_typed<float>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st, 0);
-  if (dtype == ATSPEED_BF16) {
+  if (dtype == ATS_HALF) {
     if (big_kernel_applies(m, n, k, lda, ldc, dtype, epilogue)) {
       const bf16_t* X = (const bf16_t*)a; const bf16_t* Wt = (const bf16_t*)w;
       switch (epilogue) {
@@ -2009,12 +2011,12 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
 
 bool ats_gemm_qkv_rope_applies(int m, int hidden, int head_dim, int dtype) {
   const char* e = getenv("ATSPEED_FUSE_QKV_ROPE");                 // read per forward: tests compare both paths in one process
-  return !(e && atoi(e) == 0) && dtype == ATSPEED_BF16 && head_dim == 128 && hidden % 256 == 0 && big_kernel_applies(m, 3 * hidden, hidden, hidden, 3 * hidden, dtype, EPI_STORE);
+  return !(e && atoi(e) == 0) && dtype == ATS_HALF && head_dim == 128 && hidden % 256 == 0 && big_kernel_applies(m, 3 * hidden, hidden, hidden, 3 * hidden, dtype, EPI_STORE);
 }
 
 int ats_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, int m, int hidden, const RopeEpi& rope, hipStream_t st, int pk) {
   ATS_REQUIRE(x && wqkv && qkv && rope.rows && rope.cos_tab && rope.sin_tab && rope.hidden == hidden, ATSPEED_ERR_INVALID, "gemm_qkv_rope: null / inconsistent argument");
-  ATS_REQUIRE(hidden % 256 == 0 && big_kernel_applies(m, 3 * hidden, hidden, hidden, 3 * hidden, ATSPEED_BF16, EPI_STORE), ATSPEED_ERR_INVALID,
+  ATS_REQUIRE(hidden % 256 == 0 && big_kernel_applies(m, 3 * hidden, hidden, hidden, 3 * hidden, ATS_HALF, EPI_STORE), ATSPEED_ERR_INVALID,
               "gemm_qkv_rope: shape %d x %d is not the batched kernel's", m, hidden);
   ATS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wqkv & 15) == 0 && ((uintptr_t)qkv & 15) == 0, ATSPEED_ERR_INVALID, "gemm_qkv_rope: operands must be 16-byte aligned");
   return launch_big<EPI_QKV_ROPE>((const bf16_t*)x, (const bf16_t*)wqkv, qkv, m, 3 * hidden, hidden, hidden, 3 * hidden, st, pk, rope);
@@ -2030,7 +2032,7 @@ int ats_lmhead_lse(const void* a, const void* w, float* logits, int m, int n, in
   static const int fuse = env_int("ATSPEED_FUSE_LSE", 1);
   if (fused_out) *fused_out = 0;
   if (m <= 0) return ATSPEED_OK;
-  if (fuse && dtype == ATSPEED_BF16 && part && part_bytes >= ats_lmhead_lse_part_bytes(m, n) && ((uintptr_t)part & 7) == 0 &&
+  if (fuse && dtype == ATS_HALF && part && part_bytes >= ats_lmhead_lse_part_bytes(m, n) && ((uintptr_t)part & 7) == 0 &&
       big_kernel_applies(m, n, k, lda, ldc, dtype, EPI_F32)) {
     ATS_REQUIRE(a && w && logits && lse, ATSPEED_ERR_INVALID, "lmhead_lse: null operand");
     ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "lmhead_lse: operands must be 16-byte aligned");
@@ -2048,7 +2050,7 @@ static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype,
   // from 257 tokens (two token tiles): measured against the split-K mode at 300-500 tokens, gate_up 115-138 -> 96-108 us, qkv 80 -> 75 us
   static const int big_min_m = env_int("ATSPEED_GEMM_BIG_MIN_M", 257);
   static const int min_fill = env_int("ATSPEED_GEMM_BIG_MIN_FILL", 60);   // crossover measured at ~50-60 % (o_proj, down, qkv, gate_up at 512-1920 tokens)
-  if (dtype != ATSPEED_BF16 || m < big_min_m || k % 128 != 0 || (lda % 8) != 0 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return false;
+  if (dtype != ATS_HALF || m < big_min_m || k % 128 != 0 || (lda % 8) != 0 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return false;
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
   const int tn = (n + 255) / 256;
   if (big_fill_pct(tn * ((m + 255) / 256)) >= min_fill || big_fill_pct(tn * ((m + 127) / 128)) >= min_fill) return true;
@@ -2117,24 +2119,32 @@ int ats_gemm_fp8_qkv_rope(const void* xq, const float* sx, const void* wq, const
   return launch_big_fp8<EPI_QKV_ROPE>((const unsigned char*)xq, sx, (const unsigned char*)wq, sw, qkv, m, 3 * hidden, hidden, 3 * hidden, st, pk, rope);
 }
 
+
+
+// the same GEMMs on operands in the packed layout (what the bf16 / fp8 engine runs; atspeed_pack_rows makes them): a, w packed;
+// the SwiGLU epilogue's output packed too (it is the down projection's operand), every other output row-major
+
+}  // namespace ATS_NS
+
+#ifndef ATS_F16_FLAVOUR          // the C ABI exists once; it picks the flavour by the dtype code (fp8 and packed entry points: bf16)
 extern "C" int atspeed_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int32_t m, int32_t n,
                                 int32_t k, int32_t ldc, int32_t epilogue, void* stream) {
-  return ats_gemm_fp8(xq, sx, wq, sw, c, m, n, k, ldc, epilogue, (hipStream_t)stream, 0);
+  return ats_bf16::ats_gemm_fp8(xq, sx, wq, sw, c, m, n, k, ldc, epilogue, (hipStream_t)stream, 0);
 }
 
 extern "C" int atspeed_gemm(const void* a, const void* w, void* c, int32_t m, int32_t n, int32_t k, int32_t lda,
                             int32_t ldc, int32_t dtype, int32_t epilogue, void* workspace, size_t workspace_bytes,
                             void* stream) {
-  return ats_gemm(a, w, c, m, n, k, lda, ldc, dtype, epilogue, workspace, workspace_bytes, (hipStream_t)stream, 0);
+  return ATS_KD(dtype, ats_gemm(a, w, c, m, n, k, lda, ldc, dtype, epilogue, workspace, workspace_bytes, (hipStream_t)stream, 0));
 }
 
-// the same GEMMs on operands in the packed layout (what the bf16 / fp8 engine runs; atspeed_pack_rows makes them): a, w packed;
-// the SwiGLU epilogue's output packed too (it is the down projection's operand), every other output row-major
 extern "C" int atspeed_gemm_packed(const void* a, const void* w, void* c, int32_t m, int32_t n, int32_t k, int32_t ldc, int32_t epilogue,
                                    void* workspace, size_t workspace_bytes, void* stream) {
-  return ats_gemm(a, w, c, m, n, k, k, ldc, ATSPEED_BF16, epilogue, workspace, workspace_bytes, (hipStream_t)stream, 1);
+  return ats_bf16::ats_gemm(a, w, c, m, n, k, k, ldc, ATSPEED_BF16, epilogue, workspace, workspace_bytes, (hipStream_t)stream, 1);
 }
+
 extern "C" int atspeed_gemm_fp8_packed(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int32_t m, int32_t n,
                                        int32_t k, int32_t ldc, int32_t epilogue, void* stream) {
-  return ats_gemm_fp8(xq, sx, wq, sw, c, m, n, k, ldc, epilogue, (hipStream_t)stream, 1);
+  return ats_bf16::ats_gemm_fp8(xq, sx, wq, sw, c, m, n, k, ldc, epilogue, (hipStream_t)stream, 1);
 }
+#endif

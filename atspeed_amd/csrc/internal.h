@@ -30,70 +30,15 @@ int ats_stage(const void* host_obj, size_t bytes, const void** dev_out, hipStrea
 int ats_stage_to(const void* host_obj, size_t bytes, void* dev_dst, hipStream_t st);   // same, to a fixed device address
 void ats_stage_reset();                           // after a stream synchronisation: every staged copy has landed
 
-// ---- fill.hip / elementwise.hip -------------------------------------------------------
-// `t` = host copy (sizes), `dt` = the staged device copy the kernels read
-int ats_embed_segs(const void* table, const SegTable& t, const SegTable* dt, void* out, int hidden, int vocab, int dtype, hipStream_t st);
-// qkv_slabs != nullptr: the projection's fp32 split-K slabs [splits][total_tok][3 * hidden]; q is written (rotated) to qkv, k / v only to the caches
-int ats_rope_kv_segs_slabs(const float* qkv_slabs, int splits, void* qkv, const SegTable& t, const SegTable* dt, const float* cos_tab,
-                           const float* sin_tab, size_t layer_off_bytes, int n_heads, int head_dim, int max_pos, hipStream_t st);
-int ats_rope_kv_segs(void* qkv, const SegTable& t, const SegTable* dt, const float* cos_tab, const float* sin_tab, size_t layer_off_bytes,
-                     int n_heads, int head_dim, int max_pos, int dtype, hipStream_t st);
-int ats_row_info(const SegTable& t, const SegTable* dt, RowInfo* out, int max_pos, hipStream_t st);
-int ats_gather_logit_rows(const void* h, const SegTable& t, const SegTable* dt, void* out, int hidden, int dtype, hipStream_t st);
-int ats_embed(const void* table, const int32_t* ids, void* out, int n_tokens, int hidden, int vocab, int dtype,
-              hipStream_t st);
-int ats_rmsnorm(const void* x, const void* w, void* y, int rows, int hidden, float eps, int dtype, hipStream_t st, int pk = 0);   // pk: y in the packed operand layout
-// row-major [rows][row_bytes] -> packed operand layout (common.h ats_pk_byte) or back; out of place, row_bytes % 64 == 0
-int ats_pack_rows(const void* src, void* dst, int rows, int row_bytes, int to_packed, hipStream_t st);
-// rotate q and k in place inside the fused qkv buffer ([T][3*hidden]) and scatter k,v to the cache slots
-int ats_rope_kv(void* qkv, const int32_t* pos, const int32_t* slots, const float* cos_tab, const float* sin_tab,
-                void* kcache, void* vcache, int n_tokens, int n_heads, int head_dim, int max_pos, int dtype,
-                hipStream_t st);
-
-// ---- gemm.hip -------------------------------------------------------------------------
 enum { EPI_STORE = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_SWIGLU = 3, EPI_F32_LSE = 4 /* ring kernel only: fp32 store + per-tile (max, sum exp) */,
        EPI_QKV_ROPE = 5 /* ring kernel only: qkv projection with RoPE + KV-cache scatter in the epilogue (ats_gemm_qkv_rope) */ };
-size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype);
-// pk = 1: a and w (and a SwiGLU output) are in the packed operand layout of common.h (bf16 / fp8 engine); 0: row-major (HF layout, fp32 mode, ABI tests)
-int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int dtype, int epilogue,
-             void* workspace, size_t workspace_bytes, hipStream_t st, int pk = 0);
-
-int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int k, int lda, int ldh, int dtype,
-                        const void* norm_w, void* xn, float eps, void* workspace, size_t workspace_bytes, hipStream_t st, int pk = 0);
-// The batched qkv projection with the rotation and the cache scatter in its epilogue: qkv[m][3*hidden] receives only the rotated q,
-// rotated k and v go straight to the caches (bit-identical to ats_gemm + ats_rope_kv_segs: both round the projection to bf16 first).
-// Applies to bf16, head_dim 128, hidden % 256 == 0 at shapes the ring kernel takes; the caller asks first.
-bool ats_gemm_qkv_rope_applies(int m, int hidden, int head_dim, int dtype);
-int ats_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, int m, int hidden, const RopeEpi& rope, hipStream_t st, int pk = 0);
-bool ats_gemm_fp8_qkv_rope_applies(int m, int hidden, int head_dim);
-int ats_gemm_fp8_qkv_rope(const void* xq, const float* sx, const void* wq, const float* sw, void* qkv, int m, int hidden, const RopeEpi& rope,
-                          hipStream_t st, int pk = 0);
-
-// fp8 (e4m3, per-row scales) variants of the batched projections; returns ATSPEED_ERR_INVALID if the shape does not
-// qualify (ats_gemm_fp8_applies)
-int ats_quant_rows_fp8(const void* x, int rows, int cols, int ld, void* q, float* scale, hipStream_t st, int pk = 0);          // pk: x and q packed
-// RMSNorm fused with the per-token quantisation of its output (bf16, hidden <= 8192); y may be null
-int ats_rmsnorm_quant_fp8(const void* x, const void* w, void* y, void* q, float* scale, int rows, int hidden, float eps, hipStream_t st, int pk = 0);   // pk: y and q packed
-bool ats_gemm_fp8_applies(int m, int n, int k, int ldc, int epilogue);
-int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int m, int n, int k, int ldc,
-                 int epilogue, hipStream_t st, int pk = 0);
-
-size_t ats_lmhead_lse_part_bytes(int m, int n);
-int ats_lmhead_lse(const void* a, const void* w, float* logits, int m, int n, int k, int lda, int ldc, int dtype, const unsigned char* tile_store,
-                   float* part, size_t part_bytes, float* lse, void* workspace, size_t workspace_bytes, hipStream_t st, int* fused_out = nullptr,
-                   int pk = 0);
-
-int ats_gemm_partials(const void* a, const void* w, int m, int n, int k, int lda, int dtype, void* workspace, size_t workspace_bytes,
-                      hipStream_t st, int* splits_out, int pk = 0);
-
-// ---- attn.hip -------------------------------------------------------------------------
-int ats_tree_attention(const void* q, int ldq, const void* kcache, const void* vcache, const uint64_t* vis,
-                       int vis_words, void* out, int ldo, int n_tokens, int n_slots, int n_heads, int head_dim,
-                       int dtype, hipStream_t st, int qtile_rows = 0, int rows_per_wave = 0);
-
-int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const SegTable* dt, size_t layer_off_bytes, int vis_words,
-                            void* out, int ldo, int n_heads, int head_dim, int dtype, hipStream_t st, int rows_per_wave = 0,
-                            int pk = 0);       // pk: out (the o_proj operand) in the packed operand layout
+// the kernel translation units' functions, once per flavour (declarations: kernels_decl.inc)
+namespace ats_bf16 {
+#include "kernels_decl.inc"
+}
+namespace ats_f16 {
+#include "kernels_decl.inc"
+}
 
 // ---- scan.hip -------------------------------------------------------------------------
 struct FsmDev {

@@ -16,8 +16,10 @@
  *     stream-ordered and never synchronise the device unless documented.
  *   - return value: 0 = ok, negative = atspeed_status; atspeed_last_error() gives the text
  *     (thread-local).
- *   - dtype: ATSPEED_F32 (fp32 weights/activations, exact-fp32 MFMA; parity mode) or
- *     ATSPEED_BF16 (bf16 weights/activations/KV, fp32 accumulate, fp32 logits).
+ *   - dtype: ATSPEED_F32 (fp32 weights/activations, exact-fp32 MFMA; parity mode),
+ *     ATSPEED_BF16 (bf16 weights/activations/KV, fp32 accumulate, fp32 logits) or
+ *     ATSPEED_F16 (the same engine on IEEE half: the type the reference loads both models in, code/inference.py:75-100
+ *     `torch_dtype=torch.float16` -- a checkpoint's fp16 weights are used bit for bit; same kernels, v_mfma_f32_*_f16).
  */
 #ifndef ATSPEED_HIP_H
 #define ATSPEED_HIP_H
@@ -39,7 +41,7 @@ typedef enum atspeed_status {
   ATSPEED_ERR_FILTERED = -6      /* every beam of a step fell to the post-top-k id filter of beamSD.py:80-86 (the reference then dies on a shape mismatch) */
 } atspeed_status;
 
-typedef enum atspeed_dtype { ATSPEED_F32 = 0, ATSPEED_BF16 = 1 } atspeed_dtype;
+typedef enum atspeed_dtype { ATSPEED_F32 = 0, ATSPEED_BF16 = 1, ATSPEED_F16 = 2 } atspeed_dtype;
 
 #define ATSPEED_MAX_BEAMS 64      /* K, DK <= 64 (one wavefront holds a beam list)       */
 #define ATSPEED_MAX_NEW_TOKENS 16 /* generated-suffix capacity per beam                  */

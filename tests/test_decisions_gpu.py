@@ -42,10 +42,10 @@ MIN_SAME_USERS = {None: 0, 3e-5: 0, 3e-6: 16, "games_trie": 0, "fp8_3e-5": 0, "p
 # strength: a chaotic map whose bf16 error on a 4-token score (0.63) is of the size of the gaps between candidates, so only 18 % of its
 # decisions can be judged (scaling the residual branches to a tenth and widening the head changes nothing: 18.8 % clear, noise 0.9-1.9 --
 # the layers' outputs still dwarf the 0.02-wide embeddings).  A trained model is not chaotic: here the layers' residual contributions are
-# scaled by 1e-3 (o_proj / down_proj) and the head's rows are 3 x wider (logit std ~3.8), draft and target still UNRELATED (no shared table:
+# scaled by 3e-4 (o_proj / down_proj; at 1e-3: 60 % clear, noise 0.19-0.39) and the head's rows are 3 x wider (logit std ~3.8), draft and target still UNRELATED (no shared table:
 # acceptance stays ~0, four target forwards per user, every kernel, shape and launch of the headline) -- the gaps between candidates then stand
 # clear of the engine's noise.
-PEAKED = dict(resid_scale=1e-3, head_std=0.06)
+PEAKED = dict(resid_scale=3e-4, head_std=0.06)
 
 
 def _pairs(resid_scale, V=synth.BEAUTY.vocab_size, align=True, head_std=0.02):
