@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ATSPEED_LIB: another build of the library (tuning builds under tools/probe); it must exist, there is no fallback
 LIB_PATH = os.path.abspath(os.environ["ATSPEED_LIB"]) if os.environ.get("ATSPEED_LIB") else os.path.join(_HERE, "lib", "libatspeed_hip.so")
 
-ATSPEED_F32, ATSPEED_BF16 = 0, 1
+ATSPEED_F32, ATSPEED_BF16, ATSPEED_F16 = 0, 1, 2
 WEIGHTS_ROW_MAJOR, WEIGHTS_PACKED = 0, 1
 MAX_BEAMS, MAX_NEW_TOKENS, MAX_GAMMA = 64, 16, 8
 ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_CONSTRAINT, ERR_NO_DEVICE, ERR_FILTERED = -1, -2, -3, -4, -5, -6
@@ -134,6 +134,15 @@ def check(status: int) -> None:
     if status == ERR_CONSTRAINT:
         raise ValueError(msg)          # what HF's PrefixConstrainedLogitsProcessor raises
     raise AtSpeedError(status, msg)
+
+
+def dtype_code(dtype) -> int:
+    """torch dtype -> the library's atspeed_dtype code (fp32 parity mode, bf16, fp16)."""
+    import torch
+    try:
+        return {torch.float32: ATSPEED_F32, torch.bfloat16: ATSPEED_BF16, torch.float16: ATSPEED_F16}[dtype]
+    except KeyError:
+        raise TypeError(f"libatspeed_hip computes in torch.float32, torch.bfloat16 or torch.float16, not {dtype}") from None
 
 
 def stream_ptr(device=None) -> int:

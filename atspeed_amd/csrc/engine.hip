@@ -342,7 +342,7 @@ static void kv_free(KvCache* kv) { hipFree(kv->k); hipFree(kv->v); kv->k = kv->v
 extern "C" int atspeed_llama_create(const atspeed_llama_config* cfg, const void* embed, const void* final_norm,
                                     const void* lm_head, const atspeed_llama_layer_weights* layers, atspeed_llama** out) {
   ATS_REQUIRE(cfg && embed && final_norm && lm_head && layers && out, ATSPEED_ERR_INVALID, "llama_create: null argument");
-  ATS_REQUIRE(cfg->dtype == ATSPEED_F32 || cfg->dtype == ATSPEED_BF16, ATSPEED_ERR_INVALID, "llama_create: bad dtype");
+  ATS_REQUIRE(cfg->dtype == ATSPEED_F32 || cfg->dtype == ATSPEED_BF16 || cfg->dtype == ATSPEED_F16, ATSPEED_ERR_INVALID, "llama_create: bad dtype");
   ATS_REQUIRE(cfg->n_heads > 0 && cfg->hidden % cfg->n_heads == 0, ATSPEED_ERR_INVALID, "llama_create: hidden %% n_heads != 0");
   int hd = cfg->hidden / cfg->n_heads;
   ATS_REQUIRE(hd % 8 == 0 && hd <= 256, ATSPEED_ERR_INVALID, "llama_create: head_dim %d unsupported", hd);
@@ -363,8 +363,8 @@ extern "C" int atspeed_llama_create(const atspeed_llama_config* cfg, const void*
   m->logits_ld = (cfg->vocab_size + 63) / 64 * 64;
   m->layer_kv_bytes = (size_t)cfg->max_slots * cfg->hidden * m->esz;
   m->pk = cfg->weight_layout == ATSPEED_WEIGHTS_PACKED ? 1 : 0;
-  if (m->pk && !(cfg->dtype == ATSPEED_BF16 && cfg->hidden % 32 == 0 && cfg->ffn % 32 == 0)) {
-    atspeed_set_error("llama_create: packed weights need bf16 and hidden / ffn multiples of 32 (hidden %d, ffn %d)", cfg->hidden, cfg->ffn);
+  if (m->pk && !((cfg->dtype == ATSPEED_BF16 || cfg->dtype == ATSPEED_F16) && cfg->hidden % 32 == 0 && cfg->ffn % 32 == 0)) {
+    atspeed_set_error("llama_create: packed weights need bf16 / fp16 and hidden / ffn multiples of 32 (hidden %d, ffn %d)", cfg->hidden, cfg->ffn);
     delete m;
     return ATSPEED_ERR_INVALID;
   }

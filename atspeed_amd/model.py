@@ -34,7 +34,7 @@ def _interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     return out
 
 
-COMPUTE_DTYPES = (torch.float32, torch.bfloat16)
+COMPUTE_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
 
 
 def _weight_tensors(packed: Dict):
@@ -46,14 +46,15 @@ def _weight_tensors(packed: Dict):
 
 
 def engine_dtype_for(checkpoint_dtype: torch.dtype) -> torch.dtype:
-    """The arithmetic type a checkpoint of `checkpoint_dtype` runs in.  fp32 -> fp32 (exact-fp32 MFMA, the parity mode), bf16 -> bf16,
-    and fp16 -> bf16: the reference loads both models with `torch_dtype=torch.float16` (code/inference.py:75-100); gfx950's fast MFMA path
-    here is bf16 with fp32 accumulation, so fp16 weights are converted BY VALUE (through fp32; every fp16 value is inside bf16's range,
-    its 11-bit significand is rounded to 8 bits).  Pass `dtype=torch.float32` to keep every fp16 bit."""
+    """The arithmetic type a checkpoint of `checkpoint_dtype` runs in: its own.  fp32 -> fp32 (exact-fp32 MFMA, the parity mode), bf16 ->
+    bf16, fp16 -> fp16 -- the reference loads both models with `torch_dtype=torch.float16` (code/inference.py:75-100); the engine's fp16
+    flavour (v_mfma_f32_16x16x32_f16, fp32 accumulation, the bf16 engine's kernels compiled for IEEE half) keeps every weight bit of such a
+    checkpoint.  (Through round 3 an fp16 checkpoint was converted to bf16 BY VALUE: 11-bit significands rounded to 8; `dtype=torch.bfloat16`
+    still asks for that.)"""
     if checkpoint_dtype in (torch.float32, torch.float64):
         return torch.float32
     if checkpoint_dtype in (torch.bfloat16, torch.float16):
-        return torch.bfloat16
+        return checkpoint_dtype
     raise TypeError(f"no engine dtype for a {checkpoint_dtype} checkpoint (quantised checkpoints must be dequantised first)")
 
 
@@ -65,8 +66,8 @@ class HipLlama:
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         if dtype not in COMPUTE_DTYPES:
-            # the library reads weights as ATSPEED_F32 or ATSPEED_BF16 bits; anything else (fp16!) would be silently reinterpreted
-            raise TypeError(f"HipLlama computes in torch.bfloat16 or torch.float32, not {dtype}: convert the checkpoint "
+            # the library reads weights as ATSPEED_F32, ATSPEED_BF16 or ATSPEED_F16 bits; anything else would be silently reinterpreted
+            raise TypeError(f"HipLlama computes in torch.float32, torch.bfloat16 or torch.float16, not {dtype}: convert the checkpoint "
                             "(HipLlama.from_hf / from_state_dict do, by value) instead of passing its storage dtype")
         for name, t in _weight_tensors(packed):
             if t.dtype != dtype or t.device != device:
@@ -80,9 +81,9 @@ class HipLlama:
                                       eos_token_id=2, use_cache=True)
         self.max_slots, self.max_tokens, self.max_logit_rows = max_slots, max_tokens, max_logit_rows
         lib = _lib.load()
-        # bf16: the projection weights and the lm_head go into the library's packed operand layout (two rows per 128-byte line and 64-byte
+        # bf16 / fp16: the projection weights and the lm_head go into the library's packed operand layout (two rows per 128-byte line and 64-byte
         # k-block: full cache lines for every LDS-DMA piece of the GEMMs); ATSPEED_PACK=0 keeps HF's row-major layout (A/B runs, slower)
-        self.weights_packed = (dtype == torch.bfloat16 and dims.hidden % 32 == 0 and dims.ffn % 32 == 0
+        self.weights_packed = (dtype in (torch.bfloat16, torch.float16) and dims.hidden % 32 == 0 and dims.ffn % 32 == 0
                                and os.environ.get("ATSPEED_PACK", "1") != "0")
         if self.weights_packed:
             with torch.cuda.device(device):
@@ -91,7 +92,7 @@ class HipLlama:
                         lw[k] = self._pack_rows(lw[k])
                 packed["lm_head"] = self._pack_rows(packed["lm_head"])
         cfg = _lib.LlamaConfig(dims.vocab_size, dims.hidden, dims.n_layers, dims.n_heads, dims.ffn, dims.rope_theta,
-                               dims.rms_eps, _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16,
+                               dims.rms_eps, _lib.dtype_code(dtype),
                                max_slots, max_tokens, max_logit_rows,
                                _lib.WEIGHTS_PACKED if self.weights_packed else _lib.WEIGHTS_ROW_MAJOR)
         layers = (_lib.LlamaLayerWeights * dims.n_layers)()
@@ -163,11 +164,10 @@ class HipLlama:
     def from_state_dict(cls, dims: synth.LlamaDims, state_dict: Dict, dtype: torch.dtype = torch.float32,
                         device="cuda", **kw) -> "HipLlama":
         """HF-named tensors (numpy or torch, any float dtype: values are converted through fp32, never reinterpreted) -> device weights
-        in `dtype`, which must be torch.float32 or torch.bfloat16."""
+        in `dtype`, which must be torch.float32, torch.bfloat16 or torch.float16."""
         device = torch.device(device)
         if dtype not in COMPUTE_DTYPES:
-            raise TypeError(f"HipLlama.from_state_dict: dtype must be torch.bfloat16 or torch.float32, not {dtype} "
-                            "(an fp16 checkpoint is converted by value: see engine_dtype_for)")
+            raise TypeError(f"HipLlama.from_state_dict: dtype must be torch.float32, torch.bfloat16 or torch.float16, not {dtype}")
         sd = {}
         for k, v in state_dict.items():
             t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v.detach()
@@ -177,9 +177,9 @@ class HipLlama:
     @classmethod
     def from_hf(cls, hf_model, dtype: Optional[torch.dtype] = None, device="cuda", **kw) -> "HipLlama":
         """Adapter for an HF `LlamaForCausalLM` (the object the reference loads, inference.py:75-100).  `dtype=None` picks the engine
-        dtype from the checkpoint's (`engine_dtype_for`: fp32 -> fp32, bf16 -> bf16, fp16 -> bf16 by value -- the reference's
-        `torch_dtype=torch.float16` models run in bf16 here, `.dtype` says so); `dtype=torch.float32` keeps every bit of an fp16 / bf16
-        checkpoint and computes in fp32.  Anything the kernels do not implement raises instead of approximating."""
+        dtype from the checkpoint's (`engine_dtype_for`: fp32 -> fp32, bf16 -> bf16, fp16 -> fp16: the reference's `torch_dtype=torch.float16`
+        models keep every weight bit); `dtype=torch.float32` computes an fp16 / bf16 checkpoint in fp32, `dtype=torch.bfloat16` converts an
+        fp16 one by value.  Anything the kernels do not implement raises instead of approximating."""
         c = hf_model.config
         rp = getattr(c, "rope_parameters", None) or {}
         theta = getattr(c, "rope_theta", None) or (rp.get("rope_theta") if isinstance(rp, dict) else None) or 10000.0
@@ -207,7 +207,8 @@ class HipLlama:
     @classmethod
     def from_synthetic(cls, dims: synth.LlamaDims, seed: int, std: float = 0.02, head_std: Optional[float] = None,
                        norm_jitter: float = 0.1, dtype: torch.dtype = torch.bfloat16, device="cuda",
-                       resid_scale: float = 1.0, align_to: Optional["HipLlama"] = None, round_to_bf16: bool = False, **kw) -> "HipLlama":
+                       resid_scale: float = 1.0, align_to: Optional["HipLlama"] = None, round_to_bf16: bool = False,
+                       round_to: Optional[torch.dtype] = None, **kw) -> "HipLlama":
         """Weights generated ON THE DEVICE by the same hash recipe as `synth.synthetic_state_dict`
         (bit-identical values), so 7B-sized models need no host generation or PCIe transfer.
 
@@ -217,14 +218,15 @@ class HipLlama:
         `draft.hidden` coordinates of this (wider) model, so both models rank next tokens almost alike while every
         kernel still runs on dense weights of the full shapes.
 
-        `round_to_bf16` (fp32 models): every weight is rounded to the nearest bf16 value, i.e. the fp32 engine holds EXACTLY the weights
-        of the bf16 model of the same seed -- the judge of tests/replay.py and bench.py's fp32 accepted-length comparison."""
+        `round_to_bf16` / `round_to=torch.bfloat16 | torch.float16` (fp32 models): every weight is rounded to the nearest value of that type,
+        i.e. the fp32 engine holds EXACTLY the weights of the bf16 / fp16 model of the same seed -- the judge of tests/replay.py and bench.py's
+        fp32 accepted-length comparison."""
         device = torch.device(device)
         lib = _lib.load()
         head_std = std if head_std is None else head_std
         if dtype not in COMPUTE_DTYPES:
-            raise TypeError(f"HipLlama.from_synthetic: dtype must be torch.bfloat16 or torch.float32, not {dtype}")
-        code = _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16
+            raise TypeError(f"HipLlama.from_synthetic: dtype must be torch.float32, torch.bfloat16 or torch.float16, not {dtype}")
+        code = _lib.dtype_code(dtype)
         sd: Dict[str, torch.Tensor] = {}
         with torch.cuda.device(device):
             st = _lib.stream_ptr(device)
@@ -249,9 +251,11 @@ class HipLlama:
                 sd["lm_head.weight"][:, :hd] = (align_to._unpack_rows(src["lm_head"], dims.vocab_size) if align_to.weights_packed else src["lm_head"])
                 # RMS over `hidden` coordinates of which `hd` carry the signal: rescale so norm(x)[:hd] matches the draft's
                 sd["model.norm.weight"][:hd] = (src["final_norm"].float() * (hd / dims.hidden) ** 0.5).to(dtype)
-            if round_to_bf16 and dtype == torch.float32:
+            if round_to_bf16 and round_to is None:
+                round_to = torch.bfloat16
+            if round_to is not None and dtype == torch.float32:
                 for t in sd.values():
-                    t.copy_(t.to(torch.bfloat16))
+                    t.copy_(t.to(round_to))
             packed = cls._pack(sd, dims)
             del sd
         return cls(dims, packed, dtype, device, **kw)

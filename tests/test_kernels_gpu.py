@@ -31,21 +31,25 @@ def _rand(shape, seed, std=1.0):
 
 
 # ------------------------------------------------------------------ fill
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_fill_hash_normal_bit_exact(lib, dtype):
     n, seed, std = 100003, 12345, 0.02
     t = torch.empty(n, dtype=dtype, device="cuda")
-    code = _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16
+    code = _lib.dtype_code(dtype)
     _lib.check(lib.atspeed_fill_hash_normal(t.data_ptr(), n, seed, float(synth.normal_scale(std)), 0.0, code, 0, _st()))
     ref = synth.hash_normal(n, seed, std)
     if dtype == torch.bfloat16:
         ref = synth.bf16_round(ref)
+    if dtype == torch.float16:
+        ref = ref.astype(np.float16).astype(np.float32)          # IEEE half, round to nearest even
     assert np.array_equal(t.float().cpu().numpy(), ref)
     # offset + add (norm weights)
     _lib.check(lib.atspeed_fill_hash_normal(t.data_ptr(), 1000, seed, float(synth.normal_scale(0.1)), 1.0, code, 0, _st()))
     ref = np.float32(1.0) + synth.hash_normal(1000, seed, 0.1)
     if dtype == torch.bfloat16:
         ref = synth.bf16_round(ref)
+    if dtype == torch.float16:
+        ref = ref.astype(np.float16).astype(np.float32)
     assert np.array_equal(t[:1000].float().cpu().numpy(), ref)
 
 
@@ -53,7 +57,7 @@ def test_fill_hash_normal_bit_exact(lib, dtype):
 def _gemm(lib, a, w, epi, dtype, resid=None, n_out=None):
     m, k = a.shape
     n = w.shape[0]
-    code = _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16
+    code = _lib.dtype_code(dtype)
     ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     if epi == _lib.EPI_F32:
         c = torch.zeros(m, n, dtype=torch.float32, device="cuda")
@@ -83,7 +87,7 @@ SHAPES = [(900, 1000, 512), (1024, 2304, 768), (1543, 300, 1024), (1, 128, 128),
 
 
 @pytest.mark.parametrize("m,n,k", SHAPES)
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_store_and_f32(lib, m, n, k, dtype):
     a = _rand((m, k), 1).to(dtype).cuda()
     w = _rand((n, k), 2, 0.05).to(dtype).cuda()
@@ -99,7 +103,7 @@ def test_gemm_store_and_f32(lib, m, n, k, dtype):
 
 @pytest.mark.parametrize("m,n,k", [(7, 256, 128), (40, 768, 768), (228, 4096, 11008), (228, 4096, 4096), (1100, 768, 1024), (2000, 500, 256), (100, 8192, 512), (6400, 4096, 512), (8300, 4096, 512), (4500, 8192, 256), (6400, 4104, 512),
                                    (50, 8192, 1024), (128, 12288, 768), (129, 8200, 384), (256, 8192, 256), (100, 22016, 512), (60, 32859, 576), (250, 22016, 1024), (100, 12288, 4096), (60, 4096, 11008), (225, 4096, 11008), (128, 12288, 2048)])      # ... and the split-K form of the weight-streaming kernel (qkv, down)      # one user's wide projections: the no-split weight-streaming tiles (64 / 128 / 256 token rows)
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_residual(lib, m, n, k, dtype):
     a = _rand((m, k), 3).to(dtype).cuda()
     w = _rand((n, k), 4, 0.03).to(dtype).cuda()
@@ -111,7 +115,7 @@ def test_gemm_residual(lib, m, n, k, dtype):
 
 
 @pytest.mark.parametrize("m,ffn,k", [(3, 32, 64), (40, 352, 128), (228, 11008, 4096), (20, 3072, 768), (1300, 1376, 512), (800, 496, 256), (300, 4224, 256), (4200, 4224, 256), (4200, 4240, 256), (60, 4224, 256), (110, 11008, 4096), (40, 11008, 512), (256, 11008, 1024)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_swiglu(lib, m, ffn, k, dtype):
     from atspeed_amd.model import _interleave_gate_up
     a = _rand((m, k), 6).to(dtype).cuda()
@@ -127,12 +131,12 @@ def test_gemm_swiglu(lib, m, ffn, k, dtype):
 
 # ------------------------------------------------------------------ rmsnorm
 @pytest.mark.parametrize("hidden", [768, 4096, 8192, 11008, 100])       # vectorised bf16 rows up to 8192, scalar beyond / unaligned
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_rmsnorm(lib, dtype, hidden):
     x = _rand((37, hidden), 9, 2.0).to(dtype).cuda()
     w = (1 + _rand((hidden,), 10, 0.1)).to(dtype).cuda()
     y = torch.empty_like(x)
-    code = _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16
+    code = _lib.dtype_code(dtype)
     _lib.check(lib.atspeed_rmsnorm(x.data_ptr(), w.data_ptr(), y.data_ptr(), 37, hidden, 1e-6, code, _st()))
     xf = x.float().cpu()
     ref = w.float().cpu() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))
@@ -279,7 +283,7 @@ def test_accept_equals_reference_logic(lib, k, dk, kind):
 
 
 # ------------------------------------------------------------------ attention
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("T", [23, 150, 230])       # 150 rows take the 8-wave (128-row tile) kernel, 230 the 16-wave (256-row) one
 @pytest.mark.parametrize("heads,dh", [(4, 32), (12, 64), (32, 128)])
 def test_tree_attention(lib, dtype, heads, dh, T):
@@ -296,7 +300,7 @@ def test_tree_attention(lib, dtype, heads, dh, T):
     vis[3, 149] = True           # a row with a single visible slot at the very end
     bits = vis_bits_from_bool(vis, max_slots).cuda()
     out = torch.zeros(T, H, dtype=dtype, device="cuda")
-    code = _lib.ATSPEED_F32 if dtype == torch.float32 else _lib.ATSPEED_BF16
+    code = _lib.dtype_code(dtype)
     _lib.check(lib.atspeed_tree_attention(q.data_ptr(), 3 * H, kc.data_ptr(), vc.data_ptr(), bits.data_ptr(), max_slots // 64,
                                           out.data_ptr(), T, S, heads, dh, code, _st()))
     torch.cuda.synchronize()
@@ -725,5 +729,38 @@ def test_gemm_stream_k_tail(lib, m, n, k, epi):
         got = outs[0][:, :n].float()
         assert torch.equal(cp[:, :n], outs[0][:, :n])
         tol = (2e-5 * np.sqrt(k) if epi == _lib.EPI_F32 else 1e-2) * float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    assert err <= tol, (err, tol)
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(912, 4096, 4096, 2), (912, 22016, 4096, 3), (1800, 12288, 4096, 0), (700, 32859, 2048, 1)])
+def test_gemm_fp16_flavour_on_the_batched_paths(lib, m, n, k, epi):
+    """The fp16 flavour (ATSPEED_F16: gemm.hip compiled for IEEE half, v_mfma_f32_16x16x32_f16) through the ring kernel and its split-K tail on
+    the Llama-7B projection shapes: against torch fp32 on the same fp16 values, and tighter than bf16's bound (3 more significand bits)."""
+    a = _rand((m, k), 91, 1.0).to(torch.float16).cuda()
+    w = _rand((n, k), 92, 0.03).to(torch.float16).cuda()
+    ws = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+    if epi == _lib.EPI_SWIGLU:
+        from atspeed_amd.model import _interleave_gate_up
+        w = _interleave_gate_up(w[: n // 2].contiguous(), w[n // 2:].contiguous())
+    base = _rand((m, n), 93).to(torch.float16).cuda() if epi == _lib.EPI_RESID else None
+    if epi == _lib.EPI_F32:
+        ldc = (n + 63) // 64 * 64; c = torch.zeros(m, ldc, dtype=torch.float32, device="cuda")
+    elif epi == _lib.EPI_SWIGLU:
+        ldc = n // 2; c = torch.zeros(m, ldc, dtype=torch.float16, device="cuda")
+    else:
+        ldc = n; c = base.clone() if epi == _lib.EPI_RESID else torch.zeros(m, n, dtype=torch.float16, device="cuda")
+    _lib.check(lib.atspeed_gemm(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, k, ldc, _lib.ATSPEED_F16, epi, ws.data_ptr(), ws.numel(), _st()))
+    torch.cuda.synchronize()
+    prod = a.float() @ w.float().T
+    if epi == _lib.EPI_SWIGLU:
+        v = prod.view(m, n // 32, 2, 16)
+        gate, up = v[:, :, 0].reshape(m, n // 2), v[:, :, 1].reshape(m, n // 2)
+        ref = torch.nn.functional.silu(gate.to(torch.float16).float()) * up.to(torch.float16).float()
+        got, tol = c.float(), 4e-3 * float(ref.abs().max())
+    else:
+        ref = prod + (base.float() if epi == _lib.EPI_RESID else 0.0)
+        got = c[:, :n].float()
+        tol = (2e-5 * np.sqrt(k) if epi == _lib.EPI_F32 else 1.5e-3) * float(ref.abs().max())
     err = float((got - ref).abs().max())
     assert err <= tol, (err, tol)
