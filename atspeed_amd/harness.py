@@ -280,11 +280,16 @@ def longest_prompt(data: "SeqRecTestData", L: int = 0, R: Optional[int] = None, 
 
 def run_inference(target, draft, data: SeqRecTestData, gamma: int = 4, max_new_tokens: int = 4, L: int = 0, R: Optional[int] = None,
                   users_per_batch: int = 128, prefix_allowed_tokens_fn=None, tokenizer=None, baseline: bool = False,
-                  device=None) -> InferenceResult:
+                  device=None, decoder: str = "bssd") -> InferenceResult:
     """Users [L, R) of the test set through beam-SD (inference.py:123-124,162-187), `users_per_batch` at a time in lock step.
-    `baseline=True` also runs `target_generate` per user and records its time and the speed-up columns."""
+    `baseline=True` also runs `target_generate` per user and records its time and the speed-up columns.
+    `decoder="beam"`: the same users through the plain constrained beam search of the target (`target_generate_batch`, beamSD.py:544-595) --
+    the same items (the method is lossless), and on MI355X the faster decoder once a lock-step batch is MFMA-bound (bench.py's
+    `speedup_curve`): speculation pays while the target forward is a weight stream."""
     import torch
-    from .beamSD import BSSD_batch, target_generate
+    from .beamSD import BSSD_batch, target_generate, target_generate_batch
+    if decoder not in ("bssd", "beam"):
+        raise ValueError(f"decoder must be 'bssd' or 'beam', not {decoder!r}")
 
     fn = prefix_allowed_tokens_fn if prefix_allowed_tokens_fn is not None else data.get_prefix_allowed_tokens_fn()
     dev = device if device is not None else target.device
@@ -296,7 +301,13 @@ def run_inference(target, draft, data: SeqRecTestData, gamma: int = 4, max_new_t
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for lo in range(0, len(sel), users_per_batch):
-        outs = BSSD_batch(target, draft, prompts[lo:lo + users_per_batch], gamma, max_new_tokens, prefix_allowed_tokens_fn=fn)
+        if decoder == "beam":
+            outs = target_generate_batch(target, prompts[lo:lo + users_per_batch], max_new_tokens, prefix_allowed_tokens_fn=fn)
+            for o in outs:                                  # the CSV columns of the beam-SD path (inference.py:152-156): no draft, no verification
+                o.update(draft_time_cost=0.0, target_time_cost=o["device_time_cost"], verify_time_cost=0.0, n_run=0, total_accept_steps=0,
+                         total_accept_tokens=0, ave_accept_tokens=0.0)
+        else:
+            outs = BSSD_batch(target, draft, prompts[lo:lo + users_per_batch], gamma, max_new_tokens, prefix_allowed_tokens_fn=fn)
         for u, pr, o in zip(sel[lo:lo + users_per_batch], prompts[lo:lo + users_per_batch], outs):
             P = pr["input_ids"].shape[1]
             gen = o["beam_sequence"][:, P:].cpu().tolist()

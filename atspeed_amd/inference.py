@@ -39,6 +39,10 @@ def parse(argv=None):
     ap.add_argument("--R", type=int, default=None)
     ap.add_argument("--users_per_batch", type=int, default=128, help="users decoded in lock step (1 = the reference's loop)")
     ap.add_argument("--strict_trie", action="store_true", help="strict item trie instead of the position-set mask")
+    ap.add_argument("--decoder", choices=("bssd", "beam"), default="bssd",
+                    help="bssd = beam speculative decoding (the reference's method); beam = plain constrained beam search of the target in lock "
+                         "step: identical items, and on MI355X the faster of the two once a batch of users makes the target forward MFMA-bound "
+                         "(bench.py speedup_curve)")
     ap.add_argument("--target_ckpt", type=str, default=None)
     ap.add_argument("--draft_ckpt", type=str, default=None)
     ap.add_argument("--tokenizer", type=str, default=None)
@@ -101,7 +105,7 @@ def main(argv=None):
     max_prompt = longest_prompt(data, args.L + lo, args.L + hi, tok)
     for beam in ast.literal_eval(args.run_beam_sizes):          # the reference eval()s this flag (inference.py:151); a literal list is all it needs
         tgt, drf = load_models(args, data.index.vocab_size, beam, dev, max_prompt)
-        res = run_inference(tgt, drf, data, args.gamma, 4, args.L + lo, args.L + hi, args.users_per_batch, fn, tok, args.baseline, dev)
+        res = run_inference(tgt, drf, data, args.gamma, 4, args.L + lo, args.L + hi, args.users_per_batch, fn, tok, args.baseline, dev, args.decoder)
         c = res.counters()
         per_rank = all_gather_counters(Counters(len(res.rows), int(sum(r["n_run"] for r in res.rows)),
                                                 int(sum(r["total_accept_steps"] for r in res.rows)), int(res.wall_s * 1e9)), dev)

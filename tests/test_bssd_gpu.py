@@ -438,6 +438,9 @@ def test_harness_end_to_end_on_a_tiny_dataset():
         assert [ix.decode(g) for g in tg["beam_sequence"][:, ids.shape[1]:].cpu().tolist()] == pred
     m = res.metrics(ix, topN=(1, 5, 10, 20))
     assert m["topN"] == [1, 5, 10] and all(0.0 <= x <= 1.0 for key in ("precision", "recall", "ndcg", "mrr") for x in m[key])
+    # decoder="beam": the plain lock-step beam search of the target returns the same items (the method is lossless)
+    res_b = run_inference(t, d, data, gamma=4, max_new_tokens=4, users_per_batch=4, prefix_allowed_tokens_fn=strict, decoder="beam")
+    assert res_b.predictions == res.predictions and all(r["n_run"] == 0 for r in res_b.rows)
     # the position-set mask (what inference.py really uses) may compose code tuples that are no item
     res2 = run_inference(t, d, data, users_per_batch=9)
     assert len(res2.predictions) == 9 and any(i == -1 for p in res2.predictions for i in p)
