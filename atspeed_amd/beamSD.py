@@ -21,7 +21,8 @@ beam per step, all arithmetic still in HIP).  `generation_config.do_sample` sele
 No mask at all (`prefix_allowed_tokens_fn=None`, legal in the reference: beamSD.py:460-481) runs on the device too: every token is a
 candidate, the id filter of :80-86 is off as in the reference.  Extra `logits_processor` entries (the reference always passes None,
 inference.py:175-176) are torch callables and are served by the host path: each step's log-softmax rows go through them between the
-library's forward and its expand + top-K.  Not on this path (raise): sampling with a host-side mask or processor.
+library's forward and its expand + top-K.  Sampling with a host-side mask or processors (round 4) draws on the host from the device's
+counter-based streams (hostmask.py): a callable wrapping a compilable constraint samples exactly what the device path samples for that seed.
 """
 from __future__ import annotations
 
@@ -291,12 +292,15 @@ def BSSD(target_model, draft_model, inputs: Dict, gamma: int, max_new_tokens: in
     if _host_path(logits_processor, prefix_allowed_tokens_fn):
         # arbitrary Python callables (a mask closure, extra logits processors): served like the reference does, one host call per
         # beam per step (hostmask.py); stage times are wall clock with a device sync, like the reference's Timer
-        if mode[0]:
-            raise NotImplementedError("sampling needs a compilable constraint (PositionSetConstraint / SuffixTrieConstraint / Trie) "
-                                      "and no extra logits processors")
-        from .hostmask import bssd_host_mask
-        r = bssd_host_mask(target_model, draft_model, prompt.cpu().numpy().astype(np.int64), int(gamma), int(max_new_tokens),
-                           prefix_allowed_tokens_fn, list(logits_processor or ()))
+        from .hostmask import bssd_host_mask, bssd_host_mask_sample
+        if mode[0]:                                   # do_sample with a host-side mask / processors: the draws happen on the host, from the device's streams
+            if mode[1] <= 0.0:
+                raise ValueError("sampling needs a temperature > 0")
+            r = bssd_host_mask_sample(target_model, draft_model, prompt.cpu().numpy().astype(np.int64), int(gamma), int(max_new_tokens),
+                                      prefix_allowed_tokens_fn, list(logits_processor or ()), mode[1], mode[2])
+        else:
+            r = bssd_host_mask(target_model, draft_model, prompt.cpu().numpy().astype(np.int64), int(gamma), int(max_new_tokens),
+                               prefix_allowed_tokens_fn, list(logits_processor or ()))
         out = {"beam_sequence": torch.from_numpy(r["beam_sequence"]).to(dev), "beam_scores": torch.from_numpy(r["beam_scores"]).to(dev)}
         out.update({kk: r[kk] for kk in ("n_run", "total_accept_steps", "total_accept_tokens", "ave_accept_tokens", "accept_steps",
                                          "draft_time_cost", "target_time_cost", "verify_time_cost")})
@@ -413,12 +417,15 @@ def target_generate(model, inputs: Dict, max_new_tokens: int, logits_processor=N
     P = int(prompt.numel())
     k = int(model.generation_config.num_beams)                        # beamSD.py:553
     if _host_path(logits_processor, prefix_allowed_tokens_fn):
+        from .hostmask import target_generate_host_mask, target_generate_host_mask_sample
         if mode[0]:
-            raise NotImplementedError("sampling needs a compilable constraint (PositionSetConstraint / SuffixTrieConstraint / Trie) "
-                                      "and no extra logits processors")
-        from .hostmask import target_generate_host_mask
-        r = target_generate_host_mask(model, prompt.cpu().numpy().astype(np.int64), int(max_new_tokens), prefix_allowed_tokens_fn,
-                                      list(logits_processor or ()))
+            if mode[1] <= 0.0:
+                raise ValueError("sampling needs a temperature > 0")
+            r = target_generate_host_mask_sample(model, prompt.cpu().numpy().astype(np.int64), int(max_new_tokens), prefix_allowed_tokens_fn,
+                                                 list(logits_processor or ()), mode[1], mode[2])
+        else:
+            r = target_generate_host_mask(model, prompt.cpu().numpy().astype(np.int64), int(max_new_tokens), prefix_allowed_tokens_fn,
+                                          list(logits_processor or ()))
         return {"beam_sequence": torch.from_numpy(r["beam_sequence"]).to(dev), "beam_scores": torch.from_numpy(r["beam_scores"]).to(dev),
                 "n_valid": int(len(r["beam_scores"]))}
     fsm = _compile_constraint(prefix_allowed_tokens_fn, prompt.tolist())

@@ -17,6 +17,12 @@ return (`atspeed_beam_expand_prune_free`: row-wise top-k, then the K best (row, 
 The reference's post-top-k id filter runs whenever the processor list is non-empty (beamSD.py:80), mask or not.
 Stage times (`draft/target/verify_time_cost`, the CSV columns inference.py:183-187 reads) are wall clock with a device
 synchronisation at the end of each stage, as the reference's Timer measures them (beamSD.py:12-37).
+
+Sampling mode (`generation_config.do_sample`, beamSD.py:65-75,293-321,332-369) with a host-side mask or processors (round 4): forwards and the
+full-vocabulary log-softmax stay in the library; the tempered, masked rows of a step (<= DK x V fp32, 5 MB) come to the host, where the draws
+are made from the SAME counter-based streams the device kernels use (`_HashRng`: (seed, purpose, round, step, model) -> sub-seed, one hash per
+candidate id; scan.hip) -- so a callable that wraps a compilable constraint samples exactly what the device path samples for that seed
+(tests/test_bssd_gpu.py).
 """
 from __future__ import annotations
 
@@ -27,7 +33,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, synth
 from .model import HipLlama
 
 
@@ -304,6 +310,240 @@ def bssd_host_mask(target: HipLlama, draft: HipLlama, prompt: np.ndarray, gamma:
         accept_steps.append(nm)
         torch.cuda.synchronize(target.device)
         cost["verify_time_cost"] += time.time() - t_verify
+    n_run, total = len(accept_steps), sum(accept_steps)
+    return dict(beam_sequence=seq, beam_scores=scores, n_run=n_run, total_accept_steps=total, total_accept_tokens=total * k,
+                ave_accept_tokens=total * k / n_run if n_run else 0.0, accept_steps=accept_steps, **cost)
+
+
+# ---------------------------------------------------------------------------------------------- sampling mode on the host path
+P_STEP, P_ACCEPT, P_PERM, P_RESID, P_BONUS = 1, 2, 3, 4, 5     # purposes of a random stream (scan.hip)
+
+
+class _HashRng:
+    """The device's counter-based generator (scan.hip / common.h ats_rng_sub): every draw is a pure function of
+    (seed, purpose, round, step, model tag, element id).  A draw without replacement = top-n of log w + Gumbel(hash(id)) (Plackett-Luce, the
+    law of torch.multinomial's sequential draws), a uniform = ((h >> 9) + 0.5) 2^-23, a random subset = the n smallest hashes."""
+
+    def __init__(self, seed: int):
+        self.seed, self.sub = int(seed) & 0xFFFFFFFF, 0
+
+    def begin(self, purpose: int, rnd: int, step: int, model_tag: int = 0):
+        ctr = (purpose & 0xFF) | ((rnd & 0xFF) << 8) | ((step & 0xFF) << 16) | ((model_tag & 0xFF) << 24)
+        self.sub = int(synth.hash_u32(np.array([ctr], dtype=np.uint64), self.seed)[0])
+
+    def _u01(self, ids: np.ndarray) -> np.ndarray:
+        h = synth.hash_u32(ids.astype(np.uint64), self.sub)
+        return ((h >> np.uint64(9)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)
+
+    def multinomial_log(self, logw: np.ndarray, n: int) -> np.ndarray:
+        ids = np.nonzero(np.isfinite(logw))[0]
+        u = self._u01(ids)
+        keys = logw[ids].astype(np.float32) + (-np.log(-np.log(u, dtype=np.float32), dtype=np.float32)).astype(np.float32)
+        order = np.lexsort((ids, -keys))                 # key desc, id asc
+        return ids[order[:n]].astype(np.int64)
+
+    def uniform_ids(self, ids: np.ndarray) -> np.ndarray:
+        return self._u01(ids)
+
+    def subset_ids(self, ids: np.ndarray, n: int) -> np.ndarray:
+        h = synth.hash_u32(ids.astype(np.uint64), self.sub)
+        return np.lexsort((np.arange(len(ids)), h))[:n].astype(np.int64)
+
+
+def _softmax(x: np.ndarray) -> np.ndarray:
+    """softmax over a flat fp32 vector with -inf entries (all -inf -> zeros, as the reference zeroes its NaNs, beamSD.py:319-320)"""
+    m = np.max(x) if x.size else -np.inf
+    if not np.isfinite(m):
+        return np.zeros_like(x, dtype=np.float32)
+    e = np.exp((x - m).astype(np.float32), dtype=np.float32)
+    return (e / e.sum(dtype=np.float32)).astype(np.float32)
+
+
+def _tempered_rows(model: HipLlama, logits, lse, row_ids: Sequence[int], seqs: np.ndarray, fn: Optional[Callable], procs: Sequence[Callable],
+                   temperature: float) -> np.ndarray:
+    """log-softmax over the full vocabulary (:58,:285; library), prefix mask (:60-64,:286-291), processors, temperature warper (:65-66,
+    :293-294) -> host fp32 [n, V]"""
+    lib = _lib.load()
+    dev = model.device
+    V, ld = model.dims.vocab_size, model.logits_ld
+    n = len(row_ids)
+    with torch.cuda.device(dev):
+        rows = torch.as_tensor(list(row_ids), dtype=torch.int64, device=dev)
+        lg = logits.view(-1, ld)[rows].contiguous()
+        ls = lse[rows].contiguous()
+        scores = torch.empty(n, V, dtype=torch.float32, device=dev)
+        _lib.check(lib.atspeed_log_softmax_rows(lg.data_ptr(), ld, ls.data_ptr(), n, V, scores.data_ptr(), V, _lib.stream_ptr(dev)))
+        if fn is not None:
+            mask = torch.full_like(scores, float("-inf"))
+            for r, al in enumerate(_allowed_lists(fn, seqs)):
+                mask[r, torch.as_tensor(al, dtype=torch.long, device=dev)] = 0
+            scores = scores + mask
+        if procs:
+            ids = torch.from_numpy(np.ascontiguousarray(seqs)).to(dev)
+            for proc in procs:
+                scores = proc(ids, scores)
+        out = (scores.to(torch.float32) / float(temperature)).cpu().numpy()
+    return out
+
+
+def _one_step_sample(model: HipLlama, inp: _Inputs, k: int, beam_scores: np.ndarray, beam_seq: np.ndarray, fn, procs, temperature: float,
+                     rng: _HashRng) -> Dict:
+    """one_step_beam_search with do_sample (beamSD.py:40-106, :65-75): k draws without replacement from softmax of the flattened scores."""
+    n = len(beam_scores)
+    V = model.dims.vocab_size
+    logits, lse = _forward(model, inp, n)
+    seqs = beam_seq[:1] if (n == 1 and k != 1) else beam_seq
+    flat = (_tempered_rows(model, logits, lse, range(n), seqs, fn, procs, temperature) + np.asarray(beam_scores, np.float32)[:, None]).reshape(-1)
+    idx = rng.multinomial_log(flat, k)
+    s = flat[idx]
+    p, t = idx // V, idx % V
+    if fn is not None or procs:                                                     # :80-86 (any processor switches the id filter on)
+        keep = ((t >= 32000) | (t == 2)) & np.isfinite(s)
+        idx, s, p, t = idx[keep], s[keep], p[keep], t[keep]
+    m = len(t)
+    S = inp.vis.shape[1]
+    vis = np.concatenate((inp.vis[-n:][p], np.eye(m, dtype=bool)), axis=1)
+    nxt = _Inputs(t, np.full(m, inp.pos[-1] + 1), np.arange(S, S + m), vis)
+    return dict(flat=idx, scores=s.astype(np.float32), parents=p, tokens=t, seq=np.concatenate((beam_seq[p], t[:, None]), axis=1), next=nxt,
+                probs=_softmax(flat), dist=flat)
+
+
+def _final_sort(seq: np.ndarray, scores: np.ndarray):
+    o = np.argsort(-scores, kind="stable")                                          # beamSD.py:529-531, :589-591
+    return seq[o], scores[o]
+
+
+def target_generate_host_mask_sample(model: HipLlama, prompt: np.ndarray, max_new_tokens: int, fn, procs, temperature: float, seed: int) -> Dict:
+    k = int(model.generation_config.num_beams)
+    rng = _HashRng(seed)
+    inp = _causal(prompt)
+    scores = np.zeros(1, np.float32)
+    seq = np.repeat(prompt[None, :], k, axis=0)
+    for g in range(max_new_tokens):
+        rng.begin(P_STEP, g, 0, 0)
+        o = _one_step_sample(model, inp, k, scores, seq, fn, procs, temperature, rng)
+        inp, scores, seq = o["next"], o["scores"], o["seq"]
+    seq, scores = _final_sort(seq, scores)
+    return dict(beam_sequence=seq, beam_scores=scores)
+
+
+def bssd_host_mask_sample(target: HipLlama, draft: HipLlama, prompt: np.ndarray, gamma: int, max_new_tokens: int, fn, procs,
+                          temperature: float, seed: int) -> Dict:
+    """BSSD with `generation_config.do_sample` (beamSD.py:458-542; verify :293-321 distributions, :332-369 accept / resample, :303-309 bonus
+    draw) and the mask / processors on the host.  One documented deviation, as on the device path: with no residual mass left the remaining
+    draws come from the target distribution (the reference resamples uniformly over the whole vocabulary, -inf scores included)."""
+    cost = {"draft_time_cost": 0.0, "target_time_cost": 0.0, "verify_time_cost": 0.0}
+    k, dk = int(target.generation_config.num_beams), int(draft.generation_config.num_beams)
+    V = target.dims.vocab_size
+    rng = _HashRng(seed)
+    cur_len, max_len = len(prompt), len(prompt) + max_new_tokens
+    tin = din = _causal(prompt)
+    scores = np.zeros(1, np.float32)
+    seq = np.repeat(prompt[None, :], k, axis=0)
+    accept_steps: List[int] = []
+    while cur_len < max_len:
+        rnd = len(accept_steps)
+        dl = min(gamma, max_len - cur_len - 1)
+        if dl == 0:
+            rng.begin(P_STEP, rnd, 0, 0)
+            o = _one_step_sample(target, tin, k, scores, seq, fn, procs, temperature, rng)
+            seq, scores = o["seq"], o["scores"]
+            break
+        # ---- draft
+        steps, inp, d_scores, d_seq = [], din, scores, seq
+        step_len, step_seq = [len(scores)], [seq]
+        with _Stage(cost, "draft_time_cost", draft.device):
+            for i in range(dl):
+                rng.begin(P_STEP, rnd, i, 1)
+                o = _one_step_sample(draft, inp, dk, d_scores, d_seq, fn, procs, temperature, rng)
+                inp, d_scores, d_seq = o["next"], o["scores"], o["seq"]
+                steps.append(o)
+                step_len.append(len(d_scores))
+                step_seq.append(d_seq)
+        # ---- target: one packed forward
+        blocks = [tin] + [o["next"] for o in steps]
+        width = max(b.vis.shape[1] for b in blocks)
+        packed = _Inputs(np.concatenate([b.ids for b in blocks]), np.concatenate([b.pos for b in blocks]),
+                         np.concatenate([b.slots for b in blocks]), np.concatenate([_pad(b.vis, width) for b in blocks], axis=0))
+        n_rows = sum(step_len)
+        with _Stage(cost, "target_time_cost", target.device):
+            logits, lse = _forward(target, packed, n_rows)
+        t_verify = time.time()
+        # ---- verify
+        n0 = len(tin.ids)
+        nm, lo, hi = 0, 0, step_len[0]
+        hit = None
+        v_scores = scores
+        for i in range(dl + 1):
+            rows = list(range(lo, hi))
+            if nm != dl:
+                lo, hi = hi, hi + step_len[i + 1]
+            seqs = step_seq[i]
+            if i > 0:
+                rows = [rows[h] for h in hit]
+                seqs = seqs[hit]
+            if i == 0 and len(rows) == 1 and k != 1:
+                seqs = seqs[:1]
+            bs = (_tempered_rows(target, logits, lse, rows, seqs, fn, procs, temperature) + np.asarray(v_scores, np.float32)[:, None])
+            if i > 0:                                                               # :311-321: into the draft's beam space
+                tbs = np.full((step_len[i], V), -np.inf, dtype=np.float32)
+                tbs[hit] = bs
+                bs = tbs
+            bs = bs.reshape(-1)
+            if nm == dl:                                                            # :303-309 bonus draw from the target
+                rng.begin(P_BONUS, rnd, i, 0)
+                nxt = rng.multinomial_log(bs, k)
+                v_scores = bs[nxt]
+                parents, t = nxt // V, nxt % V
+                break
+            probs = _softmax(bs)
+            dprobs, d_ids = steps[i]["probs"], steps[i]["flat"]
+            p_i, q_i = probs[d_ids], dprobs[d_ids]
+            rng.begin(P_ACCEPT, rnd, i, 0)
+            r = rng.uniform_ids(np.arange(len(d_ids)))
+            acc = (r * q_i) <= p_i                                                  # r <= p / q without the division, as the device tests it
+            acc_tokens = d_ids[acc]
+            n_acc = int(acc.sum())
+            if n_acc >= k:                                                          # :341-350
+                nm += 1
+                rng.begin(P_PERM, rnd, i, 0)
+                sel = rng.subset_ids(np.nonzero(acc)[0], k)
+                seq_tokens = np.sort(acc_tokens[sel])
+                pos_of = {int(d): j for j, d in enumerate(d_ids.tolist())}
+                hit = np.asarray([pos_of[int(y)] for y in seq_tokens.tolist()], dtype=np.int64)
+                v_scores = bs[seq_tokens]
+                parents, t = seq_tokens // V, seq_tokens % V
+            else:                                                                   # :351-369 reject: resample the missing beams
+                newp = np.clip(probs - dprobs, 0, None).astype(np.float32)
+                newp[acc_tokens] = 0
+                if float(newp.sum()) == 0.0:
+                    newp = probs.copy()
+                    newp[acc_tokens] = 0
+                rng.begin(P_RESID, rnd, i, 0)
+                with np.errstate(divide="ignore"):
+                    nxt = rng.multinomial_log(np.log(newp, dtype=np.float32), k - n_acc)
+                seq_tokens = np.sort(np.concatenate((acc_tokens, nxt)))
+                v_scores = bs[seq_tokens]
+                parents, t = seq_tokens // V, seq_tokens % V
+                break
+        seq = np.concatenate((step_seq[nm][parents], t[:, None]), axis=1)           # :383
+        scores = np.asarray(v_scores, np.float32)
+        blk_lo = n0 - step_len[0] + sum(step_len[:nm])
+        blk_rows = packed.vis[blk_lo: blk_lo + step_len[nm]]
+        base = int(packed.slots[blk_lo + step_len[nm] - 1]) + 1
+        m = len(t)
+        vis = np.concatenate((_pad(blk_rows, base)[parents], np.eye(m, dtype=bool)), axis=1)
+        tin = _Inputs(t, np.full(m, packed.pos[blk_lo] + 1), np.arange(base, base + m), vis)
+        din = tin
+        if nm == dl:
+            last = steps[dl - 1]["next"]
+            din = _Inputs(np.concatenate((last.ids, tin.ids)), np.concatenate((last.pos, tin.pos)),
+                          np.concatenate((last.slots, tin.slots)), np.concatenate((_pad(last.vis, base + m), vis), axis=0))
+        cur_len += nm + 1
+        accept_steps.append(nm)
+        torch.cuda.synchronize(target.device)
+        cost["verify_time_cost"] += time.time() - t_verify
+    seq, scores = _final_sort(seq, scores)
     n_run, total = len(accept_steps), sum(accept_steps)
     return dict(beam_sequence=seq, beam_scores=scores, n_run=n_run, total_accept_steps=total, total_accept_tokens=total * k,
                 ave_accept_tokens=total * k / n_run if n_run else 0.0, accept_steps=accept_steps, **cost)

@@ -264,13 +264,9 @@ def test_api_errors():
     inputs = {"input_ids": torch.from_numpy(ci["prompt"])[None, :].cuda()}
     with pytest.raises(TypeError):       # separator absent: the reference's fn returns None -> TypeError in HF
         BSSD(tgt, drf, {"input_ids": torch.tensor([[1, 5, 6, 7]]).cuda()}, 4, 4, prefix_allowed_tokens_fn=ci["fn"])
-    tgt.generation_config.do_sample = True        # sampling needs a compilable constraint (the draws happen on the device)
-    with pytest.raises(NotImplementedError):
-        BSSD(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=lambda b, s: ci["fn"](b, s))
+    tgt.generation_config.do_sample = True
     with pytest.raises(atspeed_amd._lib.AtSpeedError):        # mask-free search is greedy only
         BSSD(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=None)
-    with pytest.raises(NotImplementedError):                  # ... and so are host-side logits processors
-        BSSD(tgt, drf, inputs, 4, 4, logits_processor=[lambda ids, sc: sc], prefix_allowed_tokens_fn=ci["fn"])
     tgt.generation_config.temperature = 0.0
     with pytest.raises(atspeed_amd._lib.AtSpeedError):
         BSSD(tgt, drf, inputs, 4, 4, prefix_allowed_tokens_fn=ci["fn"])
@@ -568,6 +564,47 @@ def test_sampling_bssd_makes_the_oracles_decisions(name, temperature):
     a = BSSD(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"], seed=7)
     b = BSSD(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"], seed=7)
     assert torch.equal(a["beam_sequence"], b["beam_sequence"])
+
+
+@pytest.mark.parametrize("name,temperature", [("k10_dk40_sigma01", 1.3), ("k20_dk40_sigma0", 0.7), ("k5_dk10_indep", 1.0)])
+def test_sampling_with_a_host_side_mask_or_processor_samples_what_the_device_path_samples(name, temperature):
+    """do_sample with an arbitrary Python mask callable or extra logits processors (legal in the reference: beamSD.py:293-369 with any
+    `logits_processor`; NotImplementedError through round 3): the host path draws from the device's counter-based streams, so a closure that
+    wraps the compilable constraint -- and the same with an identity processor appended -- returns exactly the device path's sampled beams,
+    rounds and accepted steps for the same seed (scores within 1e-3)."""
+    case, ci, tgt, drf, rt, rd = _sampling_pair(name, temperature)
+    inputs = {"input_ids": torch.from_numpy(ci["prompt"])[None].cuda()}
+    closure = lambda b, sent: ci["fn"](b, sent)                   # no .compile(): served by hostmask.py
+    same_b = same_p = same_t = 0
+    seeds = list(range(60, 70))
+    for seed in seeds:
+        dev = BSSD(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"], seed=seed)
+        host = BSSD(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=closure, seed=seed)
+        proc = BSSD(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], logits_processor=[lambda ids, sc: sc + 0.0],
+                    prefix_allowed_tokens_fn=ci["fn"], seed=seed)
+        nv = dev["n_valid"]
+        for other, tag in ((host, "b"), (proc, "p")):
+            ok = (other["beam_sequence"].shape[0] == nv and torch.equal(other["beam_sequence"], dev["beam_sequence"][:nv])
+                  and other["accept_steps"] == dev["accept_steps"] and other["n_run"] == dev["n_run"])
+            if ok:
+                np.testing.assert_allclose(other["beam_scores"].cpu().numpy(), dev["beam_scores"][:nv].cpu().numpy(), atol=SCORE_TOL, rtol=0)
+                assert (np.diff(other["beam_scores"].cpu().numpy()) <= 0).all()
+            if tag == "b":
+                same_b += ok
+            else:
+                same_p += ok
+        d_t = target_generate(tgt, inputs, case["max_new_tokens"], prefix_allowed_tokens_fn=ci["fn"], seed=seed)
+        h_t = target_generate(tgt, inputs, case["max_new_tokens"], prefix_allowed_tokens_fn=closure, seed=seed)
+        same_t += bool(h_t["beam_sequence"].shape[0] == d_t["n_valid"] and torch.equal(h_t["beam_sequence"], d_t["beam_sequence"][: d_t["n_valid"]]))
+    print(f"[{name}] host-mask sampling equals the device path on {same_b} / {same_p} / {same_t} of {len(seeds)} seeds (closure / processor / target_generate)")
+    # a draw decided by less than fp32 rounding may differ between the host's and the device's softmax: at most one seed in ten
+    assert same_b >= len(seeds) - 1 and same_p >= len(seeds) - 1 and same_t >= len(seeds) - 1
+    # repeatable
+    a = BSSD(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=closure, seed=7)
+    b = BSSD(tgt, drf, inputs, case["gamma"], case["max_new_tokens"], prefix_allowed_tokens_fn=closure, seed=7)
+    assert torch.equal(a["beam_sequence"], b["beam_sequence"])
+    for m in (tgt, drf):
+        m.generation_config.do_sample = False
 
 
 def test_sampling_target_generate_and_batches():
