@@ -19,7 +19,8 @@ Extra objects on the JSON line (N = 1; all driver-clocked, all bounded so the de
                  batched; verify_scan: the verify step's scan vs 8 TB/s.
   configs      — BASELINE configs 3 and 5 as sub-passes with their own items/s, ms_per_step and dominant-kernel roofline:
                  games_256 / games_256_trie (Games V=33014, 256 users per lock-step batch, position-set mask / strict item
-                 trie) and fp8 (e4m3 W8A8 target projections, roofline against 5 PF, accepted-length drift vs bf16).
+                 trie), fp16 (the reference's own dtype on the engine's fp16 flavour) and fp8 (e4m3 W8A8 target projections, roofline
+                 against 5 PF, accepted-length drift vs bf16).
   aligned_weight_brackets — the same users and kernels with draft / target weights that agree (accept length 3 and ~1.1), each
                  with the fp32 ENGINE's accepted length on the same weights and >= 32 users next to the bf16 engine's.
   speedup_curve — the reference's own figure of merit (inference.py:179: speedup = target_generate time / BSSD time) on this engine at
@@ -276,7 +277,8 @@ def gemm_roofline(target, prof, prof_big, fp8: bool, measured, streams: int, wit
     # qkv: 5 = RoPE + KV scatter in the epilogue (head_dim 128 targets), as the engine's counter says
     epi = {"qkv": 5 if target.rope_fused_launches() > 0 else 0, "o_proj": 2, "gate_up": 3, "down": 2, "lm_head": 1}[kind]
     ring = (f"gemm_ring_mx_kernel<{epi}, 8>" if (f8 and os.environ.get("ATSPEED_FP8_MX", "1") != "0")
-            else f"gemm_ring_kernel<{4 if kind == 'lm_head' else epi}, 8, {'true' if f8 else 'false'}, false, 4>")
+            else f"gemm_ring_kernel<{4 if kind == 'lm_head' else epi}, 8, {'true' if f8 else 'false'}, false, 4, SK> (SK = false | true: the same kernel without / with "
+                 f"its split-K tail, chosen per launch by the tile count; rocprofv3 lists the two instantiations separately)")
     kname = (f"{ring} [{kind}] N={N} K={K} avg_M={avg_m:.0f} (launches of >= 1024 tokens)"
              if one_kernel else f"projection GEMM [{kind}] N={N} K={K} avg_M={avg_m:.0f} (all launches)")
     # PMC traffic was collected on the bf16 headline workload: it says nothing about the fp8 kernels or other batch shapes
@@ -621,6 +623,17 @@ def main():
                                      roofline=gemm_roofline(tg_, r["prof"], r["prof_big"], False, measured, args.streams, False))
             release_decoders(tg_, dg_)
             del tg_, dg_
+        if not args.target_fp8:
+            # the reference's own dtype (inference.py:75-100 loads both models in fp16): the engine's fp16 flavour on the headline workload
+            release_decoders(target, draft)
+            t16, d16 = build_pair(tdims, ddims, dtype=torch.float16)
+            r = timed_pass(t16, d16, dprompts, sub_warm, sub_steps, args.streams, fn, args, dev)
+            configs["fp16"] = dict(workload=f"{args.dataset.capitalize()} V={V}, Llama-68M / Llama-7B({args.target_layers}L) in fp16 (ATSPEED_F16: the bf16 engine's kernels "
+                                            f"compiled for IEEE half, v_mfma_f32_16x16x32_f16), K={args.beam}, {args.streams} users per lock-step batch",
+                                   steps=sub_steps, dtype="fp16", **pass_summary(r, args, ups),
+                                   roofline=gemm_roofline(t16, r["prof"], r["prof_big"], False, measured, args.streams, False))
+            release_decoders(t16, d16)
+            del t16, d16
         if not args.target_fp8:
             release_decoders(target, draft)
             target.enable_fp8()                        # from here on the headline target runs its batched projections in fp8
