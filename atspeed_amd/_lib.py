@@ -34,7 +34,8 @@ class LlamaConfig(C.Structure):
 class GenStats(C.Structure):
     _fields_ = [("n_run", C.c_int32), ("total_accept_steps", C.c_int32), ("accept_steps", C.c_int32 * MAX_NEW_TOKENS),
                 ("n_valid", C.c_int32), ("n_target_forwards", C.c_int32), ("n_draft_forwards", C.c_int32),
-                ("draft_ms", C.c_float), ("target_ms", C.c_float), ("verify_ms", C.c_float), ("total_ms", C.c_float)]
+                ("draft_ms", C.c_float), ("target_ms", C.c_float), ("verify_ms", C.c_float), ("total_ms", C.c_float),
+                ("status", C.c_int32)]
 
 
 # every symbol include/atspeed_hip.h declares: (restype, argtypes)

@@ -398,7 +398,7 @@ def BSSD_batch(target_model, draft_model, inputs_list, gamma: int, max_new_token
                     "ave_accept_tokens": total * k / n_run if n_run else 0.0,
                     "draft_time_cost": st.draft_ms * 1e-3, "target_time_cost": st.target_ms * 1e-3,
                     "verify_time_cost": st.verify_ms * 1e-3, "device_time_cost": st.total_ms * 1e-3,
-                    "time_cost": wall / n, "n_valid": int(st.n_valid),
+                    "time_cost": wall / n, "n_valid": int(st.n_valid), "status": int(st.status),
                     "accept_steps": [int(st.accept_steps[j]) for j in range(min(n_run, _lib.MAX_NEW_TOKENS))],
                     "n_target_forwards": int(st.n_target_forwards), "n_draft_forwards": int(st.n_draft_forwards)})
         outs.append(out)
@@ -484,7 +484,8 @@ def target_generate_batch(model, inputs_list, max_new_tokens: int, prefix_allowe
     results = _batch_results(_keep, toks, scores, k)
     for i in range(n):
         out = results[i]
-        out.update({"n_valid": int(stats[i].n_valid), "device_time_cost": stats[i].total_ms * 1e-3, "time_cost": wall / n})
+        out.update({"n_valid": int(stats[i].n_valid), "status": int(stats[i].status), "device_time_cost": stats[i].total_ms * 1e-3,
+                    "time_cost": wall / n})
         outs.append(out)
     return outs
 

@@ -1074,6 +1074,15 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
       atspeed_decoder* d = decs[u];
       atspeed_decoder::Run& r = d->run;
       if (r.done) continue;
+      if (n > 1 && d->mail_host->status == ATSPEED_ERR_FILTERED) {
+        // a lock-step batch does not die with one user: this user lost every beam of a step to the id filter (beamSD.py:80-86; the
+        // reference dies on a shape mismatch there) and ends with no valid beam, the others go on (the one-user call returns the error)
+        r.s.n_valid = 0; r.s.status = ATSPEED_ERR_FILTERED;
+        r.s.total_ms = r.s.draft_ms + r.s.target_ms + r.s.verify_ms;
+        if (r.stats_out) *r.stats_out = r.s;
+        r.done = true;
+        continue;
+      }
       ATS_TRY(mailbox_status(d));
       // stage times: the group's stage time shared equally by the users that were active in the round
       r.s.draft_ms += ms_d / n_act; r.s.target_ms += ms_t / n_act; r.s.verify_ms += ms_v / n_act;
@@ -1254,11 +1263,13 @@ extern "C" int atspeed_target_generate_batch(atspeed_decoder** decs, int32_t n, 
   float ms = 0.f;
   hipEventElapsedTime(&ms, g_ev[0], g_ev[1]);
   for (int u = 0; u < n; ++u) {
-    ATS_TRY(mailbox_status(decs[u]));
+    const bool filtered = n > 1 && decs[u]->mail_host->status == ATSPEED_ERR_FILTERED;    // per user, as in the beam-SD batch loop
+    if (!filtered) ATS_TRY(mailbox_status(decs[u]));
     if (stats) {
       atspeed_gen_stats gs;
       memset(&gs, 0, sizeof(gs));
-      gs.n_target_forwards = max_new; gs.n_valid = decs[u]->mail_host->n_valid;
+      gs.n_target_forwards = max_new; gs.n_valid = filtered ? 0 : decs[u]->mail_host->n_valid;
+      gs.status = filtered ? ATSPEED_ERR_FILTERED : ATSPEED_OK;
       gs.total_ms = gs.target_ms = ms / n;                      // the group's time shared equally by its users
       stats[u] = gs;
     }

@@ -259,6 +259,9 @@ typedef struct atspeed_gen_stats {
   int32_t n_valid;             /* beams with a finite score                           */
   int32_t n_target_forwards, n_draft_forwards;
   float draft_ms, target_ms, verify_ms, total_ms;   /* hipEvent stage times (Timer, beamSD.py:12-37) */
+  int32_t status;              /* batched calls: ATSPEED_OK, or ATSPEED_ERR_FILTERED for a user whose step lost every beam to the id
+                                  filter of beamSD.py:80-86 -- that user ends with n_valid = 0, the rest of the batch finishes (the
+                                  one-user calls return the error instead)                */
 } atspeed_gen_stats;
 
 /* prompt_ids_dev: [prompt_len] int32.  out_tokens_dev: [k][max_new_tokens] int32 generated

@@ -344,3 +344,35 @@ def test_batch_calls_on_a_model_that_is_not_on_the_current_device():
         assert all(o["beam_sequence"].device == dev for o in b + t)
         release_decoders(tgt, drf)
     assert outs[0] == outs[1]
+
+
+def test_a_filtered_user_does_not_abort_the_lock_step_batch():
+    """ATSPEED_ERR_FILTERED is per user in the batched calls.  A whole-sentence trie sends user B into a subtree of ordinary
+    tokens (< 32000): the reference's post-top-k id filter (beamSD.py:80-86) drops every pick of B's first step (the reference then dies on a
+    shape mismatch).  B ends with n_valid = 0 and status ERR_FILTERED, users A and C get exactly their one-user results; the one-user call for
+    B still raises."""
+    from atspeed_amd import _lib
+    from atspeed_amd.beamSD import target_generate_batch
+    case = [c for c in CASES if c["name"] == "k5_dk10_indep"][0]
+    ci = build_case_inputs(case)
+    kw = dict(max_slots=512, max_tokens=512, max_logit_rows=448, device="cuda:0")
+    tgt = HipLlama.from_state_dict(ci["target_dims"], ci["target_sd"], torch.float32, num_beams=case["K"], **kw)
+    drf = HipLlama.from_state_dict(ci["draft_dims"], ci["draft_sd"], torch.float32, num_beams=case["DK"], **kw)
+    pa, pb, pc = [1, 50, 51, 52], [1, 60, 61], [1, 70, 71, 72, 73]
+    items = [[32000 + i, 32064 + (3 * i) % 64, 32128 + (5 * i) % 64, 32192 + (7 * i) % 64, 2] for i in range(24)]
+    seqs = [pa + it for it in items] + [pc + it for it in items[:12]] + [pb + [7 + i, 8, 9, 10, 2] for i in range(6)]
+    fn = prefix_allowed_tokens_fn(Trie(seqs))
+    ins = [{"input_ids": torch.tensor([p], dtype=torch.int64).cuda()} for p in (pa, pb, pc)]
+    bat = BSSD_batch(tgt, drf, ins, 4, 4, prefix_allowed_tokens_fn=fn)
+    tgb = target_generate_batch(tgt, ins, 4, prefix_allowed_tokens_fn=fn)
+    for res in (bat, tgb):
+        assert [r["status"] for r in res] == [0, _lib.ERR_FILTERED, 0] and res[1]["n_valid"] == 0
+    for u in (0, 2):
+        one = BSSD(tgt, drf, ins[u], 4, 4, prefix_allowed_tokens_fn=fn)
+        nv = one["n_valid"]
+        assert bat[u]["n_valid"] == nv >= 1 and torch.equal(bat[u]["beam_sequence"][:nv], one["beam_sequence"][:nv])
+        assert torch.equal(tgb[u]["beam_sequence"][:nv], one["beam_sequence"][:nv])
+    with pytest.raises(_lib.AtSpeedError) as ei:
+        BSSD(tgt, drf, ins[1], 4, 4, prefix_allowed_tokens_fn=fn)
+    assert ei.value.status == _lib.ERR_FILTERED
+    release_decoders(tgt, drf)
