@@ -91,7 +91,7 @@ def parse():
 
 
 # ------------------------------------------------------------------------------------------------ roofline.traffic provenance
-TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
 KERNEL_SOURCES = ("gemm.hip", "common.h")          # the GEMM kernels and the device helpers they use (internal.h holds only host-side declarations for them)
 
 
@@ -130,9 +130,9 @@ def traffic_from_profiles(kind: str, path: str = None, sha: str = None):
 # ------------------------------------------------------------------------------------------------ CPU oracle leg
 def cpu_baseline(target, draft, prompts, fn, args, n_users=None):
     """Oracle (CPU restatement of the reference) on the same weights/prompts; bounded sample.  Returns (object, oracle outputs, oracle models)."""
-    from oracle import beamsd_ref as R
+    from oracle import beamsd_ref as R, use_allotted_cpu_threads
     from oracle.llama_ref import RefLlama
-    cores = torch.get_num_threads()
+    cores = use_allotted_cpu_threads()              # the CPUs this process really has (cgroup quota), not the host's core count
     t0 = time.perf_counter()
     rt = RefLlama(target.dims, target.export_state_dict(), max_slots=512)
     rd = RefLlama(draft.dims, draft.export_state_dict(), max_slots=512)

@@ -13,6 +13,10 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle's fp32 matmuls on the CPUs this process is really allotted (a one-GPU box: 16 of the host's 256; torch's default pool of
+    # 128 threads ran them 3 x slower)
+    from oracle import use_allotted_cpu_threads
+    use_allotted_cpu_threads()
 
 
 @pytest.fixture(scope="session")

@@ -43,9 +43,11 @@ for kind, pat in KINDS.items():
     wk = [k for k in write if pat in k]
     if not fk or not wk:
         continue
-    fc, fv = fetch[fk[0]]
-    wc, wv = write[wk[0]]
-    res[kind] = {"kernel": pat, "dispatches": fc, "FETCH_SIZE_KiB_per_launch": fv / fc, "WRITE_SIZE_KiB_per_launch": wv / wc,
+    # every instantiation the pattern covers (round 4: the ring kernel exists without and with its split-K tail, `..., 4, false>` / `..., 4, true>`,
+    # chosen per launch), dispatch-weighted
+    fc, fv = sum(fetch[k][0] for k in fk), sum(fetch[k][1] for k in fk)
+    wc, wv = sum(write[k][0] for k in wk), sum(write[k][1] for k in wk)
+    res[kind] = {"kernel": pat, "instantiations": sorted(k.split("(")[0][-60:] for k in fk), "dispatches": fc, "FETCH_SIZE_KiB_per_launch": fv / fc, "WRITE_SIZE_KiB_per_launch": wv / wc,
                  "hbm_bytes_per_launch": 2 * fv / fc * 1024 + wv / wc * 1024, "avg_m": avg_m.get(kind)}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "_method"}, indent=1))
