@@ -82,7 +82,7 @@ def parse():
                     help="position = the per-position allowed sets inference.py installs; trie = strict item trie on the generated suffix")
     ap.add_argument("--do-sample", action="store_true", help="sampling-mode beam-SD (generation_config.do_sample) instead of the greedy headline")
     ap.add_argument("--temperature", type=float, default=1.0)
-    ap.add_argument("--cpu-baseline-users", type=int, default=2, help="users the CPU oracle decodes (about 35 s each on the box's host cores)")
+    ap.add_argument("--cpu-baseline-users", type=int, default=4, help="users the CPU oracle decodes (about 7 s each on a one-GPU box's 16 allotted CPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sub-steps", type=int, default=2, help="timed batches of each sub-pass (configs 3 / 5, aligned brackets); independent of --steps so the line stays bounded")
     ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / config 5 sub-passes")
