@@ -817,8 +817,8 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
     if (RD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
     if ((VM) >= 0) {                                                                                     \
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VM) < 0 ? 0 : (VM)) : "memory");                         \
-        asm volatile("s_barrier" ::: "memory");                                                            \
-      }                                                                                                    \
+      asm volatile("s_barrier" ::: "memory");                                                            \
+    }                                                                                                    \
   }
 
   // prologue: k-steps 0..3 into stages 0..3; fragments of k-step 0
@@ -1285,13 +1285,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* _
       const int idx = i * TB + j;                                                                        \
       _Pragma("unroll") for (int t = 0; t < NIT; ++t) {                                                  \
         if (t * NMF / NIT == idx) {                                                                      \
-          if (t < NR) { if (RD) read_one(((Q) + 1) & 3, ((Q) + 1) & 1, t); }       \
-          else if (DMA) dma_piece((Q), (ks) + 4, t - NR);                          \
+          if (t < NR) { if (RD) read_one(((Q) + 1) & 3, ((Q) + 1) & 1, t); }                             \
+          else if (DMA) dma_piece((Q), (ks) + 4, t - NR);                                                \
         }                                                                                                \
       }                                                                                                  \
-      if constexpr (NWV == 4) \
+      if constexpr (NWV == 4)                                                                            \
         ATS_MFMA_MX_A(acc[i][j], ATS_CAT8(fal[(Q) & 1][i], fah[(Q) & 1][i]), ATS_CAT8(fbl[(Q) & 1][j], fbh[(Q) & 1][j]), unit_scale); \
-      else \
+      else                                                                                               \
         ATS_MFMA_MX(acc[i][j], ATS_CAT8(fal[(Q) & 1][i], fah[(Q) & 1][i]), ATS_CAT8(fbl[(Q) & 1][j], fbh[(Q) & 1][j]), unit_scale); \
     }                                                                                                    \
     if (RD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
@@ -2054,9 +2054,10 @@ static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype,
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
   const int tn = (n + 255) / 256;
   if (big_fill_pct(tn * ((m + 255) / 256)) >= min_fill || big_fill_pct(tn * ((m + 127) / 128)) >= min_fill) return true;
-  // a thin grid whose k-steps the stream-K tail spreads over the chip: from 64 tiles of 128 rows (at most 4 parts per tile; N = 4096
-  // from ~400 tokens), where it overtakes the LDS-tiled split-K kernel + reduce pass (tools/yardstick_engine_like.py)
-  static const int sk_min_tiles = env_int("ATSPEED_GEMM_SK_MIN_TILES", 64);
+  // a thin grid whose k-steps the split-K tail spreads over the chip: from 48 tiles of 128 rows (four parts per tile on 192 CUs; N = 4096
+  // from 257 tokens), where it overtakes the LDS-tiled split-K kernel + reduce pass (tools/sk_sweep.py: o_proj at 320 tokens 36.7 -> 34.1 us,
+  // down 73.6 -> 70.3; at 400 tokens 33.7 -> 29.6 and 68.4 -> 59.7)
+  static const int sk_min_tiles = env_int("ATSPEED_GEMM_SK_MIN_TILES", 48);
   const int t128 = tn * ((m + 127) / 128);
   return t128 >= sk_min_tiles && sk_any_plan(t128, k);
 }
