@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
 #include <set>
 
 #include "internal.h"
@@ -1337,15 +1338,17 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* _
   }
 }
 
-// library-owned workspace of the stream-K tail, per device: 256 workgroups x 2 slots x 256 KB of fp32 partials + one arrival counter per
-// tail tile (zeroed here once; the finishing part leaves its counter at zero).  Launches that use it are ordered by the stream; a launch
-// on ANOTHER stream than the last one first waits for that one (event), so callers with several streams stay correct.
+// library-owned workspace of the split-K tail, per device and shared by all host threads: 256 workgroups x 2 slots x 256 KB of fp32 partials
+// + one arrival counter per tail tile (zeroed here once; the finishing part leaves its counter at zero).  Launches that use it must not
+// overlap: the caller holds `g_sk_mu` from here until its kernel is enqueued, and a launch on ANOTHER stream than the previous one first
+// waits for that one (event) -- callers with several streams or threads stay correct, at the price of ordering their split-K launches.
 struct SkWorkspace { float* ws = nullptr; int* cnt = nullptr; hipStream_t last = nullptr; hipEvent_t ev = nullptr; bool have_last = false; };
-static int sk_workspace(hipStream_t st, SkWorkspace** out) {
-  static thread_local SkWorkspace per_dev[ATS_MAX_DEVICES];
+static std::mutex g_sk_mu;
+static SkWorkspace g_sk[ATS_MAX_DEVICES];
+static int sk_workspace(hipStream_t st, SkWorkspace** out) {          // g_sk_mu held by the caller
   const int d = ats_cur_device();
   ATS_REQUIRE(d >= 0, ATSPEED_ERR_HIP, "gemm: no current HIP device");
-  SkWorkspace& w = per_dev[d];
+  SkWorkspace& w = g_sk[d];
   if (!w.ws) {
     ATS_HIP(hipMalloc((void**)&w.ws, (size_t)512 * 256 * 1024));
     ATS_HIP(hipMalloc((void**)&w.cnt, 256 * sizeof(int)));
@@ -1380,6 +1383,7 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
   if (ch.sk.on) {
     // stream-K tail: n_dp whole tiles + G workgroups that share the k-steps of the remaining ones evenly
     SkWorkspace* wsp = nullptr;
+    std::lock_guard<std::mutex> lk(g_sk_mu);                      // bookkeeping + enqueue as one step (see SkWorkspace)
     ATS_TRY(sk_workspace(st, &wsp));
     const SkTail tail{ch.sk.n_dp, ch.sk.G, ch.sk.U, ch.sk.TU, wsp->ws, wsp->cnt};
     const int grid = ch.sk.n_dp + ch.sk.G;
