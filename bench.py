@@ -196,6 +196,123 @@ def disagreement_report(gpu_out, ref_out, P, ref_target, prompt):
     return rep
 
 
+
+# ------------------------------------------------------------------------------------------------ the ONE line the driver parses
+LINE_BUDGET_BYTES = 6144        # the driver keeps an 8 KB tail of stdout: r03's 14 KB line parsed, r04's 41 KB line did not (BENCH_r04.parsed = null)
+DETAIL_FILE = "bench_detail.json"
+
+
+def _num(x, sig=5):
+    """numbers of the compact line: 5 significant digits (floats), ints as they are"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _num(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_num(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d.get(k) for k in keys if d is not None and k in d} if d else None
+
+
+def _curve_rows(curve, bracket):
+    """numbers-only rows of a speedup curve: users, bracket, ms of both decoders, speedup, roofline fraction of both"""
+    rows = []
+    for p_ in curve or []:
+        b, t = p_.get("bssd", {}), p_.get("target_generate", {})
+        rows.append(dict(users=p_.get("users_per_batch"), bracket=bracket, bssd_ms=b.get("ms_to_last_result"), tg_ms=t.get("ms_to_last_result"),
+                         speedup=p_.get("speedup"), bssd_frac=(b.get("roofline") or {}).get("frac"), tg_frac=(t.get("roofline") or {}).get("frac")))
+    return rows
+
+
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "avg_launch_us", "launches",
+                 "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "peak_measured", "frac_of_measured")
+
+
+def compact_line(detail: dict) -> dict:
+    """The final stdout line: the contract's keys, `roofline`, `cpu_baseline`, `measured_peaks` and a NUMBERS-ONLY summary of every sub-pass
+    (inference.py:152-156,183-189 emit a CSV row of numbers, not a report).  Everything else -- `what` strings, per-point forward logs, the
+    per-rank disagreement rows -- lives in DETAIL_FILE.  tests/test_bench_contract.py holds this to LINE_BUDGET_BYTES."""
+    d = detail
+    line = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                  "vs_baseline", "dtype", "data")}
+    cfg = d.get("config") or {}
+    line["config"] = _pick(cfg, ("workload", "users_per_step", "users_per_gpu", "mean_prompt_len", "parallelism", "kernel_sha"))
+    line["mean_accept_len"] = d.get("mean_accept_len")
+    if d.get("decoding"):
+        line["decoding"] = d["decoding"]
+    rf = d.get("roofline") or {}
+    r = _pick(rf, ROOFLINE_KEYS)
+    if r and isinstance(r.get("kernel"), str):
+        r["kernel"] = r["kernel"].split(" (SK =")[0][:120]
+    line["roofline"] = r
+    line["measured_peaks"] = _pick(d.get("measured_peaks"), ("mfma_bf16_tflops", "hbm_read_gbs"))
+    line["cpu_baseline"] = _pick(d.get("cpu_baseline"), ("value", "unit", "cores", "kind", "sample", "mean_accept_len", "gpu_accept_len_same_users",
+                                                         "top_k_overlap_with_gpu_bf16"))
+    line["per_user"] = d.get("per_user")
+    if d.get("n_gpus", 1) > 1:
+        line["per_rank"] = [_pick(r_, ("rank", "n_users", "n_run", "accept_steps", "elapsed_ms")) for r_ in d.get("per_rank") or []]
+    vs = d.get("verify_scan")
+    line["verify_scan"] = _pick(vs, ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "bytes_per_launch"))
+    cf = {}
+    for name, c in (d.get("configs") or {}).items():
+        cf[name] = dict(items_per_s=c.get("items_per_s"), ms_per_step=c.get("ms_per_step"), mean_accept_len=c.get("mean_accept_len"),
+                        frac=(c.get("roofline") or {}).get("frac"), bound=(c.get("roofline") or {}).get("bound"))
+        dr = c.get("accepted_length_drift_vs_bf16")
+        if dr:
+            cf[name]["accept_drift_vs_bf16"] = dr.get("drift_steps")
+    line["configs"] = cf or None
+    rows = _curve_rows(d.get("speedup_curve"), "accept0")
+    br = []
+    for a in d.get("aligned_weight_brackets") or []:
+        tag = f"resid{a.get('resid_scale'):g}"
+        rows += _curve_rows(a.get("speedup_curve"), tag)
+        f32 = a.get("fp32_engine") or {}
+        br.append(dict(bracket=tag, items_per_s=a.get("items_per_s"), mean_accept_len=a.get("mean_accept_len"),
+                       fp32_engine_accept_len=f32.get("mean_accept_len"), users_equal_accept_steps=f32.get("users_with_equal_accept_steps"),
+                       fp32_users=f32.get("users")))
+    line["aligned_weight_brackets"] = br or None
+    line["speedup_curve"] = rows or None          # speedup = plain beam search ms / beam-SD ms (inference.py:179)
+    su = d.get("single_user_stream")
+    if su:
+        line["single_user_stream"] = dict(_pick(su, ("users", "items_per_s", "ms_per_user", "weights_stream_frac_of_hbm_peak")),
+                                          frac=(su.get("roofline") or {}).get("frac"), avg_launch_us=(su.get("roofline") or {}).get("avg_launch_us"))
+    if d.get("single_user_fp8"):
+        line["single_user_fp8"] = d["single_user_fp8"] if len(json.dumps(d["single_user_fp8"])) < 700 else _pick(
+            d["single_user_fp8"], ("ms_per_user", "items_per_s", "weights_stream_frac_of_hbm_peak", "mean_accept_len", "bf16_ms_per_user"))
+    errs = d.get("sub_pass_errors")
+    line["sub_pass_errors"] = {k: str(v)[:120] for k, v in errs.items()} if errs else None
+    line["detail"] = d.get("detail_file")
+    return _num(line)
+
+
+def emit(detail: dict, out_dir: str = None):
+    """Write the full report to DETAIL_FILE (under gpurun_out/ when that exists, so it comes back from the GPU box) and print the compact
+    line as the LAST line of stdout."""
+    out_dir = out_dir or (os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT)
+    path = os.path.join(out_dir, DETAIL_FILE)
+    try:
+        with open(path, "w") as f:
+            json.dump(detail, f)
+        detail["detail_file"] = os.path.relpath(path, ROOT)
+    except OSError as e:
+        detail["detail_file"] = f"not written: {e}"
+    text = json.dumps(compact_line(detail), separators=(",", ":"))
+    if len(text) > LINE_BUDGET_BYTES:            # never let a sub-pass summary cost the headline: drop the widest optional objects
+        slim = compact_line(detail)
+        for k in ("speedup_curve", "aligned_weight_brackets", "configs", "verify_scan", "single_user_stream", "per_user"):
+            slim.pop(k, None)
+            text = json.dumps(slim, separators=(",", ":"))
+            if len(text) <= LINE_BUDGET_BYTES:
+                break
+    print(text, flush=True)
+    return text
+
+
 # ------------------------------------------------------------------------------------------------ launch plumbing
 def launcher_command(n_gpus: int, argv, port: int = 0):
     """The torch.distributed.run command line that starts `n_gpus` ranks of this script (one process per GPU, RCCL rendezvous on
@@ -751,7 +868,7 @@ def main():
 
     line["cpu_baseline"] = guarded("cpu_baseline", cpu_pass) if (world == 1 and not args.no_cpu_baseline and not args.do_sample) else None
     line["sub_pass_errors"] = sub_errors or None
-    print(json.dumps(line), flush=True)
+    emit(line)
     if device_dead:
         raise SystemExit(f"bench.py: device error in sub-pass {device_dead[0]} (line printed above with sub_pass_errors); exiting non-zero")
     if world > 1:

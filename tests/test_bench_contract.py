@@ -162,3 +162,43 @@ def test_forwards_roofline_prices_each_forward_against_its_own_bound():
     assert r["forwards"] == 2 and r["forwards_hbm_bound"] == 1
     assert abs(r["ideal_ms"] - 1e3 * (hbm + mf)) < 1e-6 and abs(r["frac"] - (hbm + mf)) < 1e-9
     assert 2.0 * (w_layers * 100 + w_head * 100) / 2.5e15 < hbm < mf
+
+
+def test_final_line_is_compact_enough_for_the_driver(tmp_path, capsys):
+    """BENCH_r04.json.parsed was null: the one JSON line had grown to 41 KB and the driver keeps an 8 KB tail.  The final stdout line is now a
+    numbers-only summary built from the full report (which goes to bench_detail.json); built here from round 4's own 41 KB report."""
+    import json
+    import os
+    with open(os.path.join(bench.ROOT, "profiles", "r04_bench.json")) as f:
+        detail = json.load(f)
+    assert len(json.dumps(detail)) > 30000
+    text = bench.emit(detail, out_dir=str(tmp_path))
+    out = capsys.readouterr().out
+    assert out.endswith(text + "\n") and out.count("\n") == 1                # ONE line, the last one
+    assert len(text) < bench.LINE_BUDGET_BYTES < 8192
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in line, k
+    assert line["value"] == pytest.approx(detail["value"], rel=1e-4) and line["config"]["workload"].startswith("Beauty")
+    assert line["roofline"]["frac"] == pytest.approx(detail["roofline"]["frac"], rel=1e-4) and line["roofline"]["bound"] == "mfma"
+    assert line["roofline"]["avg_launch_us"] > 0 and line["roofline"]["algorithmic_flops_per_launch"] > 0 and "traffic" in line["roofline"]
+    assert line["cpu_baseline"]["value"] == pytest.approx(detail["cpu_baseline"]["value"], rel=1e-4)
+    assert line["cpu_baseline"]["cores"] == 16 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["sample"]
+    assert len(line["speedup_curve"]) == 15 and all(isinstance(r["speedup"], float) for r in line["speedup_curve"])
+    assert set(line["configs"]) == {"games_256", "games_256_trie", "fp16", "fp8"}
+    assert "what" not in text and "per_rank" not in text                     # no prose, no disagreement rows
+    with open(tmp_path / bench.DETAIL_FILE) as f:                            # the full report is kept beside it
+        assert json.load(f)["speedup_curve"][0]["bssd"]["roofline"]["what"]
+
+
+def test_an_oversized_summary_never_costs_the_headline(tmp_path, capsys):
+    import json
+    detail = dict(metric="m", value=1.0, unit="items/s", n_gpus=1, steps=1, warmup=0, ms_per_step=1.0, higher_is_better=True, scaling="weak",
+                  vs_baseline=None, dtype="bf16", data="synthetic", config=dict(workload="w"), roofline=dict(bound="mfma", frac=0.5, achieved=1.0, peak=2.0),
+                  cpu_baseline=dict(value=2.0, unit="items/s", cores=1, kind="port", sample="s"),
+                  speedup_curve=[dict(users_per_batch=i, bssd=dict(ms_to_last_result=1.0), target_generate=dict(ms_to_last_result=2.0), speedup=2.0)
+                                 for i in range(400)])
+    text = bench.emit(detail, out_dir=str(tmp_path))
+    capsys.readouterr()
+    line = json.loads(text)
+    assert len(text) <= bench.LINE_BUDGET_BYTES and line["roofline"]["frac"] == 0.5 and line["cpu_baseline"]["value"] == 2.0 and "speedup_curve" not in line
