@@ -86,6 +86,7 @@ SIGNATURES = {
     "atspeed_decoder_set_trace": (C.c_int, [_P, _I]),
     "atspeed_decoder_decisions": (C.c_int64, [_P, _P, C.c_int64]),
     "atspeed_gemm": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "atspeed_gemm_path_counters": (C.c_int, [_P, _I, _I]),
     "atspeed_gemm_packed": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "atspeed_gemm_fp8_packed": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "atspeed_pack_rows": (C.c_int, [_P, _P, _I, _I, _P]),

@@ -25,6 +25,14 @@ void atspeed_set_error(const char* fmt, ...) {
 
 extern "C" const char* atspeed_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* atspeed_version(void) { return "atspeed_hip 0.1 (gfx950)"; }
+std::atomic<long long> g_ats_path_cnt[ATS_N_PATHS];
+extern "C" int atspeed_gemm_path_counters(int64_t* out, int32_t n, int32_t reset) {
+  for (int i = 0; i < ATS_N_PATHS; ++i) {
+    const long long v = reset ? g_ats_path_cnt[i].exchange(0) : g_ats_path_cnt[i].load();
+    if (out && i < n) out[i] = v;
+  }
+  return ATS_N_PATHS;
+}
 extern "C" int atspeed_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -201,6 +209,7 @@ struct ActCtx {
   RowInfo* rowinfo = nullptr;                    // [cap_tok] cache / slot / rotation of each batched row (qkv projection's fused epilogue)
   void* xq = nullptr; float* sx = nullptr;       // fp8 activations [cap_tok][max(hidden, ffn)] + per-token scales
   void* ws = nullptr; size_t ws_bytes = 0;       // split-K slabs
+  SkArena sk;                                    // the ring kernel's split-K tail (16-bit models: internal.h SkArena); allocated HERE, never inside a forward
   // forwards of a recurring shape are replayed as hipGraphs (one launch instead of ~9 per layer: a user's later rounds are
   // 20-140 tokens and launch-bound); the segment table lives at a fixed device address so that it is data, not a kernel argument
   SegTable* segtab_dev = nullptr;
@@ -288,7 +297,7 @@ static void act_free(ActCtx* cx) {
   if (!cx) return;
   hipFree(cx->h); hipFree(cx->xn); hipFree(cx->qkv); hipFree(cx->att); hipFree(cx->act); hipFree(cx->gath);
   hipFree(cx->logits); hipFree(cx->lse); hipFree(cx->lse_part); hipFree(cx->ws); hipFree(cx->xq); hipFree(cx->sx); hipFree(cx->rowinfo);
-  hipFree(cx->row_cand);
+  hipFree(cx->row_cand); hipFree(cx->sk.ws); hipFree(cx->sk.cnt);
   for (hipEvent_t e : cx->prof_ev) hipEventDestroy(e);
   for (auto& g : cx->graphs) hipGraphExecDestroy(g.second);
   if (cx->cap_stream) hipStreamDestroy(cx->cap_stream);
@@ -325,6 +334,11 @@ static int ensure_act(atspeed_llama* m, int tok, int rows) {
   cx->ws_bytes = gemm_ws_for(c, cx->cap_tok, cx->cap_rows);
   ATS_HIP(hipMalloc(&cx->ws, cx->ws_bytes));
   ATS_HIP(hipMalloc((void**)&cx->segtab_dev, sizeof(SegTable)));
+  if (c.dtype != ATSPEED_F32 && c.hidden % 128 == 0 && cx->cap_tok >= 257) {      // shapes the ring kernel can take at all (big_kernel_applies)
+    ATS_HIP(hipMalloc((void**)&cx->sk.ws, ATS_SK_ARENA_BYTES));
+    ATS_HIP(hipMalloc((void**)&cx->sk.cnt, ATS_SK_ARENA_COUNTERS * sizeof(int)));
+    ATS_HIP(hipMemset(cx->sk.cnt, 0, ATS_SK_ARENA_COUNTERS * sizeof(int)));
+  }
   m->act = cx;
   return ATSPEED_OK;
 }
@@ -783,6 +797,14 @@ static int check_common(atspeed_decoder* d, const int32_t* prompt, int P, const 
   return ATSPEED_OK;
 }
 
+// a user that ends with NO valid beam (per-user ERR_FILTERED inside a lock-step batch): its result block must not keep whatever the caller's
+// buffer held before (torch.empty hands back the previous batch's block): scores = -inf, tokens = 0, stream ordered
+static int blank_outputs(int32_t* out_tokens, float* out_scores, int k, int max_new, hipStream_t st) {
+  ATS_HIP(hipMemsetAsync(out_tokens, 0, (size_t)k * max_new * sizeof(int32_t), st));
+  ATS_HIP(hipMemsetD32Async((hipDeviceptr_t)out_scores, (int)0xff800000u, (size_t)k, st));      // -inf
+  return ATSPEED_OK;
+}
+
 static int mailbox_status(atspeed_decoder* d) {
   if (d->mail_host->status == ATSPEED_ERR_CONSTRAINT) {
     atspeed_set_error("`prefix_allowed_tokens_fn` returned an empty list for batch ID 0. This means that the constraint is unsatisfiable.");
@@ -1078,6 +1100,7 @@ static int bssd_group_run(atspeed_decoder** decs, int n, hipStream_t st) {
         // a lock-step batch does not die with one user: this user lost every beam of a step to the id filter (beamSD.py:80-86; the
         // reference dies on a shape mismatch there) and ends with no valid beam, the others go on (the one-user call returns the error)
         r.s.n_valid = 0; r.s.status = ATSPEED_ERR_FILTERED;
+        ATS_TRY(blank_outputs(r.out_tokens, r.out_scores, r.k, r.max_new, st));
         r.s.total_ms = r.s.draft_ms + r.s.target_ms + r.s.verify_ms;
         if (r.stats_out) *r.stats_out = r.s;
         r.done = true;
@@ -1262,6 +1285,10 @@ extern "C" int atspeed_target_generate_batch(atspeed_decoder** decs, int32_t n, 
   ats_stage_reset();
   float ms = 0.f;
   hipEventElapsedTime(&ms, g_ev[0], g_ev[1]);
+  bool any_filtered = false;
+  for (int u = 0; u < n; ++u)
+    if (n > 1 && decs[u]->mail_host->status == ATSPEED_ERR_FILTERED) { ATS_TRY(blank_outputs(out_tokens[u], out_scores[u], k, max_new, st)); any_filtered = true; }
+  if (any_filtered) ATS_HIP(hipStreamSynchronize(st));
   for (int u = 0; u < n; ++u) {
     const bool filtered = n > 1 && decs[u]->mail_host->status == ATSPEED_ERR_FILTERED;    // per user, as in the beam-SD batch loop
     if (!filtered) ATS_TRY(mailbox_status(decs[u]));

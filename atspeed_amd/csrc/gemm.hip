@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <set>
 
@@ -1338,32 +1339,49 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* _
   }
 }
 
-// library-owned workspace of the split-K tail, per device and shared by all host threads: 256 workgroups x 2 slots x 256 KB of fp32 partials
-// + one arrival counter per tail tile (zeroed here once; the finishing part leaves its counter at zero).  Launches that use it must not
-// overlap: the caller holds `g_sk_mu` from here until its kernel is enqueued, and a launch on ANOTHER stream than the previous one first
-// waits for that one (event) -- callers with several streams or threads stay correct, at the price of ordering their split-K launches.
-struct SkWorkspace { float* ws = nullptr; int* cnt = nullptr; hipStream_t last = nullptr; hipEvent_t ev = nullptr; bool have_last = false; };
+// Arena of the split-K tail for callers that bring none (the C ABI's plain atspeed_gemm; a model's forwards pass their own, internal.h
+// SkArena): per device, shared by all host threads.  Launches that use it must not overlap: the caller holds `g_sk_mu` from here until its
+// kernel is enqueued, and a launch on ANOTHER stream than the previous one first waits for that one (event).  Never used while `st` is
+// capturing (launch_big falls back to the plain grid): the cross-stream wait and the first-use allocation are illegal inside a capture, and
+// a replayed graph would bypass the mutex.
+struct SkShared { SkArena a; hipStream_t last = nullptr; hipEvent_t ev = nullptr; bool have_last = false; bool failed = false; };
 static std::mutex g_sk_mu;
-static SkWorkspace g_sk[ATS_MAX_DEVICES];
-static int sk_workspace(hipStream_t st, SkWorkspace** out) {          // g_sk_mu held by the caller
+static SkShared g_sk[ATS_MAX_DEVICES];
+static const SkArena* sk_shared_arena(hipStream_t st) {              // g_sk_mu held by the caller; nullptr = no arena (launch without the tail)
   const int d = ats_cur_device();
-  ATS_REQUIRE(d >= 0, ATSPEED_ERR_HIP, "gemm: no current HIP device");
-  SkWorkspace& w = g_sk[d];
-  if (!w.ws) {
-    ATS_HIP(hipMalloc((void**)&w.ws, (size_t)512 * 256 * 1024));
-    ATS_HIP(hipMalloc((void**)&w.cnt, 256 * sizeof(int)));
-    ATS_HIP(hipMemset(w.cnt, 0, 256 * sizeof(int)));
-    ATS_HIP(hipEventCreateWithFlags(&w.ev, hipEventDisableTiming));
+  if (d < 0) return nullptr;
+  SkShared& w = g_sk[d];
+  if (w.failed) return nullptr;
+  if (!w.a.ws) {
+    float* ws = nullptr; int* cnt = nullptr; hipEvent_t ev = nullptr;
+    if (hipMalloc((void**)&ws, ATS_SK_ARENA_BYTES) != hipSuccess || hipMalloc((void**)&cnt, ATS_SK_ARENA_COUNTERS * sizeof(int)) != hipSuccess ||
+        hipMemset(cnt, 0, ATS_SK_ARENA_COUNTERS * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();                                     // no room for the arena: this device runs its thin grids without the tail
+      if (ws) hipFree(ws);
+      if (cnt) hipFree(cnt);
+      w.failed = true;
+      return nullptr;
+    }
+    w.a.ws = ws; w.a.cnt = cnt; w.ev = ev;
   }
-  if (w.have_last && w.last != st) { ATS_HIP(hipEventRecord(w.ev, w.last)); ATS_HIP(hipStreamWaitEvent(st, w.ev, 0)); }
+  if (w.have_last && w.last != st) {
+    const hipStream_t prev = w.last;
+    w.last = st;                                                   // before anything that can fail: a destroyed `prev` must not be recorded on again
+    if (hipEventRecord(w.ev, prev) == hipSuccess) { if (hipStreamWaitEvent(st, w.ev, 0) != hipSuccess) (void)hipGetLastError(); }
+    else (void)hipGetLastError();                                  // the previous stream is gone: so is its work
+  }
   w.last = st; w.have_last = true;
-  *out = &w;
-  return ATSPEED_OK;
+  return &w.a;
+}
+static bool stream_is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return cs != hipStreamCaptureStatusNone;
 }
 
 template <int EPI>
 int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st, int pk, const RopeEpi& rope = RopeEpi{},
-               float* lse_part = nullptr, const unsigned char* tile_store = nullptr) {
+               float* lse_part = nullptr, const unsigned char* tile_store = nullptr, const SkArena* arena = nullptr) {
   static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
   const int tiles_n = (n + 255) / 256;
   constexpr int LDS8 = EPI == EPI_F32_LSE ? 136 * 1024 : 128 * 1024, LDS4 = EPI == EPI_F32_LSE ? 100 * 1024 : 96 * 1024;
@@ -1380,23 +1398,27 @@ int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, i
   const BigChoice ch = big_choose(t256, t128, k);
   const bool use256 = ch.rows256;
   const float* none = nullptr;
-  if (ch.sk.on) {
-    // stream-K tail: n_dp whole tiles + G workgroups that share the k-steps of the remaining ones evenly
-    SkWorkspace* wsp = nullptr;
-    std::lock_guard<std::mutex> lk(g_sk_mu);                      // bookkeeping + enqueue as one step (see SkWorkspace)
-    ATS_TRY(sk_workspace(st, &wsp));
-    const SkTail tail{ch.sk.n_dp, ch.sk.G, ch.sk.U, ch.sk.TU, wsp->ws, wsp->cnt};
-    const int grid = ch.sk.n_dp + ch.sk.G;
-    if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false, false, 4, true>), dim3(grid), dim3(512), LDS8, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, lse_part, tile_store, pk, rope, tail);
-    else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false, false, 4, true>), dim3(grid), dim3(512), LDS4, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, lse_part, tile_store, pk, rope, tail);
-    ATS_LAUNCH_CHECK();
-    return ATSPEED_OK;
+  if (ch.sk.on && (arena != nullptr || !stream_is_capturing(st))) {
+    // split-K tail: n_dp whole tiles + G workgroups that share the k-steps of the remaining ones evenly.  With the caller's arena plain
+    // stream order is all there is; the shared one needs bookkeeping + enqueue as one step (see SkShared)
+    std::unique_lock<std::mutex> lk(g_sk_mu, std::defer_lock);
+    if (!arena) { lk.lock(); arena = sk_shared_arena(st); }
+    if (arena) {
+      const SkTail tail{ch.sk.n_dp, ch.sk.G, ch.sk.U, ch.sk.TU, arena->ws, arena->cnt};
+      const int grid = ch.sk.n_dp + ch.sk.G;
+      if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false, false, 4, true>), dim3(grid), dim3(512), LDS8, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, lse_part, tile_store, pk, rope, tail);
+      else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false, false, 4, true>), dim3(grid), dim3(512), LDS4, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, lse_part, tile_store, pk, rope, tail);
+      ATS_LAUNCH_CHECK();
+      ats_count_path(ATS_PATH_RING_SK);
+      return ATSPEED_OK;
+    }
   }
   // (a four-wave form, one wave per SIMD with 128 x 128 per wave and the accumulators in AGPRs, was 3 % slower on every projection and is
   // not instantiated any more: profiles/README.md)
   if (use256) hipLaunchKernelGGL((gemm_ring_kernel<EPI, 8, false>), dim3(t256), dim3(512), LDS8, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 255) / 256, gm, 1, lse_part, tile_store, pk, rope);
   else        hipLaunchKernelGGL((gemm_ring_kernel<EPI, 4, false>), dim3(t128), dim3(512), LDS4, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc, tiles_n, (m + 127) / 128, gm, 1, lse_part, tile_store, pk, rope);
   ATS_LAUNCH_CHECK();
+  ats_count_path(ATS_PATH_RING);
   return ATSPEED_OK;
 }
 
@@ -1419,9 +1441,9 @@ __global__ __launch_bounds__(256) void lse_combine_kernel(const float2* __restri
 
 // lm_head over the batched rows with the normaliser fused into the epilogue (gemm_ring_kernel<EPI_F32_LSE>)
 int launch_big_lse(const bf16_t* x, const bf16_t* w, float* c, int m, int n, int k, int ldx, int ldc, float* part, const unsigned char* tile_store,
-                   float* lse, hipStream_t st, int pk) {
+                   float* lse, hipStream_t st, int pk, const SkArena* arena) {
   const int tiles_n = (n + 255) / 256;
-  ATS_TRY(launch_big<EPI_F32_LSE>(x, w, (void*)c, m, n, k, ldx, ldc, st, pk, RopeEpi{}, part, tile_store));
+  ATS_TRY(launch_big<EPI_F32_LSE>(x, w, (void*)c, m, n, k, ldx, ldc, st, pk, RopeEpi{}, part, tile_store, arena));
   lse_combine_kernel<<<(m + 3) / 4, 256, 0, st>>>(reinterpret_cast<const float2*>(part), m, tiles_n, lse);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
@@ -1518,6 +1540,7 @@ int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char*
     else
       hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI, 4>), dim3(t128), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw, c, m, n, k, ldc, tiles_n, (m + 127) / 128, gm, pk, rope);
     ATS_LAUNCH_CHECK();
+    ats_count_path(ATS_PATH_FP8_RING);
     return ATSPEED_OK;
   }
   if (big_use_256_rows(t256, t128))
@@ -1790,6 +1813,7 @@ int launch_ring_split(const bf16_t* a, const bf16_t* w, void* c, int m, int n, i
     hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 4, false, true>), dim3(tiles_n * splits), dim3(512), 96 * 1024, st, (const void*)a, (const void*)w,
                        none, none, (void*)partial, m, n, k, lda, n, tiles_n, 1, 1, splits, (float*)nullptr, (const unsigned char*)nullptr, pk);
   ATS_LAUNCH_CHECK();
+  ats_count_path(ATS_PATH_RING_SPLIT);
   if (c == nullptr) return ATSPEED_OK;          // partials only: the caller's next kernel sums the slabs itself (ats_gemm_partials)
   return reduce_splits<bf16_t, EPI>(partial, c, m, n, ldc, splits, st, fn, pk);
 }
@@ -1804,11 +1828,13 @@ int launch_cfg(const T* a, const T* w, void* c, int m, int n, int k, int lda, in
     auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI, true>;
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a, w, c, m, n, k, lda, ldc, p.k_per_split, partial, pk);
     ATS_LAUNCH_CHECK();
+    ats_count_path(ATS_PATH_TILED);
     return reduce_splits<T, EPI>(partial, c, m, n, ldc, p.splits, st, fn, pk);
   } else {
     auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI, false>;
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a, w, c, m, n, k, lda, ldc, p.k_per_split, partial, pk);
     ATS_LAUNCH_CHECK();
+    ats_count_path(ATS_PATH_TILED);
   }
   return ATSPEED_OK;
 }
@@ -1842,6 +1868,7 @@ int launch_wdma_cfg(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int
   }
   hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN), dim3(128 * WM), lds, st, a, w, c, m, n, k, lda, ldc, pk, 1);
   ATS_LAUNCH_CHECK();
+  ats_count_path(ATS_PATH_WDMA);
   return ATSPEED_OK;
 }
 // split-K form: projections whose N gives too few 128-row tiles (qkv: 96, o_proj and down: 32) take tiles x splits = 150-256 workgroups
@@ -1871,6 +1898,7 @@ int launch_wdma_split_cfg(const bf16_t* a, const bf16_t* w, float* partial, int 
   }
   hipLaunchKernelGGL(kern, dim3((n + 127) / 128, splits), dim3(128 * WM), lds, st, a, w, (void*)partial, m, n, k, lda, n, pk, splits);
   ATS_LAUNCH_CHECK();
+  ats_count_path(ATS_PATH_WDMA_SPLIT);
   return ATSPEED_OK;
 }
 static int launch_wdma_split(const bf16_t* a, const bf16_t* w, float* partial, int m, int n, int k, int lda, int splits, hipStream_t st, int pk) {
@@ -1986,7 +2014,7 @@ int ats_gemm_partials(const void* a, const void* w, int m, int n, int k, int lda
 }
 
 int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda, int ldc, int dtype, int epilogue,
-             void* workspace, size_t workspace_bytes, hipStream_t st, int pk) {
+             void* workspace, size_t workspace_bytes, hipStream_t st, int pk, const SkArena* sk) {
   if (m <= 0 || n <= 0) return ATSPEED_OK;
   int epc = dtype == ATSPEED_F32 ? 4 : 8;
   // packed operands (common.h): bf16 only, K and the row strides multiples of one 64-byte k-block, SwiGLU output rows likewise
@@ -2001,10 +2029,10 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
     if (big_kernel_applies(m, n, k, lda, ldc, dtype, epilogue)) {
       const bf16_t* X = (const bf16_t*)a; const bf16_t* Wt = (const bf16_t*)w;
       switch (epilogue) {
-        case EPI_STORE:  return launch_big<EPI_STORE>(X, Wt, c, m, n, k, lda, ldc, st, pk);
-        case EPI_F32:    return launch_big<EPI_F32>(X, Wt, c, m, n, k, lda, ldc, st, pk);
-        case EPI_RESID:  return launch_big<EPI_RESID>(X, Wt, c, m, n, k, lda, ldc, st, pk);
-        case EPI_SWIGLU: return launch_big<EPI_SWIGLU>(X, Wt, c, m, n, k, lda, ldc, st, pk);
+        case EPI_STORE:  return launch_big<EPI_STORE>(X, Wt, c, m, n, k, lda, ldc, st, pk, RopeEpi{}, nullptr, nullptr, sk);
+        case EPI_F32:    return launch_big<EPI_F32>(X, Wt, c, m, n, k, lda, ldc, st, pk, RopeEpi{}, nullptr, nullptr, sk);
+        case EPI_RESID:  return launch_big<EPI_RESID>(X, Wt, c, m, n, k, lda, ldc, st, pk, RopeEpi{}, nullptr, nullptr, sk);
+        case EPI_SWIGLU: return launch_big<EPI_SWIGLU>(X, Wt, c, m, n, k, lda, ldc, st, pk, RopeEpi{}, nullptr, nullptr, sk);
       }
     }
     return launch_typed<bf16_t>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st, pk);
@@ -2018,12 +2046,12 @@ bool ats_gemm_qkv_rope_applies(int m, int hidden, int head_dim, int dtype) {
   return !(e && atoi(e) == 0) && dtype == ATS_HALF && head_dim == 128 && hidden % 256 == 0 && big_kernel_applies(m, 3 * hidden, hidden, hidden, 3 * hidden, dtype, EPI_STORE);
 }
 
-int ats_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, int m, int hidden, const RopeEpi& rope, hipStream_t st, int pk) {
+int ats_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, int m, int hidden, const RopeEpi& rope, hipStream_t st, int pk, const SkArena* sk) {
   ATS_REQUIRE(x && wqkv && qkv && rope.rows && rope.cos_tab && rope.sin_tab && rope.hidden == hidden, ATSPEED_ERR_INVALID, "gemm_qkv_rope: null / inconsistent argument");
   ATS_REQUIRE(hidden % 256 == 0 && big_kernel_applies(m, 3 * hidden, hidden, hidden, 3 * hidden, ATS_HALF, EPI_STORE), ATSPEED_ERR_INVALID,
               "gemm_qkv_rope: shape %d x %d is not the batched kernel's", m, hidden);
   ATS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wqkv & 15) == 0 && ((uintptr_t)qkv & 15) == 0, ATSPEED_ERR_INVALID, "gemm_qkv_rope: operands must be 16-byte aligned");
-  return launch_big<EPI_QKV_ROPE>((const bf16_t*)x, (const bf16_t*)wqkv, qkv, m, 3 * hidden, hidden, hidden, 3 * hidden, st, pk, rope);
+  return launch_big<EPI_QKV_ROPE>((const bf16_t*)x, (const bf16_t*)wqkv, qkv, m, 3 * hidden, hidden, hidden, 3 * hidden, st, pk, rope, nullptr, nullptr, sk);
 }
 
 size_t ats_lmhead_lse_part_bytes(int m, int n) { return (size_t)m * ((n + 255) / 256) * 2 * sizeof(float); }
@@ -2032,7 +2060,8 @@ size_t ats_lmhead_lse_part_bytes(int m, int n) { return (size_t)m * ((n + 255) /
 // normaliser comes out of the GEMM epilogue and only the 256-column tiles flagged in tile_store (device bytes, one per tile; NULL = all)
 // are written; otherwise the plain GEMM + the streaming lse_rows_kernel.  *fused_out tells which.
 int ats_lmhead_lse(const void* a, const void* w, float* logits, int m, int n, int k, int lda, int ldc, int dtype, const unsigned char* tile_store,
-                   float* part, size_t part_bytes, float* lse, void* workspace, size_t workspace_bytes, hipStream_t st, int* fused_out, int pk) {
+                   float* part, size_t part_bytes, float* lse, void* workspace, size_t workspace_bytes, hipStream_t st, int* fused_out, int pk,
+                   const SkArena* sk) {
   static const int fuse = env_int("ATSPEED_FUSE_LSE", 1);
   if (fused_out) *fused_out = 0;
   if (m <= 0) return ATSPEED_OK;
@@ -2041,9 +2070,9 @@ int ats_lmhead_lse(const void* a, const void* w, float* logits, int m, int n, in
     ATS_REQUIRE(a && w && logits && lse, ATSPEED_ERR_INVALID, "lmhead_lse: null operand");
     ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "lmhead_lse: operands must be 16-byte aligned");
     if (fused_out) *fused_out = 1;
-    return launch_big_lse((const bf16_t*)a, (const bf16_t*)w, logits, m, n, k, lda, ldc, part, tile_store, lse, st, pk);
+    return launch_big_lse((const bf16_t*)a, (const bf16_t*)w, logits, m, n, k, lda, ldc, part, tile_store, lse, st, pk, sk);
   }
-  ATS_TRY(ats_gemm(a, w, logits, m, n, k, lda, ldc, dtype, EPI_F32, workspace, workspace_bytes, st, pk));
+  ATS_TRY(ats_gemm(a, w, logits, m, n, k, lda, ldc, dtype, EPI_F32, workspace, workspace_bytes, st, pk, sk));
   return ats_lse_rows(logits, m, n, ldc, lse, st);
 }
 
@@ -2067,7 +2096,7 @@ static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype,
 }
 
 int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int k, int lda, int ldh, int dtype,
-                        const void* norm_w, void* xn, float eps, void* workspace, size_t workspace_bytes, hipStream_t st, int pk) {
+                        const void* norm_w, void* xn, float eps, void* workspace, size_t workspace_bytes, hipStream_t st, int pk, const SkArena* sk) {
   if (m <= 0) return ATSPEED_OK;
   FusedNorm fn{norm_w, xn, eps, false};
   int epc = dtype == ATSPEED_F32 ? 4 : 8;
@@ -2079,7 +2108,7 @@ int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int
       rc = launch_epi<bf16_t, EPI_RESID>((const bf16_t*)a, (const bf16_t*)w, h, m, n, k, lda, ldh, (float*)workspace, workspace_bytes, st, &fn, pk);
     if (rc != ATSPEED_OK) return rc;
   } else {
-    ATS_TRY(ats_gemm(a, w, h, m, n, k, lda, ldh, dtype, EPI_RESID, workspace, workspace_bytes, st, pk));
+    ATS_TRY(ats_gemm(a, w, h, m, n, k, lda, ldh, dtype, EPI_RESID, workspace, workspace_bytes, st, pk, sk));
   }
   if (!fn.done) return ats_rmsnorm(h, norm_w, xn, m, n, eps, dtype, st, pk);
   return ATSPEED_OK;
@@ -2140,12 +2169,12 @@ extern "C" int atspeed_gemm_fp8(const void* xq, const float* sx, const void* wq,
 extern "C" int atspeed_gemm(const void* a, const void* w, void* c, int32_t m, int32_t n, int32_t k, int32_t lda,
                             int32_t ldc, int32_t dtype, int32_t epilogue, void* workspace, size_t workspace_bytes,
                             void* stream) {
-  return ATS_KD(dtype, ats_gemm(a, w, c, m, n, k, lda, ldc, dtype, epilogue, workspace, workspace_bytes, (hipStream_t)stream, 0));
+  return ATS_KD(dtype, ats_gemm(a, w, c, m, n, k, lda, ldc, dtype, epilogue, workspace, workspace_bytes, (hipStream_t)stream, 0, nullptr));
 }
 
 extern "C" int atspeed_gemm_packed(const void* a, const void* w, void* c, int32_t m, int32_t n, int32_t k, int32_t ldc, int32_t epilogue,
                                    void* workspace, size_t workspace_bytes, void* stream) {
-  return ats_bf16::ats_gemm(a, w, c, m, n, k, k, ldc, ATSPEED_BF16, epilogue, workspace, workspace_bytes, (hipStream_t)stream, 1);
+  return ats_bf16::ats_gemm(a, w, c, m, n, k, k, ldc, ATSPEED_BF16, epilogue, workspace, workspace_bytes, (hipStream_t)stream, 1, nullptr);
 }
 
 extern "C" int atspeed_gemm_fp8_packed(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int32_t m, int32_t n,

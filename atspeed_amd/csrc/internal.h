@@ -1,5 +1,7 @@
 // Internal host-side interfaces between the translation units of libatspeed_hip.
 #pragma once
+#include <atomic>
+
 #include "common.h"
 
 // ---- segment table: one forward over the tokens of several users ----------------------
@@ -29,6 +31,20 @@ struct RopeEpi { const RowInfo* rows = nullptr; const float* cos_tab = nullptr; 
 int ats_stage(const void* host_obj, size_t bytes, const void** dev_out, hipStream_t st);
 int ats_stage_to(const void* host_obj, size_t bytes, void* dev_dst, hipStream_t st);   // same, to a fixed device address
 void ats_stage_reset();                           // after a stream synchronisation: every staged copy has landed
+
+// Arena of the ring kernel's split-K tail (gemm.hip, gemm_ring_kernel<..., SK = true>): 512 slots of 256 KB of fp32 partials + one arrival
+// counter per tail tile (zero between launches: the finishing part leaves its counter at zero).  Launches that share an arena must be
+// ordered: a model's forwards own one (ActCtx, allocated with the activations, so a captured graph contains no allocation and no
+// cross-stream wait); callers without one (the C ABI's plain atspeed_gemm) share a per-device arena under a mutex.
+struct SkArena { float* ws = nullptr; int* cnt = nullptr; };
+constexpr size_t ATS_SK_ARENA_BYTES = (size_t)512 * 256 * 1024;
+constexpr int ATS_SK_ARENA_COUNTERS = 256;
+
+// which kernel family a GEMM launch took (atspeed_gemm_path_counters: tests assert the path they mean to test, dispatch being a fitted model)
+enum { ATS_PATH_RING = 0, ATS_PATH_RING_SK = 1, ATS_PATH_WDMA = 2, ATS_PATH_WDMA_SPLIT = 3, ATS_PATH_RING_SPLIT = 4, ATS_PATH_TILED = 5,
+       ATS_PATH_FP8_RING = 6, ATS_PATH_FP8_WDMA = 7, ATS_PATH_FP8_WDMA_SPLIT = 8, ATS_PATH_PANEL = 9, ATS_PATH_PANEL_SPLIT = 10, ATS_N_PATHS = 16 };
+extern std::atomic<long long> g_ats_path_cnt[ATS_N_PATHS];          // engine.hip
+inline void ats_count_path(int p) { g_ats_path_cnt[p].fetch_add(1, std::memory_order_relaxed); }
 
 enum { EPI_STORE = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_SWIGLU = 3, EPI_F32_LSE = 4 /* ring kernel only: fp32 store + per-tile (max, sum exp) */,
        EPI_QKV_ROPE = 5 /* ring kernel only: qkv projection with RoPE + KV-cache scatter in the epilogue (ats_gemm_qkv_rope) */ };

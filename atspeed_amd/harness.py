@@ -310,10 +310,13 @@ def run_inference(target, draft, data: SeqRecTestData, gamma: int = 4, max_new_t
             outs = BSSD_batch(target, draft, prompts[lo:lo + users_per_batch], gamma, max_new_tokens, prefix_allowed_tokens_fn=fn)
         for u, pr, o in zip(sel[lo:lo + users_per_batch], prompts[lo:lo + users_per_batch], outs):
             P = pr["input_ids"].shape[1]
-            gen = o["beam_sequence"][:, P:].cpu().tolist()
+            # a user the library ended without a valid beam (status != 0: every beam of a step lost to the id filter, beamSD.py:80-86, where the
+            # reference dies) predicts nothing; otherwise the first n_valid beams are the result
+            nv = 0 if o.get("status", 0) != 0 else int(o.get("n_valid", o["beam_scores"].shape[0]))
+            gen = o["beam_sequence"][:nv, P:].cpu().tolist()
             res.uids.append(u.uid)
             res.predictions.append([data.index.decode(g) for g in gen])
-            res.scores.append([float(s) for s in o["beam_scores"].cpu().tolist()])
+            res.scores.append([float(s) for s in o["beam_scores"][:nv].cpu().tolist()])
             res.labels.append(list(u.labels))
             res.rows.append({"draft_time_cost": o["draft_time_cost"], "target_time_cost": o["target_time_cost"],
                              "verify_time_cost": o["verify_time_cost"], "total_time_cost": o["time_cost"], "n_run": o["n_run"],

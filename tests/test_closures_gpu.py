@@ -365,8 +365,13 @@ def test_a_filtered_user_does_not_abort_the_lock_step_batch():
     ins = [{"input_ids": torch.tensor([p], dtype=torch.int64).cuda()} for p in (pa, pb, pc)]
     bat = BSSD_batch(tgt, drf, ins, 4, 4, prefix_allowed_tokens_fn=fn)
     tgb = target_generate_batch(tgt, ins, 4, prefix_allowed_tokens_fn=fn)
+    # run twice: the second call's result buffers are the caching allocator's blocks of the first (a filtered user's block used to
+    # keep another user's items and finite scores); the filtered user's block must read scores -inf / tokens 0 after the prompt
+    bat = BSSD_batch(tgt, drf, ins, 4, 4, prefix_allowed_tokens_fn=fn)
+    tgb = target_generate_batch(tgt, ins, 4, prefix_allowed_tokens_fn=fn)
     for res in (bat, tgb):
         assert [r["status"] for r in res] == [0, _lib.ERR_FILTERED, 0] and res[1]["n_valid"] == 0
+        assert bool(torch.isneginf(res[1]["beam_scores"]).all()) and int(res[1]["beam_sequence"][:, len(pb):].abs().sum()) == 0
     for u in (0, 2):
         one = BSSD(tgt, drf, ins[u], 4, 4, prefix_allowed_tokens_fn=fn)
         nv = one["n_valid"]
