@@ -64,7 +64,7 @@ SIGNATURES = {
     "atspeed_llama_rope_fused_launches": (C.c_int64, [_P, _I]),
     "atspeed_quant_rows_fp8": (C.c_int, [_P, _I, _I, _P, _P, _P]),
     "atspeed_quant_rows_fp8_packed": (C.c_int, [_P, _I, _I, _P, _P, _P]),
-    "atspeed_gemm_fp8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "atspeed_gemm_fp8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "atspeed_llama_profile": (C.c_int, [_P, _I, _P, _P, _P]),
     "atspeed_llama_profile_big": (C.c_int, [_P, _P, _P, _P]),
     "atspeed_llama_forward_log": (C.c_int32, [_P, _I, _P, _I]),
@@ -88,7 +88,7 @@ SIGNATURES = {
     "atspeed_gemm": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "atspeed_gemm_path_counters": (C.c_int, [_P, _I, _I]),
     "atspeed_gemm_packed": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
-    "atspeed_gemm_fp8_packed": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "atspeed_gemm_fp8_packed": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "atspeed_pack_rows": (C.c_int, [_P, _P, _I, _I, _P]),
     "atspeed_unpack_rows": (C.c_int, [_P, _P, _I, _I, _P]),
     "atspeed_rmsnorm": (C.c_int, [_P, _P, _P, _I, _I, _F, _I, _P]),

@@ -289,6 +289,11 @@ static size_t gemm_ws_for(const atspeed_llama_config& c, int max_tok, int max_ro
     best = std::max(best, ATS_KD(c.dtype, ats_gemm_workspace_bytes(m, 2 * c.ffn, c.hidden, c.dtype)));
     best = std::max(best, ATS_KD(c.dtype, ats_gemm_workspace_bytes(m, c.hidden, c.ffn, c.dtype)));
     if (m <= max_rows) best = std::max(best, ATS_KD(c.dtype, ats_gemm_workspace_bytes(m, c.vocab_size, c.hidden, c.dtype)));
+    if (c.dtype == ATSPEED_BF16 && m <= 256) {     // the W8A8 copies (atspeed_llama_enable_fp8) of one user's projections: their own split plans
+      best = std::max(best, ats_bf16::ats_gemm_fp8_workspace_bytes(m, 3 * c.hidden, c.hidden));
+      best = std::max(best, ats_bf16::ats_gemm_fp8_workspace_bytes(m, c.hidden, c.hidden));
+      best = std::max(best, ats_bf16::ats_gemm_fp8_workspace_bytes(m, c.hidden, c.ffn));
+    }
   }
   return best + (1 << 20);
 }
@@ -533,7 +538,8 @@ static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits
   // opt-in (ATSPEED_GRAPHS=1): measured on MI355X, replaying a 100-token forward as one hipGraph does not shorten it (676 vs 679
   // items/s in the one-user-at-a-time loop) -- the ~10 us between dependent kernels is the GPU's own barrier / cache-flush latency,
   // not host launch cost, and a graph keeps every node boundary
-  static const int use_graphs = getenv("ATSPEED_GRAPHS") ? atoi(getenv("ATSPEED_GRAPHS")) : 0;
+  const char* ge = getenv("ATSPEED_GRAPHS");                       // read per forward: the tests compare both modes in one process
+  const int use_graphs = ge ? atoi(ge) : 0;
   static const int graph_max_tok = getenv("ATSPEED_GRAPH_MAX_TOKENS") ? atoi(getenv("ATSPEED_GRAPH_MAX_TOKENS")) : 512;
   if (use_graphs && !m->prof_on && logits_out == nullptr && T <= graph_max_tok) {
     const ActCtx::GraphKey key(T, t.total_logit, t.n, t.n_qtiles, t.qtile_rows, m->fp8.empty() ? 0 : 1);

@@ -91,6 +91,7 @@ static BigChoice big_choose(int t256, int t128, int k) {
   SkPlan p256, p128;
   const float c256 = sk_cost_us(t256, k, true, &p256), c128 = sk_cost_us(t128, k, false, &p128);
   c.rows256 = force_mt ? force_mt == 8 : c256 <= c128;
+  if (!force_mt && env_now("ATSPEED_GEMM_SK", 1) >= 2 && p256.on != p128.on) c.rows256 = p256.on;   // forced tail (tests, sweeps): the height that has a plan
   c.sk = c.rows256 ? p256 : p128;
   return c;
 }
@@ -1454,10 +1455,13 @@ int launch_big_lse(const bf16_t* x, const bf16_t* w, float* c, int m, int n, int
 //   xn[m][:] = w * (h[m][:] * rsqrt(mean(h^2) + eps))   (the NEXT op's input norm)
 // Saves one launch and one read of h per projection; numerics identical to the unfused pair
 // (statistics are taken from the stored, dtype-rounded h).
-template <typename T, int NPT, int V>
+// QUANT (the consumer is a W8A8 projection, one user's fp8 forwards): the normalised row also leaves as OCP e4m3 with its per-token scale --
+// what ats_rmsnorm_quant_fp8 makes of the same h, bit for bit (amax over the bf16-rounded outputs, scale = amax / 448) --; xn may then be null.
+template <typename T, int NPT, int V, bool QUANT = false>
 __global__ __launch_bounds__(1024) void splitk_resid_rmsnorm_kernel(const float* __restrict__ partial, T* __restrict__ h,
                                                                     const T* __restrict__ norm_w, T* __restrict__ xn, int M, int N,
-                                                                    int ldh, int splits, float eps, int pk) {
+                                                                    int ldh, int splits, float eps, int pk,
+                                                                    unsigned char* __restrict__ q = nullptr, float* __restrict__ qscale = nullptr) {
   // thread t owns columns (t + i*1024) * V .. + V-1, i < NPT / V   (V = 4: 16-byte slab loads; needs N % 4 == 0)
   __shared__ float red[16];
   const int m = blockIdx.x;
@@ -1496,6 +1500,7 @@ __global__ __launch_bounds__(1024) void splitk_resid_rmsnorm_kernel(const float*
 #pragma unroll
   for (int w = 0; w < 16; ++w) tot += red[w];
   const float rs = rsqrtf(tot / (float)N + eps);
+  float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < NPT / V; ++i) {
     const int n = (threadIdx.x + i * 1024) * V;
@@ -1505,7 +1510,39 @@ __global__ __launch_bounds__(1024) void splitk_resid_rmsnorm_kernel(const float*
       for (int j = 0; j < V; ++j) {
         float v = vals[i * V + j] * rs;
         if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
-        Elt<T>::store(xo + j, Elt<T>::load(norm_w + n + j) * v);
+        v = Elt<T>::load(norm_w + n + j) * v;
+        if constexpr (QUANT) {
+          v = bf2f(f2bf(v));                                  // the stored, 16-bit-rounded output is what gets quantised
+          vals[i * V + j] = v;
+          amax = fmaxf(amax, fabsf(v));
+          if (xn) Elt<T>::store(xo + j, v);
+        } else Elt<T>::store(xo + j, v);
+      }
+    }
+  }
+  if constexpr (QUANT) {
+    static_assert(V == 4, "four e4m3 bytes per store");
+    amax = wave_max_f32(amax);
+    __syncthreads();                                          // red[] was read by everyone above
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) amax = fmaxf(amax, red[w]);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (threadIdx.x == 0) qscale[m] = sc;
+#pragma unroll
+    for (int i = 0; i < NPT / V; ++i) {
+      const int n = (threadIdx.x + i * 1024) * V;
+      if (n < N) {
+        float f[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = fminf(fmaxf(vals[i * V + j] * inv, -448.f), 448.f);
+        int w4 = 0;
+        w4 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w4, false);
+        w4 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w4, true);
+        *reinterpret_cast<int*>(q + ats_opnd_idx<1>(pk, m, n, N)) = w4;
       }
     }
   }
@@ -1573,10 +1610,21 @@ int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char*
 // WM: waves along the token rows (2 x WM waves per workgroup).  2 x 2 up to 128 tokens, where the MFMAs are free (ablation builds,
 // profiles/r03_one_user_stream_ceiling.txt); 2 x 4 for the 256-row tile, whose 64 MFMAs per k-tile and wave at one wave per SIMD showed
 // (73.8 us against 60 without them at 225 tokens): two waves per SIMD overlap one's fragment reads with the other's MFMAs.
-template <int BM, int BN, int NST, int EPI, bool SPLIT = false, int WM = 2>
-__global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, void* __restrict__ Cv,
-                                                             int M, int N, int K, int ldx, int ldc, int pk, int n_split) {
+// F8 (round 5; BASELINE config 5 in the reference's own regime, one user per call, inference.py:86-91 `load_in_8bit`): the same ring on e4m3
+// operands with per-row scales (W8A8: W rows scaled per output row, X rows per token).  A 128-byte LDS row then holds 128 k, the DMA pieces,
+// the LDS image and the waits are unchanged (row bytes = K instead of 2 K), and a stage's MFMA work is ONE block-scaled
+// v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile with unit E8M0 scales (tools/probe/mx16_probe.hip: lane l holds row l & 15; twice the
+// flops per cycle of the bf16 form, so a stage costs the same cycles for twice the k): the weight bytes per launch halve.  A lane's 32 bytes are
+// chunks g and 4 + g of its row -- not 2g, 2g + 1: with the c ^ (r & 7) swizzle the lanes {0-3,12-15,20-27} of a ds_read_b128 group would
+// meet two to a bank -- the same k permutation on both operands, so the product is unchanged.  The fp32 scales multiply the accumulators
+// (acc * sx[m] * sw[n]) before the epilogue, also on the fp32 split-K partials (the sum is linear), so every consumer is the bf16 form's.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+template <int BM, int BN, int NST, int EPI, bool SPLIT = false, int WM = 2, bool F8 = false>
+__global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restrict__ X, const void* __restrict__ W, void* __restrict__ Cv,
+                                                             int M, int N, int K, int ldx, int ldc, int pk, int n_split,
+                                                             const float* __restrict__ sx = nullptr, const float* __restrict__ sw = nullptr) {
   constexpr int RB = 128, STAGE = (BM + BN) * RB, NWAVE = 2 * WM;
+  constexpr int ESZ = F8 ? 1 : 2, BK = RB / ESZ;                       // k per stage: 64 (16-bit) or 128 (e4m3)
   constexpr int NPIECE = (BM + BN) / 8, NP = NPIECE / NWAVE;           // 1 KB pieces per stage; per wave
   constexpr int NI = BN / 2 / 16, MI = BM / WM / 16;                   // wave tile (2 x WM waves): BN/2 weight rows x BM/WM token rows
   static_assert(NPIECE % NWAVE == 0 && (NST - 2) * NP <= 63 && BM % (16 * WM) == 0, "pieces per wave / vmcnt range");
@@ -1584,7 +1632,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const bf16_t* __res
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WM, wm = wave % WM, lq = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * BN;
-  int kt0 = 0, n_kt = K / 64;                                          // launcher: K % 64 == 0; this part's tiles are kt0 .. kt0 + n_kt - 1
+  int kt0 = 0, n_kt = K / BK;                                          // launcher: K % BK == 0; this part's tiles are kt0 .. kt0 + n_kt - 1
   if constexpr (SPLIT) {
     const int all = n_kt, z = blockIdx.y;
     kt0 = (int)((long long)z * all / n_split);
@@ -1601,13 +1649,13 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const bf16_t* __res
     const int piece = wave * NP + j, row = piece * 8 + (lane >> 3), pos = lane & 7, c = pos ^ (row & 7);
     const bool w = row >= BM;                                          // uniform per piece (BM % 8 == 0)
     const int gr = w ? min(n0 + row - BM, N - 1) : min(row, M - 1);
-    const unsigned ld = w ? (unsigned)K : (unsigned)ldx;
-    voff[j] = pk ? (unsigned)(gr >> 1) * (ld * 4u) + (gr & 1) * 64 + (unsigned)(c >> 2) * 128 + (c & 3) * 16 : (unsigned)gr * (ld * 2u) + c * 16;
+    const unsigned ldb = (w ? (unsigned)K : (unsigned)ldx) * ESZ;      // row bytes
+    voff[j] = pk ? (unsigned)(gr >> 1) * (ldb * 2u) + (gr & 1) * 64 + (unsigned)(c >> 2) * 128 + (c & 3) * 16 : (unsigned)gr * ldb + c * 16;
     m0p[j] = __builtin_amdgcn_readfirstlane((int)lbase + piece * 1024);
     is_w[j] = __builtin_amdgcn_readfirstlane(piece * 8 >= BM ? 1 : 0) != 0;
   }
   const unsigned long long wb = (unsigned long long)W, xb = (unsigned long long)X;
-  const unsigned long long kstep = pk ? 256 : 128;                     // bytes from one 64-k tile of a row to the next
+  const unsigned long long kstep = pk ? 256 : 128;                     // bytes from one 128-byte tile of a row to the next
   auto issue = [&](int kt) {                                           // kt: tile index inside this part
     const int so = (kt % NST) * STAGE;
 #pragma unroll
@@ -1627,26 +1675,55 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const bf16_t* __res
     else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");                            // everyone's pieces of tile kt; and stage (kt-1) % NST is read out
     if (kt + NST - 1 < n_kt) issue(kt + NST - 1);
-    const unsigned char* sx = smem + (kt % NST) * STAGE + (wm * (BM / WM)) * RB;
-    const unsigned char* sw = smem + (kt % NST) * STAGE + BM * RB + (wn * (BN / 2)) * RB;
+    const unsigned char* sxl = smem + (kt % NST) * STAGE + (wm * (BM / WM)) * RB;
+    const unsigned char* swl = smem + (kt % NST) * STAGE + BM * RB + (wn * (BN / 2)) * RB;
+    if constexpr (F8) {
+      i32x8_t wf[NI], xf[MI];                                          // chunks g (low 16 bytes) and 4 + g (high) of row lq of each 16-row tile
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {                                   // two k-steps of 32 per 128-byte row
-      s16x8_t wf[NI], xf[MI];
+      for (int i = 0; i < NI; ++i) {
+        const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(swl + swz<8>(i * 16 + lq, g)), hi = *reinterpret_cast<const u32x4_t*>(swl + swz<8>(i * 16 + lq, 4 + g));
+        wf[i] = i32x8_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      }
 #pragma unroll
-      for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const s16x8_t*>(sw + swz<8>(i * 16 + lq, ks * 4 + g));
-#pragma unroll
-      for (int j = 0; j < MI; ++j) xf[j] = *reinterpret_cast<const s16x8_t*>(sx + swz<8>(j * 16 + lq, ks * 4 + g));
+      for (int j = 0; j < MI; ++j) {
+        const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(sxl + swz<8>(j * 16 + lq, g)), hi = *reinterpret_cast<const u32x4_t*>(sxl + swz<8>(j * 16 + lq, 4 + g));
+        xf[j] = i32x8_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      }
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < MI; ++j)
-          acc[i][j] = ATS_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, wf[i]), __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j]);
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[i], xf[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {                                 // two k-steps of 32 per 128-byte row
+        s16x8_t wf[NI], xf[MI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const s16x8_t*>(swl + swz<8>(i * 16 + lq, ks * 4 + g));
+#pragma unroll
+        for (int j = 0; j < MI; ++j) xf[j] = *reinterpret_cast<const s16x8_t*>(sxl + swz<8>(j * 16 + lq, ks * 4 + g));
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < MI; ++j)
+            acc[i][j] = ATS_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, wf[i]), __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j]);
+      }
     }
   }
 
   // epilogue: acc[i][j][r] = C[m][n] with m = wm*BM/WM + j*16 + lq (token row), n = n0 + wn*BN/2 + i*16 + g*4 + r (weight row): a lane
   // holds four adjacent output columns of one token row
   const int nw = n0 + wn * (BN / 2);
+  if constexpr (F8) {                                                  // W8A8: per-token x per-output-row scales on the accumulators
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const float fx = sx[min(wm * (BM / WM) + j * 16 + lq, M - 1)];
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] *= fx * sw[min(nw + i * 16 + g * 4 + r, N - 1)];
+    }
+  }
   if constexpr (SPLIT) {
     float* P = reinterpret_cast<float*>(Cv) + (size_t)blockIdx.y * M * N;
 #pragma unroll
@@ -1745,14 +1822,23 @@ Plan make_plan(int m, int n, int k) {
   return p;
 }
 
-struct FusedNorm { const void* w; void* xn; float eps; bool done; };
+struct FusedNorm { const void* w; void* xn; float eps; bool done; void* q = nullptr; float* qscale = nullptr; };   // q: also / instead the e4m3 row + per-token scale
 
 // second pass of a split-K GEMM: sum the fp32 slabs and apply the epilogue (fused with the next RMSNorm for the residual projections)
 template <typename T, int EPI>
 int reduce_splits(const float* partial, void* c, int m, int n, int ldc, int splits, hipStream_t st, FusedNorm* fn, int pk) {
   const bool v4 = (n % 4) == 0 && (ldc % 4) == 0 && ((uintptr_t)partial & 15) == 0;
   if constexpr (EPI == EPI_RESID) {
-    if (fn && n <= 8192) {
+    if constexpr (sizeof(T) == 2) {
+      if (fn && fn->q && n <= 8192 && v4) {                     // W8A8 consumer: e4m3 row + scale (and xn if asked for)
+        if (n <= 4096) splitk_resid_rmsnorm_kernel<T, 4, 4, true><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps, pk, (unsigned char*)fn->q, fn->qscale);
+        else           splitk_resid_rmsnorm_kernel<T, 8, 4, true><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps, pk, (unsigned char*)fn->q, fn->qscale);
+        ATS_LAUNCH_CHECK();
+        fn->done = true;
+        return ATSPEED_OK;
+      }
+    }
+    if (fn && !fn->q && n <= 8192) {
       if (n <= 4096) {
         if (v4) splitk_resid_rmsnorm_kernel<T, 4, 4><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps, pk);
         else    splitk_resid_rmsnorm_kernel<T, 4, 1><<<m, 1024, 0, st>>>(partial, (T*)c, (const T*)fn->w, (T*)fn->xn, m, n, ldc, splits, fn->eps, pk);
@@ -1866,7 +1952,7 @@ int launch_wdma_cfg(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int
     ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN), dim3(128 * WM), lds, st, a, w, c, m, n, k, lda, ldc, pk, 1);
+  hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN), dim3(128 * WM), lds, st, (const void*)a, (const void*)w, c, m, n, k, lda, ldc, pk, 1, (const float*)nullptr, (const float*)nullptr);
   ATS_LAUNCH_CHECK();
   ats_count_path(ATS_PATH_WDMA);
   return ATSPEED_OK;
@@ -1896,7 +1982,7 @@ int launch_wdma_split_cfg(const bf16_t* a, const bf16_t* w, float* partial, int 
     ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((n + 127) / 128, splits), dim3(128 * WM), lds, st, a, w, (void*)partial, m, n, k, lda, n, pk, splits);
+  hipLaunchKernelGGL(kern, dim3((n + 127) / 128, splits), dim3(128 * WM), lds, st, (const void*)a, (const void*)w, (void*)partial, m, n, k, lda, n, pk, splits, (const float*)nullptr, (const float*)nullptr);
   ATS_LAUNCH_CHECK();
   ats_count_path(ATS_PATH_WDMA_SPLIT);
   return ATSPEED_OK;
@@ -2114,20 +2200,92 @@ int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int
   return ATSPEED_OK;
 }
 
+// ---- one user's W8A8 projections (1-256 tokens): gemm_wdma_kernel<..., F8 = true>.  Every launch is a pass over the e4m3 weights (half the
+// bytes of the 16-bit form).  Wide projections (150-256 tiles of 128 weight rows: gate_up) run without split and apply their epilogue
+// directly; the others are cut in K so that tiles x parts fill the chip (qkv 96 x 2, o_proj / down 32 x 8) and leave scaled fp32 slabs to
+// the 16-bit form's consumers (reduce + residual + RMSNorm [+ e4m3 quantisation for the next projection], RoPE + KV scatter).
+static bool wdma8_applies(int m, int n, int k) {
+  static const int on = env_int("ATSPEED_FP8_SMALL", 1);               // 0: one user's forwards stay on the 16-bit kernels (A/B)
+  return on && m >= 1 && m <= 256 && k % 128 == 0 && k >= 512 && n >= 16 && dma_offsets_fit(n, k, 1) && dma_offsets_fit(m, k, 1);
+}
+static int wdma8_split_count(int n, int k) {                           // 1: no split
+  const int t128 = (n + 127) / 128, n_kt = k / 128;
+  if (t128 >= 150) return 1;
+  return std::max(1, std::min(256 / t128, n_kt / 4));                  // at least 4 tiles (512 k) per part
+}
+template <int BM, int NST, int EPI, bool SPLIT, int WM = 2>
+int launch_wdma8_cfg(const unsigned char* xq, const float* sx, const unsigned char* wq, const float* sw, void* c, int m, int n, int k, int ldc,
+                     int splits, hipStream_t st, int pk) {
+  auto kern = gemm_wdma_kernel<BM, 128, NST, EPI, SPLIT, WM, true>;
+  constexpr int lds = NST * (BM + 128) * 128;
+  static thread_local AtsPerDeviceFlag attr_flag;
+  bool& attr_done = attr_flag.cur();
+  if (!attr_done) {
+    ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((n + 127) / 128, SPLIT ? splits : 1), dim3(128 * WM), lds, st, (const void*)xq, (const void*)wq, c, m, n, k, k, ldc, pk, splits, sx, sw);
+  ATS_LAUNCH_CHECK();
+  ats_count_path(SPLIT ? ATS_PATH_FP8_WDMA_SPLIT : ATS_PATH_FP8_WDMA);
+  return ATSPEED_OK;
+}
+template <int EPI, bool SPLIT>
+int launch_wdma8(const unsigned char* xq, const float* sx, const unsigned char* wq, const float* sw, void* c, int m, int n, int k, int ldc,
+                 int splits, hipStream_t st, int pk) {
+  if (m <= 32)  return launch_wdma8_cfg<32, 6, EPI, SPLIT>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);        // 20 KB x 6
+  if (m <= 64)  return launch_wdma8_cfg<64, 6, EPI, SPLIT>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);        // 24 KB x 6
+  if (m <= 128) return launch_wdma8_cfg<128, 4, EPI, SPLIT>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);       // 32 KB x 4
+  return launch_wdma8_cfg<256, 3, EPI, SPLIT, 4>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);                  // 48 KB x 3, 8 waves
+}
+// the slabs of a split launch: [splits][m][n] fp32 in `ws`
+static bool wdma8_ws_ok(int m, int n, int splits, const void* ws, size_t ws_bytes) {
+  return ws && ((uintptr_t)ws & 15) == 0 && (size_t)splits * m * n * sizeof(float) <= ws_bytes;
+}
+
 bool ats_gemm_fp8_applies(int m, int n, int k, int ldc, int epilogue) {
-  if (m < 512 || k % 256 != 0) return false;
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
+  if (m <= 256) return wdma8_applies(m, n, k);
+  if (k % 256 != 0) return false;
+  if (m < 512) return true;                                            // 257-511 tokens (a long prompt's first verification): the ring kernel whatever its fill
   const int tn = (n + 255) / 256;
   return big_fill_pct(tn * ((m + 255) / 256)) >= 60 || big_fill_pct(tn * ((m + 127) / 128)) >= 60;
 }
+size_t ats_gemm_fp8_workspace_bytes(int m, int n, int k) {
+  return (m <= 256 && wdma8_applies(m, n, k)) ? (size_t)wdma8_split_count(n, k) * m * n * sizeof(float) : 0;
+}
 
 int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int m, int n, int k, int ldc,
-                 int epilogue, hipStream_t st, int pk) {
+                 int epilogue, hipStream_t st, int pk, void* ws, size_t ws_bytes) {
   ATS_REQUIRE(xq && sx && wq && sw && c, ATSPEED_ERR_INVALID, "gemm_fp8: null argument");
+  const unsigned char* X = (const unsigned char*)xq; const unsigned char* Wq = (const unsigned char*)wq;
+  if (m >= 1 && m <= 256 && wdma8_applies(m, n, k)) {
+    ATS_REQUIRE(epilogue != EPI_SWIGLU || ((ldc & 3) == 0 && n % 32 == 0), ATSPEED_ERR_INVALID, "gemm_fp8: SwiGLU needs N %% 32 == 0 and ldc %% 4 == 0");
+    ATS_REQUIRE((((uintptr_t)xq | (uintptr_t)wq) & 15) == 0, ATSPEED_ERR_INVALID, "gemm_fp8: operands must be 16-byte aligned");
+    int s_ = wdma8_split_count(n, k);
+    if (s_ > 1 && !wdma8_ws_ok(m, n, s_, ws, ws_bytes)) s_ = 1;         // no room for the slabs: one part per tile
+    if (s_ == 1 && epilogue != EPI_RESID) {
+      switch (epilogue) {
+        case EPI_STORE:  return launch_wdma8<EPI_STORE, false>(X, sx, Wq, sw, c, m, n, k, ldc, 1, st, pk);
+        case EPI_F32:    return launch_wdma8<EPI_F32, false>(X, sx, Wq, sw, c, m, n, k, ldc, 1, st, pk);
+        case EPI_SWIGLU: return launch_wdma8<EPI_SWIGLU, false>(X, sx, Wq, sw, c, m, n, k, ldc, 1, st, pk);
+      }
+      atspeed_set_error("gemm_fp8: unknown epilogue %d", epilogue);
+      return ATSPEED_ERR_INVALID;
+    }
+    ATS_REQUIRE(wdma8_ws_ok(m, n, s_, ws, ws_bytes), ATSPEED_ERR_CAPACITY, "gemm_fp8: %d x %d x %d parts of fp32 partial sums do not fit the workspace (%zu bytes)", s_, m, n, ws_bytes);
+    ATS_TRY((launch_wdma8<EPI_F32, true>(X, sx, Wq, sw, ws, m, n, k, n, s_, st, pk)));
+    switch (epilogue) {
+      case EPI_STORE:  return reduce_splits<bf16_t, EPI_STORE>((const float*)ws, c, m, n, ldc, s_, st, nullptr, pk);
+      case EPI_F32:    return reduce_splits<bf16_t, EPI_F32>((const float*)ws, c, m, n, ldc, s_, st, nullptr, pk);
+      case EPI_RESID:  return reduce_splits<bf16_t, EPI_RESID>((const float*)ws, c, m, n, ldc, s_, st, nullptr, pk);
+      case EPI_SWIGLU: return reduce_splits<bf16_t, EPI_SWIGLU>((const float*)ws, c, m, n, ldc, s_, st, nullptr, pk);
+    }
+    atspeed_set_error("gemm_fp8: unknown epilogue %d", epilogue);
+    return ATSPEED_ERR_INVALID;
+  }
   ATS_REQUIRE(m >= 1 && n >= 1 && k % 256 == 0, ATSPEED_ERR_INVALID, "gemm_fp8: K=%d must be a multiple of 256", k);
   ATS_REQUIRE(dma_offsets_fit(n, k, 1) && dma_offsets_fit(m, k, 1), ATSPEED_ERR_CAPACITY, "gemm_fp8: an operand of %d x %d or %d x %d bytes exceeds the kernel's 32-bit row offsets", n, k, m, k);
   ATS_REQUIRE(epilogue != EPI_SWIGLU || ((ldc & 3) == 0 && n % 32 == 0), ATSPEED_ERR_INVALID, "gemm_fp8: SwiGLU needs N %% 32 == 0 and ldc %% 4 == 0");
-  const unsigned char* X = (const unsigned char*)xq; const unsigned char* Wq = (const unsigned char*)wq;
   switch (epilogue) {
     case EPI_STORE:  return launch_big_fp8<EPI_STORE>(X, sx, Wq, sw, c, m, n, k, ldc, st, pk);
     case EPI_F32:    return launch_big_fp8<EPI_F32>(X, sx, Wq, sw, c, m, n, k, ldc, st, pk);
@@ -2138,11 +2296,47 @@ int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* s
   return ATSPEED_ERR_INVALID;
 }
 
+// One user's W8A8 qkv projection as scaled fp32 split-K slabs [splits][m][n] in the workspace, without the reduce pass (ats_gemm_partials'
+// fp8 form: RoPE + the KV scatter sum the slabs).  *splits_out = 0: this shape takes another path, the caller runs ats_gemm_fp8.
+int ats_gemm_fp8_partials(const void* xq, const float* sx, const void* wq, const float* sw, int m, int n, int k, void* ws, size_t ws_bytes,
+                          hipStream_t st, int* splits_out, int pk) {
+  *splits_out = 0;
+  if (m < 1 || m > 256 || !wdma8_applies(m, n, k) || (n % 4) != 0) return ATSPEED_OK;
+  const int s_ = wdma8_split_count(n, k);
+  if (s_ < 2 || !wdma8_ws_ok(m, n, s_, ws, ws_bytes)) return ATSPEED_OK;
+  ATS_REQUIRE(xq && sx && wq && sw && (((uintptr_t)xq | (uintptr_t)wq) & 15) == 0, ATSPEED_ERR_INVALID, "gemm_fp8_partials: null / unaligned operand");
+  ATS_TRY((launch_wdma8<EPI_F32, true>((const unsigned char*)xq, sx, (const unsigned char*)wq, sw, ws, m, n, k, n, s_, st, pk)));
+  *splits_out = s_;
+  return ATSPEED_OK;
+}
+
+// h += xq wq^T (W8A8), then the NEXT op's input norm of the updated rows: xn (16-bit operand; may be null when q_out is given) and / or the
+// e4m3 rows + per-token scales (q_out, s_out) a following W8A8 projection consumes.  One user's tokens: split-K slabs + ONE fused reduce /
+// residual / norm / quantisation pass; batched: the ring kernel's residual epilogue, then the norm kernels.
+int ats_gemm_fp8_resid_norm(const void* xq, const float* sx, const void* wq, const float* sw, void* h, int m, int n, int k, int ldh,
+                            const void* norm_w, void* xn, void* q_out, float* s_out, float eps, void* ws, size_t ws_bytes, hipStream_t st, int pk) {
+  if (m <= 0) return ATSPEED_OK;
+  ATS_REQUIRE(xn || (q_out && s_out), ATSPEED_ERR_INVALID, "gemm_fp8_resid_norm: no output for the norm");
+  if (m <= 256 && wdma8_applies(m, n, k) && n <= 8192 && (n % 4) == 0 && (ldh % 4) == 0) {
+    const int s_ = wdma8_split_count(n, k);
+    if (wdma8_ws_ok(m, n, s_, ws, ws_bytes)) {
+      ATS_REQUIRE(xq && sx && wq && sw && h && norm_w && (((uintptr_t)xq | (uintptr_t)wq) & 15) == 0, ATSPEED_ERR_INVALID, "gemm_fp8_resid_norm: null / unaligned operand");
+      ATS_TRY((launch_wdma8<EPI_F32, true>((const unsigned char*)xq, sx, (const unsigned char*)wq, sw, ws, m, n, k, n, s_, st, pk)));
+      FusedNorm fn{norm_w, xn, eps, false, q_out, s_out};
+      ATS_TRY((reduce_splits<bf16_t, EPI_RESID>((const float*)ws, h, m, n, ldh, s_, st, &fn, pk)));
+      if (fn.done) return ATSPEED_OK;
+      return q_out ? ats_rmsnorm_quant_fp8(h, norm_w, xn, q_out, s_out, m, n, eps, st, pk) : ats_rmsnorm(h, norm_w, xn, m, n, eps, ATS_HALF, st, pk);
+    }
+  }
+  ATS_TRY(ats_gemm_fp8(xq, sx, wq, sw, h, m, n, k, ldh, EPI_RESID, st, pk, ws, ws_bytes));
+  return q_out ? ats_rmsnorm_quant_fp8(h, norm_w, xn, q_out, s_out, m, n, eps, st, pk) : ats_rmsnorm(h, norm_w, xn, m, n, eps, ATS_HALF, st, pk);
+}
+
 // the fp8 qkv projection with RoPE + the KV scatter in its epilogue (see ats_gemm_qkv_rope); the caller checks ats_gemm_fp8_applies,
 // head_dim == 128 and hidden % 256 == 0 (ats_gemm_fp8_qkv_rope_applies)
 bool ats_gemm_fp8_qkv_rope_applies(int m, int hidden, int head_dim) {
   const char* e = getenv("ATSPEED_FUSE_QKV_ROPE");
-  return !(e && atoi(e) == 0) && head_dim == 128 && hidden % 256 == 0 && ats_gemm_fp8_applies(m, 3 * hidden, hidden, 3 * hidden, EPI_STORE);
+  return !(e && atoi(e) == 0) && m >= 257 && head_dim == 128 && hidden % 256 == 0 && ats_gemm_fp8_applies(m, 3 * hidden, hidden, 3 * hidden, EPI_STORE);   // the ring kernel's epilogue
 }
 
 int ats_gemm_fp8_qkv_rope(const void* xq, const float* sx, const void* wq, const float* sw, void* qkv, int m, int hidden, const RopeEpi& rope,
@@ -2162,8 +2356,8 @@ int ats_gemm_fp8_qkv_rope(const void* xq, const float* sx, const void* wq, const
 
 #ifndef ATS_F16_FLAVOUR          // the C ABI exists once; it picks the flavour by the dtype code (fp8 and packed entry points: bf16)
 extern "C" int atspeed_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int32_t m, int32_t n,
-                                int32_t k, int32_t ldc, int32_t epilogue, void* stream) {
-  return ats_bf16::ats_gemm_fp8(xq, sx, wq, sw, c, m, n, k, ldc, epilogue, (hipStream_t)stream, 0);
+                                int32_t k, int32_t ldc, int32_t epilogue, void* workspace, size_t workspace_bytes, void* stream) {
+  return ats_bf16::ats_gemm_fp8(xq, sx, wq, sw, c, m, n, k, ldc, epilogue, (hipStream_t)stream, 0, workspace, workspace_bytes);
 }
 
 extern "C" int atspeed_gemm(const void* a, const void* w, void* c, int32_t m, int32_t n, int32_t k, int32_t lda,
@@ -2178,7 +2372,7 @@ extern "C" int atspeed_gemm_packed(const void* a, const void* w, void* c, int32_
 }
 
 extern "C" int atspeed_gemm_fp8_packed(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int32_t m, int32_t n,
-                                       int32_t k, int32_t ldc, int32_t epilogue, void* stream) {
-  return ats_bf16::ats_gemm_fp8(xq, sx, wq, sw, c, m, n, k, ldc, epilogue, (hipStream_t)stream, 1);
+                                       int32_t k, int32_t ldc, int32_t epilogue, void* workspace, size_t workspace_bytes, void* stream) {
+  return ats_bf16::ats_gemm_fp8(xq, sx, wq, sw, c, m, n, k, ldc, epilogue, (hipStream_t)stream, 1, workspace, workspace_bytes);
 }
 #endif

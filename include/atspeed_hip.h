@@ -334,15 +334,20 @@ int atspeed_gemm_path_counters(int64_t* out, int32_t n, int32_t reset);
 int atspeed_gemm_packed(const void* a_dev, const void* w_dev, void* c_dev, int32_t m, int32_t n, int32_t k, int32_t ldc, int32_t epilogue,
                         void* workspace_dev, size_t workspace_bytes, void* stream);
 int atspeed_gemm_fp8_packed(const void* xq_dev, const float* sx_dev, const void* wq_dev, const float* sw_dev, void* c_dev, int32_t m,
-                            int32_t n, int32_t k, int32_t ldc, int32_t epilogue, void* stream);
+                            int32_t n, int32_t k, int32_t ldc, int32_t epilogue, void* workspace_dev, size_t workspace_bytes, void* stream);
 /* per-row e4m3 quantisation q = e4m3(x / scale[r]), scale[r] = max|x[r]| / 448, and the W8A8 GEMM over such operands */
 int atspeed_quant_rows_fp8(const void* x_bf16_dev, int32_t rows, int32_t cols, void* q_dev, float* scale_dev, void* stream);
 /* the same on operands in the packed layout (x through atspeed_pack_rows with row_bytes = 2 cols, q comes out as atspeed_pack_rows with
  * row_bytes = cols would lay it out; cols % 64 == 0; both buffers hold an even number of rows): what the engine runs between a bf16
  * producer (attention, SwiGLU) and the fp8 projection that consumes it -- one workgroup per row PAIR, whole 128-byte lines in and out */
 int atspeed_quant_rows_fp8_packed(const void* x_bf16_packed_dev, int32_t rows, int32_t cols, void* q_packed_dev, float* scale_dev, void* stream);
+/* m >= 257: the block-scaled MFMA ring kernel (K % 256 == 0, lock-step batches).  m <= 256 (round 5: one user's forwards, the reference's
+ * own regime -- code/inference.py:86-91 loads its target 8-bit for every batch-1 forward): the weight-streaming kernel on e4m3 rows
+ * (K % 128 == 0, K >= 512).  There a narrow N is cut in K and finished by a reduce pass over fp32 partial sums in `workspace_dev`
+ * (parts x m x n x 4 bytes, parts <= 8; 64 MB always suffices); with too little workspace the launch runs one part per tile, except the
+ * residual epilogue (2), which needs the workspace and returns ATSPEED_ERR_CAPACITY without it. */
 int atspeed_gemm_fp8(const void* xq_dev, const float* sx_dev, const void* wq_dev, const float* sw_dev, void* c_dev, int32_t m,
-                     int32_t n, int32_t k, int32_t ldc, int32_t epilogue, void* stream);
+                     int32_t n, int32_t k, int32_t ldc, int32_t epilogue, void* workspace_dev, size_t workspace_bytes, void* stream);
 int atspeed_rmsnorm(const void* x_dev, const void* w_dev, void* y_dev, int32_t rows, int32_t hidden,
                     float eps, int32_t dtype, void* stream);
 /* bf16 RMSNorm fused with the per-token e4m3 quantisation of its output (what the fp8 forward runs in front of the qkv and

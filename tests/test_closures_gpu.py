@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 import atspeed_amd
 from atspeed_amd import synth
 from atspeed_amd.beamSD import BSSD, BSSD_batch, _Decoder, last_trace, release_decoders, target_generate
-from atspeed_amd.generation_trie import SuffixTrieConstraint, Trie, prefix_allowed_tokens_fn
+from atspeed_amd.generation_trie import PositionSetConstraint, SuffixTrieConstraint, Trie, prefix_allowed_tokens_fn
 from atspeed_amd.model import HipLlama, vis_bits_from_bool
 from oracle import beamsd_ref as R
 from oracle.llama_ref import RefLlama
@@ -380,4 +380,42 @@ def test_a_filtered_user_does_not_abort_the_lock_step_batch():
     with pytest.raises(_lib.AtSpeedError) as ei:
         BSSD(tgt, drf, ins[1], 4, 4, prefix_allowed_tokens_fn=fn)
     assert ei.value.status == _lib.ERR_FILTERED
+    release_decoders(tgt, drf)
+
+
+def test_graph_replay_of_a_forward_that_takes_the_split_k_tail():
+    """VERDICT r4 #7 / ADVICE r4: with ATSPEED_GRAPHS=1 a recurring forward of <= 512 tokens is captured and replayed as a hipGraph, and from 257
+    tokens the N = 4096 projections take the ring kernel's split-K tail -- whose arena used to be allocated, and waited for across streams,
+    inside the launch (illegal in a capture).  The arena now belongs to the model's activation context: the 300-token first verification of a
+    180-token prompt is captured (second sight) and replayed (third), and every call returns the bits of the ungraphed engine."""
+    from atspeed_amd import _lib
+    import ctypes as C
+    V = synth.BEAUTY.vocab_size
+    kw = dict(max_slots=512, max_tokens=512, max_logit_rows=384, device="cuda:0")
+    drf = HipLlama.from_synthetic(synth.llama_68m(V), 12, std=0.02, head_std=0.02, dtype=torch.bfloat16, num_beams=40, **kw)
+    tgt = HipLlama.from_synthetic(synth.llama_7b(V, 2), 11, std=0.02, head_std=0.02, dtype=torch.bfloat16, num_beams=20, **kw)
+    fn = PositionSetConstraint(synth.BEAUTY.allowed_tokens(), synth.RESPONSE_SEP)
+    inp = {"input_ids": torch.from_numpy(synth.synthetic_prompt(180, 77))[None].cuda()}
+    cnt = (C.c_int64 * 16)()
+    lib = _lib.load()
+    old = os.environ.get("ATSPEED_GRAPHS")
+    res = {}
+    try:
+        for mode in ("0", "1"):
+            os.environ["ATSPEED_GRAPHS"] = mode
+            lib.atspeed_gemm_path_counters(cnt, 16, 1)
+            res[mode] = [BSSD(tgt, drf, inp, 4, 4, prefix_allowed_tokens_fn=fn) for _ in range(4)]
+            torch.cuda.synchronize()
+            lib.atspeed_gemm_path_counters(cnt, 16, 0)
+            res[mode + "sk"] = int(cnt[1])
+    finally:
+        if old is None:
+            os.environ.pop("ATSPEED_GRAPHS", None)
+        else:
+            os.environ["ATSPEED_GRAPHS"] = old
+    # ungraphed: every call's 300-token forward launches its o_proj / down tails (2 layers x 2); graphed: the capture launches them once
+    assert res["0sk"] >= 4 * 4 and 4 <= res["1sk"] < res["0sk"], (res["0sk"], res["1sk"])
+    for a in res["0"] + res["1"]:
+        assert torch.equal(a["beam_sequence"], res["0"][0]["beam_sequence"]) and torch.equal(a["beam_scores"], res["0"][0]["beam_scores"])
+        assert a["accept_steps"] == res["0"][0]["accept_steps"]
     release_decoders(tgt, drf)

@@ -15,7 +15,7 @@ for name, n, k, epi in (("qkv", 12288, 4096, 0), ("o_proj", 4096, 4096, 2), ("ga
         sx = torch.full((m,), 0.01, device="cuda"); sw = torch.full((n,), 0.001, device="cuda")
         ldc = n // 2 if epi == 3 else n
         c = torch.zeros(m, ldc, dtype=torch.bfloat16, device="cuda")
-        f = lambda: _lib.check(lib.atspeed_gemm_fp8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), c.data_ptr(), m, n, k, ldc, epi, st))
+        f = lambda: _lib.check(lib.atspeed_gemm_fp8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), c.data_ptr(), m, n, k, ldc, epi, None, 0, st))
         for _ in range(3): f()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
