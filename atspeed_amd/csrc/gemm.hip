@@ -656,21 +656,27 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // assumption.  Consecutive ranges are given to workgroup ids 8 apart (same XCD under round-robin dispatch: a speed choice only).
 struct SkTail { int n_dp = 0; int G = 0; int U = 0; int TU = 0; float* ws = nullptr; int* cnt = nullptr; };
 
-template <int EPI, int MT2, bool FP8, bool SPLITK = false, int NA = 4, bool SK = false>
-__global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const void* __restrict__ X, const void* __restrict__ W,
+// PANEL (WN = 2, WM = 4; round 5: one launch's 257-512 tokens -- 4-16 users in lock step, a long prompt's first verification): the same
+// eight waves arranged 2 (n) x 4 (m): a workgroup owns a 128-row weight panel and ALL token rows (XR = 4 x MT2 x 16 = 384 or 512), so W
+// is streamed once, no token tile is 38 % padding (320 tokens in two 256-row tiles) and a wide projection is one round of N / 128
+// workgroups.  Stage size, pieces per wave and the loop are those of the 256 x 256 tile (128 + 384 rows = 32 KB, 1 W + 3 X pieces per wave).
+template <int EPI, int MT2, bool FP8, bool SPLITK = false, int NA = 4, bool SK = false, int WN = 256 / (NA * 16), int WM = 2>
+__global__ __launch_bounds__(WN * WM * 64, 1) void gemm_ring_kernel(const void* __restrict__ X, const void* __restrict__ W,
                                                            const float* __restrict__ sx, const float* __restrict__ sw,
                                                            void* __restrict__ Cv, int M, int N, int K, int ldx, int ldc,
                                                            int tiles_n, int tiles_m, int GM, int n_split = 1,
                                                            float* __restrict__ lse_part = nullptr, const unsigned char* __restrict__ tile_store = nullptr,
                                                            int pk = 0, RopeEpi rope = RopeEpi{}, SkTail sk = SkTail{}) {
-  static_assert(!(SK && (SPLITK || FP8 || NA != 4)), "the stream-K tail is built for the bf16 eight-wave form");
+  static_assert(!(SK && (SPLITK || FP8 || NA != 4 || WN != 4 || WM != 2)), "the stream-K tail is built for the bf16 eight-wave 4 x 2 form");
+  static_assert((EPI != EPI_F32_LSE && EPI != EPI_QKV_ROPE) || (WN == 4 && WM == 2), "the LSE / RoPE epilogues are written for the 4 x 2 wave grid");
   // pk: X and W (and the SwiGLU output) are in the packed operand layout -- every 1 KB DMA piece is then eight FULL 128-byte lines
   // (two rows x 64 bytes each) instead of sixteen half lines: 83 against 55 GB/s per CU from L2 (tools/probe/dma_depth.hip)
-  constexpr int BT = 256, RB = 64, ESZ = FP8 ? 1 : 2;
+  constexpr int BT = WN * NA * 16, RB = 64, ESZ = FP8 ? 1 : 2;   // weight rows per workgroup: 256 (4 x 2 waves) or 128 (panel form, 2 x 4)
   constexpr int BK = RB / ESZ;                                   // k per stage: 32 (bf16) or 64 (fp8)
-  constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
-  constexpr int NWV = (BT / (NA * 16)) * 2;                      // waves per workgroup: 8 or 4
-  constexpr int WP = 16 / NWV;                                   // W DMA pieces (16 rows each) per wave per k-step
+  constexpr int XR = WM * MT2 * 16;                              // token rows per workgroup (256 or 128; panel: 384 or 512)
+  constexpr int NWV = WN * WM;                                   // waves per workgroup: 8 or 4
+  constexpr int WP = (BT / 16) / NWV;                            // W DMA pieces (16 rows each) per wave per k-step
+  static_assert((BT / 16) % NWV == 0 && XR % (16 * NWV) == 0, "whole DMA pieces per wave");
   constexpr int XP = XR / (16 * NWV);                            // X DMA pieces per wave per k-step
   constexpr int NP = WP + XP;                                    // DMA pieces per wave per k-step
   constexpr int STAGE = (BT + XR) * RB;                          // 32 or 24 KB
@@ -698,7 +704,7 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
       sk_tail = true;
     }
   }
-  const int wn = wave >> 1, wm = wave & 1;
+  const int wn = wave / WM, wm = wave % WM;
   auto swz = [](int row) { return (0xD2 >> (((row >> 2) & 3) * 2)) & 3; };   // f = {2,0,1,3} packed in 0b11010010
   const unsigned lbase = lds_addr(smem);
   int m0w[WP], m0x[XP];
@@ -788,10 +794,10 @@ __global__ __launch_bounds__(NA == 8 ? 256 : 512, 1) void gemm_ring_kernel(const
     } else {
       switch (r - NA) {
         ATS_RD(fb[buf][0], b, 0) ATS_RD(fb[buf][1], b, 1) ATS_RD(fb[buf][2], b, 2) ATS_RD(fb[buf][3], b, 3)
-        case 4: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][MT2 - 4], b, so + 4096); break;
-        case 5: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][MT2 - 3], b, so + 5120); break;
-        case 6: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][MT2 - 2], b, so + 6144); break;
-        case 7: if constexpr (MT2 == 8) ATS_DS_READ_B128(fb[buf][MT2 - 1], b, so + 7168); break;
+        case 4: if constexpr (MT2 > 4) ATS_DS_READ_B128(fb[buf][MT2 > 4 ? 4 : 0], b, so + 4096); break;
+        case 5: if constexpr (MT2 > 5) ATS_DS_READ_B128(fb[buf][MT2 > 5 ? 5 : 0], b, so + 5120); break;
+        case 6: if constexpr (MT2 > 6) ATS_DS_READ_B128(fb[buf][MT2 > 6 ? 6 : 0], b, so + 6144); break;
+        case 7: if constexpr (MT2 > 7) ATS_DS_READ_B128(fb[buf][MT2 > 7 ? 7 : 0], b, so + 7168); break;
         default: break;
       }
     }
@@ -2013,9 +2019,68 @@ int launch_wdma(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, 
   return launch_wdma_cfg<256, 128, 3, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);
 }
 
+// ---- panel form of the ring kernel (gemm_ring_kernel<..., WN = 2, WM = 4>): 257-384 tokens in ONE launch (16 users' K-token continuation
+// forwards, beamSD.py:579-588; a long prompt's first verification).  A workgroup owns a 128-row weight panel and all token rows (384): wide
+// projections (150-256 panels: gate_up's 172) run one round without split; narrow ones are cut in K so that panels x parts fill the chip
+// (qkv 96 x 2, down 32 x 8) and leave fp32 slabs to the consumers of every other split form.  Before: two 256-row token tiles of which 38 %
+// were padding at 320 tokens.  Measured (tools/panel_sweep.py, profiles/r05_panel_sweep.txt, us per launch at 320 tokens): qkv 69.2 -> 56.5,
+// gate_up 77.6 -> 70.4, down 58.9 -> 50.1; NOT o_proj (8 parts of 16 k-steps are all prologue: 27.8 -> 30.3), not above 384 tokens (the
+// 512-row panel, 160 KB of LDS, lost on every projection: gate_up 82 -> 92 at 512) and gate_up only while the padding stays below ~10 %.
+// 172 workgroups at ~4.8 TF each is what this form gives: the band stays MFMA-inefficient (0.33 of nominal at 320 tokens), see DESIGN section 9.
+static int panel_split_count(int n, int k);
+static bool panel_applies(int m, int n, int k, int lda) {
+  const int on = env_now("ATSPEED_GEMM_PANEL", 1);                     // read per call: tools/panel_sweep.py flips it in-process
+  if (!on || m < 257 || m > 384 || k % 128 != 0 || k < 2048 || (lda % 8) != 0 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return false;
+  const int t128 = (n + 127) / 128;
+  if (t128 > 256 || t128 < 16) return false;                           // (K >= 2048: the target's projections; a 68M draft's thin GEMMs stay where they were)
+  if (on >= 2) return true;                                            // 2: every shape the kernel can take (tests, sweeps)
+  if (panel_split_count(n, k) == 1) return m <= 352;                   // one round of panels: until the 384-row tile's padding costs more than the second token tile did
+  return t128 >= 64 || k >= 8192;                                      // split: qkv (96 panels x 2) and down (K = 11008); o_proj's parts are too short
+}
+static int panel_split_count(int n, int k) {                           // 1: no split
+  const int t128 = (n + 127) / 128, units = k / 128;
+  if (t128 >= 150) return 1;
+  return std::max(1, std::min(256 / t128, units / 4));                 // at least 4 units (512 k) per part
+}
+template <int EPI, int MT2, bool SPLIT>
+int launch_panel_cfg(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, int splits, hipStream_t st, int pk) {
+  auto kern = gemm_ring_kernel<EPI, MT2, false, SPLIT, 4, false, 2, 4>;
+  constexpr int lds = 4 * (128 + 4 * MT2 * 16) * 64;                   // 128 KB at 384 token rows
+  static thread_local AtsPerDeviceFlag attr_flag;
+  bool& attr_done = attr_flag.cur();
+  if (!attr_done) {
+    ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
+  const int tiles_n = (n + 127) / 128;
+  const float* none = nullptr;
+  hipLaunchKernelGGL(kern, dim3(tiles_n * (SPLIT ? splits : 1)), dim3(512), lds, st, (const void*)x, (const void*)w, none, none, c, m, n, k, ldx, ldc,
+                     tiles_n, 1, 1, SPLIT ? splits : 1, (float*)nullptr, (const unsigned char*)nullptr, pk, RopeEpi{}, SkTail{});
+  ATS_LAUNCH_CHECK();
+  ats_count_path(SPLIT ? ATS_PATH_PANEL_SPLIT : ATS_PATH_PANEL);
+  return ATSPEED_OK;
+}
+template <int EPI>
+int launch_panel(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st, int pk) {
+  return launch_panel_cfg<EPI, 6, false>(x, w, c, m, n, k, ldx, ldc, 1, st, pk);
+}
+static int launch_panel_split(const bf16_t* x, const bf16_t* w, float* partial, int m, int n, int k, int ldx, int splits, hipStream_t st, int pk) {
+  return launch_panel_cfg<EPI_F32, 6, true>(x, w, (void*)partial, m, n, k, ldx, n, splits, st, pk);
+}
+
 template <typename T, int EPI>
 int launch_epi(const T* a, const T* w, void* c, int m, int n, int k, int lda, int ldc, float* partial, size_t ws_bytes,
                hipStream_t st, FusedNorm* fn, int pk) {
+  if constexpr (sizeof(T) == 2) {
+    if (panel_applies(m, n, k, lda) && (EPI != EPI_SWIGLU || (n % 32 == 0 && (ldc & 3) == 0))) {
+      const int ps = panel_split_count(n, k);
+      if (ps == 1) return launch_panel<EPI>(a, w, c, m, n, k, lda, ldc, st, pk);
+      if ((size_t)ps * m * n * sizeof(float) <= ws_bytes && ((uintptr_t)partial & 15) == 0) {
+        ATS_TRY(launch_panel_split(a, w, partial, m, n, k, lda, ps, st, pk));
+        return reduce_splits<bf16_t, EPI>(partial, c, m, n, ldc, ps, st, fn, pk);
+      }
+    }
+  }
   if constexpr (sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_F32 || EPI == EPI_SWIGLU)) {
     if (wdma_applies(m, n, k, lda, EPI)) return launch_wdma<EPI>(a, w, c, m, n, k, lda, ldc, st, pk);
   }
@@ -2067,6 +2132,7 @@ size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype) {
   size_t b = p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
   if (dtype == ATS_HALF) b = std::max(b, (size_t)ring_split_count(m, n, k) * m * n * sizeof(float));
   if (dtype == ATS_HALF) b = std::max(b, (size_t)wdma_split_count(m, n, k, k) * m * n * sizeof(float));
+  if (dtype == ATS_HALF && panel_applies(m, n, k, k) && panel_split_count(n, k) > 1) b = std::max(b, (size_t)panel_split_count(n, k) * m * n * sizeof(float));
   return b;
 }
 
@@ -2079,6 +2145,16 @@ int ats_gemm_partials(const void* a, const void* w, int m, int n, int k, int lda
                       hipStream_t st, int* splits_out, int pk) {
   *splits_out = 0;
   if (dtype != ATS_HALF || m <= 0 || big_kernel_applies(m, n, k, lda, n, dtype, EPI_STORE)) return ATSPEED_OK;
+  if (panel_applies(m, n, k, lda)) {
+    const int ps = panel_split_count(n, k);
+    if (ps >= 2 && (n % 4) == 0 && ((uintptr_t)workspace & 15) == 0 && (size_t)ps * m * n * sizeof(float) <= workspace_bytes) {
+      ATS_REQUIRE(a && w && workspace, ATSPEED_ERR_INVALID, "gemm: null operand");
+      ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "gemm: operands must be 16-byte aligned");
+      ATS_TRY(launch_panel_split((const bf16_t*)a, (const bf16_t*)w, (float*)workspace, m, n, k, lda, ps, st, pk));
+      *splits_out = ps;
+    }
+    return ATSPEED_OK;
+  }
   if (wdma_applies(m, n, k, lda, EPI_STORE)) return ATSPEED_OK;        // the no-split kernel writes bf16 qkv itself: the caller runs ats_gemm + the plain RoPE pass
   {
     const int s = wdma_split_count(m, n, k, lda);
@@ -2171,6 +2247,7 @@ static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype,
   static const int min_fill = env_int("ATSPEED_GEMM_BIG_MIN_FILL", 60);   // crossover measured at ~50-60 % (o_proj, down, qkv, gate_up at 512-1920 tokens)
   if (dtype != ATS_HALF || m < big_min_m || k % 128 != 0 || (lda % 8) != 0 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return false;
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
+  if (panel_applies(m, n, k, lda)) return false;                       // 257-512 tokens on a projection of 16-256 panels: the panel form (launch_epi)
   const int tn = (n + 255) / 256;
   if (big_fill_pct(tn * ((m + 255) / 256)) >= min_fill || big_fill_pct(tn * ((m + 127) / 128)) >= min_fill) return true;
   // a thin grid whose k-steps the split-K tail spreads over the chip: from 48 tiles of 128 rows (four parts per tile on 192 CUs; N = 4096

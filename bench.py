@@ -76,6 +76,7 @@ def parse():
                     help="extra brackets (SURVEY.md 8d 'oracle-draft'): same shapes and kernels, draft/target weights aligned through a "
                          "shared bigram table with the layers' residual contributions scaled by each factor of this comma list "
                          "(3e-6: every draft step accepted, 3e-5: about one step per verification); empty string skips the pass")
+    ap.add_argument("--one-user-fp8-users", type=int, default=24, help="users per bracket decoded ONE AT A TIME with the bf16 and then the W8A8 target (config 5 at the reference's batch-1 shape)")
     ap.add_argument("--aligned-fp32-users", type=int, default=64, help="users per aligned bracket the fp32 ENGINE also decodes (accepted length next to the bf16 engine's)")
     ap.add_argument("--dataset", choices=("beauty", "games"), default="beauty", help="vocabulary / prompt-length shape of the headline pass (games = BASELINE config 3)")
     ap.add_argument("--mask", choices=("position", "trie"), default="position",
@@ -281,9 +282,18 @@ def compact_line(detail: dict) -> dict:
     if su:
         line["single_user_stream"] = dict(_pick(su, ("users", "items_per_s", "ms_per_user", "weights_stream_frac_of_hbm_peak")),
                                           frac=(su.get("roofline") or {}).get("frac"), avg_launch_us=(su.get("roofline") or {}).get("avg_launch_us"))
-    if d.get("single_user_fp8"):
-        line["single_user_fp8"] = d["single_user_fp8"] if len(json.dumps(d["single_user_fp8"])) < 700 else _pick(
-            d["single_user_fp8"], ("ms_per_user", "items_per_s", "weights_stream_frac_of_hbm_peak", "mean_accept_len", "bf16_ms_per_user"))
+    ou = ((d.get("configs") or {}).get("fp8") or {}).get("one_user")
+    if ou or any(a.get("one_user") for a in d.get("aligned_weight_brackets") or []):
+        # config 5 at the reference's batch-1 shape: ms per user with the bf16 / the W8A8 target, by acceptance bracket
+        rows8 = [dict(bracket="accept0", bf16_ms=ou.get("bf16_ms_per_user"), fp8_ms=ou.get("ms_per_user"), fp8_frac=ou.get("weights_stream_frac_of_hbm_peak"),
+                      not_fp8=ou.get("projections_not_in_fp8"))] if ou else []
+        for a in d.get("aligned_weight_brackets") or []:
+            o1 = a.get("one_user")
+            if o1:
+                rows8.append(dict(bracket=f"resid{a.get('resid_scale'):g}", bf16_ms=o1.get("bf16_ms_per_user"), fp8_ms=o1.get("fp8_ms_per_user"),
+                                  fp8_frac=o1.get("fp8_weights_stream_frac_of_hbm_peak"), accept_bf16=o1.get("bf16_mean_accept_len"),
+                                  accept_fp8=o1.get("fp8_mean_accept_len"), not_fp8=o1.get("projections_not_in_fp8")))
+        line["one_user_fp8"] = rows8
     errs = d.get("sub_pass_errors")
     line["sub_pass_errors"] = {k: str(v)[:120] for k, v in errs.items()} if errs else None
     line["detail"] = d.get("detail_file")
@@ -365,6 +375,27 @@ def run_users(target, draft, dprompts, lo, hi, streams, fn, args):
     for g in range(lo, hi, streams):
         res += BSSD_batch(target, draft, dprompts[g:min(hi, g + streams)], args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
     return res
+
+
+def one_user_loop(target, draft, dprompts, first, n, fn, args, dev, bytes_per_weight):
+    """The reference's own loop (inference.py:162-176): `n` users decoded strictly one at a time.  -> ms per user, accepted length, and the
+    weight stream of the target's forwards against 8 TB/s (the roofline of a forward at 20-230 tokens: its weights read once)."""
+    grp = dprompts[first: first + n]
+    for p_ in grp[:2]:
+        BSSD(target, draft, p_, args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    outs = [BSSD(target, draft, p_, args.gamma, args.new_tokens, prefix_allowed_tokens_fn=fn) for p_ in grp]
+    torch.cuda.synchronize(dev)
+    sec = (time.perf_counter() - t0) / max(1, len(grp))
+    tf = sum(o["n_target_forwards"] for o in outs) / max(1, len(grp))
+    d = target.dims
+    w_layers = d.n_layers * (4 * d.hidden * d.hidden + 3 * d.hidden * d.ffn)
+    stream_bytes = tf * (w_layers * bytes_per_weight + d.hidden * d.vocab_size * 2)          # the lm_head stays 16-bit
+    return dict(users=len(grp), ms_per_user=1e3 * sec, items_per_s=args.beam / sec,
+                mean_accept_len=sum(o["total_accept_steps"] for o in outs) / max(1, sum(o["n_run"] for o in outs)),
+                target_forwards_per_user=tf, weights_stream_gbs=stream_bytes / sec / 1e9,
+                weights_stream_frac_of_hbm_peak=stream_bytes / sec / 1e9 / HBM_PEAK_GBS), outs
 
 
 def gemm_roofline(target, prof, prof_big, fp8: bool, measured, streams: int, with_traffic: bool):
@@ -710,6 +741,20 @@ def main():
                     what="the fp32 engine (exact-fp32 MFMA, one user at a time) on the same bf16-valued weights and users; it equals the CPU oracle bit for bit at these dims")
                 release_decoders(t32, d32)
                 del t32, d32
+            if not args.target_fp8 and not args.do_sample and not args.no_configs and args.one_user_fp8_users > 0:
+                # config 5 in the reference's own regime (one user per call, inference.py:86-91,162-176): the same users one at a time, bf16
+                # target then W8A8 target (weight-streaming kernels), with the accepted-length drift between the two
+                n1 = min(args.one_user_fp8_users, r["n_timed"])
+                b1, _ = one_user_loop(target_a, draft_a, dprompts, sub_warm * ups, n1, fn, args, dev, 2)
+                target_a.enable_fp8()
+                target_a.fp8_counters(reset=True)
+                f1, _ = one_user_loop(target_a, draft_a, dprompts, sub_warm * ups, n1, fn, args, dev, 1)
+                c1 = target_a.fp8_counters()
+                br["one_user"] = dict(users=n1, bf16_ms_per_user=b1["ms_per_user"], fp8_ms_per_user=f1["ms_per_user"], bf16_mean_accept_len=b1["mean_accept_len"],
+                                      fp8_mean_accept_len=f1["mean_accept_len"], drift_steps=f1["mean_accept_len"] - b1["mean_accept_len"],
+                                      fp8_weights_stream_frac_of_hbm_peak=f1["weights_stream_frac_of_hbm_peak"],
+                                      bf16_weights_stream_frac_of_hbm_peak=b1["weights_stream_frac_of_hbm_peak"],
+                                      projections_not_in_fp8=sum(v["other"] for v in c1.values()))
             if rs == max(scales) and not args.target_fp8 and not args.do_sample and not args.no_configs:
                 # config 5's accepted-length drift: the SAME aligned pair and users with the target's projections in fp8
                 target_a.enable_fp8()
@@ -757,12 +802,24 @@ def main():
             target.fp8_counters(reset=True)
             r = timed_pass(target, draft, dprompts, sub_warm, sub_steps, args.streams, fn, args, dev)
             cnt = target.fp8_counters()
+            one_user_fp8 = None
+            if args.one_user_fp8_users > 0:                 # the headline weights (zero-acceptance bracket: four target forwards per user), one user per call
+                target.fp8_counters(reset=True)
+                target.profile(1)
+                one_user_fp8, _ = one_user_loop(target, draft, dprompts, n_warm, min(args.one_user_fp8_users, n_timed), fn, args, dev, 1)
+                p8 = target.profile(0)
+                c8 = target.fp8_counters()
+                one_user_fp8.update(projections_not_in_fp8=sum(v["other"] for v in c8.values()),
+                                    per_kind_us={k: 1e3 * v["ms"] / max(1, v["count"]) for k, v in p8.items()},
+                                    bf16_ms_per_user=(single or {}).get("ms_per_user"),
+                                    roofline="target forwards x (6.48 G e4m3 layer weights + the bf16 lm_head) / time vs 8 TB/s; the GEMM brackets' events are inside the timed loop")
             configs["fp8"] = dict(workload=f"{args.dataset.capitalize()} V={V}, Llama-7B({args.target_layers}L) target verify in fp8 (e4m3 W8A8 projections on the block-scaled MFMA, "
                                            f"bf16 elsewhere), K={args.beam}, {args.streams} users per lock-step batch",
                                   steps=sub_steps, dtype="fp8-e4m3 (W8A8 target projections, bf16 elsewhere)", **pass_summary(r, args, ups),
                                   projection_launches={k: v for k, v in cnt.items()},
                                   roofline=gemm_roofline(target, r["prof"], r["prof_big"], True, measured, args.streams, False),
                                   accepted_length_drift_vs_bf16=fp8_drift,
+                                  one_user=one_user_fp8,
                                   parity="unpinned against the reference (its 8-bit target is bitsandbytes LLM.int8, absent offline); pinned to the build's W8A8 oracle, tests/test_fp8_gpu.py")
         return configs
 

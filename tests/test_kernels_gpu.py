@@ -720,6 +720,7 @@ def test_gemm_stream_k_tail(lib, m, n, k, epi):
         ldc = n; mk = lambda: (base.clone() if epi == _lib.EPI_RESID else torch.zeros(m, n, dtype=torch.bfloat16, device="cuda"))
     outs = []
     os.environ["ATSPEED_GEMM_SK"] = "2"                             # read per launch: two parts per tail tile wherever they fit, whatever the cost model says
+    os.environ["ATSPEED_GEMM_PANEL"] = "0"                          # (257-384 tokens: the panel form would take some of these shapes first)
     try:
         _path_counters(lib, reset=True)
         for _ in range(3):
@@ -732,7 +733,7 @@ def test_gemm_stream_k_tail(lib, m, n, k, epi):
         _lib.check(lib.atspeed_gemm_packed(ap.data_ptr(), wp.data_ptr(), cp.data_ptr(), m, n, k, ldc, epi, ws.data_ptr(), ws.numel(), _st()))
         assert _path_counters(lib)[PATH_RING_SK] == 4
     finally:
-        del os.environ["ATSPEED_GEMM_SK"]
+        del os.environ["ATSPEED_GEMM_SK"], os.environ["ATSPEED_GEMM_PANEL"]
     cd = mk()                                                       # what the fitted cost model picks by itself (tail or not): same product, its own summation order
     _lib.check(lib.atspeed_gemm(a.data_ptr(), w.data_ptr(), cd.data_ptr(), m, n, k, k, ldc, _lib.ATSPEED_BF16, epi, ws.data_ptr(), ws.numel(), _st()))
     torch.cuda.synchronize()
@@ -900,3 +901,71 @@ def test_gemm_fp8_weight_streaming_form(lib, m, n, k, epi):
         assert torch.equal(c1[:m], c0[:m])
     if epi != _lib.EPI_RESID:
         np.testing.assert_allclose(c2.double().cpu()[:m, : ref.shape[1]].numpy(), ref.numpy(), atol=tol, rtol=0)
+
+
+# ------------------------------------------------------------------ panel form of the ring kernel: 257-512 tokens in one launch
+PANEL_SHAPES = [(320, 22016, 4096, 3), (320, 4096, 11008, 2), (320, 4096, 4096, 2), (384, 12288, 4096, 0), (257, 4096, 4096, 0), (384, 22016, 4096, 3),
+                (383, 4096, 4096, 2), (300, 8192, 2048, 1), (320, 22016, 4096, 0), (352, 12288, 4096, 0)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k,epi", PANEL_SHAPES)
+def test_gemm_panel_form(lib, m, n, k, epi, dtype):
+    """VERDICT r4 missing #2 / weak #3: 257-512 tokens (4-16 users per lock-step batch, the K-token continuation forwards x users of
+    beamSD.py:579-588; a long prompt's first verification, :221) used to take two 256-row token tiles of the ring kernel (38 % padding at 320
+    tokens) or a thin grid with a split-K tail.  gemm_ring_kernel<..., WN = 2, WM = 4>: a workgroup owns a 128-row weight panel and all
+    token rows (384 / 512); narrow projections are cut in K (fp32 slabs + the usual reduce).  Against torch fp32 on the same 16-bit values,
+    packed = row-major bit for bit, two runs identical, and the launch counters say the panel kernel ran."""
+    code = _lib.ATSPEED_BF16 if dtype == torch.bfloat16 else _lib.ATSPEED_F16
+    a = _rand((m, k), 281, 1.0).to(dtype).cuda()
+    w = _rand((n, k), 282, 0.03).to(dtype).cuda()
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    if epi == _lib.EPI_SWIGLU:
+        from atspeed_amd.model import _interleave_gate_up
+        w = _interleave_gate_up(w[: n // 2].contiguous(), w[n // 2:].contiguous())
+    base = _rand((m, n), 283).to(dtype).cuda() if epi == _lib.EPI_RESID else None
+    mp = (m + 1) // 2 * 2
+    if epi == _lib.EPI_F32:
+        ldc = (n + 63) // 64 * 64; mk = lambda: torch.zeros(m, ldc, dtype=torch.float32, device="cuda")
+    elif epi == _lib.EPI_SWIGLU:
+        ldc = n // 2; mk = lambda: torch.zeros(mp, ldc, dtype=dtype, device="cuda")
+    else:
+        ldc = n; mk = lambda: (base.clone() if epi == _lib.EPI_RESID else torch.zeros(m, n, dtype=dtype, device="cuda"))
+    os.environ["ATSPEED_GEMM_PANEL"] = "2"                          # read per call: every shape the kernel can take, whatever the dispatch prefers
+    try:
+        _path_counters(lib, reset=True)
+        outs = []
+        for _ in range(2):
+            c = mk()
+            _lib.check(lib.atspeed_gemm(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, k, ldc, code, epi, ws.data_ptr(), ws.numel(), _st()))
+            outs.append(c)
+        cnt = _path_counters(lib)
+        split = (n + 127) // 128 < 150
+        assert cnt[PATH_PANEL_SPLIT if split else PATH_PANEL] == 2 and cnt[PATH_RING] == cnt[PATH_RING_SK] == cnt[PATH_TILED] == 0, cnt
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1])
+        if dtype == torch.bfloat16:                                 # the packed-operand entry point is the bf16 engine's
+            ap, wp = _pack(lib, a), _pack(lib, w)
+            cp = mk()
+            _lib.check(lib.atspeed_gemm_packed(ap.data_ptr(), wp.data_ptr(), cp.data_ptr(), m, n, k, ldc, epi, ws.data_ptr(), ws.numel(), _st()))
+            torch.cuda.synchronize()
+    finally:
+        del os.environ["ATSPEED_GEMM_PANEL"]
+    if dtype == torch.bfloat16:
+        if epi == _lib.EPI_SWIGLU:
+            assert torch.equal(_unpack(lib, cp, m), outs[0][:m])
+        else:
+            assert torch.equal(cp[:, :n], outs[0][:, :n])
+    prod = a.float() @ w.float().T
+    if epi == _lib.EPI_SWIGLU:
+        v = prod.view(m, n // 32, 2, 16)
+        gate, up = v[:, :, 0].reshape(m, n // 2), v[:, :, 1].reshape(m, n // 2)
+        ref = torch.nn.functional.silu(gate.to(dtype).float()) * up.to(dtype).float()
+        got = outs[0][:m].float()
+        tol = (3e-2 if dtype == torch.bfloat16 else 5e-3) * float(ref.abs().max())
+    else:
+        ref = prod + (base.float() if epi == _lib.EPI_RESID else 0.0)
+        got = outs[0][:, :n].float()
+        tol = (2e-5 * np.sqrt(k) if epi == _lib.EPI_F32 else (1e-2 if dtype == torch.bfloat16 else 2e-3)) * float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    assert err <= tol, (err, tol)
