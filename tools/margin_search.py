@@ -53,23 +53,23 @@ for beta in betas:
     tsd["lm_head.weight"] = head_t * a[:, None]
     dsd["lm_head.weight"] = head_d * a[:, None]
     rt, rd = RefLlama(tdims, tsd, max_slots=512), RefLlama(ddims, dsd, max_slots=512)
-  for K, DK in beams:
-    mins = []
-    for u in range(users):
-        P = PROMPTS[u % len(PROMPTS)]
-        prompt = synth.synthetic_prompt(P, synth.tensor_seed(2025, f"user{u}"))
-        R.MARGINS = []
-        t1 = time.time()
-        ref = R.BSSD(rt, rd, prompt, 4, 4, K, DK, fn)
-        m, R.MARGINS = sorted(R.MARGINS), None
-        mins.append(m[0])
-        # fp32 summation noise: the same oracle with another thread count (another blocking of every matmul's sum)
-        torch.set_num_threads(3)
-        ref2 = R.BSSD(rt, rd, prompt, 4, 4, K, DK, fn)
-        torch.set_num_threads(8)
-        same = ref2["beam_sequence"].tolist() == ref["beam_sequence"].tolist()
-        noise = float((ref2["beam_scores"] - ref["beam_scores"]).abs().max())
-        print(f"   noise proxy (8 vs 3 threads): items equal {same}, max |score diff| {noise:.3e}, min margin / noise {m[0] / max(noise, 1e-12):.1f}", flush=True)
-        print(f"beta {beta} resid {rs} K {K} DK {DK} user {u}: n_run {ref['n_run']} accept {ref['total_accept_steps']} decisions {len(m)} min margin {m[0]:.3e} "
-              f"next {m[1]:.3e} {m[2]:.3e} median {m[len(m) // 2]:.3e} best score {float(ref['beam_scores'][0]):.3f} worst {float(ref['beam_scores'][-1]):.3f} ({time.time() - t1:.0f}s)", flush=True)
-    print(f"== beta {beta} resid {rs} K {K} DK {DK}: min over users {min(mins):.3e}, users below 1e-4: {sum(x < 1e-4 for x in mins)} of {users}", flush=True)
+    for K, DK in beams:
+        mins = []
+        for u in range(users):
+            P = PROMPTS[u % len(PROMPTS)]
+            prompt = synth.synthetic_prompt(P, synth.tensor_seed(2025, f"user{u}"))
+            R.MARGINS = []
+            t1 = time.time()
+            ref = R.BSSD(rt, rd, prompt, 4, 4, K, DK, fn)
+            m, R.MARGINS = sorted(R.MARGINS), None
+            mins.append(m[0])
+            # fp32 summation noise: the same oracle with another thread count (another blocking of every matmul's sum)
+            torch.set_num_threads(3)
+            ref2 = R.BSSD(rt, rd, prompt, 4, 4, K, DK, fn)
+            torch.set_num_threads(8)
+            same = ref2["beam_sequence"].tolist() == ref["beam_sequence"].tolist()
+            noise = float((ref2["beam_scores"] - ref["beam_scores"]).abs().max())
+            print(f"   noise proxy (8 vs 3 threads): items equal {same}, max |score diff| {noise:.3e}, min margin / noise {m[0] / max(noise, 1e-12):.1f}", flush=True)
+            print(f"beta {beta} resid {rs} K {K} DK {DK} user {u}: n_run {ref['n_run']} accept {ref['total_accept_steps']} decisions {len(m)} min margin {m[0]:.3e} "
+                  f"next {m[1]:.3e} {m[2]:.3e} median {m[len(m) // 2]:.3e} best score {float(ref['beam_scores'][0]):.3f} worst {float(ref['beam_scores'][-1]):.3f} ({time.time() - t1:.0f}s)", flush=True)
+        print(f"== beta {beta} resid {rs} K {K} DK {DK}: min over users {min(mins):.3e}, users below 1e-4: {sum(x < 1e-4 for x in mins)} of {users}", flush=True)
