@@ -92,7 +92,7 @@ def parse():
 
 
 # ------------------------------------------------------------------------------------------------ roofline.traffic provenance
-TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
 KERNEL_SOURCES = ("gemm.hip", "common.h")          # the GEMM kernels and the device helpers they use (internal.h holds only host-side declarations for them)
 
 
@@ -230,7 +230,7 @@ def _curve_rows(curve, bracket):
     return rows
 
 
-ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "avg_launch_us", "launches",
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "avg_launch_us", "launches", "avg_m",
                  "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "peak_measured", "frac_of_measured")
 
 
@@ -437,7 +437,7 @@ def gemm_roofline(target, prof, prof_big, fp8: bool, measured, streams: int, wit
     return dict(bound=bound, kernel=kname, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
                 peak_measured=m_peak, frac_of_measured=(achieved / m_peak) if m_peak else None,
                 traffic=traffic, traffic_source=traffic_source, traffic_over_algorithmic=(traffic / alg_bytes) if traffic else None,
-                avg_launch_us=avg_ms * 1e3, launches=pk["count"],
+                avg_launch_us=avg_ms * 1e3, launches=pk["count"], avg_m=avg_m,
                 algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=alg_flops, arithmetic_intensity=intensity,
                 gemm_ms_share={k: v["ms"] / gemm_ms_total for k, v in prof.items()} if gemm_ms_total else {},
                 all_gemms_tflops=(sum(2.0 * v["rows"] * target.gemm_shape(k)[0] * target.gemm_shape(k)[1] for k, v in prof.items())

@@ -33,9 +33,9 @@ res["workload"] = os.environ.get("ATSPEED_PMC_WORKLOAD", "python bench.py --step
 # average M of each GEMM kind over the same workload's launches, from the bench line of the same script run (hipEvent brackets, rows / count)
 avg_m = {}
 try:
-    line = json.load(open(os.path.join(root, "bench_default.json")))
+    line = json.loads(open(os.path.join(root, "bench_default.json")).read().strip().splitlines()[-1])
     k = line["roofline"]["kernel"]
-    avg_m["gate_up"] = float(k.split("avg_M=")[1].split()[0]) if "gate_up" in k else None
+    avg_m["gate_up"] = (line["roofline"].get("avg_m") or (float(k.split("avg_M=")[1].split()[0]) if "avg_M=" in k else None)) if ("<3, 8" in k or "gate_up" in k) else None
 except Exception:
     pass
 for kind, pat in KINDS.items():
