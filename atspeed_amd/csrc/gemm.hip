@@ -1389,7 +1389,7 @@ static bool stream_is_capturing(hipStream_t st) {
 template <int EPI>
 int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st, int pk, const RopeEpi& rope = RopeEpi{},
                float* lse_part = nullptr, const unsigned char* tile_store = nullptr, const SkArena* arena = nullptr) {
-  static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
+  constexpr int gm = 4;
   const int tiles_n = (n + 255) / 256;
   constexpr int LDS8 = EPI == EPI_F32_LSE ? 136 * 1024 : 128 * 1024, LDS4 = EPI == EPI_F32_LSE ? 100 * 1024 : 96 * 1024;
   static thread_local AtsPerDeviceFlag attr_flag;
@@ -1557,7 +1557,7 @@ __global__ __launch_bounds__(1024) void splitk_resid_rmsnorm_kernel(const float*
 template <int EPI>
 int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char* w, const float* sw, void* c, int m, int n, int k,
                    int ldc, hipStream_t st, int pk, const RopeEpi& rope = RopeEpi{}) {
-  static const int gm = env_int("ATSPEED_GEMM_BIG_GM", 4);
+  constexpr int gm = 4;
   const int tiles_n = (n + 255) / 256;
   static thread_local AtsPerDeviceFlag attr_flag;
   bool& attr_done = attr_flag.cur();
@@ -1871,14 +1871,12 @@ int reduce_splits(const float* partial, void* c, int m, int n, int ldc, int spli
 static bool dma_offsets_fit(long long rows, long long ld_elems, int esz) { return (rows + 1) * ld_elems * esz <= 0xffffffffll; }
 
 static int ring_split_count(int m, int n, int k) {
-  static const int on = env_int("ATSPEED_GEMM_RING_SPLIT", 1);
-  static const int min_m = env_int("ATSPEED_GEMM_RING_SPLIT_MIN_M", 33);
-  static const int max_m = env_int("ATSPEED_GEMM_RING_SPLIT_MAX_M", 512);
+  constexpr int min_m = 33, max_m = 512;
   // measured (tools/yardstick_small.py, cold weights): wins 5-15 % over the LDS-tiled kernel on the wide projections (qkv, gate_up) at
   // 33-256 tokens, loses on N = 4096 where 16 slabs of partials outweigh the weight stream
-  static const int min_n = env_int("ATSPEED_GEMM_RING_SPLIT_MIN_N", 8192);
-  static const int max_s = env_int("ATSPEED_GEMM_RING_SPLIT_MAX_SPLITS", 256);
-  if (!on || m < min_m || m > max_m || k % 128 != 0 || k < 256 || n < min_n || !dma_offsets_fit(n, k, 2)) return 0;
+  constexpr int min_n = 8192;
+  constexpr int max_s = 256;
+  if (m < min_m || m > max_m || k % 128 != 0 || k < 256 || n < min_n || !dma_offsets_fit(n, k, 2)) return 0;
   const int tiles = ((n + 255) / 256) * ((m + 255) / 256), units = k / 128;
   int s = 256 / tiles;
   if (s > units) s = units;
@@ -1940,8 +1938,8 @@ int launch_cfg(const T* a, const T* w, void* c, int m, int n, int k, int lda, in
 // bf16 store + separate RoPE pass of this form gives back: 22.71 vs 22.65 ms per user) and not N = 4096 (split-K + fused reduce / norm).
 static bool wdma_applies(int m, int n, int k, int lda, int epilogue) {
   static const int on = env_int("ATSPEED_GEMM_WDMA", 1);
-  static const int min_m = env_int("ATSPEED_GEMM_WDMA_MIN_M", 33);
-  static const int max_m = env_int("ATSPEED_GEMM_WDMA_MAX_M", 256);
+  constexpr int min_m = 33;
+  constexpr int max_m = 256;
   if (!on || m < min_m || m > max_m || k % 64 != 0 || k < 512 || (lda % 8) != 0 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return false;
   const int t192 = (n + 191) / 192, t128 = (n + 127) / 128;
   const bool ok128 = t128 >= 150 && t128 <= 256, ok192 = t192 >= 150 && t192 <= 256;
@@ -1965,16 +1963,14 @@ int launch_wdma_cfg(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int
 }
 // split-K form: projections whose N gives too few 128-row tiles (qkv: 96, o_proj and down: 32) take tiles x splits = 150-256 workgroups
 static int wdma_split_count(int m, int n, int k, int lda) {
-  static const int on = env_int("ATSPEED_GEMM_WDMA_SPLIT", 1);
   static const int on_all = env_int("ATSPEED_GEMM_WDMA", 1);
-  static const int min_m = env_int("ATSPEED_GEMM_WDMA_MIN_M", 33);
-  if (!on || !on_all || m < min_m || m > 256 || k % 64 != 0 || (lda % 8) != 0 || n < 2048 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return 0;
+  constexpr int min_m = 33;
+  if (!on_all || m < min_m || m > 256 || k % 64 != 0 || (lda % 8) != 0 || n < 2048 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return 0;
   const int t128 = (n + 127) / 128, n_kt = k / 64;
   if (t128 >= 150) return 0;                                           // wide enough for the no-split form (or too wide for one round)
   // k-tiles per part at least: 8 up to 128 tokens (o_proj, K = 4096: 8 parts of 8 tiles, 15.8 / 18.8 -> 13.5 / 16.0 us at 60 / 100 tokens), 16 above
   // (at 225 tokens the 8 x 8 form lost: 24.4 vs 23.7 us)
-  static const int min_tiles_env = env_int("ATSPEED_GEMM_WDMA_MIN_TILES", 0);
-  const int min_tiles = min_tiles_env > 0 ? min_tiles_env : (m <= 128 ? 8 : 16);
+  const int min_tiles = m <= 128 ? 8 : 16;
   const int s = std::min(256 / t128, n_kt / min_tiles);
   return (s >= 2 && t128 * s >= 150) ? s : 0;
 }
@@ -1996,9 +1992,7 @@ int launch_wdma_split_cfg(const bf16_t* a, const bf16_t* w, float* partial, int 
 static int launch_wdma_split(const bf16_t* a, const bf16_t* w, float* partial, int m, int n, int k, int lda, int splits, hipStream_t st, int pk) {
   if (m <= 64)  return launch_wdma_split_cfg<64, 6>(a, w, partial, m, n, k, lda, splits, st, pk);
   if (m <= 128) return launch_wdma_split_cfg<128, 4>(a, w, partial, m, n, k, lda, splits, st, pk);
-  static const int wm4 = env_int("ATSPEED_GEMM_WDMA_WM4", 1);
-  if (wm4) return launch_wdma_split_cfg<256, 3, 4>(a, w, partial, m, n, k, lda, splits, st, pk);
-  return launch_wdma_split_cfg<256, 3>(a, w, partial, m, n, k, lda, splits, st, pk);
+  return launch_wdma_split_cfg<256, 3, 4>(a, w, partial, m, n, k, lda, splits, st, pk);      // 2 x 4 waves (the 2 x 2 form: +12-15 % at 150-256 tokens, round 3)
 }
 template <int EPI>
 int launch_wdma(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, int lda, int ldc, hipStream_t st, int pk) {
@@ -2014,9 +2008,7 @@ int launch_wdma(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, 
     return launch_wdma_cfg<128, 192, 3, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);                     // 40 KB x 3
   }
   (void)t192;
-  static const int wm4 = env_int("ATSPEED_GEMM_WDMA_WM4", 1);
-  if (wm4) return launch_wdma_cfg<256, 128, 3, EPI, 4>(a, w, c, m, n, k, lda, ldc, st, pk);           // 129-256 tokens: 48 KB x 3 (the X rows are two thirds of a stage), 8 waves
-  return launch_wdma_cfg<256, 128, 3, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);
+  return launch_wdma_cfg<256, 128, 3, EPI, 4>(a, w, c, m, n, k, lda, ldc, st, pk);                    // 129-256 tokens: 48 KB x 3 (the X rows are two thirds of a stage), 8 waves
 }
 
 // ---- panel form of the ring kernel (gemm_ring_kernel<..., WN = 2, WM = 4>): 257-384 tokens in ONE launch (16 users' K-token continuation
@@ -2243,8 +2235,8 @@ static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype,
   // the 256-wide ring kernel vs the 128-wide LDS-tiled kernel (with split-K): the ring kernel wins once its tile grid keeps
   // a fair share of the 256 CUs busy (measured, tools/gemm_ab.py with ATSPEED_GEMM_BIG_MIN_FILL)
   // from 257 tokens (two token tiles): measured against the split-K mode at 300-500 tokens, gate_up 115-138 -> 96-108 us, qkv 80 -> 75 us
-  static const int big_min_m = env_int("ATSPEED_GEMM_BIG_MIN_M", 257);
-  static const int min_fill = env_int("ATSPEED_GEMM_BIG_MIN_FILL", 60);   // crossover measured at ~50-60 % (o_proj, down, qkv, gate_up at 512-1920 tokens)
+  constexpr int big_min_m = 257;
+  constexpr int min_fill = 60;   // crossover measured at ~50-60 % (o_proj, down, qkv, gate_up at 512-1920 tokens)
   if (dtype != ATS_HALF || m < big_min_m || k % 128 != 0 || (lda % 8) != 0 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return false;
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
   if (panel_applies(m, n, k, lda)) return false;                       // 257-512 tokens on a projection of 16-256 panels: the panel form (launch_epi)
@@ -2253,7 +2245,7 @@ static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype,
   // a thin grid whose k-steps the split-K tail spreads over the chip: from 48 tiles of 128 rows (four parts per tile on 192 CUs; N = 4096
   // from 257 tokens), where it overtakes the LDS-tiled split-K kernel + reduce pass (tools/sk_sweep.py: o_proj at 320 tokens 36.7 -> 34.1 us,
   // down 73.6 -> 70.3; at 400 tokens 33.7 -> 29.6 and 68.4 -> 59.7)
-  static const int sk_min_tiles = env_int("ATSPEED_GEMM_SK_MIN_TILES", 48);
+  constexpr int sk_min_tiles = 48;
   const int t128 = tn * ((m + 127) / 128);
   return t128 >= sk_min_tiles && sk_any_plan(t128, k);
 }

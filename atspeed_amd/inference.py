@@ -49,6 +49,9 @@ def parse(argv=None):
     ap.add_argument("--target_layers", type=int, default=32)
     ap.add_argument("--aligned", type=float, default=None, metavar="RESID_SCALE", help="synthetic weights: align draft and target (see bench.py)")
     ap.add_argument("--target_fp8", action="store_true")
+    ap.add_argument("--dtype", choices=("auto", "fp16", "bf16", "fp32"), default="auto",
+                    help="engine arithmetic.  auto: a checkpoint runs in the type it is stored in (fp16 -- what the reference loads, inference.py:75-100 -- "
+                         "takes the engine's fp16 flavour and keeps every weight bit; bf16 and fp32 likewise), synthetic weights are bf16")
     ap.add_argument("--baseline", action="store_true", help="also time target_generate per user (speedup / overhead columns)")
     ap.add_argument("--output_dir", type=str, default="AnaResult")
     return ap.parse_args(argv)
@@ -61,16 +64,23 @@ def load_models(args, vocab_size: int, beam: int, dev, max_prompt: int = 0):
     # KV arenas, token buffers and logit rows sized from the longest prompt of the users this rank decodes (the reference cuts prompts at
     # cutoff_len = 512 tokens, code/utils.py:119: 512 + 3 x 40 draft tokens no longer fit the library's default 512 slots)
     kw = dict(capacity_for(max_prompt, beam, args.draft_beam_size, args.gamma, 4), device=dev)
+    want = {"auto": None, "fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
     if args.target_ckpt and args.draft_ckpt:
         from transformers import AutoModelForCausalLM
-        tgt = HipLlama.from_hf(AutoModelForCausalLM.from_pretrained(args.target_ckpt, torch_dtype=torch.bfloat16), torch.bfloat16, dev, num_beams=beam, **{k: v for k, v in kw.items() if k != "device"})
-        drf = HipLlama.from_hf(AutoModelForCausalLM.from_pretrained(args.draft_ckpt, torch_dtype=torch.bfloat16), torch.bfloat16, dev, num_beams=args.draft_beam_size, **{k: v for k, v in kw.items() if k != "device"})
+        # torch_dtype="auto": the checkpoint's own type (no rounding on load); from_hf(dtype=None) then picks the engine flavour of that type
+        load = lambda path: AutoModelForCausalLM.from_pretrained(path, torch_dtype="auto" if want is None else want)
+        kw_hf = {k: v for k, v in kw.items() if k != "device"}
+        tgt = HipLlama.from_hf(load(args.target_ckpt), want, dev, num_beams=beam, **kw_hf)
+        drf = HipLlama.from_hf(load(args.draft_ckpt), want, dev, num_beams=args.draft_beam_size, **kw_hf)
     else:
         rs = 1.0 if args.aligned is None else args.aligned
-        drf = HipLlama.from_synthetic(synth.llama_68m(vocab_size), args.seed + 1, dtype=torch.bfloat16, num_beams=args.draft_beam_size, resid_scale=rs, **kw)
-        tgt = HipLlama.from_synthetic(synth.llama_7b(vocab_size, args.target_layers), args.seed, dtype=torch.bfloat16, num_beams=beam, resid_scale=rs,
+        syn = torch.bfloat16 if want is None else want
+        drf = HipLlama.from_synthetic(synth.llama_68m(vocab_size), args.seed + 1, dtype=syn, num_beams=args.draft_beam_size, resid_scale=rs, **kw)
+        tgt = HipLlama.from_synthetic(synth.llama_7b(vocab_size, args.target_layers), args.seed, dtype=syn, num_beams=beam, resid_scale=rs,
                                       align_to=drf if args.aligned is not None else None, **kw)
     if args.target_fp8:
+        if tgt.dtype != torch.bfloat16:
+            raise SystemExit(f"--target_fp8 makes its e4m3 copies from bf16 weights; the target runs in {tgt.dtype} (use --dtype bf16)")
         tgt.enable_fp8()
     return tgt, drf
 

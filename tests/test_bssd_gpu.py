@@ -467,6 +467,13 @@ def test_inference_cli_on_generated_dataset(tmp_path):
         assert r["metrics"]["users"] == r["users"] and len(r["metrics"]["recall"]) == len(r["metrics"]["topN"])
         assert {"draft_time_cost", "target_time_cost", "verify_time_cost", "total_time_cost", "speedup"} <= set(r["timing_mean_rank0"])
     assert len(list((tmp_path / "AnaResult" / "toys").glob("timing_mean_*.json"))) == 2
+    # --dtype: the engine's fp16 flavour -- the reference's own type, inference.py:75-100 -- is reachable from the CLI; same decoder, same columns
+    out16 = inference.main(["--data_path", str(tmp_path / "data"), "--dataset", "toys", "--target_layers", "2", "--aligned", "3e-6", "--dtype", "fp16",
+                            "--run_beam_sizes", "[5]", "--users_per_batch", "8", "--strict_trie", "--output_dir", str(tmp_path / "AnaResult16")])
+    assert out16[0]["users"] == out[0]["users"] and out16[0]["mean_accept_len"] == 3.0
+    with pytest.raises(SystemExit):                                                  # the e4m3 copies are made of bf16 weights only
+        inference.main(["--data_path", str(tmp_path / "data"), "--dataset", "toys", "--target_layers", "2", "--dtype", "fp16", "--target_fp8",
+                        "--run_beam_sizes", "[5]", "--output_dir", str(tmp_path / "AnaResult8")])
 
 
 def test_target_generate_batch_equals_single_calls(bssd_golden):
