@@ -805,14 +805,15 @@ def main():
             one_user_fp8 = None
             if args.one_user_fp8_users > 0:                 # the headline weights (zero-acceptance bracket: four target forwards per user), one user per call
                 target.fp8_counters(reset=True)
-                target.profile(1)
                 one_user_fp8, _ = one_user_loop(target, draft, dprompts, n_warm, min(args.one_user_fp8_users, n_timed), fn, args, dev, 1)
-                p8 = target.profile(0)
                 c8 = target.fp8_counters()
+                target.profile(1)                           # GEMM brackets from a second, untimed pass (512 event pairs per user cost ~20 % of the loop)
+                one_user_loop(target, draft, dprompts, n_warm, min(3, n_timed), fn, args, dev, 1)
+                p8 = target.profile(0)
                 one_user_fp8.update(projections_not_in_fp8=sum(v["other"] for v in c8.values()),
                                     per_kind_us={k: 1e3 * v["ms"] / max(1, v["count"]) for k, v in p8.items()},
                                     bf16_ms_per_user=(single or {}).get("ms_per_user"),
-                                    roofline="target forwards x (6.48 G e4m3 layer weights + the bf16 lm_head) / time vs 8 TB/s; the GEMM brackets' events are inside the timed loop")
+                                    roofline="target forwards x (6.48 G e4m3 layer weights + the bf16 lm_head) / time vs 8 TB/s")
             configs["fp8"] = dict(workload=f"{args.dataset.capitalize()} V={V}, Llama-7B({args.target_layers}L) target verify in fp8 (e4m3 W8A8 projections on the block-scaled MFMA, "
                                            f"bf16 elsewhere), K={args.beam}, {args.streams} users per lock-step batch",
                                   steps=sub_steps, dtype="fp8-e4m3 (W8A8 target projections, bf16 elsewhere)", **pass_summary(r, args, ups),

@@ -3,6 +3,7 @@
 set -x
 mkdir -p gpurun_out/final
 python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err || exit 1
+cp gpurun_out/bench_detail.json gpurun_out/final/bench_detail.json      # the full report of THIS run (the passes below overwrite gpurun_out/bench_detail.json)
 cd /tmp && export TMPDIR=/tmp
 # the same command under the kernel trace (sub-passes off: the summary is the headline workload's)
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final/stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --aligned-resid-scale '' --single-stream-users 0 --no-configs --no-latency-curve > $GRAFT_REPO_ROOT/gpurun_out/final/stats.log 2>&1 || exit 1
