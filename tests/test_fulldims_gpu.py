@@ -46,24 +46,37 @@ def _bench_models(dtype, layers=32, k=20, dk=40, **kw):
 # (per-token log-normal row scales: gaps x 25, noise x 20) leave the ratio smallest gap / noise at 0.1-3 for K = 20 -- it is set by the number
 # of gaps (~400 per user), not by the recipe.  With K = 1 or 2 (BASELINE config 1's greedy setting, DK = 2K) a user has 10-30 gaps and the
 # smallest is 1e-3-6e-3 on all users tried: 20-100 x the noise, on the HEADLINE weights with all 32 layers at full strength.
+@pytest.fixture(scope="module")
+def fulldims_fp32():
+    """The headline pair in fp32 and the oracle on exactly the weights the device holds, built ONCE for the three parametrisations below (27 GB of
+    weights: building and exporting them is half of a test's time); a test sets its own beam counts on the models' generation_config."""
+    from atspeed_amd.beamSD import release_decoders
+    tgt, drf = _bench_models(torch.float32)
+    rt = RefLlama(tgt.dims, tgt.export_state_dict(), max_slots=512)       # the oracle on exactly the weights the device holds
+    rd = RefLlama(drf.dims, drf.export_state_dict(), max_slots=512)
+    yield tgt, drf, rt, rd
+    release_decoders(tgt, drf)
+
+
 @pytest.mark.parametrize("K,DK", [(1, 2), (2, 4)])
-def test_fp32_engine_at_full_dims_is_exact_where_exactness_is_decidable(K, DK):
+def test_fp32_engine_at_full_dims_is_exact_where_exactness_is_decidable(fulldims_fp32, K, DK):
     """Full Llama-7B(32L) / Llama-68M dims, headline weights, K = 1 / 2 beams: item ids, per-round n_matches, accepted steps, the draft's
     candidate ids in order and the lossless property hold EXACTLY on all twelve users -- no near-tie branch (`near_ties == 0` asserted)."""
-    checked, near_ties = _fulldims_against_oracle(K, DK, strict=True)
+    checked, near_ties = _fulldims_against_oracle(fulldims_fp32, K, DK, strict=True)
     assert near_ties == 0 and checked == 12
 
 
-def test_fp32_engine_at_llama7b_llama68m_dims_equals_oracle():
-    checked, near_ties = _fulldims_against_oracle(20, 40, strict=False)
+def test_fp32_engine_at_llama7b_llama68m_dims_equals_oracle(fulldims_fp32):
+    checked, near_ties = _fulldims_against_oracle(fulldims_fp32, 20, 40, strict=False)
     assert checked >= 8 and checked + near_ties == 12
 
 
-def _fulldims_against_oracle(K, DK, strict):
-    tgt, drf = _bench_models(torch.float32, k=K, dk=DK)
+def _fulldims_against_oracle(models, K, DK, strict):
+    from atspeed_amd.beamSD import release_decoders
+    tgt, drf, rt, rd = models
+    release_decoders(tgt, drf)                                            # decoders (beam blocks) of another beam count
+    tgt.generation_config.num_beams, drf.generation_config.num_beams = K, DK
     fn = atspeed_amd.PositionSetConstraint(synth.BEAUTY.allowed_tokens(), synth.RESPONSE_SEP)
-    rt = RefLlama(tgt.dims, tgt.export_state_dict(), max_slots=512)       # the oracle on exactly the weights the device holds
-    rd = RefLlama(drf.dims, drf.export_state_dict(), max_slots=512)
     checked = near_ties = 0
     # twelve users (VERDICT r3 #6: this engine is the judge of tests/test_decisions_gpu.py, so its own pin to the oracle must not be a
     # two-user link): the mean Beauty prompt, short ones, long ones; ~7 s of CPU oracle per user on the box's 16 allotted CPUs
@@ -114,7 +127,6 @@ def _fulldims_against_oracle(K, DK, strict):
         assert torch.equal(tg["beam_sequence"], out["beam_sequence"])
     print(f"K={K} DK={DK}: checked exactly {checked}, near ties {near_ties} of {len(PROMPTS)} users")
     assert checked + near_ties == len(PROMPTS)
-    del tgt, drf
     return checked, near_ties
 
 
