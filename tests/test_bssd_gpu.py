@@ -471,6 +471,10 @@ def test_inference_cli_on_generated_dataset(tmp_path):
     out16 = inference.main(["--data_path", str(tmp_path / "data"), "--dataset", "toys", "--target_layers", "2", "--aligned", "3e-6", "--dtype", "fp16",
                             "--run_beam_sizes", "[5]", "--users_per_batch", "8", "--strict_trie", "--output_dir", str(tmp_path / "AnaResult16")])
     assert out16[0]["users"] == out[0]["users"] and out16[0]["mean_accept_len"] == 3.0
+    # config 5 in the reference's own loop: --target_fp8 with ONE user per call (inference.py:86-91,162-176) through the W8A8 weight-streaming kernels
+    out8 = inference.main(["--data_path", str(tmp_path / "data"), "--dataset", "toys", "--target_layers", "2", "--aligned", "3e-6", "--target_fp8",
+                           "--run_beam_sizes", "[20]", "--users_per_batch", "1", "--strict_trie", "--output_dir", str(tmp_path / "AnaResult8u1")])
+    assert out8[0]["users"] == out[1]["users"] and out8[0]["mean_accept_len"] >= 2.5 and out8[0]["items_per_s"] > 0
     with pytest.raises(SystemExit):                                                  # the e4m3 copies are made of bf16 weights only
         inference.main(["--data_path", str(tmp_path / "data"), "--dataset", "toys", "--target_layers", "2", "--dtype", "fp16", "--target_fp8",
                         "--run_beam_sizes", "[5]", "--output_dir", str(tmp_path / "AnaResult8")])
