@@ -61,9 +61,10 @@ def fulldims_fp32():
 @pytest.mark.parametrize("K,DK", [(1, 2), (2, 4)])
 def test_fp32_engine_at_full_dims_is_exact_where_exactness_is_decidable(fulldims_fp32, K, DK):
     """Full Llama-7B(32L) / Llama-68M dims, headline weights, K = 1 / 2 beams: item ids, per-round n_matches, accepted steps, the draft's
-    candidate ids in order and the lossless property hold EXACTLY on all twelve users -- no near-tie branch (`near_ties == 0` asserted)."""
-    checked, near_ties = _fulldims_against_oracle(fulldims_fp32, K, DK, strict=True)
-    assert near_ties == 0 and checked == 12
+    candidate ids in order and the lossless property hold EXACTLY on all twelve (K = 1) / eight (K = 2) users -- no near-tie branch (`near_ties == 0` asserted)."""
+    n_users = 12 if K == 1 else 8                                   # (the 900 s budget of the GPU suite: K = 2 on eight of the twelve prompts)
+    checked, near_ties = _fulldims_against_oracle(fulldims_fp32, K, DK, strict=True, n_users=n_users)
+    assert near_ties == 0 and checked == n_users
 
 
 def test_fp32_engine_at_llama7b_llama68m_dims_equals_oracle(fulldims_fp32):
@@ -71,7 +72,7 @@ def test_fp32_engine_at_llama7b_llama68m_dims_equals_oracle(fulldims_fp32):
     assert checked >= 8 and checked + near_ties == 12
 
 
-def _fulldims_against_oracle(models, K, DK, strict):
+def _fulldims_against_oracle(models, K, DK, strict, n_users=12):
     from atspeed_amd.beamSD import release_decoders
     tgt, drf, rt, rd = models
     release_decoders(tgt, drf)                                            # decoders (beam blocks) of another beam count
@@ -80,7 +81,7 @@ def _fulldims_against_oracle(models, K, DK, strict):
     checked = near_ties = 0
     # twelve users (this engine is the judge of tests/test_decisions_gpu.py, so its own pin to the oracle must not be a
     # two-user link): the mean Beauty prompt, short ones, long ones; ~7 s of CPU oracle per user on the box's 16 allotted CPUs
-    PROMPTS = (108, 70, 66, 84, 96, 78, 120, 150, 186, 72, 102, 132)
+    PROMPTS = (108, 70, 66, 84, 96, 78, 120, 150, 186, 72, 102, 132)[:n_users]
     for u, P in enumerate(PROMPTS):
         prompt = synth.synthetic_prompt(P, synth.tensor_seed(2025, f"user{u}"))
         inputs = {"input_ids": torch.from_numpy(prompt)[None].cuda()}
