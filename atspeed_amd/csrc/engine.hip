@@ -289,7 +289,7 @@ static size_t gemm_ws_for(const atspeed_llama_config& c, int max_tok, int max_ro
     best = std::max(best, ATS_KD(c.dtype, ats_gemm_workspace_bytes(m, 2 * c.ffn, c.hidden, c.dtype)));
     best = std::max(best, ATS_KD(c.dtype, ats_gemm_workspace_bytes(m, c.hidden, c.ffn, c.dtype)));
     if (m <= max_rows) best = std::max(best, ATS_KD(c.dtype, ats_gemm_workspace_bytes(m, c.vocab_size, c.hidden, c.dtype)));
-    if (c.dtype == ATSPEED_BF16 && m <= 256) {     // the W8A8 copies (atspeed_llama_enable_fp8) of one user's projections: their own split plans
+    if (c.dtype == ATSPEED_BF16) {                 // the W8A8 copies (atspeed_llama_enable_fp8): the split plans of one user's projections and of thin ring grids
       best = std::max(best, ats_bf16::ats_gemm_fp8_workspace_bytes(m, 3 * c.hidden, c.hidden));
       best = std::max(best, ats_bf16::ats_gemm_fp8_workspace_bytes(m, c.hidden, c.hidden));
       best = std::max(best, ats_bf16::ats_gemm_fp8_workspace_bytes(m, c.hidden, c.ffn));

@@ -1206,10 +1206,14 @@ __device__ __forceinline__ void mx_qkv_rope_epilogue(f32x16_t (&acc)[TA][TB], bf
 // NWV = 8: waves 4 (n) x 2 (m), wave tile 64 x MT2*16 (2 x MT2/2 tiles of 32x32), two waves per SIMD.  NWV = 4: waves 2 x 2, wave tile
 // 128 x MT2*16 (4 x MT2/2 tiles), ONE wave per SIMD with up to 512 registers: a third fewer LDS fragment bytes per flop and no two waves
 // contending for a SIMD's matrix pipe and issue slots (measured 2-5 % slower; the launcher instantiates NWV = 8 only).
-template <int EPI, int MT2, int NWV = 8>
+// SPLITK (round 5: the N = 4096 projections of 257-2000-token forwards in fp8, whose tile grids fill a fifth to a half of a round): the grid is
+// tiles x n_split, part z accumulates its share of the 256-k units and stores SCALED fp32 partial sums to slab z of Cv ([z][M][N]); the reduce
+// kernels of every other split form finish the job (residual + RMSNorm + the next projection's e4m3 rows).
+template <int EPI, int MT2, int NWV = 8, bool SPLITK = false>
 __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* __restrict__ X, const void* __restrict__ W, const float* __restrict__ sx,
                                                               const float* __restrict__ sw, void* __restrict__ Cv, int M, int N, int K, int ldc,
-                                                              int tiles_n, int tiles_m, int GM, int pk, RopeEpi rope = RopeEpi{}) {
+                                                              int tiles_n, int tiles_m, int GM, int pk, RopeEpi rope = RopeEpi{}, int n_split = 1) {
+  static_assert(!SPLITK || EPI == EPI_F32, "split-K parts leave fp32 slabs");
   constexpr int BT = 256, RB = 64;                                // 64-byte LDS rows = 64 k of e4m3 per stage
   constexpr int XR = 2 * MT2 * 16;                               // token rows per workgroup (256 or 128)
   constexpr int WP = 16 / NWV, XP = XR / (16 * NWV), NP = WP + XP;   // DMA pieces (16 rows x 64 B) per wave per k-step
@@ -1223,7 +1227,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* _
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, h = lane >> 5;
   const int nwg = tiles_n * tiles_m;
-  int bid = blockIdx.x;
+  int bid = blockIdx.x, zpart = 0;
+  if constexpr (SPLITK) { zpart = bid / nwg; bid -= zpart * nwg; }
   {
     const int q = nwg / 8, r = nwg % 8, x = bid % 8;             // XCD-contiguous runs of tiles (see gemm_ring_kernel)
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
@@ -1233,7 +1238,12 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* _
   const int tn = rem / band_rows, tm = band * GM + rem % band_rows;
   const int n0 = tn * BT, m0 = tm * XR;
   const int wn = wave >> 1, wm = wave & 1;                        // NWV/2 waves along the weight rows, 2 along the token rows
-  const int nks = K / 64;                                         // launcher: K % 256 == 0
+  int ks0 = 0, nks = K / 64;                                      // launcher: K % 256 == 0; nks = END of this part's k-steps
+  if constexpr (SPLITK) {
+    const int units = nks >> 2;                                   // launcher: n_split <= units
+    ks0 = 4 * (int)((long long)zpart * units / n_split);
+    nks = 4 * (int)((long long)(zpart + 1) * units / n_split);
+  }
 
   auto swz = [](int row) { return (0xD2 >> (((row >> 2) & 3) * 2)) & 3; };   // f = {2,0,1,3}
   unsigned woff[WP], xoff[XP];
@@ -1314,7 +1324,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* _
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int d = 0; d < NP; ++d) dma_piece(q, q, d);
+    for (int d = 0; d < NP; ++d) dma_piece(q, ks0 + q, d);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP) : "memory");
   asm volatile("s_barrier" ::: "memory");
 #pragma unroll
@@ -1323,7 +1333,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* _
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
   asm volatile("s_barrier" ::: "memory");
 
-  int ks = 0;
+  int ks = ks0;
   for (; ks + 4 < nks; ks += 4) {
     ATS_MX_SEGMENT(0, true, true, 2 * NP, ks);
     ATS_MX_SEGMENT(1, true, true, 2 * NP, ks + 1);
@@ -1342,7 +1352,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ring_mx_kernel(const void* _
     mx_qkv_rope_epilogue<TA, TB>(acc, reinterpret_cast<bf16_t*>(Cv), M, N, ldc, m0, n0, wave, lane, sx, sw, rope, smem);
   } else {
     const int m0w = m0 + wm * (TB * 32), n0w = n0 + wn * (TA * 32);
-    mx_epilogue<EPI, TA, TB>(acc, Cv, M, N, ldc, m0w, n0w, lane, sx, sw, pk);
+    if constexpr (SPLITK) mx_epilogue<EPI_F32, TA, TB>(acc, reinterpret_cast<float*>(Cv) + (size_t)zpart * M * N, M, N, N, m0w, n0w, lane, sx, sw, 0);
+    else                  mx_epilogue<EPI, TA, TB>(acc, Cv, M, N, ldc, m0w, n0w, lane, sx, sw, pk);
   }
 }
 
@@ -2269,6 +2280,40 @@ int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int
   return ATSPEED_OK;
 }
 
+// ---- W8A8 projections whose 256-wide tile grid is thin (N = 4096 at 257-2000 tokens: o_proj, down): the block-scaled ring kernel cut in K
+// (gemm_ring_mx_kernel<EPI_F32, 4, 8, SPLITK>): 128-row token tiles x parts ~ one round of 256 workgroups, scaled fp32 slabs, the usual reduce.
+// Before: 32-80 workgroups on 256 CUs (down at 300 tokens 71 us against 50 us in bf16), and from 512 tokens these projections ran bf16.
+static int mx_split_count(int m, int n, int k, bool* rows256 = nullptr) {   // 0: this shape takes the plain ring kernel (or is not an fp8 shape at all)
+  if (m < 257 || k % 256 != 0 || !dma_offsets_fit(n, k, 1) || !dma_offsets_fit(m, k, 1)) return 0;
+  const int tn = (n + 255) / 256, t256 = tn * ((m + 255) / 256), t128 = tn * ((m + 127) / 128);
+  if (big_fill_pct(t256) >= 60 || big_fill_pct(t128) >= 60) return 0;
+  const bool r256 = t128 > 128;                                        // 128-row token tiles while two parts of them fit a round, else 256-row ones
+  const int tiles = r256 ? t256 : t128;
+  if (rows256) *rows256 = r256;
+  const int s_ = std::min(256 / tiles, (k / 256) / 2);                // at least 2 units (512 k) per part
+  return s_ >= 2 ? s_ : 0;
+}
+static int launch_mx_split(const unsigned char* x, const float* sx, const unsigned char* w, const float* sw, float* partial, int m, int n, int k,
+                           int splits, hipStream_t st, int pk) {
+  static thread_local AtsPerDeviceFlag attr_flag;
+  bool& attr_done = attr_flag.cur();
+  if (!attr_done) {
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_mx_kernel<EPI_F32, 4, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_mx_kernel<EPI_F32, 8, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_done = true;
+  }
+  bool r256 = false;
+  (void)mx_split_count(m, n, k, &r256);
+  const int tiles_n = (n + 255) / 256, tiles_m = r256 ? (m + 255) / 256 : (m + 127) / 128;
+  if (r256) hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI_F32, 8, 8, true>), dim3(tiles_n * tiles_m * splits), dim3(512), 128 * 1024, st, (const void*)x, (const void*)w, sx, sw,
+                               (void*)partial, m, n, k, n, tiles_n, tiles_m, 4, pk, RopeEpi{}, splits);
+  else      hipLaunchKernelGGL((gemm_ring_mx_kernel<EPI_F32, 4, 8, true>), dim3(tiles_n * tiles_m * splits), dim3(512), 96 * 1024, st, (const void*)x, (const void*)w, sx, sw,
+                               (void*)partial, m, n, k, n, tiles_n, tiles_m, 4, pk, RopeEpi{}, splits);
+  ATS_LAUNCH_CHECK();
+  ats_count_path(ATS_PATH_FP8_RING_SPLIT);
+  return ATSPEED_OK;
+}
+
 // ---- one user's W8A8 projections (1-256 tokens): gemm_wdma_kernel<..., F8 = true>.  Every launch is a pass over the e4m3 weights (half the
 // bytes of the 16-bit form).  Wide projections (150-256 tiles of 128 weight rows: gate_up) run without split and apply their epilogue
 // directly; the others are cut in K so that tiles x parts fill the chip (qkv 96 x 2, o_proj / down 32 x 8) and leave scaled fp32 slabs to
@@ -2316,11 +2361,13 @@ bool ats_gemm_fp8_applies(int m, int n, int k, int ldc, int epilogue) {
   if (m <= 256) return wdma8_applies(m, n, k);
   if (k % 256 != 0) return false;
   if (m < 512) return true;                                            // 257-511 tokens (a long prompt's first verification): the ring kernel whatever its fill
+  if (mx_split_count(m, n, k) >= 2) return true;                       // thin grids: the ring kernel cut in K
   const int tn = (n + 255) / 256;
   return big_fill_pct(tn * ((m + 255) / 256)) >= 60 || big_fill_pct(tn * ((m + 127) / 128)) >= 60;
 }
 size_t ats_gemm_fp8_workspace_bytes(int m, int n, int k) {
-  return (m <= 256 && wdma8_applies(m, n, k)) ? (size_t)wdma8_split_count(n, k) * m * n * sizeof(float) : 0;
+  if (m <= 256) return wdma8_applies(m, n, k) ? (size_t)wdma8_split_count(n, k) * m * n * sizeof(float) : 0;
+  return (size_t)mx_split_count(m, n, k) * m * n * sizeof(float);
 }
 
 int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* sw, void* c, int m, int n, int k, int ldc,
@@ -2355,6 +2402,20 @@ int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* s
   ATS_REQUIRE(m >= 1 && n >= 1 && k % 256 == 0, ATSPEED_ERR_INVALID, "gemm_fp8: K=%d must be a multiple of 256", k);
   ATS_REQUIRE(dma_offsets_fit(n, k, 1) && dma_offsets_fit(m, k, 1), ATSPEED_ERR_CAPACITY, "gemm_fp8: an operand of %d x %d or %d x %d bytes exceeds the kernel's 32-bit row offsets", n, k, m, k);
   ATS_REQUIRE(epilogue != EPI_SWIGLU || ((ldc & 3) == 0 && n % 32 == 0), ATSPEED_ERR_INVALID, "gemm_fp8: SwiGLU needs N %% 32 == 0 and ldc %% 4 == 0");
+  {
+    const int ms = mx_split_count(m, n, k);
+    if (ms >= 2 && wdma8_ws_ok(m, n, ms, ws, ws_bytes) && (n % 4) == 0) {
+      ATS_TRY(launch_mx_split(X, sx, Wq, sw, (float*)ws, m, n, k, ms, st, pk));
+      switch (epilogue) {
+        case EPI_STORE:  return reduce_splits<bf16_t, EPI_STORE>((const float*)ws, c, m, n, ldc, ms, st, nullptr, pk);
+        case EPI_F32:    return reduce_splits<bf16_t, EPI_F32>((const float*)ws, c, m, n, ldc, ms, st, nullptr, pk);
+        case EPI_RESID:  return reduce_splits<bf16_t, EPI_RESID>((const float*)ws, c, m, n, ldc, ms, st, nullptr, pk);
+        case EPI_SWIGLU: return reduce_splits<bf16_t, EPI_SWIGLU>((const float*)ws, c, m, n, ldc, ms, st, nullptr, pk);
+      }
+      atspeed_set_error("gemm_fp8: unknown epilogue %d", epilogue);
+      return ATSPEED_ERR_INVALID;
+    }
+  }
   switch (epilogue) {
     case EPI_STORE:  return launch_big_fp8<EPI_STORE>(X, sx, Wq, sw, c, m, n, k, ldc, st, pk);
     case EPI_F32:    return launch_big_fp8<EPI_F32>(X, sx, Wq, sw, c, m, n, k, ldc, st, pk);
@@ -2393,6 +2454,17 @@ int ats_gemm_fp8_resid_norm(const void* xq, const float* sx, const void* wq, con
       ATS_TRY((launch_wdma8<EPI_F32, true>((const unsigned char*)xq, sx, (const unsigned char*)wq, sw, ws, m, n, k, n, s_, st, pk)));
       FusedNorm fn{norm_w, xn, eps, false, q_out, s_out};
       ATS_TRY((reduce_splits<bf16_t, EPI_RESID>((const float*)ws, h, m, n, ldh, s_, st, &fn, pk)));
+      if (fn.done) return ATSPEED_OK;
+      return q_out ? ats_rmsnorm_quant_fp8(h, norm_w, xn, q_out, s_out, m, n, eps, st, pk) : ats_rmsnorm(h, norm_w, xn, m, n, eps, ATS_HALF, st, pk);
+    }
+  }
+  {
+    const int ms = mx_split_count(m, n, k);                           // thin grid: K-split ring + ONE fused reduce / residual / norm / quantisation pass
+    if (ms >= 2 && wdma8_ws_ok(m, n, ms, ws, ws_bytes) && n <= 8192 && (n % 4) == 0 && (ldh % 4) == 0) {
+      ATS_REQUIRE(xq && sx && wq && sw && h && norm_w, ATSPEED_ERR_INVALID, "gemm_fp8_resid_norm: null operand");
+      ATS_TRY(launch_mx_split((const unsigned char*)xq, sx, (const unsigned char*)wq, sw, (float*)ws, m, n, k, ms, st, pk));
+      FusedNorm fn{norm_w, xn, eps, false, q_out, s_out};
+      ATS_TRY((reduce_splits<bf16_t, EPI_RESID>((const float*)ws, h, m, n, ldh, ms, st, &fn, pk)));
       if (fn.done) return ATSPEED_OK;
       return q_out ? ats_rmsnorm_quant_fp8(h, norm_w, xn, q_out, s_out, m, n, eps, st, pk) : ats_rmsnorm(h, norm_w, xn, m, n, eps, ATS_HALF, st, pk);
     }

@@ -42,7 +42,8 @@ constexpr int ATS_SK_ARENA_COUNTERS = 256;
 
 // which kernel family a GEMM launch took (atspeed_gemm_path_counters: tests assert the path they mean to test, dispatch being a fitted model)
 enum { ATS_PATH_RING = 0, ATS_PATH_RING_SK = 1, ATS_PATH_WDMA = 2, ATS_PATH_WDMA_SPLIT = 3, ATS_PATH_RING_SPLIT = 4, ATS_PATH_TILED = 5,
-       ATS_PATH_FP8_RING = 6, ATS_PATH_FP8_WDMA = 7, ATS_PATH_FP8_WDMA_SPLIT = 8, ATS_PATH_PANEL = 9, ATS_PATH_PANEL_SPLIT = 10, ATS_N_PATHS = 16 };
+       ATS_PATH_FP8_RING = 6, ATS_PATH_FP8_WDMA = 7, ATS_PATH_FP8_WDMA_SPLIT = 8, ATS_PATH_PANEL = 9, ATS_PATH_PANEL_SPLIT = 10, ATS_PATH_FP8_RING_SPLIT = 11,
+       ATS_N_PATHS = 16 };
 extern std::atomic<long long> g_ats_path_cnt[ATS_N_PATHS];          // engine.hip
 inline void ats_count_path(int p) { g_ats_path_cnt[p].fetch_add(1, std::memory_order_relaxed); }
 

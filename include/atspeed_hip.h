@@ -326,7 +326,7 @@ int atspeed_gemm(const void* a_dev, const void* w_dev, void* c_dev, int32_t m, i
 /* Which kernel family the library's GEMM launches took since the last reset (dispatch is a fitted cost model: tests assert the path they
  * mean to exercise).  out[i], i < n: 0 ring kernel, 1 ring kernel with its split-K tail, 2 weight-streaming kernel, 3 the same split in K,
  * 4 ring kernel in split-K mode, 5 LDS-tiled kernel, 6 fp8 ring kernel, 7 / 8 fp8 weight-streaming kernel / split, 9 / 10 panel kernel /
- * split.  Returns the number of counters the library keeps. */
+ * split, 11 fp8 ring kernel cut in K.  Returns the number of counters the library keeps. */
 int atspeed_gemm_path_counters(int64_t* out, int32_t n, int32_t reset);
 /* atspeed_gemm / atspeed_gemm_fp8 on operands in the packed layout (a / xq and w / wq through atspeed_pack_rows; K % 32 == 0, for fp8 K % 64 == 0):
  * what the bf16 / fp8 engine runs.  The SwiGLU epilogue's output (ldc % 32 == 0) is packed as well -- it is the down projection's operand --,

@@ -969,3 +969,50 @@ def test_gemm_panel_form(lib, m, n, k, epi, dtype):
         tol = (2e-5 * np.sqrt(k) if epi == _lib.EPI_F32 else (1e-2 if dtype == torch.bfloat16 else 2e-3)) * float(ref.abs().max())
     err = float((got - ref).abs().max())
     assert err <= tol, (err, tol)
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(300, 4096, 4096, 2), (456, 4096, 11008, 2), (912, 4096, 4096, 2), (1100, 4096, 11008, 2), (1000, 4096, 4096, 0), (640, 4096, 11008, 1),
+                                      (300, 1024, 2048, 3)])
+def test_gemm_fp8_ring_cut_in_k(lib, m, n, k, epi):
+    """Round 5: the W8A8 projections whose 256-wide tile grid is thin (N = 4096 at 257-2000 tokens: o_proj and down of 2-8 users per lock-step batch)
+    used to run on 32-80 workgroups (257-511 tokens) or fall back to bf16 (from 512).  gemm_ring_mx_kernel<..., SPLITK>: tiles x parts ~ one
+    round, scaled fp32 slabs, the usual reduce.  Against the exact fp64 product of the dequantised operands; packed = row-major; counters."""
+    x = _rand((m, k), 51, 1.5).to(torch.bfloat16).cuda()
+    w = _rand((n, k), 52, 0.05).to(torch.bfloat16).cuda()
+    xq = torch.empty(m, k, dtype=torch.uint8, device="cuda"); sx = torch.empty(m, device="cuda")
+    wq = torch.empty(n, k, dtype=torch.uint8, device="cuda"); sw = torch.empty(n, device="cuda")
+    _lib.check(lib.atspeed_quant_rows_fp8(x.data_ptr(), m, k, xq.data_ptr(), sx.data_ptr(), _st()))
+    _lib.check(lib.atspeed_quant_rows_fp8(w.data_ptr(), n, k, wq.data_ptr(), sw.data_ptr(), _st()))
+    ref = (_fp8_to_float(xq).double() @ _fp8_to_float(wq).double().T) * sx.cpu().double()[:, None] * sw.cpu().double()[None, :]
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    mp = (m + 1) // 2 * 2
+    if epi == _lib.EPI_F32:
+        ldc = (n + 63) // 64 * 64; mk = lambda: torch.zeros(mp, ldc, dtype=torch.float32, device="cuda")
+    elif epi == _lib.EPI_SWIGLU:
+        ldc = n // 2; mk = lambda: torch.zeros(mp, ldc, dtype=torch.bfloat16, device="cuda")
+        g = ref.view(m, n // 32, 2, 16)
+        ref = (torch.nn.functional.silu(g[:, :, 0]) * g[:, :, 1]).reshape(m, n // 2)
+    else:
+        ldc = n; base = torch.zeros(mp, n, dtype=torch.bfloat16, device="cuda")
+        if epi == _lib.EPI_RESID:
+            base[:m] = _rand((m, n), 53).to(torch.bfloat16).cuda()
+            ref = ref + base[:m].double().cpu()
+        mk = lambda: base.clone()
+    _path_counters(lib, reset=True)
+    c0, c1, c2 = mk(), mk(), mk()
+    _lib.check(lib.atspeed_gemm_fp8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), c0.data_ptr(), m, n, k, ldc, epi, ws.data_ptr(), ws.numel(), _st()))
+    cnt = _path_counters(lib)
+    assert cnt[11] == 1 and cnt[PATH_FP8_RING] == 0, cnt                  # 11: fp8 ring kernel cut in K
+    xp, wp = _pack(lib, xq), _pack(lib, wq)
+    _lib.check(lib.atspeed_gemm_fp8_packed(xp.data_ptr(), sx.data_ptr(), wp.data_ptr(), sw.data_ptr(), c1.data_ptr(), m, n, k, ldc, epi, ws.data_ptr(), ws.numel(), _st()))
+    _lib.check(lib.atspeed_gemm_fp8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), c2.data_ptr(), m, n, k, ldc, epi, None, 0, _st()))   # no workspace: the plain grid
+    assert _path_counters(lib)[PATH_FP8_RING] == 1
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    tol = 2e-5 * scale * np.sqrt(k) if epi == _lib.EPI_F32 else 2e-2 * scale
+    for c in (c0, c2):
+        np.testing.assert_allclose(c.double().cpu()[:m, : ref.shape[1]].numpy(), ref.numpy(), atol=tol, rtol=0)
+    if epi == _lib.EPI_SWIGLU:
+        assert torch.equal(_unpack(lib, c1, m), c0[:m])
+    else:
+        assert torch.equal(c1[:m], c0[:m])
