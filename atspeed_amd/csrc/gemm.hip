@@ -2287,6 +2287,10 @@ static int mx_split_count(int m, int n, int k, bool* rows256 = nullptr) {   // 0
   if (m < 257 || k % 256 != 0 || !dma_offsets_fit(n, k, 1) || !dma_offsets_fit(m, k, 1)) return 0;
   const int tn = (n + 255) / 256, t256 = tn * ((m + 255) / 256), t128 = tn * ((m + 127) / 128);
   if (big_fill_pct(t256) >= 60 || big_fill_pct(t128) >= 60) return 0;
+  // measured (tools/gemm_fp8_ab.py with / without a workspace, us per launch incl. the reduce): down 70.9 -> 37.4 at 300 tokens, 72.1 -> 42.7 at 456,
+  // 76.5 -> 54.4 at 640, 77.7 -> 66.2 at 912; o_proj (K = 4096: short parts) 30.7 -> 27.6 at 300, 36.2 -> 32.4 at 456 but 35.5 -> 39.1 at 640; qkv (96
+  // tiles of 256 rows already) 32.3 -> 50.1 at 300: only really thin grids, and K = 4096 only up to 512 tokens
+  if (t256 > 64 || (k < 8192 && m > 512)) return 0;
   const bool r256 = t128 > 128;                                        // 128-row token tiles while two parts of them fit a round, else 256-row ones
   const int tiles = r256 ? t256 : t128;
   if (rows256) *rows256 = r256;
