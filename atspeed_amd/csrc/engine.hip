@@ -340,9 +340,13 @@ static int ensure_act(atspeed_llama* m, int tok, int rows) {
   ATS_HIP(hipMalloc(&cx->ws, cx->ws_bytes));
   ATS_HIP(hipMalloc((void**)&cx->segtab_dev, sizeof(SegTable)));
   if (c.dtype != ATSPEED_F32 && c.hidden % 128 == 0 && cx->cap_tok >= 257) {      // shapes the ring kernel can take at all (big_kernel_applies)
-    ATS_HIP(hipMalloc((void**)&cx->sk.ws, ATS_SK_ARENA_BYTES));
-    ATS_HIP(hipMalloc((void**)&cx->sk.cnt, ATS_SK_ARENA_COUNTERS * sizeof(int)));
-    ATS_HIP(hipMemset(cx->sk.cnt, 0, ATS_SK_ARENA_COUNTERS * sizeof(int)));
+    // optional: without room for it the model still runs (thin / partly filled grids then take the device's shared arena or the plain grid)
+    if (hipMalloc((void**)&cx->sk.ws, ATS_SK_ARENA_BYTES) != hipSuccess || hipMalloc((void**)&cx->sk.cnt, ATS_SK_ARENA_COUNTERS * sizeof(int)) != hipSuccess ||
+        hipMemset(cx->sk.cnt, 0, ATS_SK_ARENA_COUNTERS * sizeof(int)) != hipSuccess) {
+      (void)hipGetLastError();
+      hipFree(cx->sk.ws); hipFree(cx->sk.cnt);
+      cx->sk = SkArena{};
+    }
   }
   m->act = cx;
   return ATSPEED_OK;
