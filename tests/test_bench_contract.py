@@ -202,3 +202,26 @@ def test_an_oversized_summary_never_costs_the_headline(tmp_path, capsys):
     capsys.readouterr()
     line = json.loads(text)
     assert len(text) <= bench.LINE_BUDGET_BYTES and line["roofline"]["frac"] == 0.5 and line["cpu_baseline"]["value"] == 2.0 and "speedup_curve" not in line
+
+
+def test_round5_report_compacts_with_the_one_user_fp8_rows(tmp_path, capsys):
+    """The round-5 report (profiles/r05_bench_detail.json: what `python bench.py` wrote beside the line the driver parsed) through the same
+    builder: still under the budget with the new `one_user_fp8` rows (config 5 at the reference's batch-1 shape), traffic quoted with its ratio."""
+    import json
+    import os
+    p = os.path.join(bench.ROOT, "profiles", "r05_bench_detail.json")
+    if not os.path.exists(p):
+        pytest.skip("no round-5 report in profiles/")
+    with open(p) as f:
+        detail = json.load(f)
+    text = bench.emit(detail, out_dir=str(tmp_path))
+    capsys.readouterr()
+    line = json.loads(text)
+    assert len(text) < bench.LINE_BUDGET_BYTES
+    rows = {r["bracket"]: r for r in line["one_user_fp8"]}
+    assert set(rows) == {"accept0", "resid3e-06", "resid3e-05"} and all(r["not_fp8"] == 0 and r["fp8_ms"] < r["bf16_ms"] for r in rows.values())
+    assert abs(rows["resid3e-05"]["accept_fp8"] - rows["resid3e-05"]["accept_bf16"]) <= 0.05          # accepted-length drift of the W8A8 target, one user per call
+    assert line["roofline"]["traffic"] and 7.0 < line["roofline"]["traffic_over_algorithmic"] < 9.5 and line["roofline"]["avg_m"] > 20000
+    with open(os.path.join(bench.ROOT, "profiles", "r05_bench.json")) as f:                             # the committed line IS what the builder makes of the committed report
+        committed = json.loads(f.read().strip().splitlines()[-1])
+    assert committed["value"] == line["value"] and committed["roofline"]["frac"] == line["roofline"]["frac"]
