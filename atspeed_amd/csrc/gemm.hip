@@ -2326,23 +2326,31 @@ static bool wdma8_applies(int m, int n, int k) {
   static const int on = env_int("ATSPEED_FP8_SMALL", 1);               // 0: one user's forwards stay on the 16-bit kernels (A/B)
   return on && m >= 1 && m <= 256 && k % 128 == 0 && k >= 512 && n >= 16 && dma_offsets_fit(n, k, 1) && dma_offsets_fit(m, k, 1);
 }
+// 64-row weight tiles for the projections of up to 256 such tiles (N <= 16384: qkv, o_proj, down): the PMC passes of the 128-row form showed the split
+// launches' traffic to be their fp32 slabs (down at 228 tokens: 29.9 MB written + 31.8 MB re-read next to 47.6 MB of operands), and 64 tiles x 4 parts
+// halve them; qkv's 192 tiles need no split at all (bf16 store + the plain RoPE pass instead of 2 slabs).  One user 16.8 -> 15.75 ms at zero
+// acceptance, 5.97 -> 5.48 ms at three accepted steps (A/B ATSPEED_FP8_SMALL_BN64 = 0 / 1 (N <= 4096 only: 16.0 / 5.6) / 2 on one box).
+static bool wdma8_bn64(int n) {
+  static const int on = env_int("ATSPEED_FP8_SMALL_BN64", 2);
+  return on && n <= (on >= 2 ? 16384 : 4096) && n % 64 == 0;
+}
 static int wdma8_split_count(int n, int k) {                           // 1: no split
-  const int t128 = (n + 127) / 128, n_kt = k / 128;
+  const int t128 = wdma8_bn64(n) ? (n + 63) / 64 : (n + 127) / 128, n_kt = k / 128;
   if (t128 >= 150) return 1;
   return std::max(1, std::min(256 / t128, n_kt / 4));                  // at least 4 tiles (512 k) per part (8: the same within 2 %, 16: +3 % per user)
 }
-template <int BM, int NST, int EPI, bool SPLIT, int WM = 2>
+template <int BM, int NST, int EPI, bool SPLIT, int WM = 2, int BN = 128>
 int launch_wdma8_cfg(const unsigned char* xq, const float* sx, const unsigned char* wq, const float* sw, void* c, int m, int n, int k, int ldc,
                      int splits, hipStream_t st, int pk) {
-  auto kern = gemm_wdma_kernel<BM, 128, NST, EPI, SPLIT, WM, true>;
-  constexpr int lds = NST * (BM + 128) * 128;
+  auto kern = gemm_wdma_kernel<BM, BN, NST, EPI, SPLIT, WM, true>;
+  constexpr int lds = NST * (BM + BN) * 128;
   static thread_local AtsPerDeviceFlag attr_flag;
   bool& attr_done = attr_flag.cur();
   if (!attr_done) {
     ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((n + 127) / 128, SPLIT ? splits : 1), dim3(128 * WM), lds, st, (const void*)xq, (const void*)wq, c, m, n, k, k, ldc, pk, splits, sx, sw);
+  hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN, SPLIT ? splits : 1), dim3(128 * WM), lds, st, (const void*)xq, (const void*)wq, c, m, n, k, k, ldc, pk, splits, sx, sw);
   ATS_LAUNCH_CHECK();
   ats_count_path(SPLIT ? ATS_PATH_FP8_WDMA_SPLIT : ATS_PATH_FP8_WDMA);
   return ATSPEED_OK;
@@ -2350,6 +2358,14 @@ int launch_wdma8_cfg(const unsigned char* xq, const float* sx, const unsigned ch
 template <int EPI, bool SPLIT>
 int launch_wdma8(const unsigned char* xq, const float* sx, const unsigned char* wq, const float* sw, void* c, int m, int n, int k, int ldc,
                  int splits, hipStream_t st, int pk) {
+  {
+    if (wdma8_bn64(n)) {
+      if (m <= 32)  return launch_wdma8_cfg<32, 8, EPI, SPLIT, 2, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);     // 12 KB x 8
+      if (m <= 64)  return launch_wdma8_cfg<64, 8, EPI, SPLIT, 2, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);     // 16 KB x 8
+      if (m <= 128) return launch_wdma8_cfg<128, 6, EPI, SPLIT, 2, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);    // 24 KB x 6
+      return launch_wdma8_cfg<256, 4, EPI, SPLIT, 4, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);                  // 40 KB x 4, 8 waves
+    }
+  }
   if (m <= 32)  return launch_wdma8_cfg<32, 6, EPI, SPLIT>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);        // 20 KB x 6
   if (m <= 64)  return launch_wdma8_cfg<64, 6, EPI, SPLIT>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);        // 24 KB x 6
   if (m <= 128) return launch_wdma8_cfg<128, 4, EPI, SPLIT>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);       // 32 KB x 4

@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SWITCHES = [{"ATSPEED_GEMM_WDMA": "0"}, {"ATSPEED_FP8_SMALL": "0"}, {"ATSPEED_FUSE_QKV_REDUCE": "0"}, {"ATSPEED_FUSE_LSE": "0"},
+SWITCHES = [{"ATSPEED_GEMM_WDMA": "0"}, {"ATSPEED_FP8_SMALL": "0"}, {"ATSPEED_FP8_SMALL_BN64": "0"}, {"ATSPEED_FUSE_QKV_REDUCE": "0"}, {"ATSPEED_FUSE_LSE": "0"},
             {"ATSPEED_ATTN32": "0", "ATSPEED_ATTN_RING": "0"}, {"ATSPEED_RMSNORM_PAIRS": "0", "ATSPEED_QUANT_PAIRS": "0"},
             {"ATSPEED_GEMM_SK": "0", "ATSPEED_GEMM_PANEL": "0"}, {"ATSPEED_FP8_MX": "0"}, {"ATSPEED_GRAPHS": "1"}]
 

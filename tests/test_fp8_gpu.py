@@ -193,7 +193,7 @@ def test_fp8_one_user_forward_at_llama7b_width_matches_the_w8a8_oracle(T):
     fc = m.fp8_counters()
     assert all(c["fp8"] == layers and c["other"] == 0 for c in fc.values()), fc
     _lib.load().atspeed_gemm_path_counters(cnt, 16, 0)
-    assert cnt[7] == layers and cnt[8] == 3 * layers and cnt[6] == 0, list(cnt)      # gate_up without split; qkv, o_proj, down cut in K; no ring launch
+    assert cnt[7] == 2 * layers and cnt[8] == 2 * layers and cnt[6] == 0, list(cnt)  # gate_up and qkv without split; o_proj, down cut in K; no ring launch
     want8 = ref8.forward(ids, pos, pos, vis, n_logit_rows=rows)
     want32 = ref32.forward(ids, pos, pos, vis, n_logit_rows=rows)
     scale = float(want8.abs().max())

@@ -882,7 +882,8 @@ def test_gemm_fp8_weight_streaming_form(lib, m, n, k, epi):
     c0, c1, c2 = mk(), mk(), mk()
     _lib.check(lib.atspeed_gemm_fp8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), c0.data_ptr(), m, n, k, ldc, epi, ws.data_ptr(), ws.numel(), _st()))
     cnt = _path_counters(lib)
-    split = (n + 127) // 128 < 150 and k // 128 >= 8
+    tiles = (n + 63) // 64 if (n <= 16384 and n % 64 == 0) else (n + 127) // 128      # 64-row weight tiles up to N = 16384, else 128-row ones
+    split = tiles < 150 and min(256 // tiles, (k // 128) // 4) >= 2                    # narrow projections are cut in K (at least 4 tiles of 128 k per part)
     assert cnt[PATH_FP8_WDMA_SPLIT if (split or epi == _lib.EPI_RESID) else PATH_FP8_WDMA] == 1 and cnt[PATH_FP8_RING] == 0, cnt
     xp, wp = _pack(lib, xq), _pack(lib, wq)
     _lib.check(lib.atspeed_gemm_fp8_packed(xp.data_ptr(), sx.data_ptr(), wp.data_ptr(), sw.data_ptr(), c1.data_ptr(), m, n, k, ldc, epi, ws.data_ptr(), ws.numel(), _st()))
