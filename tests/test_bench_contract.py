@@ -225,3 +225,16 @@ def test_round5_report_compacts_with_the_one_user_fp8_rows(tmp_path, capsys):
     with open(os.path.join(bench.ROOT, "profiles", "r05_bench.json")) as f:                             # the committed line IS what the builder makes of the committed report
         committed = json.loads(f.read().strip().splitlines()[-1])
     assert committed["value"] == line["value"] and committed["roofline"]["frac"] == line["roofline"]["frac"]
+
+
+def test_compact_line_of_a_multi_gpu_run_keeps_the_per_rank_rows():
+    """N > 1: rank 0's line carries what every rank decoded (straggler visibility), numbers only."""
+    import json
+    from atspeed_amd.dist import Counters
+    detail = dict(metric="m", value=4.0e4, unit="items/s", n_gpus=8, steps=2, warmup=1, ms_per_step=1000.0, higher_is_better=True, scaling="weak",
+                  vs_baseline=None, dtype="bf16", data="synthetic", config=dict(workload="w", parallelism="user-shard x8"), mean_accept_len=0.0,
+                  roofline=dict(bound="mfma", frac=0.59, achieved=1475.0, peak=2500.0, unit="TFLOP/s", traffic=None),
+                  per_rank=bench.per_rank_report([Counters(512, 1536, 0, int(1.02e9 + 1e7 * r)) for r in range(8)], beam=20), cpu_baseline=None)
+    line = bench.compact_line(detail)
+    assert line["n_gpus"] == 8 and [r["rank"] for r in line["per_rank"]] == list(range(8)) and line["per_rank"][7]["elapsed_ms"] > line["per_rank"][0]["elapsed_ms"]
+    assert line["cpu_baseline"] is None and len(json.dumps(line)) < bench.LINE_BUDGET_BYTES
