@@ -104,7 +104,8 @@ def test_gemm_store_and_f32(lib, m, n, k, dtype):
 
 
 @pytest.mark.parametrize("m,n,k", [(7, 256, 128), (40, 768, 768), (228, 4096, 11008), (228, 4096, 4096), (1100, 768, 1024), (2000, 500, 256), (100, 8192, 512), (6400, 4096, 512), (8300, 4096, 512), (4500, 8192, 256), (6400, 4104, 512),
-                                   (50, 8192, 1024), (128, 12288, 768), (129, 8200, 384), (256, 8192, 256), (100, 22016, 512), (60, 32859, 576), (250, 22016, 1024), (100, 12288, 4096), (60, 4096, 11008), (225, 4096, 11008), (128, 12288, 2048)])      # ... and the split-K form of the weight-streaming kernel (qkv, down)      # one user's wide projections: the no-split weight-streaming tiles (64 / 128 / 256 token rows)
+                                   (50, 8192, 1024), (128, 12288, 768), (129, 8200, 384), (256, 8192, 256), (100, 22016, 512), (60, 32859, 576), (250, 22016, 1024), (100, 12288, 4096), (60, 4096, 11008), (225, 4096, 11008), (128, 12288, 2048),
+                                   (320, 4096, 11008), (320, 4096, 4096), (400, 4096, 11008)])      # ... the split-K form of the weight-streaming kernel (qkv, down), and the 257-640-token band (panel split, split-K tail)      # one user's wide projections: the no-split weight-streaming tiles (64 / 128 / 256 token rows)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_residual(lib, m, n, k, dtype):
     a = _rand((m, k), 3).to(dtype).cuda()
@@ -550,7 +551,9 @@ def test_pack_rows_layout_and_round_trip(lib):
 
 
 @pytest.mark.parametrize("m,n,k,epi", [(20, 768, 256, 0), (100, 12288, 512, 0), (228, 4096, 4096, 2), (228, 22016, 512, 3), (121, 32859, 256, 1), (50, 12288, 512, 0), (50, 8448, 256, 3), (121, 32859, 512, 1), (110, 22016, 512, 3), (64, 8448, 1024, 3), (128, 8192, 4096, 0), (33, 16384, 576, 0), (225, 22016, 512, 3), (256, 12288, 1024, 0), (129, 32859, 512, 1), (64, 22016, 1024, 3), (40, 32859, 576, 1), (100, 22016, 512, 0), (200, 22000, 512, 0), (128, 28672, 512, 1),
-                                      (1300, 1024, 1280, 2), (900, 2752, 512, 3), (4200, 8192, 256, 0), (1543, 1001, 256, 1), (777, 4096, 11008, 2)])
+                                      (1300, 1024, 1280, 2), (900, 2752, 512, 3), (4200, 8192, 256, 0), (1543, 1001, 256, 1), (777, 4096, 11008, 2),
+                                      # the 257-640-token band at the Llama-7B shapes: panel form, its split form, split-K tail, plain ring, as the default dispatch picks
+                                      (320, 22016, 4096, 3), (320, 4096, 11008, 2), (320, 4096, 4096, 2), (400, 12288, 4096, 0), (640, 22016, 4096, 3)])
 def test_gemm_packed_equals_row_major_bit_for_bit(lib, m, n, k, epi):
     """Every bf16 GEMM path (LDS-tiled, its split-K + reduce, the split-K ring, the 256-wide ring) on packed operands: the same products
     in the same order as on row-major operands, so the outputs are IDENTICAL (the SwiGLU output comes back packed)."""
