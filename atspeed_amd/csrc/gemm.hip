@@ -60,6 +60,10 @@ static SkPlan sk_plan_s(int tiles, int k, int S) {
   p.G = R * S;
   p.parts = S;
   p.on = true;
+  // test hook (tests/test_kernels_gpu.py): an UNALIGNED deal of the tail's k-units over G workgroups -- a workgroup then ends one tile and starts the next,
+  // the kernel's segment loop and second slot, which no plan of the launcher uses (they lost to the aligned plans, see above) but the kernel keeps
+  const int g_env = env_now("ATSPEED_GEMM_SK_G", 0);
+  if (g_env >= R && g_env <= 256 && g_env <= p.TU) p.G = g_env;     // (G >= R: a workgroup's range never spans more than two tiles)
   return p;
 }
 static float ring_tile_us(int k, bool rows256, int concurrent) {

@@ -1020,3 +1020,46 @@ def test_gemm_fp8_ring_cut_in_k(lib, m, n, k, epi):
         assert torch.equal(_unpack(lib, c1, m), c0[:m])
     else:
         assert torch.equal(c1[:m], c0[:m])
+
+
+@pytest.mark.parametrize("m,n,k,epi,G", [(900, 4096, 4096, 2, 150), (912, 22016, 4096, 3, 201), (400, 4096, 4096, 0, 100), (640, 4096, 11008, 2, 90), (700, 32859, 2048, 1, 10)])
+def test_split_k_tail_with_an_unaligned_deal(lib, m, n, k, epi, G):
+    """the ring kernel's tail accepts ANY even deal of the tail's k-units over G workgroups (a workgroup may end one tile and start the next:
+    the segment loop, the second slot), but the launcher only makes aligned plans, so that code ran in no test.  `ATSPEED_GEMM_SK_G` (read per launch)
+    forces an unaligned G: same product as torch fp32 on the bf16 values, bit-identical across runs (the sum must not depend on the arrival order)."""
+    a = _rand((m, k), 381, 1.0).to(torch.bfloat16).cuda()
+    w = _rand((n, k), 382, 0.03).to(torch.bfloat16).cuda()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    if epi == _lib.EPI_SWIGLU:
+        from atspeed_amd.model import _interleave_gate_up
+        w = _interleave_gate_up(w[: n // 2].contiguous(), w[n // 2:].contiguous())
+    base = _rand((m, n), 383).to(torch.bfloat16).cuda() if epi == _lib.EPI_RESID else None
+    if epi == _lib.EPI_F32:
+        ldc = (n + 63) // 64 * 64; mk = lambda: torch.zeros(m, ldc, dtype=torch.float32, device="cuda")
+    elif epi == _lib.EPI_SWIGLU:
+        ldc = n // 2; mk = lambda: torch.zeros(m, ldc, dtype=torch.bfloat16, device="cuda")
+    else:
+        ldc = n; mk = lambda: (base.clone() if epi == _lib.EPI_RESID else torch.zeros(m, n, dtype=torch.bfloat16, device="cuda"))
+    os.environ.update(ATSPEED_GEMM_SK="2", ATSPEED_GEMM_PANEL="0", ATSPEED_GEMM_SK_G=str(G))
+    try:
+        _path_counters(lib, reset=True)
+        outs = []
+        for _ in range(3):
+            c = mk()
+            _lib.check(lib.atspeed_gemm(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, k, ldc, _lib.ATSPEED_BF16, epi, ws.data_ptr(), ws.numel(), _st()))
+            outs.append(c)
+        assert _path_counters(lib)[PATH_RING_SK] == 3
+        torch.cuda.synchronize()
+    finally:
+        for v in ("ATSPEED_GEMM_SK", "ATSPEED_GEMM_PANEL", "ATSPEED_GEMM_SK_G"):
+            del os.environ[v]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    prod = a.float() @ w.float().T
+    if epi == _lib.EPI_SWIGLU:
+        v = prod.view(m, n // 32, 2, 16)
+        ref = torch.nn.functional.silu(v[:, :, 0].reshape(m, n // 2).to(torch.bfloat16).float()) * v[:, :, 1].reshape(m, n // 2).to(torch.bfloat16).float()
+        got, tol = outs[0].float(), 3e-2 * float(ref.abs().max())
+    else:
+        ref = prod + (base.float() if epi == _lib.EPI_RESID else 0.0)
+        got, tol = outs[0][:, :n].float(), (2e-5 * np.sqrt(k) if epi == _lib.EPI_F32 else 1e-2) * float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= tol
