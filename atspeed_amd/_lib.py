@@ -62,6 +62,7 @@ SIGNATURES = {
     "atspeed_llama_enable_fp8": (C.c_int, [_P, _P]),
     "atspeed_llama_fp8_counters": (C.c_int, [_P, _P, _P, _I]),
     "atspeed_llama_rope_fused_launches": (C.c_int64, [_P, _I]),
+    "atspeed_llama_sk_arena_bytes": (C.c_int64, [_P]),
     "atspeed_quant_rows_fp8": (C.c_int, [_P, _I, _I, _P, _P, _P]),
     "atspeed_quant_rows_fp8_packed": (C.c_int, [_P, _I, _I, _P, _P, _P]),
     "atspeed_gemm_fp8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
@@ -87,6 +88,8 @@ SIGNATURES = {
     "atspeed_decoder_decisions": (C.c_int64, [_P, _P, C.c_int64]),
     "atspeed_gemm": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "atspeed_gemm_path_counters": (C.c_int, [_P, _I, _I]),
+    "atspeed_set_switch": (C.c_int, [C.c_char_p, _I]),
+    "atspeed_get_switch": (C.c_int, [C.c_char_p, C.POINTER(_I)]),
     "atspeed_gemm_packed": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "atspeed_gemm_fp8_packed": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "atspeed_pack_rows": (C.c_int, [_P, _P, _I, _I, _P]),
@@ -136,6 +139,31 @@ def check(status: int) -> None:
     if status == ERR_CONSTRAINT:
         raise ValueError(msg)          # what HF's PrefixConstrainedLogitsProcessor raises
     raise AtSpeedError(status, msg)
+
+
+class switches:
+    """`with _lib.switches(gemm_sk=2, gemm_panel=0): ...` -- set process-wide library switches (atspeed_set_switch) and restore them on exit.
+    The environment variables (ATSPEED_GEMM_SK, ...) only give the INITIAL values, read once by the library; tests and sweeps that compare
+    two settings in one process go through here."""
+
+    def __init__(self, **values: int):
+        self.values = values
+        self.old = {}
+
+    def __enter__(self):
+        lib = load()
+        for name, v in self.values.items():
+            cur = _I(0)
+            check(lib.atspeed_get_switch(name.encode(), C.byref(cur)))
+            self.old[name] = cur.value
+            check(lib.atspeed_set_switch(name.encode(), int(v)))
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for name, v in self.old.items():
+            lib.atspeed_set_switch(name.encode(), v)
+        return False
 
 
 def dtype_code(dtype) -> int:

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "internal.h"
@@ -24,7 +25,45 @@ void atspeed_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* atspeed_last_error(void) { return g_last_error.c_str(); }
-extern "C" const char* atspeed_version(void) { return "atspeed_hip 0.1 (gfx950)"; }
+// 0.2 (round 6): atspeed_gemm_fp8 / atspeed_gemm_fp8_packed take (workspace, bytes) before the stream (changed in round 5 without a bump);
+// atspeed_set_switch / atspeed_get_switch; atspeed_llama_enable_fp8 on fp16 models
+extern "C" const char* atspeed_version(void) { return "atspeed_hip 0.2 (gfx950)"; }
+
+// ---- process-wide switches (internal.h: ATS_SW_*)
+namespace {
+struct SwDef { const char* name; const char* env; int dflt; };
+const SwDef kSwitches[ATS_N_SW] = {{"gemm_sk", "ATSPEED_GEMM_SK", 1},           {"gemm_sk_g", nullptr, 0},
+                                   {"gemm_panel", "ATSPEED_GEMM_PANEL", 1},     {"gemm_force_mt", "ATSPEED_GEMM_FORCE_MT", 0},
+                                   {"graphs", "ATSPEED_GRAPHS", 0},             {"fuse_qkv_rope", "ATSPEED_FUSE_QKV_ROPE", 1},
+                                   {"gemm_kcut", "ATSPEED_GEMM_KCUT", 1}};
+std::atomic<int> g_switch[ATS_N_SW];
+std::once_flag g_switch_once;
+void switches_init() {
+  std::call_once(g_switch_once, [] {
+    for (int i = 0; i < ATS_N_SW; ++i) {
+      const char* v = kSwitches[i].env ? getenv(kSwitches[i].env) : nullptr;
+      g_switch[i].store(v ? atoi(v) : kSwitches[i].dflt, std::memory_order_relaxed);
+    }
+  });
+}
+}  // namespace
+int ats_switch(int id) { switches_init(); return g_switch[id].load(std::memory_order_relaxed); }
+extern "C" int atspeed_set_switch(const char* name, int32_t value) {
+  ATS_REQUIRE(name, ATSPEED_ERR_INVALID, "set_switch: null name");
+  switches_init();
+  for (int i = 0; i < ATS_N_SW; ++i)
+    if (!strcmp(name, kSwitches[i].name)) { g_switch[i].store(value, std::memory_order_relaxed); return ATSPEED_OK; }
+  atspeed_set_error("set_switch: unknown switch '%s'", name);
+  return ATSPEED_ERR_INVALID;
+}
+extern "C" int atspeed_get_switch(const char* name, int32_t* value_out) {
+  ATS_REQUIRE(name && value_out, ATSPEED_ERR_INVALID, "get_switch: null argument");
+  switches_init();
+  for (int i = 0; i < ATS_N_SW; ++i)
+    if (!strcmp(name, kSwitches[i].name)) { *value_out = g_switch[i].load(std::memory_order_relaxed); return ATSPEED_OK; }
+  atspeed_set_error("get_switch: unknown switch '%s'", name);
+  return ATSPEED_ERR_INVALID;
+}
 std::atomic<long long> g_ats_path_cnt[ATS_N_PATHS];
 extern "C" int atspeed_gemm_path_counters(int64_t* out, int32_t n, int32_t reset) {
   for (int i = 0; i < ATS_N_PATHS; ++i) {
@@ -209,7 +248,8 @@ struct ActCtx {
   RowInfo* rowinfo = nullptr;                    // [cap_tok] cache / slot / rotation of each batched row (qkv projection's fused epilogue)
   void* xq = nullptr; float* sx = nullptr;       // fp8 activations [cap_tok][max(hidden, ffn)] + per-token scales
   void* ws = nullptr; size_t ws_bytes = 0;       // split-K slabs
-  SkArena sk;                                    // the ring kernel's split-K tail (16-bit models: internal.h SkArena); allocated HERE, never inside a forward
+  SkArena sk;                                    // the ring kernel's split-K tail (16-bit models: internal.h SkArena): allocated in front of the first forward of
+  bool sk_tried = false;                         // >= 257 tokens that is not being captured (sk_arena_lazy), never inside the launch sequence
   // forwards of a recurring shape are replayed as hipGraphs (one launch instead of ~9 per layer: a user's later rounds are
   // 20-140 tokens and launch-bound); the segment table lives at a fixed device address so that it is data, not a kernel argument
   SegTable* segtab_dev = nullptr;
@@ -289,10 +329,10 @@ static size_t gemm_ws_for(const atspeed_llama_config& c, int max_tok, int max_ro
     best = std::max(best, ATS_KD(c.dtype, ats_gemm_workspace_bytes(m, 2 * c.ffn, c.hidden, c.dtype)));
     best = std::max(best, ATS_KD(c.dtype, ats_gemm_workspace_bytes(m, c.hidden, c.ffn, c.dtype)));
     if (m <= max_rows) best = std::max(best, ATS_KD(c.dtype, ats_gemm_workspace_bytes(m, c.vocab_size, c.hidden, c.dtype)));
-    if (c.dtype == ATSPEED_BF16) {                 // the W8A8 copies (atspeed_llama_enable_fp8): the split plans of one user's projections and of thin ring grids
-      best = std::max(best, ats_bf16::ats_gemm_fp8_workspace_bytes(m, 3 * c.hidden, c.hidden));
-      best = std::max(best, ats_bf16::ats_gemm_fp8_workspace_bytes(m, c.hidden, c.hidden));
-      best = std::max(best, ats_bf16::ats_gemm_fp8_workspace_bytes(m, c.hidden, c.ffn));
+    if (c.dtype != ATSPEED_F32) {                  // the W8A8 copies (atspeed_llama_enable_fp8): the split plans of one user's projections and of thin ring grids
+      best = std::max(best, ATS_KD(c.dtype, ats_gemm_fp8_workspace_bytes(m, 3 * c.hidden, c.hidden)));
+      best = std::max(best, ATS_KD(c.dtype, ats_gemm_fp8_workspace_bytes(m, c.hidden, c.hidden)));
+      best = std::max(best, ATS_KD(c.dtype, ats_gemm_fp8_workspace_bytes(m, c.hidden, c.ffn)));
     }
   }
   return best + (1 << 20);
@@ -339,18 +379,31 @@ static int ensure_act(atspeed_llama* m, int tok, int rows) {
   cx->ws_bytes = gemm_ws_for(c, cx->cap_tok, cx->cap_rows);
   ATS_HIP(hipMalloc(&cx->ws, cx->ws_bytes));
   ATS_HIP(hipMalloc((void**)&cx->segtab_dev, sizeof(SegTable)));
-  if (c.dtype != ATSPEED_F32 && c.hidden % 128 == 0 && cx->cap_tok >= 257) {      // shapes the ring kernel can take at all (big_kernel_applies)
-    // optional: without room for it the model still runs (thin / partly filled grids then take the device's shared arena or the plain grid)
-    if (hipMalloc((void**)&cx->sk.ws, ATS_SK_ARENA_BYTES) != hipSuccess || hipMalloc((void**)&cx->sk.cnt, ATS_SK_ARENA_COUNTERS * sizeof(int)) != hipSuccess ||
-        hipMemset(cx->sk.cnt, 0, ATS_SK_ARENA_COUNTERS * sizeof(int)) != hipSuccess) {
-      (void)hipGetLastError();
-      hipFree(cx->sk.ws); hipFree(cx->sk.cnt);
-      cx->sk = SkArena{};
-    }
-  }
   m->act = cx;
   return ATSPEED_OK;
 }
+
+// The split-K tail's arena (128 MB + counters) belongs to the model, but only a model that really runs forwards of >= 257 tokens gets one
+// (every model used to own one from creation -- the 68M draft and every rank's one-user target included, whose forwards never reach
+// the ring kernel).  Allocated HERE, in front of the launch sequence of the first such forward, never inside it; a forward whose stream is
+// being captured by the caller allocates nothing (its thin grids run the plain kernel, as before).  Optional: without room for it the model
+// still runs (thin / partly filled grids then take the device's shared arena or the plain grid).  atspeed_llama_sk_arena_bytes reports it.
+static void sk_arena_lazy(atspeed_llama* m, int T, hipStream_t st) {
+  ActCtx* cx = m->act;
+  const atspeed_llama_config& c = m->cfg;
+  if (cx->sk.ws || cx->sk_tried || T < 257 || c.dtype == ATSPEED_F32 || c.hidden % 128 != 0) return;   // shapes the ring kernel can take at all (big_kernel_applies)
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (cs != hipStreamCaptureStatusNone) return;
+  cx->sk_tried = true;
+  if (hipMalloc((void**)&cx->sk.ws, ATS_SK_ARENA_BYTES) != hipSuccess || hipMalloc((void**)&cx->sk.cnt, ATS_SK_ARENA_COUNTERS * sizeof(int)) != hipSuccess ||
+      hipMemsetAsync(cx->sk.cnt, 0, ATS_SK_ARENA_COUNTERS * sizeof(int), st) != hipSuccess) {
+    (void)hipGetLastError();
+    hipFree(cx->sk.ws); hipFree(cx->sk.cnt);
+    cx->sk = SkArena{};
+  }
+}
+extern "C" int64_t atspeed_llama_sk_arena_bytes(const atspeed_llama* m) { return m && m->act && m->act->sk.ws ? (int64_t)ATS_SK_ARENA_BYTES : 0; }
 
 static int kv_create(atspeed_llama* m, KvCache* kv) {
   size_t bytes = (size_t)m->cfg.n_layers * m->layer_kv_bytes;
@@ -491,15 +544,17 @@ extern "C" int32_t atspeed_llama_logits_ld(const atspeed_llama* m) { return m ? 
 
 extern "C" int atspeed_llama_enable_fp8(atspeed_llama* m, void* stream) {
   ATS_REQUIRE(m, ATSPEED_ERR_INVALID, "enable_fp8: null model");
-  ATS_REQUIRE(m->cfg.dtype == ATSPEED_BF16, ATSPEED_ERR_INVALID, "enable_fp8: the model must hold bf16 weights");
+  // bf16 or fp16 weights (round 6: the reference loads fp16 checkpoints and runs the target 8-bit, code/inference.py:75-91): the e4m3 copies are
+  // made from the model's own 16-bit values by the quantisation kernel of its flavour, the activations between the W8A8 projections stay in that type
+  ATS_REQUIRE(m->cfg.dtype == ATSPEED_BF16 || m->cfg.dtype == ATSPEED_F16, ATSPEED_ERR_INVALID, "enable_fp8: the model must hold bf16 or fp16 weights");
   ATS_REQUIRE(m->cfg.hidden % 256 == 0 && m->cfg.ffn % 256 == 0, ATSPEED_ERR_INVALID, "enable_fp8: hidden and ffn must be multiples of 256");
   if (!m->fp8.empty()) return ATSPEED_OK;
   hipStream_t st = (hipStream_t)stream;
   const int H = m->cfg.hidden, F = m->cfg.ffn;
-  auto quant = [&](const void* w, int rows, int cols, void** q, float** sc) -> int {     // packed bf16 rows -> packed e4m3 rows (or row-major both)
+  auto quant = [&](const void* w, int rows, int cols, void** q, float** sc) -> int {     // packed 16-bit rows -> packed e4m3 rows (or row-major both)
     ATS_HIP(hipMalloc(q, (size_t)((rows + 1) & ~1) * cols));
     ATS_HIP(hipMalloc((void**)sc, (size_t)rows * sizeof(float)));
-    return ats_bf16::ats_quant_rows_fp8(w, rows, cols, cols, *q, *sc, st, m->pk);
+    return ATS_KD(m->cfg.dtype, ats_quant_rows_fp8(w, rows, cols, cols, *q, *sc, st, m->pk));
   };
   m->fp8.resize(m->cfg.n_layers);
   for (int l = 0; l < m->cfg.n_layers; ++l) {
@@ -536,14 +591,14 @@ static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits
   }
   if (m->prof_on) prof_harvest(m);
   if (m->fwd_log_on && m->fwd_log.size() < 2 * 4096) { m->fwd_log.push_back(T); m->fwd_log.push_back(t.total_logit); }
+  sk_arena_lazy(m, T, st);
   // the table travels through the pinned ring to its fixed device address (stream ordered behind the previous forward)
   ATS_TRY(ats_stage_to(&t, sizeof(t), cx->segtab_dev, st));
   const SegTable* dtab = cx->segtab_dev;
   // opt-in (ATSPEED_GRAPHS=1): measured on MI355X, replaying a 100-token forward as one hipGraph does not shorten it (676 vs 679
   // items/s in the one-user-at-a-time loop) -- the ~10 us between dependent kernels is the GPU's own barrier / cache-flush latency,
   // not host launch cost, and a graph keeps every node boundary
-  const char* ge = getenv("ATSPEED_GRAPHS");                       // read per forward: the tests compare both modes in one process
-  const int use_graphs = ge ? atoi(ge) : 0;
+  const int use_graphs = ats_switch(ATS_SW_GRAPHS);                // (atspeed_set_switch("graphs", 1): the tests compare both modes in one process)
   static const int graph_max_tok = getenv("ATSPEED_GRAPH_MAX_TOKENS") ? atoi(getenv("ATSPEED_GRAPH_MAX_TOKENS")) : 512;
   if (use_graphs && !m->prof_on && logits_out == nullptr && T <= graph_max_tok) {
     const ActCtx::GraphKey key(T, t.total_logit, t.n, t.n_qtiles, t.qtile_rows, m->fp8.empty() ? 0 : 1);

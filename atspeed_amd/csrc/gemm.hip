@@ -49,7 +49,6 @@ static bool big_use_256_rows(int t256, int t128) { return big_rounds(t256) <= 0.
 // (82 us for a 256-row tile at K = 4096 and 172 tiles, 94 at 240; 42 / 50 / 64 us for a 128-row one at 160 / 192 / 240) -- and a seam costs
 // 22 / 38 / 46 us (256 KB slots) or 14 / 24 / 27 us (128 KB slots) for 2 / 3 / 4 parts: second prologue, dump, ticket, the finisher's reads.
 struct SkPlan { bool on; int n_dp, G, U, TU, parts; };
-static int env_now(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }   // read per call: tools flip these in-process
 static SkPlan sk_plan_s(int tiles, int k, int S) {
   SkPlan p{false, 0, 0, 0, 0, 1};
   p.U = k / 128;
@@ -60,9 +59,10 @@ static SkPlan sk_plan_s(int tiles, int k, int S) {
   p.G = R * S;
   p.parts = S;
   p.on = true;
-  // test hook (tests/test_kernels_gpu.py): an UNALIGNED deal of the tail's k-units over G workgroups -- a workgroup then ends one tile and starts the next,
-  // the kernel's segment loop and second slot, which no plan of the launcher uses (they lost to the aligned plans, see above) but the kernel keeps
-  const int g_env = env_now("ATSPEED_GEMM_SK_G", 0);
+  // test hook (tests/test_kernels_gpu.py, atspeed_set_switch("gemm_sk_g", G); no environment variable): an UNALIGNED deal of the tail's k-units over G
+  // workgroups -- a workgroup then ends one tile and starts the next, the kernel's segment loop and second slot, which no plan of the launcher uses
+  // (they lost to the aligned plans, see above) but the kernel keeps
+  const int g_env = ats_switch(ATS_SW_GEMM_SK_G);
   if (g_env >= R && g_env <= 256 && g_env <= p.TU) p.G = g_env;     // (G >= R: a workgroup's range never spans more than two tiles)
   return p;
 }
@@ -70,7 +70,7 @@ static float ring_tile_us(int k, bool rows256, int concurrent) {
   return 1e-3f * (float)k * ((rows256 ? 14.5f : 7.f) + 7.5f * (float)concurrent / 256.f);
 }
 static float sk_cost_us(int tiles, int k, bool rows256, SkPlan* plan_out) {
-  const int mode = env_now("ATSPEED_GEMM_SK", 1);                  // 0: off, 1: cost model, 2-4: that many parts wherever they fit
+  const int mode = ats_switch(ATS_SW_GEMM_SK);                     // 0: off, 1: cost model, 2-4: that many parts wherever they fit
   const int full = tiles / 256, R = tiles % 256;
   const float whole = (float)full * ring_tile_us(k, rows256, 256);
   if (plan_out) *plan_out = SkPlan{false, 0, 0, 0, 0, 1};
@@ -90,12 +90,12 @@ static float sk_cost_us(int tiles, int k, bool rows256, SkPlan* plan_out) {
 // tile height and split decision of a ring-kernel launch
 struct BigChoice { bool rows256; SkPlan sk; };
 static BigChoice big_choose(int t256, int t128, int k) {
-  const int force_mt = env_now("ATSPEED_GEMM_FORCE_MT", 0);        // tuning: 8 / 4 = always 256- / 128-row token tiles
+  const int force_mt = ats_switch(ATS_SW_GEMM_FORCE_MT);           // tuning: 8 / 4 = always 256- / 128-row token tiles
   BigChoice c;
   SkPlan p256, p128;
   const float c256 = sk_cost_us(t256, k, true, &p256), c128 = sk_cost_us(t128, k, false, &p128);
   c.rows256 = force_mt ? force_mt == 8 : c256 <= c128;
-  if (!force_mt && env_now("ATSPEED_GEMM_SK", 1) >= 2 && p256.on != p128.on) c.rows256 = p256.on;   // forced tail (tests, sweeps): the height that has a plan
+  if (!force_mt && ats_switch(ATS_SW_GEMM_SK) >= 2 && p256.on != p128.on) c.rows256 = p256.on;   // forced tail (tests, sweeps): the height that has a plan
   c.sk = c.rows256 ? p256 : p128;
   return c;
 }
@@ -1643,7 +1643,15 @@ typedef int i32x8_t __attribute__((ext_vector_type(8)));
 template <int BM, int BN, int NST, int EPI, bool SPLIT = false, int WM = 2, bool F8 = false>
 __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restrict__ X, const void* __restrict__ W, void* __restrict__ Cv,
                                                              int M, int N, int K, int ldx, int ldc, int pk, int n_split,
-                                                             const float* __restrict__ sx = nullptr, const float* __restrict__ sw = nullptr) {
+                                                             const float* __restrict__ sx = nullptr, const float* __restrict__ sw = nullptr,
+                                                             RopeEpi rope = RopeEpi{}) {
+  // EPI_QKV_ROPE (round 6; one user's W8A8 qkv projection at head_dim 128, 64-row weight tiles, no split): RoPE and the KV-cache scatter in
+  // the epilogue, as in the ring kernels' EPI_QKV_ROPE.  A rotation pairs columns d and d + 64 of a head, and a 64-row tile cannot hold a whole
+  // head; since the DMA's per-lane source address is free, tile t (0 / 1) of a head takes the weight rows {32 t + 16 wn + q, 64 + 32 t + 16 wn + q}
+  // (wn = the wave's half of the tile, q < 16) laid out so that a lane's accumulators acc[0][j][r] and acc[1][j][r] ARE the pair (d, d + 64):
+  // no exchange between lanes or waves.  Numerics = the plain store + rope_kv_segs_vec_kernel: the projection rounded to the 16-bit type,
+  // the rotation in fp32 on those values (rope_first / rope_second), one more rounding -- bit-identical (tests/test_closures_gpu.py).
+  static_assert(EPI != EPI_QKV_ROPE || (F8 && !SPLIT && BN == 64), "RoPE epilogue: the W8A8 no-split form with 64-row weight tiles");
   constexpr int RB = 128, STAGE = (BM + BN) * RB, NWAVE = 2 * WM;
   constexpr int ESZ = F8 ? 1 : 2, BK = RB / ESZ;                       // k per stage: 64 (16-bit) or 128 (e4m3)
   constexpr int NPIECE = (BM + BN) / 8, NP = NPIECE / NWAVE;           // 1 KB pieces per stage; per wave
@@ -1669,7 +1677,12 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restr
   for (int j = 0; j < NP; ++j) {
     const int piece = wave * NP + j, row = piece * 8 + (lane >> 3), pos = lane & 7, c = pos ^ (row & 7);
     const bool w = row >= BM;                                          // uniform per piece (BM % 8 == 0)
-    const int gr = w ? min(n0 + row - BM, N - 1) : min(row, M - 1);
+    int wr = n0 + row - BM;                                            // weight row of this LDS row
+    if constexpr (EPI == EPI_QKV_ROPE) {
+      const int rw = row - BM;                                         // LDS row (wn, i, q) = (rw >> 5, (rw >> 4) & 1, rw & 15) -> column i * 64 + 32 t + 16 wn + q of the head
+      wr = (int)(blockIdx.x >> 1) * 128 + ((rw >> 4) & 1) * 64 + (int)(blockIdx.x & 1) * 32 + (rw >> 5) * 16 + (rw & 15);
+    }
+    const int gr = w ? min(wr, N - 1) : min(row, M - 1);
     const unsigned ldb = (w ? (unsigned)K : (unsigned)ldx) * ESZ;      // row bytes
     voff[j] = pk ? (unsigned)(gr >> 1) * (ldb * 2u) + (gr & 1) * 64 + (unsigned)(c >> 2) * 128 + (c & 3) * 16 : (unsigned)gr * ldb + c * 16;
     m0p[j] = __builtin_amdgcn_readfirstlane((int)lbase + piece * 1024);
@@ -1735,6 +1748,11 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restr
   // epilogue: acc[i][j][r] = C[m][n] with m = wm*BM/WM + j*16 + lq (token row), n = n0 + wn*BN/2 + i*16 + g*4 + r (weight row): a lane
   // holds four adjacent output columns of one token row
   const int nw = n0 + wn * (BN / 2);
+  // weight row (= output column) of acc[i][.][r]
+  auto wcol = [&](int i, int r) {
+    if constexpr (EPI == EPI_QKV_ROPE) return (int)(blockIdx.x >> 1) * 128 + i * 64 + (int)(blockIdx.x & 1) * 32 + wn * 16 + g * 4 + r;
+    else return nw + i * 16 + g * 4 + r;
+  };
   if constexpr (F8) {                                                  // W8A8: per-token x per-output-row scales on the accumulators
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
@@ -1742,8 +1760,42 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restr
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] *= fx * sw[min(nw + i * 16 + g * 4 + r, N - 1)];
+        for (int r = 0; r < 4; ++r) acc[i][j][r] *= fx * sw[min(wcol(i, r), N - 1)];
     }
+  }
+  if constexpr (EPI == EPI_QKV_ROPE) {
+    static_assert(NI == 2, "a lane holds the pair (d, d + 64) in its two weight tiles");
+    bf16_t* qkv = reinterpret_cast<bf16_t*>(Cv);
+    const int H = rope.hidden;
+    const int hb = (int)(blockIdx.x >> 1) * 128;                       // the head's first column in [q | k | v]
+    const int sec = hb / H, fsec = hb - sec * H;                       // 0 q, 1 k, 2 v (uniform over the workgroup); the head's first column inside it
+    const int d0 = (int)(blockIdx.x & 1) * 32 + wn * 16 + g * 4;       // pair index of r = 0: this lane owns d0 .. d0 + 3 and their partners 64 further
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int gm = wm * (BM / WM) + j * 16 + lq;
+      if (gm >= M) continue;
+      const RowInfo ri = rope.rows[gm];
+      const uint32_t a01 = f2bf_pk(acc[0][j][0], acc[0][j][1]), a23 = f2bf_pk(acc[0][j][2], acc[0][j][3]);     // x[d]: the projection's 16-bit outputs
+      const uint32_t b01 = f2bf_pk(acc[1][j][0], acc[1][j][1]), b23 = f2bf_pk(acc[1][j][2], acc[1][j][3]);     // x[d + 64]
+      if (sec == 2) {
+        bf16_t* dst = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.vc) + rope.layer_off) + (size_t)ri.slot * H + fsec + d0;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(a01, a23);
+        *reinterpret_cast<uint2*>(dst + 64) = make_uint2(b01, b23);
+      } else {
+        const float4 c = *reinterpret_cast<const float4*>(rope.cos_tab + (size_t)ri.pos * 64 + d0);
+        const float4 sn = *reinterpret_cast<const float4*>(rope.sin_tab + (size_t)ri.pos * 64 + d0);
+        uint2 o0, o1;
+        o0.x = f2bf_pk(rope_first(bf_lo(a01), bf_lo(b01), c.x, sn.x), rope_first(bf_hi(a01), bf_hi(b01), c.y, sn.y));
+        o0.y = f2bf_pk(rope_first(bf_lo(a23), bf_lo(b23), c.z, sn.z), rope_first(bf_hi(a23), bf_hi(b23), c.w, sn.w));
+        o1.x = f2bf_pk(rope_second(bf_lo(a01), bf_lo(b01), c.x, sn.x), rope_second(bf_hi(a01), bf_hi(b01), c.y, sn.y));
+        o1.y = f2bf_pk(rope_second(bf_lo(a23), bf_lo(b23), c.z, sn.z), rope_second(bf_hi(a23), bf_hi(b23), c.w, sn.w));
+        bf16_t* dst = (sec == 0 ? qkv + (size_t)gm * ldc
+                                : reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.kc) + rope.layer_off) + (size_t)ri.slot * H) + fsec + d0;
+        *reinterpret_cast<uint2*>(dst) = o0;
+        *reinterpret_cast<uint2*>(dst + 64) = o1;
+      }
+    }
+    return;
   }
   if constexpr (SPLIT) {
     float* P = reinterpret_cast<float*>(Cv) + (size_t)blockIdx.y * M * N;
@@ -1794,7 +1846,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restr
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (gn + r < N) C[r] = acc[i][j][r];
         } else {
-          static_assert(EPI == EPI_STORE || EPI == EPI_SWIGLU || EPI == EPI_F32, "store / fp32 / SwiGLU");
+          static_assert(EPI == EPI_STORE || EPI == EPI_SWIGLU || EPI == EPI_F32 || EPI == EPI_QKV_ROPE, "store / fp32 / SwiGLU (the RoPE epilogue returned above)");
           bf16_t* C = reinterpret_cast<bf16_t*>(Cv) + (size_t)gm * ldc + gn;
           if (gn + 3 < N && (ldc & 3) == 0) *reinterpret_cast<uint2*>(C) = make_uint2(f2bf_pk(acc[i][j][0], acc[i][j][1]), f2bf_pk(acc[i][j][2], acc[i][j][3]));
           else
@@ -1885,6 +1937,7 @@ int reduce_splits(const float* partial, void* c, int m, int n, int ldc, int spli
 // more (rows x row bytes) does not fit and takes the LDS-tiled kernel (64-bit pointers) instead
 static bool dma_offsets_fit(long long rows, long long ld_elems, int esz) { return (rows + 1) * ld_elems * esz <= 0xffffffffll; }
 
+static bool panel_applies(int m, int n, int k, int lda);
 static int ring_split_count(int m, int n, int k) {
   constexpr int min_m = 33, max_m = 512;
   // measured (tools/yardstick_small.py, cold weights): wins 5-15 % over the LDS-tiled kernel on the wide projections (qkv, gate_up) at
@@ -1921,6 +1974,46 @@ int launch_ring_split(const bf16_t* a, const bf16_t* w, void* c, int m, int n, i
   ats_count_path(ATS_PATH_RING_SPLIT);
   if (c == nullptr) return ATSPEED_OK;          // partials only: the caller's next kernel sums the slabs itself (ats_gemm_partials)
   return reduce_splits<bf16_t, EPI>(partial, c, m, n, ldc, splits, st, fn, pk);
+}
+
+// ---- K-cut form of the ring kernel for the bf16 / fp16 N <= 4096 projections (o_proj, down) at 257-1100 tokens (round 6; 4-16 users in lock
+// step: K-token continuation forwards x users, beamSD.py:579-588).  Their 256-wide tile grid is 16 x 2-9 tiles on 256 CUs; the in-launch
+// split-K tail spreads the k-steps but pays a seam per tile, the panel form covers 257-384 tokens only.  This is the plain form that won in fp8
+// (gemm_ring_mx_kernel<..., SPLITK>, round 5): grid = tiles x parts ~ one round of 256 workgroups, part z takes its share of the 128-k units
+// (>= 4 units = 512 k per part), 128-row token tiles while two parts of them fit a round (else 256-row ones), fp32 slabs [z][M][N] in the
+// caller's workspace, finished by the reduce kernels of every other split form (splitk_resid_rmsnorm_kernel fuses residual + next RMSNorm).
+// Switch "gemm_kcut" (ATSPEED_GEMM_KCUT): 0 off, 1 where the panel form does not apply, 2 before the panel form too (A/B).
+static int kcut_split_count(int m, int n, int k, int lda, bool* rows256 = nullptr) {
+  if (m < 257 || m > 1100 || n > 4096) return 0;                       // (cheap guards first: every GEMM of every forward passes through here)
+  const int on = ats_switch(ATS_SW_GEMM_KCUT);
+  if (!on || n < 1024 || k % 128 != 0 || k < 2048 || (lda % 8) != 0 || (n % 4) != 0 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return 0;
+  if (on < 2 && panel_applies(m, n, k, lda)) return 0;
+  const int tn = (n + 255) / 256, t256 = tn * ((m + 255) / 256), t128 = tn * ((m + 127) / 128);
+  const bool r256 = t128 > 128;
+  const int tiles = r256 ? t256 : t128;
+  if (rows256) *rows256 = r256;
+  const int s_ = std::min(256 / tiles, (k / 128) / 4);
+  return s_ >= 2 ? s_ : 0;
+}
+static int launch_ring_kcut(const bf16_t* a, const bf16_t* w, float* partial, int m, int n, int k, int lda, int splits, bool rows256, hipStream_t st, int pk) {
+  static thread_local AtsPerDeviceFlag attr_flag;
+  bool& attr_done = attr_flag.cur();
+  if (!attr_done) {
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI_F32, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    ATS_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI_F32, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_done = true;
+  }
+  const int tiles_n = (n + 255) / 256, tiles_m = rows256 ? (m + 255) / 256 : (m + 127) / 128;
+  const float* none = nullptr;
+  if (rows256)
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 8, false, true>), dim3(tiles_n * tiles_m * splits), dim3(512), 128 * 1024, st, (const void*)a, (const void*)w,
+                       none, none, (void*)partial, m, n, k, lda, n, tiles_n, tiles_m, 4, splits, (float*)nullptr, (const unsigned char*)nullptr, pk);
+  else
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 4, false, true>), dim3(tiles_n * tiles_m * splits), dim3(512), 96 * 1024, st, (const void*)a, (const void*)w,
+                       none, none, (void*)partial, m, n, k, lda, n, tiles_n, tiles_m, 4, splits, (float*)nullptr, (const unsigned char*)nullptr, pk);
+  ATS_LAUNCH_CHECK();
+  ats_count_path(ATS_PATH_RING_SPLIT);
+  return ATSPEED_OK;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int EPI>
@@ -1971,7 +2064,7 @@ int launch_wdma_cfg(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int
     ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN), dim3(128 * WM), lds, st, (const void*)a, (const void*)w, c, m, n, k, lda, ldc, pk, 1, (const float*)nullptr, (const float*)nullptr);
+  hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN), dim3(128 * WM), lds, st, (const void*)a, (const void*)w, c, m, n, k, lda, ldc, pk, 1, (const float*)nullptr, (const float*)nullptr, RopeEpi{});
   ATS_LAUNCH_CHECK();
   ats_count_path(ATS_PATH_WDMA);
   return ATSPEED_OK;
@@ -1999,7 +2092,7 @@ int launch_wdma_split_cfg(const bf16_t* a, const bf16_t* w, float* partial, int 
     ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((n + 127) / 128, splits), dim3(128 * WM), lds, st, (const void*)a, (const void*)w, (void*)partial, m, n, k, lda, n, pk, splits, (const float*)nullptr, (const float*)nullptr);
+  hipLaunchKernelGGL(kern, dim3((n + 127) / 128, splits), dim3(128 * WM), lds, st, (const void*)a, (const void*)w, (void*)partial, m, n, k, lda, n, pk, splits, (const float*)nullptr, (const float*)nullptr, RopeEpi{});
   ATS_LAUNCH_CHECK();
   ats_count_path(ATS_PATH_WDMA_SPLIT);
   return ATSPEED_OK;
@@ -2036,8 +2129,9 @@ int launch_wdma(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, 
 // 172 workgroups at ~4.8 TF each is what this form gives: the band stays MFMA-inefficient (0.33 of nominal at 320 tokens), see DESIGN section 9.
 static int panel_split_count(int n, int k);
 static bool panel_applies(int m, int n, int k, int lda) {
-  const int on = env_now("ATSPEED_GEMM_PANEL", 1);                     // read per call: tools/panel_sweep.py flips it in-process
-  if (!on || m < 257 || m > 384 || k % 128 != 0 || k < 2048 || (lda % 8) != 0 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return false;
+  if (m < 257 || m > 384) return false;                                // (the cheap guard first: every one-user GEMM passes through here)
+  const int on = ats_switch(ATS_SW_GEMM_PANEL);                        // tools/panel_sweep.py flips it in-process (atspeed_set_switch)
+  if (!on || k % 128 != 0 || k < 2048 || (lda % 8) != 0 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return false;
   const int t128 = (n + 127) / 128;
   if (t128 > 256 || t128 < 16) return false;                           // (K >= 2048: the target's projections; a 68M draft's thin GEMMs stay where they were)
   if (on >= 2) return true;                                            // 2: every shape the kernel can take (tests, sweeps)
@@ -2078,6 +2172,14 @@ static int launch_panel_split(const bf16_t* x, const bf16_t* w, float* partial, 
 template <typename T, int EPI>
 int launch_epi(const T* a, const T* w, void* c, int m, int n, int k, int lda, int ldc, float* partial, size_t ws_bytes,
                hipStream_t st, FusedNorm* fn, int pk) {
+  if constexpr (sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_F32 || EPI == EPI_RESID)) {
+    bool r256 = false;
+    const int ks = kcut_split_count(m, n, k, lda, &r256);
+    if (ks >= 2 && (size_t)ks * m * n * sizeof(float) <= ws_bytes && ((uintptr_t)partial & 15) == 0) {
+      ATS_TRY(launch_ring_kcut(a, w, partial, m, n, k, lda, ks, r256, st, pk));
+      return reduce_splits<bf16_t, EPI>(partial, c, m, n, ldc, ks, st, fn, pk);
+    }
+  }
   if constexpr (sizeof(T) == 2) {
     if (panel_applies(m, n, k, lda) && (EPI != EPI_SWIGLU || (n % 32 == 0 && (ldc & 3) == 0))) {
       const int ps = panel_split_count(n, k);
@@ -2140,10 +2242,17 @@ size_t ats_gemm_workspace_bytes(int m, int n, int k, int dtype) {
   if (dtype == ATS_HALF) b = std::max(b, (size_t)ring_split_count(m, n, k) * m * n * sizeof(float));
   if (dtype == ATS_HALF) b = std::max(b, (size_t)wdma_split_count(m, n, k, k) * m * n * sizeof(float));
   if (dtype == ATS_HALF && panel_applies(m, n, k, k) && panel_split_count(n, k) > 1) b = std::max(b, (size_t)panel_split_count(n, k) * m * n * sizeof(float));
+  if (dtype == ATS_HALF) b = std::max(b, (size_t)kcut_split_count(m, n, k, k) * m * n * sizeof(float));
   return b;
 }
 
-static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype, int epilogue);
+static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype, int epilogue, bool lm_head = false);
+// does this launch take the K-cut form (launch_epi)?  Then the ring kernel's dispatch (big_kernel_applies) does not get it.
+static bool kcut_takes(int m, int n, int k, int lda, int dtype, int epilogue, const void* ws, size_t ws_bytes) {
+  if (dtype != ATS_HALF || !(epilogue == EPI_STORE || epilogue == EPI_F32 || epilogue == EPI_RESID)) return false;
+  const int ks = kcut_split_count(m, n, k, lda);
+  return ks >= 2 && ws && ((uintptr_t)ws & 15) == 0 && (size_t)ks * m * n * sizeof(float) <= ws_bytes;
+}
 
 // One user's wide bf16 projection as fp32 split-K slabs [splits][m][n] in the workspace, WITHOUT the reduce pass: the consumer sums the
 // slabs while it reads them (RoPE + KV scatter after the qkv projection: one launch less per layer).  *splits_out = 0 when this shape does
@@ -2195,7 +2304,7 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
   ATS_REQUIRE(epilogue != EPI_SWIGLU || n % 32 == 0, ATSPEED_ERR_INVALID, "gemm: SwiGLU needs N %% 32 == 0 (N=%d)", n);
   if (dtype == ATSPEED_F32) return launch_typed<float>(a, w, c, m, n, k, lda, ldc, epilogue, workspace, workspace_bytes, st, 0);
   if (dtype == ATS_HALF) {
-    if (big_kernel_applies(m, n, k, lda, ldc, dtype, epilogue)) {
+    if (!kcut_takes(m, n, k, lda, dtype, epilogue, workspace, workspace_bytes) && big_kernel_applies(m, n, k, lda, ldc, dtype, epilogue)) {
       const bf16_t* X = (const bf16_t*)a; const bf16_t* Wt = (const bf16_t*)w;
       switch (epilogue) {
         case EPI_STORE:  return launch_big<EPI_STORE>(X, Wt, c, m, n, k, lda, ldc, st, pk, RopeEpi{}, nullptr, nullptr, sk);
@@ -2211,8 +2320,7 @@ int ats_gemm(const void* a, const void* w, void* c, int m, int n, int k, int lda
 }
 
 bool ats_gemm_qkv_rope_applies(int m, int hidden, int head_dim, int dtype) {
-  const char* e = getenv("ATSPEED_FUSE_QKV_ROPE");                 // read per forward: tests compare both paths in one process
-  return !(e && atoi(e) == 0) && dtype == ATS_HALF && head_dim == 128 && hidden % 256 == 0 && big_kernel_applies(m, 3 * hidden, hidden, hidden, 3 * hidden, dtype, EPI_STORE);
+  return ats_switch(ATS_SW_FUSE_QKV_ROPE) != 0 && dtype == ATS_HALF && head_dim == 128 && hidden % 256 == 0 && big_kernel_applies(m, 3 * hidden, hidden, hidden, 3 * hidden, dtype, EPI_STORE);
 }
 
 int ats_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, int m, int hidden, const RopeEpi& rope, hipStream_t st, int pk, const SkArena* sk) {
@@ -2235,7 +2343,7 @@ int ats_lmhead_lse(const void* a, const void* w, float* logits, int m, int n, in
   if (fused_out) *fused_out = 0;
   if (m <= 0) return ATSPEED_OK;
   if (fuse && dtype == ATS_HALF && part && part_bytes >= ats_lmhead_lse_part_bytes(m, n) && ((uintptr_t)part & 7) == 0 &&
-      big_kernel_applies(m, n, k, lda, ldc, dtype, EPI_F32)) {
+      big_kernel_applies(m, n, k, lda, ldc, dtype, EPI_F32, true)) {
     ATS_REQUIRE(a && w && logits && lse, ATSPEED_ERR_INVALID, "lmhead_lse: null operand");
     ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "lmhead_lse: operands must be 16-byte aligned");
     if (fused_out) *fused_out = 1;
@@ -2246,7 +2354,7 @@ int ats_lmhead_lse(const void* a, const void* w, float* logits, int m, int n, in
 }
 
 // h += a * w^T, then xn = rmsnorm(h) * norm_w  (split-K path fuses the reduce, the residual and the norm)
-static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype, int epilogue) {
+static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype, int epilogue, bool lm_head) {
   // the 256-wide ring kernel vs the 128-wide LDS-tiled kernel (with split-K): the ring kernel wins once its tile grid keeps
   // a fair share of the 256 CUs busy (measured, tools/gemm_ab.py with ATSPEED_GEMM_BIG_MIN_FILL)
   // from 257 tokens (two token tiles): measured against the split-K mode at 300-500 tokens, gate_up 115-138 -> 96-108 us, qkv 80 -> 75 us
@@ -2254,7 +2362,10 @@ static bool big_kernel_applies(int m, int n, int k, int lda, int ldc, int dtype,
   constexpr int min_fill = 60;   // crossover measured at ~50-60 % (o_proj, down, qkv, gate_up at 512-1920 tokens)
   if (dtype != ATS_HALF || m < big_min_m || k % 128 != 0 || (lda % 8) != 0 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return false;
   if (epilogue == EPI_SWIGLU && ((ldc & 3) != 0 || n % 32 != 0)) return false;
-  if (panel_applies(m, n, k, lda)) return false;                       // 257-512 tokens on a projection of 16-256 panels: the panel form (launch_epi)
+  // 257-384 tokens on a projection of 16-256 panels: the panel form (launch_epi).  Not the lm_head with the fused normaliser (a vocabulary of
+  // 150-256 panels, e.g. the stock 32000, at 257-352 logit rows would leave the fused-LSE / tile_store ring path for panel<EPI_F32> + a separate LSE pass,
+  // a regime the panel sweep never measured; Beauty's 32859 misses the band by one panel)
+  if (!lm_head && panel_applies(m, n, k, lda)) return false;
   const int tn = (n + 255) / 256;
   if (big_fill_pct(tn * ((m + 255) / 256)) >= min_fill || big_fill_pct(tn * ((m + 127) / 128)) >= min_fill) return true;
   // a thin grid whose k-steps the split-K tail spreads over the chip: from 48 tiles of 128 rows (four parts per tile on 192 CUs; N = 4096
@@ -2270,7 +2381,7 @@ int ats_gemm_resid_norm(const void* a, const void* w, void* h, int m, int n, int
   if (m <= 0) return ATSPEED_OK;
   FusedNorm fn{norm_w, xn, eps, false};
   int epc = dtype == ATSPEED_F32 ? 4 : 8;
-  if (!big_kernel_applies(m, n, k, lda, ldh, dtype, EPI_RESID) && k % epc == 0 && lda % epc == 0) {
+  if ((kcut_takes(m, n, k, lda, dtype, EPI_RESID, workspace, workspace_bytes) || !big_kernel_applies(m, n, k, lda, ldh, dtype, EPI_RESID)) && k % epc == 0 && lda % epc == 0) {
     int rc;
     if (dtype == ATSPEED_F32)
       rc = launch_epi<float, EPI_RESID>((const float*)a, (const float*)w, h, m, n, k, lda, ldh, (float*)workspace, workspace_bytes, st, &fn, 0);
@@ -2345,7 +2456,7 @@ static int wdma8_split_count(int n, int k) {                           // 1: no 
 }
 template <int BM, int NST, int EPI, bool SPLIT, int WM = 2, int BN = 128>
 int launch_wdma8_cfg(const unsigned char* xq, const float* sx, const unsigned char* wq, const float* sw, void* c, int m, int n, int k, int ldc,
-                     int splits, hipStream_t st, int pk) {
+                     int splits, hipStream_t st, int pk, const RopeEpi& rope = RopeEpi{}) {
   auto kern = gemm_wdma_kernel<BM, BN, NST, EPI, SPLIT, WM, true>;
   constexpr int lds = NST * (BM + BN) * 128;
   static thread_local AtsPerDeviceFlag attr_flag;
@@ -2354,26 +2465,29 @@ int launch_wdma8_cfg(const unsigned char* xq, const float* sx, const unsigned ch
     ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN, SPLIT ? splits : 1), dim3(128 * WM), lds, st, (const void*)xq, (const void*)wq, c, m, n, k, k, ldc, pk, splits, sx, sw);
+  hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN, SPLIT ? splits : 1), dim3(128 * WM), lds, st, (const void*)xq, (const void*)wq, c, m, n, k, k, ldc, pk, splits, sx, sw, rope);
   ATS_LAUNCH_CHECK();
   ats_count_path(SPLIT ? ATS_PATH_FP8_WDMA_SPLIT : ATS_PATH_FP8_WDMA);
   return ATSPEED_OK;
 }
 template <int EPI, bool SPLIT>
 int launch_wdma8(const unsigned char* xq, const float* sx, const unsigned char* wq, const float* sw, void* c, int m, int n, int k, int ldc,
-                 int splits, hipStream_t st, int pk) {
+                 int splits, hipStream_t st, int pk, const RopeEpi& rope = RopeEpi{}) {
   {
-    if (wdma8_bn64(n)) {
-      if (m <= 32)  return launch_wdma8_cfg<32, 8, EPI, SPLIT, 2, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);     // 12 KB x 8
-      if (m <= 64)  return launch_wdma8_cfg<64, 8, EPI, SPLIT, 2, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);     // 16 KB x 8
-      if (m <= 128) return launch_wdma8_cfg<128, 6, EPI, SPLIT, 2, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);    // 24 KB x 6
-      return launch_wdma8_cfg<256, 4, EPI, SPLIT, 4, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);                  // 40 KB x 4, 8 waves
+    if (EPI == EPI_QKV_ROPE || wdma8_bn64(n)) {                        // (the RoPE epilogue exists for 64-row tiles only: the caller asked ats_gemm_fp8_qkv_rope_applies)
+      if (m <= 32)  return launch_wdma8_cfg<32, 8, EPI, SPLIT, 2, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk, rope);     // 12 KB x 8
+      if (m <= 64)  return launch_wdma8_cfg<64, 8, EPI, SPLIT, 2, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk, rope);     // 16 KB x 8
+      if (m <= 128) return launch_wdma8_cfg<128, 6, EPI, SPLIT, 2, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk, rope);    // 24 KB x 6
+      return launch_wdma8_cfg<256, 4, EPI, SPLIT, 4, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk, rope);                  // 40 KB x 4, 8 waves
     }
   }
+  if constexpr (EPI == EPI_QKV_ROPE) return ATSPEED_ERR_INVALID;
+  else {
   if (m <= 32)  return launch_wdma8_cfg<32, 6, EPI, SPLIT>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);        // 20 KB x 6
   if (m <= 64)  return launch_wdma8_cfg<64, 6, EPI, SPLIT>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);        // 24 KB x 6
   if (m <= 128) return launch_wdma8_cfg<128, 4, EPI, SPLIT>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);       // 32 KB x 4
   return launch_wdma8_cfg<256, 3, EPI, SPLIT, 4>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk);                  // 48 KB x 3, 8 waves
+  }
 }
 // the slabs of a split launch: [splits][m][n] fp32 in `ws`
 static bool wdma8_ws_ok(int m, int n, int splits, const void* ws, size_t ws_bytes) {
@@ -2412,6 +2526,8 @@ int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* s
       atspeed_set_error("gemm_fp8: unknown epilogue %d", epilogue);
       return ATSPEED_ERR_INVALID;
     }
+    if (!wdma8_ws_ok(m, n, s_, ws, ws_bytes) && epilogue == EPI_RESID && k % 256 == 0)       // residual epilogue without room for the slabs: the ring kernel's own (as before round 5)
+      return launch_big_fp8<EPI_RESID>(X, sx, Wq, sw, c, m, n, k, ldc, st, pk);
     ATS_REQUIRE(wdma8_ws_ok(m, n, s_, ws, ws_bytes), ATSPEED_ERR_CAPACITY, "gemm_fp8: %d x %d x %d parts of fp32 partial sums do not fit the workspace (%zu bytes)", s_, m, n, ws_bytes);
     ATS_TRY((launch_wdma8<EPI_F32, true>(X, sx, Wq, sw, ws, m, n, k, n, s_, st, pk)));
     switch (epilogue) {
@@ -2500,8 +2616,10 @@ int ats_gemm_fp8_resid_norm(const void* xq, const float* sx, const void* wq, con
 // the fp8 qkv projection with RoPE + the KV scatter in its epilogue (see ats_gemm_qkv_rope); the caller checks ats_gemm_fp8_applies,
 // head_dim == 128 and hidden % 256 == 0 (ats_gemm_fp8_qkv_rope_applies)
 bool ats_gemm_fp8_qkv_rope_applies(int m, int hidden, int head_dim) {
-  const char* e = getenv("ATSPEED_FUSE_QKV_ROPE");
-  return !(e && atoi(e) == 0) && m >= 257 && head_dim == 128 && hidden % 256 == 0 && ats_gemm_fp8_applies(m, 3 * hidden, hidden, 3 * hidden, EPI_STORE);   // the ring kernel's epilogue
+  if (!ats_switch(ATS_SW_FUSE_QKV_ROPE) || m < 1 || head_dim != 128 || hidden % 256 != 0) return false;
+  // one user's tokens: the weight-streaming kernel's epilogue, where the projection runs as 150-256 unsplit tiles of 64 weight rows (Llama-7B: 192)
+  if (m <= 256) return wdma8_applies(m, 3 * hidden, hidden) && wdma8_bn64(3 * hidden) && wdma8_split_count(3 * hidden, hidden) == 1 && (3 * hidden + 63) / 64 <= 256;
+  return ats_gemm_fp8_applies(m, 3 * hidden, hidden, 3 * hidden, EPI_STORE);   // the ring kernel's epilogue
 }
 
 int ats_gemm_fp8_qkv_rope(const void* xq, const float* sx, const void* wq, const float* sw, void* qkv, int m, int hidden, const RopeEpi& rope,
@@ -2509,6 +2627,11 @@ int ats_gemm_fp8_qkv_rope(const void* xq, const float* sx, const void* wq, const
   ATS_REQUIRE(xq && sx && wq && sw && qkv && rope.rows && rope.cos_tab && rope.sin_tab && rope.hidden == hidden, ATSPEED_ERR_INVALID,
               "gemm_fp8_qkv_rope: null / inconsistent argument");
   ATS_REQUIRE(m >= 1 && hidden % 256 == 0, ATSPEED_ERR_INVALID, "gemm_fp8_qkv_rope: hidden=%d must be a multiple of 256", hidden);
+  if (m <= 256) {
+    ATS_REQUIRE(ats_gemm_fp8_qkv_rope_applies(m, hidden, 128) && (((uintptr_t)xq | (uintptr_t)wq) & 15) == 0, ATSPEED_ERR_INVALID,
+                "gemm_fp8_qkv_rope: %d x %d is not a shape of the weight-streaming kernel's RoPE epilogue", m, hidden);
+    return launch_wdma8<EPI_QKV_ROPE, false>((const unsigned char*)xq, sx, (const unsigned char*)wq, sw, qkv, m, 3 * hidden, hidden, 3 * hidden, 1, st, pk, rope);
+  }
   return launch_big_fp8<EPI_QKV_ROPE>((const unsigned char*)xq, sx, (const unsigned char*)wq, sw, qkv, m, 3 * hidden, hidden, 3 * hidden, st, pk, rope);
 }
 

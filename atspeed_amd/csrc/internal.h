@@ -47,6 +47,18 @@ enum { ATS_PATH_RING = 0, ATS_PATH_RING_SK = 1, ATS_PATH_WDMA = 2, ATS_PATH_WDMA
 extern std::atomic<long long> g_ats_path_cnt[ATS_N_PATHS];          // engine.hip
 inline void ats_count_path(int p) { g_ats_path_cnt[p].fetch_add(1, std::memory_order_relaxed); }
 
+// Process-wide tuning / test switches (engine.hip): each is an int initialised ONCE from its environment variable and changeable afterwards
+// only through the C ABI (atspeed_set_switch) -- no getenv on the dispatch path, no race with a host thread that edits the environment.
+enum { ATS_SW_GEMM_SK = 0,        // "gemm_sk"       ATSPEED_GEMM_SK (1): ring kernel's split-K tail -- 0 off, 1 cost model, 2-4 that many parts wherever they fit
+       ATS_SW_GEMM_SK_G,          // "gemm_sk_g"     (no variable: test hook) an UNALIGNED deal of the tail's k-units over G workgroups
+       ATS_SW_GEMM_PANEL,         // "gemm_panel"    ATSPEED_GEMM_PANEL (1): panel form for 257-384 tokens -- 0 off, 1 where it won, 2 every shape it can take
+       ATS_SW_GEMM_FORCE_MT,      // "gemm_force_mt" ATSPEED_GEMM_FORCE_MT (0): 8 / 4 = always 256- / 128-row token tiles
+       ATS_SW_GRAPHS,             // "graphs"        ATSPEED_GRAPHS (0): replay recurring forwards as hipGraphs
+       ATS_SW_FUSE_QKV_ROPE,      // "fuse_qkv_rope" ATSPEED_FUSE_QKV_ROPE (1): RoPE + KV scatter in the qkv projection's epilogue
+       ATS_SW_GEMM_KCUT,          // "gemm_kcut"     ATSPEED_GEMM_KCUT (1): bf16 N <= 4096 projections at 257-1100 tokens cut in K over the whole chip
+       ATS_N_SW };
+int ats_switch(int id);
+
 enum { EPI_STORE = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_SWIGLU = 3, EPI_F32_LSE = 4 /* ring kernel only: fp32 store + per-tile (max, sum exp) */,
        EPI_QKV_ROPE = 5 /* ring kernel only: qkv projection with RoPE + KV-cache scatter in the epilogue (ats_gemm_qkv_rope) */ };
 // the kernel translation units' functions, once per flavour (declarations: kernels_decl.inc)

@@ -48,13 +48,18 @@ def parse(argv=None):
     ap.add_argument("--tokenizer", type=str, default=None)
     ap.add_argument("--target_layers", type=int, default=32)
     ap.add_argument("--aligned", type=float, default=None, metavar="RESID_SCALE", help="synthetic weights: align draft and target (see bench.py)")
-    ap.add_argument("--target_fp8", action="store_true")
+    ap.add_argument("--target_fp8", action="store_true",
+                    help="W8A8 (e4m3) target projections -- the place of the reference's `load_in_8bit` target (inference.py:86-91); works on bf16 and "
+                         "fp16 targets (an fp16 checkpoint under --dtype auto keeps its type), not with --dtype fp32")
     ap.add_argument("--dtype", choices=("auto", "fp16", "bf16", "fp32"), default="auto",
                     help="engine arithmetic.  auto: a checkpoint runs in the type it is stored in (fp16 -- what the reference loads, inference.py:75-100 -- "
                          "takes the engine's fp16 flavour and keeps every weight bit; bf16 and fp32 likewise), synthetic weights are bf16")
     ap.add_argument("--baseline", action="store_true", help="also time target_generate per user (speedup / overhead columns)")
     ap.add_argument("--output_dir", type=str, default="AnaResult")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.target_fp8 and args.dtype == "fp32":
+        ap.error("--target_fp8 makes its e4m3 copies from 16-bit weights: use --dtype auto, fp16 or bf16")
+    return args
 
 
 def load_models(args, vocab_size: int, beam: int, dev, max_prompt: int = 0):
@@ -79,8 +84,6 @@ def load_models(args, vocab_size: int, beam: int, dev, max_prompt: int = 0):
         tgt = HipLlama.from_synthetic(synth.llama_7b(vocab_size, args.target_layers), args.seed, dtype=syn, num_beams=beam, resid_scale=rs,
                                       align_to=drf if args.aligned is not None else None, **kw)
     if args.target_fp8:
-        if tgt.dtype != torch.bfloat16:
-            raise SystemExit(f"--target_fp8 makes its e4m3 copies from bf16 weights; the target runs in {tgt.dtype} (use --dtype bf16)")
         tgt.enable_fp8()
     return tgt, drf
 

@@ -261,7 +261,9 @@ class HipLlama:
         return cls(dims, packed, dtype, device, **kw)
 
     def enable_fp8(self) -> "HipLlama":
-        """fp8 (e4m3, W8A8 with per-row scales) layer projections for the batched forwards (BASELINE config 5)."""
+        """fp8 (e4m3, W8A8 with per-row scales) layer projections (BASELINE config 5; the place of the reference's `load_in_8bit` target,
+        code/inference.py:86-91).  bf16 and fp16 models: the e4m3 copies are made from the model's own 16-bit weight values, the activations
+        between the W8A8 projections stay in the model's type (an fp16 checkpoint, the reference's, keeps the fp16 flavour)."""
         with torch.cuda.device(self._device):
             _lib.check(_lib.load().atspeed_llama_enable_fp8(self._handle, _lib.stream_ptr(self._device)))
         self.fp8 = True
@@ -277,6 +279,10 @@ class HipLlama:
     def rope_fused_launches(self, reset: bool = False) -> int:
         """qkv projections that carried RoPE + the KV scatter in their epilogue since the last reset (atspeed_llama_rope_fused_launches)."""
         return int(_lib.load().atspeed_llama_rope_fused_launches(self._handle, 1 if reset else 0))
+
+    def sk_arena_bytes(self) -> int:
+        """Bytes of the ring kernel's split-K arena this model owns: 0 until its first forward of >= 257 tokens (atspeed_llama_sk_arena_bytes)."""
+        return int(_lib.load().atspeed_llama_sk_arena_bytes(self._handle))
 
     # ---- measurement hooks --------------------------------------------------------------
     GEMM_KINDS = ("qkv", "o_proj", "gate_up", "down", "lm_head")

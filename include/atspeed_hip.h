@@ -184,6 +184,9 @@ int atspeed_llama_fp8_counters(atspeed_llama* m, int64_t* fp8_out, int64_t* othe
  * called from beamSD.py:120, without re-reading the projection) rather than as the separate pass, since the last reset; -1 on a NULL
  * model.  ATSPEED_FUSE_QKV_ROPE=0 in the environment (read at each forward) selects the separate pass: results are bit-identical. */
 int64_t atspeed_llama_rope_fused_launches(atspeed_llama* m, int32_t reset);
+/* bytes of the split-K arena this model owns (0: none yet -- it is allocated in front of the model's first forward of >= 257 tokens, so a
+ * draft or a one-user target never holds one; thin ring-kernel grids of a model without one take the device's shared arena or the plain grid) */
+int64_t atspeed_llama_sk_arena_bytes(const atspeed_llama* m);
 
 /* lm_head fused with the full-vocabulary normaliser of beamSD.py:58,285 (log_softmax over ALL columns, before masking): bf16
  * x [rows, hidden] times w [vocab, hidden]^T -> fp32 logits (row stride ld) and lse[row] = log sum_v exp(logits[row][v]).  On the
@@ -328,6 +331,13 @@ int atspeed_gemm(const void* a_dev, const void* w_dev, void* c_dev, int32_t m, i
  * 4 ring kernel in split-K mode, 5 LDS-tiled kernel, 6 fp8 ring kernel, 7 / 8 fp8 weight-streaming kernel / split, 9 / 10 panel kernel /
  * split, 11 fp8 ring kernel cut in K.  Returns the number of counters the library keeps. */
 int atspeed_gemm_path_counters(int64_t* out, int32_t n, int32_t reset);
+/* Process-wide tuning / test switches.  Each is an int read ONCE from its environment variable when the library first needs one (the
+ * variable is the way to set it for a whole run) and changeable afterwards only through this call (tests and sweeps that compare two
+ * settings in one process) -- the dispatch path never calls getenv.  Names: "gemm_sk" (ATSPEED_GEMM_SK, 1), "gemm_sk_g" (no variable; test
+ * hook, 0), "gemm_panel" (ATSPEED_GEMM_PANEL, 1), "gemm_force_mt" (ATSPEED_GEMM_FORCE_MT, 0), "graphs" (ATSPEED_GRAPHS, 0),
+ * "fuse_qkv_rope" (ATSPEED_FUSE_QKV_ROPE, 1), "gemm_kcut" (ATSPEED_GEMM_KCUT, 1); meanings in INTEGRATION.md.  Unknown name: ATSPEED_ERR_INVALID. */
+int atspeed_set_switch(const char* name, int32_t value);
+int atspeed_get_switch(const char* name, int32_t* value_out);
 /* atspeed_gemm / atspeed_gemm_fp8 on operands in the packed layout (a / xq and w / wq through atspeed_pack_rows; K % 32 == 0, for fp8 K % 64 == 0):
  * what the bf16 / fp8 engine runs.  The SwiGLU epilogue's output (ldc % 32 == 0) is packed as well -- it is the down projection's operand --,
  * every other output is row-major.  Same arithmetic as the row-major calls: results are bit-identical. */
@@ -344,8 +354,11 @@ int atspeed_quant_rows_fp8_packed(const void* x_bf16_packed_dev, int32_t rows, i
 /* m >= 257: the block-scaled MFMA ring kernel (K % 256 == 0, lock-step batches).  m <= 256 (round 5: one user's forwards, the reference's
  * own regime -- code/inference.py:86-91 loads its target 8-bit for every batch-1 forward): the weight-streaming kernel on e4m3 rows
  * (K % 128 == 0, K >= 512).  There a narrow N is cut in K and finished by a reduce pass over fp32 partial sums in `workspace_dev`
- * (parts x m x n x 4 bytes, parts <= 8; 64 MB always suffices); with too little workspace the launch runs one part per tile, except the
- * residual epilogue (2), which needs the workspace and returns ATSPEED_ERR_CAPACITY without it. */
+ * (parts x m x n x 4 bytes with parts = min(256 / tiles, K / 512), tiles = N / 64 up to N = 16384, else N / 128 -- up to 256 parts for a very
+ * small N; 64 MB always suffices); with too little workspace the launch runs one part per tile; the residual epilogue (2) then takes the ring
+ * kernel when K % 256 == 0 and returns ATSPEED_ERR_CAPACITY otherwise.
+ * SIGNATURE NOTE: (workspace_dev, workspace_bytes) were inserted before `stream` in round 5; atspeed_version() reports 0.2 since round 6 so
+ * that a caller built against the 0.1 header (stream in the workspace position) can tell. */
 int atspeed_gemm_fp8(const void* xq_dev, const float* sx_dev, const void* wq_dev, const float* sw_dev, void* c_dev, int32_t m,
                      int32_t n, int32_t k, int32_t ldc, int32_t epilogue, void* workspace_dev, size_t workspace_bytes, void* stream);
 int atspeed_rmsnorm(const void* x_dev, const void* w_dev, void* y_dev, int32_t rows, int32_t hidden,

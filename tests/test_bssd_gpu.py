@@ -475,8 +475,12 @@ def test_inference_cli_on_generated_dataset(tmp_path):
     out8 = inference.main(["--data_path", str(tmp_path / "data"), "--dataset", "toys", "--target_layers", "2", "--aligned", "3e-6", "--target_fp8",
                            "--run_beam_sizes", "[20]", "--users_per_batch", "1", "--strict_trie", "--output_dir", str(tmp_path / "AnaResult8u1")])
     assert out8[0]["users"] == out[1]["users"] and out8[0]["mean_accept_len"] >= 2.5 and out8[0]["items_per_s"] > 0
-    with pytest.raises(SystemExit):                                                  # the e4m3 copies are made of bf16 weights only
-        inference.main(["--data_path", str(tmp_path / "data"), "--dataset", "toys", "--target_layers", "2", "--dtype", "fp16", "--target_fp8",
+    # the reference's own dtype combination (inference.py:75-91: fp16 checkpoints, 8-bit target): the fp16 flavour with W8A8 target projections
+    out816 = inference.main(["--data_path", str(tmp_path / "data"), "--dataset", "toys", "--target_layers", "2", "--aligned", "3e-6", "--dtype", "fp16",
+                             "--target_fp8", "--run_beam_sizes", "[20]", "--users_per_batch", "1", "--strict_trie", "--output_dir", str(tmp_path / "AnaResult8f16")])
+    assert out816[0]["users"] == out[1]["users"] and out816[0]["mean_accept_len"] >= 2.5 and out816[0]["items_per_s"] > 0
+    with pytest.raises(SystemExit):                                                  # the e4m3 copies are made of 16-bit weights: refused before anything is loaded
+        inference.main(["--data_path", str(tmp_path / "data"), "--dataset", "toys", "--target_layers", "2", "--dtype", "fp32", "--target_fp8",
                         "--run_beam_sizes", "[5]", "--output_dir", str(tmp_path / "AnaResult8")])
 
 

@@ -12,7 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import atspeed_amd
-from atspeed_amd import synth
+from atspeed_amd import _lib, synth
 from atspeed_amd.beamSD import BSSD, BSSD_batch, _Decoder, last_trace, release_decoders, target_generate
 from atspeed_amd.generation_trie import PositionSetConstraint, SuffixTrieConstraint, Trie, prefix_allowed_tokens_fn
 from atspeed_amd.model import HipLlama, vis_bits_from_bool
@@ -256,10 +256,8 @@ def test_rope_and_kv_scatter_in_the_qkv_epilogue_equal_the_separate_pass(n_seq, 
         vis2[5:, T + 2] = False
         second.append((ids2, torch.arange(T, T + B, dtype=torch.int32), torch.arange(T, T + B, dtype=torch.int32), vis_bits_from_bool(vis2, 256), T + B, 5))
     res = {}
-    old = os.environ.get("ATSPEED_FUSE_QKV_ROPE")
-    try:
-        for mode in ("1", "0"):
-            os.environ["ATSPEED_FUSE_QKV_ROPE"] = mode
+    for mode in ("1", "0"):
+        with _lib.switches(fuse_qkv_rope=int(mode)):
             m.rope_fused_launches(reset=True)
             m.fp8_counters(reset=True)
             a = [o.clone() for o in m.forward_raw_batch(first)]
@@ -267,15 +265,52 @@ def test_rope_and_kv_scatter_in_the_qkv_epilogue_equal_the_separate_pass(n_seq, 
             torch.cuda.synchronize()
             res[mode] = (a, b, m.rope_fused_launches())
             assert m.fp8_counters()["qkv"] == (dict(fp8=2 * dims.n_layers, other=0) if fp8 else dict(fp8=0, other=2 * dims.n_layers))
-    finally:
-        if old is None:
-            os.environ.pop("ATSPEED_FUSE_QKV_ROPE", None)
-        else:
-            os.environ["ATSPEED_FUSE_QKV_ROPE"] = old
     assert res["1"][2] == 2 * dims.n_layers and res["0"][2] == 0, (res["1"][2], res["0"][2])
     for k in (0, 1):
         for x, y in zip(res["1"][k], res["0"][k]):
             assert bool(torch.isfinite(x).all()) and torch.equal(x, y), f"forward {k}: max |diff| {float((x - y).abs().max()):.3e} of max |logit| {float(y.abs().max()):.3f}"
+
+
+@pytest.mark.parametrize("T,dtype", [(20, torch.bfloat16), (60, torch.bfloat16), (100, torch.bfloat16), (228, torch.bfloat16), (121, torch.float16)],
+                         ids=["20", "60", "100", "228", "121_fp16"])
+def test_one_user_fp8_rope_in_the_weight_streaming_qkv_epilogue_equals_the_separate_pass(T, dtype):
+    """Round 6: ONE user's W8A8 qkv projection (gemm_wdma_kernel<..., EPI_QKV_ROPE, F8>: 192 unsplit tiles of 64 weight rows at hidden 4096)
+    rotates q / k and scatters k / v to the caches in its epilogue -- one launch less per layer in the reference's batch-1 regime
+    (code/inference.py:162-176).  Bit-identical logits to the `fuse_qkv_rope` switch off (ATSPEED_FUSE_QKV_ROPE=0: 16-bit store + rope_kv_segs_vec_kernel) for a first forward
+    under a tree mask and for a second one that attends to the cached K / V the epilogue wrote; every token-tile height (32 / 64 / 128 / 256)."""
+    import os
+    V = 32000 + 256
+    dims = synth.LlamaDims(V, 4096, 2, 32, 1024)
+    m = HipLlama.from_synthetic(dims, 93, std=0.02, head_std=0.05, dtype=dtype, max_slots=512, max_tokens=512, max_logit_rows=448)
+    m.enable_fp8()
+    g = torch.Generator().manual_seed(12)
+    ids = torch.randint(3, V, (T,), generator=g).to(torch.int32)
+    vis = torch.tril(torch.ones(T, T, dtype=torch.bool))
+    if T > 12:
+        vis[8:, 3] = False
+    ar = torch.arange(T, dtype=torch.int32)
+    B = 40
+    ids2 = torch.randint(3, V, (B,), generator=g).to(torch.int32)
+    vis2 = torch.zeros(B, T + B, dtype=torch.bool)
+    vis2[:, :T] = True
+    vis2[:, 3] = False
+    vis2[:, T:] = torch.tril(torch.ones(B, B, dtype=torch.bool))
+    vis2[5:, T + 2] = False
+    ar2 = torch.arange(T, T + B, dtype=torch.int32)
+    res = {}
+    for mode in ("1", "0"):
+        with _lib.switches(fuse_qkv_rope=int(mode)):
+            m.rope_fused_launches(reset=True)
+            m.fp8_counters(reset=True)
+            a = m.forward_raw(ids.cuda(), ar.cuda(), ar.clone().cuda(), vis_bits_from_bool(vis, 512).cuda(), T, min(T, 6)).clone()
+            b = m.forward_raw(ids2.cuda(), ar2.cuda(), ar2.clone().cuda(), vis_bits_from_bool(vis2, 512).cuda(), T + B, 5).clone()
+            torch.cuda.synchronize()
+            res[mode] = (a, b, m.rope_fused_launches())
+            assert m.fp8_counters()["qkv"] == dict(fp8=2 * dims.n_layers, other=0)
+    assert res["1"][2] == 2 * dims.n_layers and res["0"][2] == 0, (res["1"][2], res["0"][2])
+    for k in (0, 1):
+        x, y = res["1"][k], res["0"][k]
+        assert bool(torch.isfinite(x).all()) and torch.equal(x, y), f"forward {k}: max |diff| {float((x - y).abs().max()):.3e} of max |logit| {float(y.abs().max()):.3f}"
 
 
 def test_rccl_two_ranks(tmp_path):
@@ -285,7 +320,6 @@ def test_rccl_two_ranks(tmp_path):
     import json
     import subprocess
     import sys
-    from atspeed_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     n_users, port = 5, 29671
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
@@ -351,7 +385,6 @@ def test_a_filtered_user_does_not_abort_the_lock_step_batch():
     tokens (< 32000): the reference's post-top-k id filter (beamSD.py:80-86) drops every pick of B's first step (the reference then dies on a
     shape mismatch).  B ends with n_valid = 0 and status ERR_FILTERED, users A and C get exactly their one-user results; the one-user call for
     B still raises."""
-    from atspeed_amd import _lib
     from atspeed_amd.beamSD import target_generate_batch
     case = [c for c in CASES if c["name"] == "k5_dk10_indep"][0]
     ci = build_case_inputs(case)
@@ -384,11 +417,10 @@ def test_a_filtered_user_does_not_abort_the_lock_step_batch():
 
 
 def test_graph_replay_of_a_forward_that_takes_the_split_k_tail():
-    """VERDICT r4 #7 / ADVICE r4: with ATSPEED_GRAPHS=1 a recurring forward of <= 512 tokens is captured and replayed as a hipGraph, and from 257
+    """VERDICT r4 #7 / ADVICE r4: with the `graphs` switch on (ATSPEED_GRAPHS=1) a recurring forward of <= 512 tokens is captured and replayed as a hipGraph, and from 257
     tokens the N = 4096 projections take the ring kernel's split-K tail -- whose arena used to be allocated, and waited for across streams,
     inside the launch (illegal in a capture).  The arena now belongs to the model's activation context: the 300-token first verification of a
     180-token prompt is captured (second sight) and replayed (third), and every call returns the bits of the ungraphed engine."""
-    from atspeed_amd import _lib
     import ctypes as C
     V = synth.BEAUTY.vocab_size
     kw = dict(max_slots=512, max_tokens=512, max_logit_rows=384, device="cuda:0")
@@ -398,24 +430,20 @@ def test_graph_replay_of_a_forward_that_takes_the_split_k_tail():
     inp = {"input_ids": torch.from_numpy(synth.synthetic_prompt(180, 77))[None].cuda()}
     cnt = (C.c_int64 * 16)()
     lib = _lib.load()
-    old = os.environ.get("ATSPEED_GRAPHS")
+    assert tgt.sk_arena_bytes() == 0 and drf.sk_arena_bytes() == 0     # no model owns a split-K arena before it runs a forward that can use one
     res = {}
-    try:
-        for mode in ("0", "1"):
-            os.environ["ATSPEED_GRAPHS"] = mode
+    for mode in ("0", "1"):
+        # (gemm_kcut=0: round 6's K-cut form would take o_proj at 300 tokens; this test is about the tail's arena inside a capture)
+        with _lib.switches(graphs=int(mode), gemm_kcut=0):
             lib.atspeed_gemm_path_counters(cnt, 16, 1)
             res[mode] = [BSSD(tgt, drf, inp, 4, 4, prefix_allowed_tokens_fn=fn) for _ in range(4)]
             torch.cuda.synchronize()
             lib.atspeed_gemm_path_counters(cnt, 16, 0)
             res[mode + "sk"] = int(cnt[1])
-    finally:
-        if old is None:
-            os.environ.pop("ATSPEED_GRAPHS", None)
-        else:
-            os.environ["ATSPEED_GRAPHS"] = old
     # ungraphed: every call's 300-token forward launches its o_proj tails (2 layers; down takes the panel form at 300 tokens); graphed: calls 1
     # and 2 (the capture) launch them, calls 3 and 4 replay the graph
     assert res["0sk"] >= 4 * 2 and 2 <= res["1sk"] < res["0sk"], (res["0sk"], res["1sk"])
+    assert tgt.sk_arena_bytes() == 128 << 20 and drf.sk_arena_bytes() == 0   # the target's 300-token verification brought its arena; the draft (<= 180 tokens) has none
     for a in res["0"] + res["1"]:
         assert torch.equal(a["beam_sequence"], res["0"][0]["beam_sequence"]) and torch.equal(a["beam_scores"], res["0"][0]["beam_scores"])
         assert a["accept_steps"] == res["0"][0]["accept_steps"]

@@ -48,11 +48,14 @@ def _target(dtype=torch.bfloat16, V=synth.BEAUTY.vocab_size, width="small", laye
                                          max_slots=512, max_tokens=512, max_logit_rows=448, **kw)
 
 
-@pytest.mark.parametrize("width,layers", [("small", LAYERS), ("llama7b", 3)], ids=["hidden2048", "llama7b_width"])
-def test_fp8_forward_logits_match_the_w8a8_oracle(width, layers):
-    dims, m = _target(width=width, layers=layers)
+@pytest.mark.parametrize("width,layers,dtype", [("small", LAYERS, torch.bfloat16), ("llama7b", 3, torch.bfloat16), ("llama7b", 3, torch.float16)],
+                         ids=["hidden2048", "llama7b_width", "llama7b_width_fp16"])
+def test_fp8_forward_logits_match_the_w8a8_oracle(width, layers, dtype):
+    """fp16: the reference's dtype combination (inference.py:75-91: fp16 checkpoints, 8-bit target) -- the e4m3 copies come from the fp16 weight
+    values, the activations between the W8A8 projections are fp16; the oracle is RefLlama(w8a8=True) on those fp16-valued weights."""
+    dims, m = _target(dtype=dtype, width=width, layers=layers)
     LAYERS_ = layers
-    sd = m.export_state_dict()                                    # the bf16 weight values the device holds (and quantises)
+    sd = m.export_state_dict()                                    # the 16-bit weight values the device holds (and quantises)
     ref8, ref32 = RefLlama(dims, sd, max_slots=512, w8a8=True), RefLlama(dims, sd, max_slots=512)
     m.enable_fp8()
     g = torch.Generator().manual_seed(5)
@@ -164,8 +167,9 @@ def test_fp8_accept_length_drift_on_an_aligned_pair(width):
 
 
 # ------------------------------------------------------------------ config 5 in the reference's own regime: ONE user per call (round 5)
-@pytest.mark.parametrize("T", [121, 228, 20])
-def test_fp8_one_user_forward_at_llama7b_width_matches_the_w8a8_oracle(T):
+@pytest.mark.parametrize("T,dtype", [(121, torch.bfloat16), (228, torch.bfloat16), (20, torch.bfloat16), (228, torch.float16), (60, torch.float16)],
+                         ids=["121", "228", "20", "228_fp16", "60_fp16"])
+def test_fp8_one_user_forward_at_llama7b_width_matches_the_w8a8_oracle(T, dtype):
     """VERDICT r4 missing #1: the reference's 8-bit target runs every forward at batch 1 (inference.py:86-91, beamSD.py:221: T = 228 for the
     first verification, K + dl * DK = 60-140 later, K = 20 for the final step); here m < 512 used to fall back to bf16 silently.  One
     sequence at hidden 4096 / ffn 11008 / 32 heads x 128 through the weight-streaming W8A8 kernels (gemm_wdma_kernel<..., F8>): every layer
@@ -173,7 +177,7 @@ def test_fp8_one_user_forward_at_llama7b_width_matches_the_w8a8_oracle(T):
     from atspeed_amd import _lib
     import ctypes as C
     layers = 3
-    dims, m = _target(width="llama7b", layers=layers)
+    dims, m = _target(dtype=dtype, width="llama7b", layers=layers)
     sd = m.export_state_dict()
     ref8, ref32 = RefLlama(dims, sd, max_slots=512, w8a8=True), RefLlama(dims, sd, max_slots=512)
     m.enable_fp8()

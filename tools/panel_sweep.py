@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Panel form of the ring kernel (gemm_ring_kernel<..., WN = 2, WM = 4>, 257-512 tokens) against what the dispatch did before it, on the
 Llama-7B projections as the ENGINE runs them (packed operands, the projection's own epilogue, rotating weights): us per launch with
-ATSPEED_GEMM_PANEL=0 / 1 (read per call).  The split forms include their reduce launch.
+the `gemm_panel` switch 0 / 1 (atspeed_set_switch; round 6's K-cut form held off).  The split forms include their reduce launch.
 usage: python tools/panel_sweep.py [M list]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,10 +30,9 @@ for name, n, k, epi in (("qkv", 12288, 4096, _lib.EPI_STORE), ("o_proj", 4096, 4
         c = torch.zeros((m + 1) // 2 * 2, ldc, dtype=torch.bfloat16, device="cuda")
         fs = [(lambda w=w: _lib.check(lib.atspeed_gemm_packed(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, ldc, epi, ws.data_ptr(), ws.numel(), st))) for w in wl]
         cells = []
-        for p in ("0", "1"):
-            os.environ["ATSPEED_GEMM_PANEL"] = p
-            cells.append(timeit(fs))
+        for p in (0, 1):
+            with _lib.switches(gemm_panel=p, gemm_kcut=0):
+                cells.append(timeit(fs))
         flops = 2.0 * m * n * k
         print(f"{name:8s} M={m:4d}  before {cells[0]:6.1f} us  panel {cells[1]:6.1f} us  ({cells[0] / cells[1]:.2f}x; panel = {flops / cells[1] / 1e6:6.0f} TF, weights {n * k * 2 / cells[1] / 1e3:5.0f} GB/s)", flush=True)
     del wl
-os.environ.pop("ATSPEED_GEMM_PANEL", None)

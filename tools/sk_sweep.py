@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Split-K tail of the ring GEMM (gemm_ring_kernel<..., SK>) on the Llama-7B projections in the 4-64-user band, as the ENGINE runs them (packed
 operands, the projection's own epilogue, cold weights): us per launch for every (token-tile height, parts per tail tile), next to the default
-dispatch.  The cost model in gemm.hip (sk_cost_us) is fitted to this table.  ATSPEED_GEMM_FORCE_MT / ATSPEED_GEMM_SK are read per call.
+dispatch.  The cost model in gemm.hip (sk_cost_us) is fitted to this table.  The `gemm_force_mt` / `gemm_sk` switches are set per cell (atspeed_set_switch).
 usage: python tools/sk_sweep.py [M list]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,14 +33,13 @@ for name, n, k, epi in (("qkv", 12288, 4096, _lib.EPI_STORE), ("o_proj", 4096, 4
         fs = [(lambda w=w: _lib.check(lib.atspeed_gemm_packed(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, ldc, epi, ws.data_ptr(), ws.numel(), st))) for w in wl]
         tn = (n + 255) // 256
         row = [f"{name:8s} M={m:5d} t256={tn * ((m + 255) // 256):5d} t128={tn * ((m + 127) // 128):5d}"]
-        os.environ.pop("ATSPEED_GEMM_FORCE_MT", None); os.environ["ATSPEED_GEMM_SK"] = "1"
-        row.append(f"default {timeit(fs):6.1f}")
+        with _lib.switches(gemm_force_mt=0, gemm_sk=1, gemm_kcut=0):
+            row.append(f"default {timeit(fs):6.1f}")
         for mt in (8, 4):
-            os.environ["ATSPEED_GEMM_FORCE_MT"] = str(mt)
             cells = []
             for S in (0, 2, 3, 4):
-                os.environ["ATSPEED_GEMM_SK"] = str(S)
-                cells.append(f"S{S} {timeit(fs):6.1f}")
+                with _lib.switches(gemm_force_mt=mt, gemm_sk=S, gemm_kcut=0):
+                    cells.append(f"S{S} {timeit(fs):6.1f}")
             row.append(f"mt{mt}: " + " ".join(cells))
         print(" | ".join(row), flush=True)
     del wl
