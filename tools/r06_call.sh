@@ -1,0 +1,14 @@
+#!/bin/bash
+# round-6 measurement calls (run through gpurun): $1 = step name
+set -o pipefail
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+case "$1" in
+a)
+  timeout -k 10 600 python -m pytest tests/test_closures_gpu.py -x -q -m gpu -k "one_user_fp8_rope or rope_and_kv or graph_replay" > gpurun_out/r06a_t1.log 2>&1 && \
+  for v in 1 0; do ATSPEED_FUSE_QKV_ROPE=$v timeout -k 10 300 python tools/batch_run.py 1 bssd 12 none fp8 2>&1 | grep MARK | sed "s/^/rope=$v /" >> gpurun_out/r06a_ab.log || exit 1; done && \
+  for v in 1 0; do ATSPEED_FUSE_QKV_ROPE=$v timeout -k 10 300 python tools/batch_run.py 1 bssd 12 3e-6 fp8 2>&1 | grep MARK | sed "s/^/rope=$v /" >> gpurun_out/r06a_ab.log || exit 1; done && \
+  for u in "16 tg" "4 bssd" "16 bssd" "4 tg"; do for v in 0 1 2; do ATSPEED_GEMM_KCUT=$v timeout -k 10 300 python tools/batch_run.py $u 6 2>&1 | grep MARK | sed "s/^/kcut=$v /" >> gpurun_out/r06a_ab.log || exit 1; done; done && \
+  timeout -k 10 900 python -m pytest tests/test_fp8_gpu.py tests/test_kernels_gpu.py tests/test_bssd_gpu.py -x -q -m gpu -k "fp8 or stream_k or panel or unaligned or two_streams or residual or packed_equals or inference_cli" > gpurun_out/r06a_t2.log 2>&1
+  ;;
+esac
