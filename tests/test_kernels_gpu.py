@@ -1054,8 +1054,8 @@ def test_split_k_tail_with_an_unaligned_deal(lib, m, n, k, epi, G):
     assert float((got - ref).abs().max()) <= tol
 
 # ------------------------------------------------------------------ round 6: fragment double buffering of the weight-streaming kernels, K-cut ring form
-WDMA_DB_SHAPES = [("bf16", 228, 22016, 4096, 3), ("bf16", 228, 12288, 4096, 0), ("bf16", 228, 4096, 11008, 2), ("bf16", 100, 4096, 4096, 2), ("bf16", 200, 32859, 4096, 1),
-                  ("bf16", 100, 22016, 4096, 3), ("bf16", 121, 4096, 11008, 2), ("bf16", 100, 32859, 1024, 1), ("bf16", 130, 22016, 256, 3),
+WDMA_DB_SHAPES = [("bf16", 228, 22016, 4096, 3), ("bf16", 228, 12288, 4096, 0), ("bf16", 228, 4096, 11008, 2), ("bf16", 100, 4096, 4096, 2), ("bf16", 120, 32859, 4096, 1),
+                  ("bf16", 100, 22016, 4096, 3), ("bf16", 121, 4096, 11008, 2), ("bf16", 100, 32859, 1024, 1), ("bf16", 130, 22016, 512, 3),
                   ("fp16", 228, 22016, 4096, 3), ("fp16", 228, 4096, 11008, 2),
                   ("fp8", 228, 22016, 4096, 3), ("fp8", 228, 12288, 4096, 0), ("fp8", 228, 4096, 11008, 2), ("fp8", 228, 4096, 4096, 2), ("fp8", 256, 22016, 4096, 3),
                   ("fp8", 121, 22016, 4096, 3), ("fp8", 100, 4096, 4096, 2), ("fp8", 121, 4096, 11008, 2), ("fp8", 100, 12288, 4096, 0), ("fp8", 130, 3072, 1024, 3)]
