@@ -1640,11 +1640,7 @@ int launch_big_fp8(const unsigned char* x, const float* sx, const unsigned char*
 // meet two to a bank -- the same k permutation on both operands, so the product is unchanged.  The fp32 scales multiply the accumulators
 // (acc * sx[m] * sw[n]) before the epilogue, also on the fp32 split-K partials (the sum is linear), so every consumer is the bf16 form's.
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
-// DB (round 6): the fragments of k-tile kt + 1 are read into a second register set while the MFMAs of k-tile kt run.  Without it a k-tile is
-// two phases -- after the barrier all waves read their fragments (8 waves x 16 KB through the one LDS port: ~1000 cycles at BM = 256), then all
-// of them issue MFMAs (~1000 cycles per SIMD) -- and the measured 0.86 us per k-tile of gate_up at 228 tokens is their SUM.  The ring depth is
-// unchanged: stage kt % NST is re-filled right after the barrier that follows the (explicitly waited) fragment reads of tile kt.
-template <int BM, int BN, int NST, int EPI, bool SPLIT = false, int WM = 2, bool F8 = false, bool DB = false>
+template <int BM, int BN, int NST, int EPI, bool SPLIT = false, int WM = 2, bool F8 = false>
 __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restrict__ X, const void* __restrict__ W, void* __restrict__ Cv,
                                                              int M, int N, int K, int ldx, int ldc, int pk, int n_split,
                                                              const float* __restrict__ sx = nullptr, const float* __restrict__ sw = nullptr,
@@ -1667,11 +1663,9 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restr
   const int n0 = blockIdx.x * BN;
   int kt0 = 0, n_kt = K / BK;                                          // launcher: K % BK == 0; this part's tiles are kt0 .. kt0 + n_kt - 1
   if constexpr (SPLIT) {
-    // parts in units of TWO k-tiles when the count is even (round 6: the double-buffered loop below walks tile pairs; the plain loop uses the
-    // same cut, so that both forms sum the same slabs and stay bit-identical), else in single tiles
-    const int z = blockIdx.y, unit = (n_kt & 1) ? 1 : 2, all = n_kt / unit;
-    kt0 = unit * (int)((long long)z * all / n_split);
-    n_kt = unit * (int)((long long)(z + 1) * all / n_split) - kt0;
+    const int all = n_kt, z = blockIdx.y;
+    kt0 = (int)((long long)z * all / n_split);
+    n_kt = (int)((long long)(z + 1) * all / n_split) - kt0;
   }
   const unsigned lbase = lds_addr(smem);
 
@@ -1710,83 +1704,6 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restr
 
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t) if (t < n_kt) issue(t);           // (a part shorter than the ring only ever waits vmcnt(0) below)
-  if constexpr (DB) {
-    // The loop is inline asm like the ring kernels' (fragment reads, MFMAs, waits): written as compiler-scheduled code, two alternating register
-    // sets cost a copy of every accumulator through the AGPRs per MFMA and 120 extra registers (hipcc 7.2: ISA inspected, round 6).  volatile asm
-    // statements keep their order; the ISA scan of the build (tools/scan_mfma_loops.py) refuses compiler moves / spills between the MFMAs.
-    // A 16-row tile's fragment = chunks g ("lo") and 4 + g ("hi") of row lq: e4m3: the two halves of ONE 128-k operand; 16-bit: k-steps 0 and 1.
-    u32x4_t wl[2][NI], wh[2][NI], xl[2][MI], xh[2][MI];
-    const unsigned c_lo = (unsigned)((g ^ (lq & 7)) * 16), c_hi = (unsigned)(((4 + g) ^ (lq & 7)) * 16);       // (tile rows start at multiples of 16: row & 7 = lq & 7)
-    const unsigned a_x = lbase + (unsigned)((wm * (BM / WM) + lq) * RB), a_w = lbase + (unsigned)(BM * RB + (wn * (BN / 2) + lq) * RB);
-    const unsigned unit_scale = 0x7f7f7f7fu;                           // E8M0 1.0 for every 32-k block of both operands
-    auto read_tile = [&](int kt, int buf) {                            // buf: compile-time after inlining
-      const unsigned so = (unsigned)((kt % NST) * STAGE);
-      const unsigned awl = a_w + so + c_lo, awh = a_w + so + c_hi, axl = a_x + so + c_lo, axh = a_x + so + c_hi;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) { ATS_DS_READ_B128(wl[buf][i], awl, i * 16 * RB); ATS_DS_READ_B128(wh[buf][i], awh, i * 16 * RB); }
-#pragma unroll
-      for (int j = 0; j < MI; ++j) { ATS_DS_READ_B128(xl[buf][j], axl, j * 16 * RB); ATS_DS_READ_B128(xh[buf][j], axh, j * 16 * RB); }
-    };
-    // accumulators in AGPRs where accumulators + two fragment sets exceed the 256 architectural VGPRs (the 256 x 128 tile on 2 x 2 waves)
-    constexpr bool ACC_A = NI * MI * 4 + 2 * (NI + MI) * 8 > 224;
-    auto mma_tile = [&](int buf) {
-      if constexpr (F8) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-          for (int j = 0; j < MI; ++j) {
-#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass checks asm constraints against x86, where "a" is rax: see ATS_MFMA_MX_A)
-            if constexpr (ACC_A)
-              asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
-                           : "+a"(acc[i][j])
-                           : "v"(__builtin_shufflevector(wl[buf][i], wh[buf][i], 0, 1, 2, 3, 4, 5, 6, 7)),
-                             "v"(__builtin_shufflevector(xl[buf][j], xh[buf][j], 0, 1, 2, 3, 4, 5, 6, 7)), "v"(unit_scale));
-            else
-              asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
-                           : "+v"(acc[i][j])
-                           : "v"(__builtin_shufflevector(wl[buf][i], wh[buf][i], 0, 1, 2, 3, 4, 5, 6, 7)),
-                             "v"(__builtin_shufflevector(xl[buf][j], xh[buf][j], 0, 1, 2, 3, 4, 5, 6, 7)), "v"(unit_scale));
-#endif
-          }
-      } else {
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-          for (int j = 0; j < MI; ++j) { if constexpr (ACC_A) ATS_MFMA_BF16_A(acc[i][j], wl[buf][i], xl[buf][j]); else ATS_MFMA_BF16(acc[i][j], wl[buf][i], xl[buf][j]); }
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-          for (int j = 0; j < MI; ++j) { if constexpr (ACC_A) ATS_MFMA_BF16_A(acc[i][j], wh[buf][i], xh[buf][j]); else ATS_MFMA_BF16(acc[i][j], wh[buf][i], xh[buf][j]); }
-      }
-    };
-    // one k-tile with a successor: MFMAs of tile kt from register set `buf` (read during the previous step), fragments of tile kt + 1 into the
-    // other set meanwhile.  No branch around the fragment reads (a conditionally written register set costs copies at the join).
-    auto step = [&](int kt, int buf) {
-      if (kt + NST - 1 < n_kt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NP) : "memory");   // tile kt+1 landed; kt+2 .. kt+NST-1 may still fly
-      else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");                          // everyone's pieces of tile kt+1; and everyone's reads of tile kt are complete (waited below)
-      if (kt + NST < n_kt) issue(kt + NST);                            // into stage kt % NST
-      read_tile(kt + 1, buf ^ 1);
-      mma_tile(buf);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's reads of tile kt+1 are done before it reaches the barrier that frees their stage
-    };
-    if (n_kt > 0) {
-      if (NST - 2 < n_kt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NP) : "memory");
-      else                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");
-      if (NST - 1 < n_kt) issue(NST - 1);
-      read_tile(0, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // launcher: an even number of k-tiles per part (K % (2 BK) == 0 and the cut above) -- ONE path through the loop and its tail: a join of two
-      // tails made the register allocator copy accumulators right behind asm MFMAs (refused by the ISA scan)
-      // (and at least FOUR: a loop that may run zero times joins two register assignments of the accumulators at its exit)
-      int kt = 0;
-      do { step(kt, 0); step(kt + 1, 1); kt += 2; } while (kt + 2 < n_kt);
-      step(kt, 0);
-      mma_tile(1);                                                     // the last tile has no successor
-    }
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");    // MFMA results -> VALU reads (the compiler cannot see the asm MFMAs)
-  } else
   for (int kt = 0; kt < n_kt; ++kt) {
     if (kt + NST - 2 < n_kt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NP) : "memory");   // tiles kt+1 .. kt+NST-2 may still fly
     else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2137,14 +2054,9 @@ static bool wdma_applies(int m, int n, int k, int lda, int epilogue) {
   if (!(ok128 || (ok192 && m <= 128))) return false;                  // 129-256 rows: 128-row tiles only
   return epilogue == EPI_STORE || epilogue == EPI_F32 || (epilogue == EPI_SWIGLU && n % 32 == 0);
 }
-// fragment double buffering (gemm_wdma_kernel<..., DB>): switch "wdma_db" (ATSPEED_WDMA_DB) 0 off, 1 the 256-row token tile, 2 also the 128-row one
-static bool wdma_db(int bm) { const int v = ats_switch(ATS_SW_WDMA_DB); return v >= 2 ? bm >= 128 : (v == 1 && bm >= 256); }
-template <int BM, int BN, int NST, int EPI, int WM = 2, bool DB = false>
+template <int BM, int BN, int NST, int EPI, int WM = 2>
 int launch_wdma_cfg(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, int lda, int ldc, hipStream_t st, int pk) {
-  // (256 x 128 with two fragment sets does not fit two waves per SIMD -- 260+ registers, scratch in the counted window: refused by the build's ISA scan --,
-  // so that tile runs 2 x 2 waves, one per SIMD with 512 registers, which also reads a quarter fewer fragment bytes per k-tile)
-  if constexpr (!DB && BM >= 128) { if (wdma_db(BM) && k % 128 == 0 && k >= 256) return launch_wdma_cfg<BM, BN, NST, EPI, (BM == 256 && BN >= 128) ? 2 : WM, true>(a, w, c, m, n, k, lda, ldc, st, pk); }
-  auto kern = gemm_wdma_kernel<BM, BN, NST, EPI, false, WM, false, DB>;
+  auto kern = gemm_wdma_kernel<BM, BN, NST, EPI, false, WM>;
   constexpr int lds = NST * (BM + BN) * 128;
   static thread_local AtsPerDeviceFlag attr_flag;
   bool& attr_done = attr_flag.cur();
@@ -2170,10 +2082,9 @@ static int wdma_split_count(int m, int n, int k, int lda) {
   const int s = std::min(256 / t128, n_kt / min_tiles);
   return (s >= 2 && t128 * s >= 150) ? s : 0;
 }
-template <int BM, int NST, int WM = 2, bool DB = false>
+template <int BM, int NST, int WM = 2>
 int launch_wdma_split_cfg(const bf16_t* a, const bf16_t* w, float* partial, int m, int n, int k, int lda, int splits, hipStream_t st, int pk) {
-  if constexpr (!DB && BM >= 128) { if (wdma_db(BM) && k % 128 == 0 && (k / 128) / splits >= 2) return launch_wdma_split_cfg<BM, NST, BM == 256 ? 2 : WM, true>(a, w, partial, m, n, k, lda, splits, st, pk); }
-  auto kern = gemm_wdma_kernel<BM, 128, NST, EPI_F32, true, WM, false, DB>;
+  auto kern = gemm_wdma_kernel<BM, 128, NST, EPI_F32, true, WM>;
   constexpr int lds = NST * (BM + 128) * 128;
   static thread_local AtsPerDeviceFlag attr_flag;
   bool& attr_done = attr_flag.cur();
@@ -2543,11 +2454,10 @@ static int wdma8_split_count(int n, int k) {                           // 1: no 
   if (t128 >= 150) return 1;
   return std::max(1, std::min(256 / t128, n_kt / 4));                  // at least 4 tiles (512 k) per part (8: the same within 2 %, 16: +3 % per user)
 }
-template <int BM, int NST, int EPI, bool SPLIT, int WM = 2, int BN = 128, bool DB = false>
+template <int BM, int NST, int EPI, bool SPLIT, int WM = 2, int BN = 128>
 int launch_wdma8_cfg(const unsigned char* xq, const float* sx, const unsigned char* wq, const float* sw, void* c, int m, int n, int k, int ldc,
                      int splits, hipStream_t st, int pk, const RopeEpi& rope = RopeEpi{}) {
-  if constexpr (!DB && BM >= 128) { if (wdma_db(BM) && k % 256 == 0 && (k / 256) / (SPLIT ? splits : 1) >= 2) return launch_wdma8_cfg<BM, NST, EPI, SPLIT, (BM == 256 && BN >= 128) ? 2 : WM, BN, true>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk, rope); }
-  auto kern = gemm_wdma_kernel<BM, BN, NST, EPI, SPLIT, WM, true, DB>;
+  auto kern = gemm_wdma_kernel<BM, BN, NST, EPI, SPLIT, WM, true>;
   constexpr int lds = NST * (BM + BN) * 128;
   static thread_local AtsPerDeviceFlag attr_flag;
   bool& attr_done = attr_flag.cur();

@@ -1053,60 +1053,7 @@ def test_split_k_tail_with_an_unaligned_deal(lib, m, n, k, epi, G):
         got, tol = outs[0][:, :n].float(), (2e-5 * np.sqrt(k) if epi == _lib.EPI_F32 else 1e-2) * float(ref.abs().max())
     assert float((got - ref).abs().max()) <= tol
 
-# ------------------------------------------------------------------ round 6: fragment double buffering of the weight-streaming kernels, K-cut ring form
-WDMA_DB_SHAPES = [("bf16", 228, 22016, 4096, 3), ("bf16", 228, 12288, 4096, 0), ("bf16", 228, 4096, 11008, 2), ("bf16", 100, 4096, 4096, 2), ("bf16", 120, 32859, 4096, 1),
-                  ("bf16", 100, 22016, 4096, 3), ("bf16", 121, 4096, 11008, 2), ("bf16", 100, 32859, 1024, 1), ("bf16", 130, 22016, 512, 3),
-                  ("fp16", 228, 22016, 4096, 3), ("fp16", 228, 4096, 11008, 2),
-                  ("fp8", 228, 22016, 4096, 3), ("fp8", 228, 12288, 4096, 0), ("fp8", 228, 4096, 11008, 2), ("fp8", 228, 4096, 4096, 2), ("fp8", 256, 22016, 4096, 3),
-                  ("fp8", 121, 22016, 4096, 3), ("fp8", 100, 4096, 4096, 2), ("fp8", 121, 4096, 11008, 2), ("fp8", 100, 12288, 4096, 0), ("fp8", 130, 3072, 1024, 3)]
-
-
-@pytest.mark.parametrize("kind,m,n,k,epi", WDMA_DB_SHAPES)
-def test_wdma_double_buffered_fragments_equal_the_plain_loop(lib, kind, m, n, k, epi):
-    """gemm_wdma_kernel<..., DB> (round 6) reads the next k-tile's fragments into a second register set during the MFMAs of the current one; its
-    loop is inline asm (fragment reads, MFMAs, waits).  Same products in the same order as the compiler-scheduled loop, same K cut for the split
-    forms: the switch `wdma_db` = 0 / 2 must give identical bits, on every tile height it serves (128 and 256 rows), every epilogue and the
-    split forms' slabs + reduce; the launch counters say the same kernel family ran."""
-    a = _rand((m, k), 61, 1.0).to(torch.bfloat16).cuda()
-    w = _rand((n, k), 62, 0.03).to(torch.bfloat16).cuda()
-    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
-    mp = (m + 1) // 2 * 2
-    if epi == _lib.EPI_SWIGLU:
-        from atspeed_amd.model import _interleave_gate_up
-        w = _interleave_gate_up(w[: n // 2].contiguous(), w[n // 2:].contiguous())
-    odt = torch.float16 if kind == "fp16" else torch.bfloat16
-    if kind == "fp16":
-        a, w = a.to(torch.float16), w.to(torch.float16)
-    if epi == _lib.EPI_F32:
-        ldc = (n + 63) // 64 * 64; mk = lambda: torch.zeros(mp, ldc, dtype=torch.float32, device="cuda")
-    elif epi == _lib.EPI_SWIGLU:
-        ldc = n // 2; mk = lambda: torch.zeros(mp, ldc, dtype=odt, device="cuda")
-    else:
-        ldc = n; base = (_rand((mp, n), 63).to(odt).cuda() if epi == _lib.EPI_RESID else torch.zeros(mp, n, dtype=odt, device="cuda"))
-        mk = lambda: base.clone()
-    if kind == "fp8":
-        xq = torch.empty(m, k, dtype=torch.uint8, device="cuda"); sx = torch.empty(m, device="cuda")
-        wq = torch.empty(n, k, dtype=torch.uint8, device="cuda"); sw = torch.empty(n, device="cuda")
-        _lib.check(lib.atspeed_quant_rows_fp8(a.data_ptr(), m, k, xq.data_ptr(), sx.data_ptr(), _st()))
-        _lib.check(lib.atspeed_quant_rows_fp8(w.data_ptr(), n, k, wq.data_ptr(), sw.data_ptr(), _st()))
-        run = lambda c: _lib.check(lib.atspeed_gemm_fp8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), c.data_ptr(), m, n, k, ldc, epi, ws.data_ptr(), ws.numel(), _st()))
-    else:
-        code = _lib.ATSPEED_F16 if kind == "fp16" else _lib.ATSPEED_BF16
-        run = lambda c: _lib.check(lib.atspeed_gemm(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, k, ldc, code, epi, ws.data_ptr(), ws.numel(), _st()))
-    outs, cnts = [], []
-    for db in (0, 2, 2):
-        with _lib.switches(wdma_db=db):
-            _path_counters(lib, reset=True)
-            c = mk()
-            run(c)
-            torch.cuda.synchronize()
-            outs.append(c); cnts.append(_path_counters(lib))
-    fam = (PATH_FP8_WDMA, PATH_FP8_WDMA_SPLIT) if kind == "fp8" else (PATH_WDMA, PATH_WDMA_SPLIT)
-    assert sum(cnts[0][f] for f in fam) == 1 and cnts[0] == cnts[1], (cnts[0], cnts[1])      # a weight-streaming launch, the same family both times
-    assert bool(torch.isfinite(outs[0].float()).all())
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), f"max |diff| {float((outs[0].float() - outs[1].float()).abs().max()):.3e}"
-
-
+# ------------------------------------------------------------------ round 6: K-cut ring form
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("m,n,k,epi", [(320, 4096, 4096, 2), (320, 4096, 11008, 2), (640, 4096, 4096, 2), (640, 4096, 11008, 2), (1100, 4096, 11008, 2), (1054, 4096, 4096, 2),
                                         (257, 4096, 4096, 0), (900, 4096, 4096, 1), (700, 2048, 8192, 0)])

@@ -23,8 +23,7 @@ MOVE = re.compile(r'\s+(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32|v_accvgp
 def scan(path, verbose=True):
     s = open(path).read()
     findings, kernels = 0, 0
-    # (gemm_wdma_kernel<..., DB = true>, round 6: the last template argument before the parameter list -- its loop is asm as well)
-    for m in re.finditer(r'^(_Z\w*(?:gemm_ring\w+|gemm_wdma_kernel\w+?Lb1EEEvPKv\w+)):[^\n]*\n(.*?)s_endpgm', s, re.S | re.M):
+    for m in re.finditer(r'^(_Z\w*gemm_ring\w+):[^\n]*\n(.*?)s_endpgm', s, re.S | re.M):
         name, lines = m.group(1), m.group(2).splitlines()
         mf = [i for i, l in enumerate(lines) if re.match(r'\s+v_mfma', l)]
         if not mf:
@@ -39,12 +38,7 @@ def scan(path, verbose=True):
                 continue
             mm = MOVE.match(t)
             if mm and re.match(r'[va](\d+|\[)', mm.group(3).rstrip(',')):
-                src = mm.group(3).rstrip(',')
-                # a copy of a register that the same block has just loaded with the literal 0 is part of the zero fill (the compiler mixes `v_mov vN, 0`
-                # and `v_mov vN, vZERO` when it zeroes accumulators on a side path, e.g. a split part without k-tiles)
-                if any(re.match(r'\s+v_mov_b32_e32 ' + re.escape(src) + r', 0\s*$', lines[b]) for b in range(max(0, i - 48), i)):
-                    continue
-                moves.append((i, t.strip(), src))
+                moves.append((i, t.strip(), mm.group(3).rstrip(',')))
         # runs of consecutive moves from one source register = the zero fill
         k = 0
         while k < len(moves):
