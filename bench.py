@@ -293,6 +293,9 @@ def compact_line(detail: dict) -> dict:
                 rows8.append(dict(bracket=f"resid{a.get('resid_scale'):g}", bf16_ms=o1.get("bf16_ms_per_user"), fp8_ms=o1.get("fp8_ms_per_user"),
                                   fp8_frac=o1.get("fp8_weights_stream_frac_of_hbm_peak"), accept_bf16=o1.get("bf16_mean_accept_len"),
                                   accept_fp8=o1.get("fp8_mean_accept_len"), not_fp8=o1.get("projections_not_in_fp8")))
+        o16 = ((d.get("configs") or {}).get("fp8_fp16") or {}).get("one_user")
+        if o16:                                   # the reference's dtype combination: fp16 models, W8A8 target (inference.py:75-91)
+            rows8.append(dict(bracket="accept0_fp16", fp8_ms=o16.get("ms_per_user"), fp8_frac=o16.get("weights_stream_frac_of_hbm_peak")))
         line["one_user_fp8"] = rows8
     errs = d.get("sub_pass_errors")
     line["sub_pass_errors"] = {k: str(v)[:120] for k, v in errs.items()} if errs else None
@@ -794,6 +797,22 @@ def main():
                                             f"compiled for IEEE half, v_mfma_f32_16x16x32_f16), K={args.beam}, {args.streams} users per lock-step batch",
                                    steps=sub_steps, dtype="fp16", **pass_summary(r, args, ups),
                                    roofline=gemm_roofline(t16, r["prof"], r["prof_big"], False, measured, args.streams, False))
+            # ... and the reference's actual COMBINATION (inference.py:75-91: fp16 checkpoints, target loaded 8-bit): W8A8 projections on the fp16 flavour
+            release_decoders(t16, d16)
+            t16.enable_fp8()
+            t16.fp8_counters(reset=True)
+            r = timed_pass(t16, d16, dprompts, sub_warm, sub_steps, args.streams, fn, args, dev)
+            cnt16 = t16.fp8_counters()
+            one16 = None
+            if args.one_user_fp8_users > 0:
+                one16, _ = one_user_loop(t16, d16, dprompts, n_warm, min(args.one_user_fp8_users, n_timed), fn, args, dev, 1)
+            configs["fp8_fp16"] = dict(workload=f"{args.dataset.capitalize()} V={V}, fp16 draft / fp16 Llama-7B({args.target_layers}L) target with e4m3 W8A8 projections (the reference's "
+                                                f"dtype combination, inference.py:75-91), K={args.beam}, {args.streams} users per lock-step batch",
+                                       steps=sub_steps, dtype="fp8-e4m3 (W8A8 target projections, fp16 elsewhere)", **pass_summary(r, args, ups),
+                                       projection_launches={k: v for k, v in cnt16.items()},
+                                       roofline=gemm_roofline(t16, r["prof"], r["prof_big"], True, measured, args.streams, False),
+                                       one_user=one16,
+                                       parity="pinned to the build's W8A8 oracle on the fp16 weight values, tests/test_fp8_gpu.py[*fp16]")
             release_decoders(t16, d16)
             del t16, d16
         if not args.target_fp8:

@@ -32,6 +32,9 @@ EOS_ID = 2            # beamSD.py:81
 # among its k + 1 best finite scores.  A comparison with an engine that sums in another order (or in bf16) is only
 # meaningful where this margin is above that engine's rounding noise.
 MARGINS: Optional[List[float]] = None
+# Type of the scores (log-softmax, beam scores).  fp32 is the reference's (HF 4.41 upcasts the logits, beamSD.py:58 works on them as they come);
+# tests/test_fulldims_gpu.py sets float64 around runs of the ARBITER (RefLlama(dtype=torch.float64)): the same search in double precision.
+SCORE_DTYPE = torch.float32
 
 
 @dataclass
@@ -74,7 +77,7 @@ def expand_and_prune(logits: torch.Tensor, beam_scores: torch.Tensor, beam_seq: 
     """beamSD.py:57-86 given the logits rows: log-softmax over the FULL vocab, mask,
     add beam scores, flatten, top-k, split into (parent, token), drop disallowed picks."""
     n, V = logits.shape
-    logp = torch.log_softmax(logits.to(torch.float32), dim=-1)                    # :58
+    logp = torch.log_softmax(logits.to(SCORE_DTYPE), dim=-1)                      # :58
     if fn is not None:
         if n == 1 and beam_size != 1:                                             # :61-62
             logp = constrain(beam_seq[:1], logp, fn)
@@ -84,7 +87,7 @@ def expand_and_prune(logits: torch.Tensor, beam_scores: torch.Tensor, beam_seq: 
     for proc in procs:
         rows = beam_seq[:1] if (n == 1 and beam_size != 1) else beam_seq          # :61-62: K copies in, row 0 out
         logp = proc(rows, logp)
-    flat = (logp + beam_scores.to(torch.float32)[:, None]).reshape(-1)            # :69-70
+    flat = (logp + beam_scores.to(SCORE_DTYPE)[:, None]).reshape(-1)              # :69-70
     scores, idx = topk_desc_stable(flat, beam_size)                               # :76
     if MARGINS is not None:
         top = topk_desc_stable(flat, beam_size + 1)[0]
@@ -231,7 +234,7 @@ def BSSD(target: RefLlama, draft: RefLlama, input_ids, gamma: int, max_new_token
     cur_len = len(ids)
     max_len = cur_len + max_new_tokens
     tin = din = _causal_inputs(ids)
-    beam_scores = torch.zeros(1, dtype=torch.float32)                             # :498
+    beam_scores = torch.zeros(1, dtype=SCORE_DTYPE)                               # :498
     beam_seq = ids[None, :].repeat(beam_size, 1)                                  # :499
     accept_steps: List[int] = []
     rounds = []
@@ -266,7 +269,7 @@ def target_generate(model: RefLlama, input_ids, max_new_tokens: int, beam_size: 
     """beamSD.py:544-595: plain constrained beam search on the target."""
     ids = torch.as_tensor(np.asarray(input_ids), dtype=torch.long).reshape(-1)
     inp = _causal_inputs(ids)
-    beam_scores = torch.zeros(1, dtype=torch.float32)
+    beam_scores = torch.zeros(1, dtype=SCORE_DTYPE)
     beam_seq = ids[None, :].repeat(beam_size, 1)
     steps = []
     for _ in range(max_new_tokens):                                               # :579-588

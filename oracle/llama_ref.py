@@ -82,10 +82,15 @@ class RefLlama:
 
     PROJ = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")
 
-    def __init__(self, dims, state_dict: Dict[str, object], max_slots: int = 1024, w8a8: bool = False):
+    def __init__(self, dims, state_dict: Dict[str, object], max_slots: int = 1024, w8a8: bool = False, dtype: torch.dtype = torch.float32):
+        """dtype=torch.float64: the ARBITER mode (round 6) -- the same model (the fp32 weight VALUES, HF's fp32 rotary angles) evaluated in
+        double precision: what two fp32 evaluations that sum in different orders are both approximating (tests/test_fulldims_gpu.py judges
+        near-tied decisions with it).  The weights stay stored in fp32 and are widened per use, so the mode costs no second copy of a 7B model."""
         self.d = RefDims(dims.vocab_size, dims.hidden, dims.n_layers, dims.n_heads, dims.ffn,
                          dims.rope_theta, dims.rms_eps)
         self.w = {k: _t(v) for k, v in state_dict.items()}
+        self.cdt = dtype
+        assert dtype in (torch.float32, torch.float64) and not (w8a8 and dtype != torch.float32)
         self.w8a8 = w8a8
         self.wq: Dict[str, tuple] = {}
         if w8a8:
@@ -94,8 +99,8 @@ class RefLlama:
                     name = f"model.layers.{l}.{pj}.weight"
                     self.wq[name] = quant_rows_e4m3(self.w[name])
         d = self.d
-        self.kcache = torch.zeros(d.n_layers, max_slots, d.n_heads, d.head_dim)
-        self.vcache = torch.zeros(d.n_layers, max_slots, d.n_heads, d.head_dim)
+        self.kcache = torch.zeros(d.n_layers, max_slots, d.n_heads, d.head_dim, dtype=dtype)
+        self.vcache = torch.zeros(d.n_layers, max_slots, d.n_heads, d.head_dim, dtype=dtype)
         half = d.head_dim // 2
         # HF LlamaRotaryEmbedding: inv_freq = 1 / theta^(2i/dh)
         self.inv_freq = 1.0 / (d.rope_theta ** (torch.arange(0, half, dtype=torch.float32) * 2.0 / d.head_dim))
@@ -104,10 +109,14 @@ class RefLlama:
     def _proj(self, x: torch.Tensor, name: str) -> torch.Tensor:
         """x W^T for a layer projection: fp32, or W8A8 (e4m3 x e4m3 products are exact in fp32; the sum is fp32)."""
         if not self.w8a8:
-            return x @ self.w[name].T
+            return x @ self._W(name).T
         xq, sx = quant_rows_e4m3(x)
         wq, sw = self.wq[name]
         return (xq @ wq.T) * sx[:, None] * sw[None, :]
+
+    def _W(self, name: str) -> torch.Tensor:
+        """A weight in the compute type (fp32: the stored tensor itself; fp64: widened on use)."""
+        return self.w[name].to(self.cdt)
 
     def _rmsnorm(self, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
         var = x.pow(2).mean(-1, keepdim=True)
@@ -115,7 +124,7 @@ class RefLlama:
 
     def _rope(self, x: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
         # x [T, H, dh]; rotate_half convention: pairs (i, i + dh/2)
-        ang = pos.to(torch.float32)[:, None] * self.inv_freq[None, :]      # [T, dh/2]
+        ang = (pos.to(torch.float32)[:, None] * self.inv_freq[None, :]).to(self.cdt)      # [T, dh/2]; the angle is fp32 in HF (part of the model), its cos / sin in the compute type
         cos = torch.cat((ang.cos(), ang.cos()), -1)[:, None, :]
         sin = torch.cat((ang.sin(), ang.sin()), -1)[:, None, :]
         half = x.shape[-1] // 2
@@ -134,12 +143,12 @@ class RefLlama:
         slots = torch.as_tensor(np.asarray(slots), dtype=torch.long)
         vis = torch.as_tensor(np.asarray(vis), dtype=torch.bool)
         T, S = vis.shape
-        h = self.w["model.embed_tokens.weight"][ids]
+        h = self.w["model.embed_tokens.weight"][ids].to(self.cdt)
         scale = 1.0 / math.sqrt(d.head_dim)
-        neg = torch.finfo(torch.float32).min
+        neg = torch.finfo(torch.float32).min                         # (also in fp64 mode: a masked score contributes exactly 0 either way)
         for l in range(d.n_layers):
             p = f"model.layers.{l}."
-            x = self._rmsnorm(h, self.w[p + "input_layernorm.weight"])
+            x = self._rmsnorm(h, self._W(p + "input_layernorm.weight"))
             q = self._proj(x, p + "self_attn.q_proj.weight").view(T, d.n_heads, d.head_dim)
             k = self._proj(x, p + "self_attn.k_proj.weight").view(T, d.n_heads, d.head_dim)
             v = self._proj(x, p + "self_attn.v_proj.weight").view(T, d.n_heads, d.head_dim)
@@ -151,14 +160,14 @@ class RefLlama:
             V = self.vcache[l, :S]
             sc = torch.einsum("thd,shd->hts", q, K) * scale          # [H, T, S]
             sc = torch.where(vis[None], sc, torch.full_like(sc, neg))
-            pr = torch.softmax(sc, dim=-1, dtype=torch.float32)
+            pr = torch.softmax(sc, dim=-1, dtype=self.cdt)
             a = torch.einsum("hts,shd->thd", pr, V).reshape(T, d.hidden)
             h = h + self._proj(a, p + "self_attn.o_proj.weight")
-            x = self._rmsnorm(h, self.w[p + "post_attention_layernorm.weight"])
+            x = self._rmsnorm(h, self._W(p + "post_attention_layernorm.weight"))
             g = self._proj(x, p + "mlp.gate_proj.weight")
             u = self._proj(x, p + "mlp.up_proj.weight")
             h = h + self._proj(torch.nn.functional.silu(g) * u, p + "mlp.down_proj.weight")
         if n_logit_rows is not None:
             h = h[T - n_logit_rows:]
-        x = self._rmsnorm(h, self.w["model.norm.weight"])
-        return (x @ self.w["lm_head.weight"].T).to(torch.float32)
+        x = self._rmsnorm(h, self._W("model.norm.weight"))
+        return (x @ self._W("lm_head.weight").T).to(self.cdt)        # fp32 logits (fp64 in the arbiter mode)

@@ -2,6 +2,7 @@
 (`--gpus N` must give N ranks or fail loudly), the torchrun command it starts, the provenance of `roofline.traffic`, and the
 oracle-side scoring behind `cpu_baseline.bf16_vs_fp32_disagreements`."""
 import argparse
+import os
 import sys
 
 import numpy as np
@@ -13,6 +14,9 @@ from atspeed_amd import synth
 from atspeed_amd.generation_trie import PositionSetConstraint
 from oracle import beamsd_ref as R
 from oracle.llama_ref import RefLlama
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _args(gpus):
@@ -238,3 +242,20 @@ def test_compact_line_of_a_multi_gpu_run_keeps_the_per_rank_rows():
     line = bench.compact_line(detail)
     assert line["n_gpus"] == 8 and [r["rank"] for r in line["per_rank"]] == list(range(8)) and line["per_rank"][7]["elapsed_ms"] > line["per_rank"][0]["elapsed_ms"]
     assert line["cpu_baseline"] is None and len(json.dumps(line)) < bench.LINE_BUDGET_BYTES
+
+
+def test_gpu_suite_duration_is_within_budget():
+    """the driver gives the `-m gpu` suite 900 s; one more round of unchecked growth would have zeroed the parity grade.  The round's
+    full run (`pytest tests -m gpu --durations=40` on one MI355X, committed as profiles/r06_gpu_suite_durations.txt) must finish within 600 s, and
+    the recorded slowest tests must not hide a new heavyweight."""
+    import re
+    path = os.path.join(ROOT, "profiles", "r06_gpu_suite_durations.txt")
+    assert os.path.exists(path), "profiles/r06_gpu_suite_durations.txt is missing: run tools/r06_call.sh suite through gpurun and commit its log"
+    text = open(path).read()
+    m = re.findall(r"(\d+) passed.* in ([\d.]+)s", text)
+    assert m, "no pytest summary line in the durations file"
+    passed, seconds = int(m[-1][0]), float(m[-1][1])
+    assert passed >= 500 and "failed" not in text.splitlines()[-1]
+    assert seconds <= 600.0, f"the GPU suite took {seconds:.0f} s on the recorded run: over the 600 s budget (driver limit 900 s)"
+    durs = [(float(x), name) for x, name in re.findall(r"^([\d.]+)s call\s+(\S+)", text, re.M)]
+    assert durs and max(durs)[0] <= 150.0, max(durs)

@@ -58,16 +58,30 @@ def fulldims_fp32():
     release_decoders(tgt, drf)
 
 
+FP64_LEG_USERS = 2      # near-tied users judged by the fp64 arbiter (~40 s of CPU each at these dims); further ones keep the fp32 criterion
+
+
+def _arbiter(rt, rd):
+    """The SAME two models in double precision (RefLlama(dtype=float64): the fp32 weight values widened per use -- no second copy)."""
+    if not hasattr(rt, "_arbiter"):
+        rt._arbiter = (RefLlama(rt.d, rt.w, max_slots=512, dtype=torch.float64), RefLlama(rd.d, rd.w, max_slots=512, dtype=torch.float64))
+    return rt._arbiter
+
+
 @pytest.mark.parametrize("K,DK", [(1, 2), (2, 4)])
 def test_fp32_engine_at_full_dims_is_exact_where_exactness_is_decidable(fulldims_fp32, K, DK):
     """Full Llama-7B(32L) / Llama-68M dims, headline weights, K = 1 / 2 beams: item ids, per-round n_matches, accepted steps, the draft's
-    candidate ids in order and the lossless property hold EXACTLY on all twelve (K = 1) / eight (K = 2) users -- no near-tie branch (`near_ties == 0` asserted)."""
-    n_users = 12 if K == 1 else 8                                   # (the 900 s budget of the GPU suite: K = 2 on eight of the twelve prompts)
+    candidate ids in order and the lossless property hold EXACTLY on all twelve (K = 1) / six (K = 2) users -- no near-tie branch (`near_ties == 0` asserted)."""
+    n_users = 12 if K == 1 else 6                                   # (the 600 s budget of the GPU suite: K = 2 on six of the twelve prompts)
     checked, near_ties = _fulldims_against_oracle(fulldims_fp32, K, DK, strict=True, n_users=n_users)
     assert near_ties == 0 and checked == n_users
 
 
 def test_fp32_engine_at_llama7b_llama68m_dims_equals_oracle(fulldims_fp32):
+    """K = 20 / DK = 40 (the headline): exact where the engine and the fp32 oracle agree; where they differ (a user makes ~400 adjacent top-k gaps and
+    the smallest is of the size of fp32 re-association noise, profiles/r05_margin_search.txt) BOTH are held to the fp64 arbiter: every rank of each
+    list scores, in double precision, within 4 x FP32_NOISE of the fp64 search's own score at that rank (round 6, VERDICT r5 #4: the truth judges,
+    not one fp32 evaluation the other)."""
     checked, near_ties = _fulldims_against_oracle(fulldims_fp32, 20, 40, strict=False)
     assert checked >= 8 and checked + near_ties == 12
 
@@ -78,7 +92,8 @@ def _fulldims_against_oracle(models, K, DK, strict, n_users=12):
     release_decoders(tgt, drf)                                            # decoders (beam blocks) of another beam count
     tgt.generation_config.num_beams, drf.generation_config.num_beams = K, DK
     fn = atspeed_amd.PositionSetConstraint(synth.BEAUTY.allowed_tokens(), synth.RESPONSE_SEP)
-    checked = near_ties = 0
+    checked = near_ties = fp64_legs = 0
+    max_fp64_gap = 0.0
     # twelve users (this engine is the judge of tests/test_decisions_gpu.py, so its own pin to the oracle must not be a
     # two-user link): the mean Beauty prompt, short ones, long ones; ~7 s of CPU oracle per user on the box's 16 allotted CPUs
     PROMPTS = (108, 70, 66, 84, 96, 78, 120, 150, 186, 72, 102, 132)[:n_users]
@@ -97,15 +112,53 @@ def _fulldims_against_oracle(models, K, DK, strict, n_users=12):
               f"max score diff={float((out['beam_scores'].cpu() - ref['beam_scores']).abs().max()):.2e}")
         if strict:
             assert same, f"user {u}: item token ids differ from the oracle (decision margin {margin:.3e})"
+        if same and not strict and u == 0:
+            # the arbiter is exercised on every box (a near tie may occur on none of the twelve users): user 0's list, which equals the fp32 oracle's,
+            # against the fp64 search -- the engine held to the truth directly
+            rt64, rd64 = _arbiter(rt, rd)
+            R.SCORE_DTYPE = torch.float64
+            try:
+                truth = R.BSSD(rt64, rd64, prompt, 4, 4, K, DK, fn)
+                t_sc = [float(x) for x in truth["beam_scores"]]
+                sc64 = _oracle_scores_of(rt64, prompt, out["beam_sequence"][:, P:].cpu().tolist(), dtype=torch.float64)
+            finally:
+                R.SCORE_DTYPE = torch.float32
+            gap = max(abs(a - b) for a, b in zip(sc64, t_sc))
+            max_fp64_gap = max(max_fp64_gap, gap)
+            print(f"  user 0 against the fp64 search: same items {out['beam_sequence'][:, P:].cpu().tolist() == truth['beam_sequence'][:, P:].tolist()}, "
+                  f"largest fp64 score gap at a rank {gap:.2e}, engine's own scores off by {float(np.abs(out['beam_scores'].cpu().double().numpy() - np.asarray(t_sc)).max()):.2e}")
+            assert gap < 4 * FP32_NOISE
+            np.testing.assert_allclose(out["beam_scores"].cpu().double().numpy(), np.asarray(t_sc), atol=SCORE_TOL, rtol=0)
+            fp64_legs += 1
         if not same:
             # no silent skip: a difference is only tolerated when the oracle's own smallest decision margin is below fp32 summation noise
             # AND every item the engine ranked differently is, by the oracle's own arithmetic, within that noise of the oracle's item there
             assert margin < FP32_NOISE, f"user {u}: item token ids differ from the oracle at full dims (decision margin {margin:.3e})"
             g_items, r_items = out["beam_sequence"][:, P:].cpu().tolist(), ref["beam_sequence"][:, P:].tolist()
-            ranks = [i for i, (a, b) in enumerate(zip(g_items, r_items)) if a != b]
-            sc = _oracle_scores_of(rt, prompt, [g_items[i] for i in ranks])
-            for i, s_gpu in zip(ranks, sc):
-                assert abs(float(ref["beam_scores"][i]) - s_gpu) < 4 * FP32_NOISE, (u, i, float(ref["beam_scores"][i]), s_gpu)
+            if fp64_legs < FP64_LEG_USERS:
+                # the fp64 arbiter: the same beam search on the same weight values in double precision is the truth both fp32 evaluations approximate;
+                # each list's items are scored in fp64 (one packed forward) and held, rank by rank, to the fp64 search's own scores
+                rt64, rd64 = _arbiter(rt, rd)
+                R.SCORE_DTYPE = torch.float64
+                try:
+                    truth = R.BSSD(rt64, rd64, prompt, 4, 4, K, DK, fn)
+                    t_sc = [float(x) for x in truth["beam_scores"]]
+                    for who, items in (("engine", g_items), ("fp32 oracle", r_items)):
+                        sc64 = _oracle_scores_of(rt64, prompt, items, dtype=torch.float64)
+                        gap = max(abs(a - b) for a, b in zip(sc64, t_sc))
+                        max_fp64_gap = max(max_fp64_gap, gap)
+                        n_same = sum(a == b for a, b in zip(items, truth["beam_sequence"][:, P:].tolist()))
+                        print(f"  user {u}: {who}'s list against the fp64 search: {n_same} of {K} ranks hold the same item, largest fp64 score gap at a rank {gap:.2e}")
+                        assert gap < 4 * FP32_NOISE, (u, who, gap)
+                finally:
+                    R.SCORE_DTYPE = torch.float32
+                np.testing.assert_allclose(out["beam_scores"].cpu().double().numpy(), np.asarray(t_sc), atol=SCORE_TOL, rtol=0)
+                fp64_legs += 1
+            else:
+                ranks = [i for i, (a, b) in enumerate(zip(g_items, r_items)) if a != b]
+                sc = _oracle_scores_of(rt, prompt, [g_items[i] for i in ranks])
+                for i, s_gpu in zip(ranks, sc):
+                    assert abs(float(ref["beam_scores"][i]) - s_gpu) < 4 * FP32_NOISE, (u, i, float(ref["beam_scores"][i]), s_gpu)
             np.testing.assert_allclose(out["beam_scores"].cpu().numpy(), ref["beam_scores"].numpy(), atol=SCORE_TOL, rtol=0)
             near_ties += 1
             continue
@@ -126,13 +179,13 @@ def _fulldims_against_oracle(models, K, DK, strict, n_users=12):
                     assert len(got) == len(gids) and len(set(got) ^ set(gids)) <= 2 and sum(a != b for a, b in zip(got, gids)) <= 4, (u, got, gids)
         # lossless (beamSD.py:544-595): the plain beam search of the same engine gives the same items
         assert torch.equal(tg["beam_sequence"], out["beam_sequence"])
-    print(f"K={K} DK={DK}: checked exactly {checked}, near ties {near_ties} of {len(PROMPTS)} users")
+    print(f"K={K} DK={DK}: checked exactly {checked}, near ties {near_ties} of {len(PROMPTS)} users ({fp64_legs} judged by the fp64 arbiter, largest fp64 gap {max_fp64_gap:.2e})")
     assert checked + near_ties == len(PROMPTS)
     return checked, near_ties
 
 
-def _oracle_scores_of(ref_model, prompt, seqs):
-    """fp32 oracle beam scores of arbitrary generated sequences (sum of full-vocabulary log-probabilities, beamSD.py:58,69-70) from one
+def _oracle_scores_of(ref_model, prompt, seqs, dtype=torch.float32):
+    """oracle beam scores (fp32; fp64 with the arbiter model and dtype=torch.float64) of arbitrary generated sequences (sum of full-vocabulary log-probabilities, beamSD.py:58,69-70) from one
     packed forward: the prompt once, every sequence a branch under a tree mask."""
     P, L, n = len(prompt), len(seqs[0]), len(seqs)
     ids = [int(t) for t in prompt] + [int(t) for sq in seqs for t in sq[:-1]]
@@ -144,7 +197,7 @@ def _oracle_scores_of(ref_model, prompt, seqs):
         lo = P + i * (L - 1)
         vis[lo: lo + L - 1, :P] = True
         vis[lo: lo + L - 1, lo: lo + L - 1] = torch.tril(torch.ones(L - 1, L - 1, dtype=torch.bool))
-    logp = torch.log_softmax(ref_model.forward(torch.tensor(ids), torch.tensor(pos), torch.arange(T), vis, n_logit_rows=T - P + 1), dim=-1)
+    logp = torch.log_softmax(ref_model.forward(torch.tensor(ids), torch.tensor(pos), torch.arange(T), vis, n_logit_rows=T - P + 1).to(dtype), dim=-1)
     return [float(sum(logp[r, int(t)] for r, t in zip([0] + [1 + i * (L - 1) + j for j in range(L - 1)], sq))) for i, sq in enumerate(seqs)]
 
 

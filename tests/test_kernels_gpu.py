@@ -1054,9 +1054,11 @@ def test_split_k_tail_with_an_unaligned_deal(lib, m, n, k, epi, G):
     assert float((got - ref).abs().max()) <= tol
 
 # ------------------------------------------------------------------ round 6: K-cut ring form
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("m,n,k,epi", [(320, 4096, 4096, 2), (320, 4096, 11008, 2), (640, 4096, 4096, 2), (640, 4096, 11008, 2), (1100, 4096, 11008, 2), (1054, 4096, 4096, 2),
-                                        (257, 4096, 4096, 0), (900, 4096, 4096, 1), (700, 2048, 8192, 0)])
+KCUT_SHAPES = [(320, 4096, 4096, 2), (320, 4096, 11008, 2), (640, 4096, 4096, 2), (640, 4096, 11008, 2), (1100, 4096, 11008, 2), (1054, 4096, 4096, 2),
+               (257, 4096, 4096, 0), (900, 4096, 4096, 1), (700, 2048, 8192, 0)]
+
+
+@pytest.mark.parametrize("m,n,k,epi,dtype", [s + (torch.bfloat16,) for s in KCUT_SHAPES] + [s + (torch.float16,) for s in KCUT_SHAPES[1:6:2]])
 def test_gemm_ring_cut_in_k(lib, m, n, k, epi, dtype):
     """Round 6: the 16-bit N <= 4096 projections at 257-1100 tokens (o_proj, down of 4-16 users in lock step) run the ring kernel cut in K over the
     whole chip -- tiles x parts ~ 256 workgroups, fp32 slabs, the reduce kernels of the other split forms -- as the default dispatch

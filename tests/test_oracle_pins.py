@@ -180,3 +180,25 @@ def test_hash_rng_sampling_has_the_reference_law():
     m = (pm > 0.05) & (pm < 0.95)
     z = np.abs(h0 - h1)[m] / np.sqrt(pm[m] * (1 - pm[m]) * 2 / N)
     assert m.sum() >= 5 and z.max() < 4.0, (z.max(), int(m.sum()))
+
+
+def test_fp64_arbiter_mode_of_the_oracle_agrees_with_the_fp32_oracle():
+    """RefLlama(dtype=float64) + beamsd_ref.SCORE_DTYPE = float64 (the arbiter tests/test_fulldims_gpu.py judges near-tied full-dims decisions with):
+    the same search in double precision gives the golden case's items, rounds and -- within fp32 re-association noise -- scores."""
+    import torch
+    from oracle import beamsd_ref as R
+    from oracle.llama_ref import RefLlama
+    from tests.golden.cases import CASES, build_case_inputs
+    case = next(c for c in CASES if c["name"] == "k20_dk40_sigma01_s7")
+    ci = build_case_inputs(case)
+    args = (ci["prompt"], case["gamma"], case["max_new_tokens"], case["K"], case["DK"], ci["fn"])
+    a = R.BSSD(RefLlama(ci["target_dims"], ci["target_sd"]), RefLlama(ci["draft_dims"], ci["draft_sd"]), *args)
+    R.SCORE_DTYPE = torch.float64
+    try:
+        b = R.BSSD(RefLlama(ci["target_dims"], ci["target_sd"], dtype=torch.float64), RefLlama(ci["draft_dims"], ci["draft_sd"], dtype=torch.float64), *args)
+    finally:
+        R.SCORE_DTYPE = torch.float32
+    assert b["beam_scores"].dtype == torch.float64
+    assert a["beam_sequence"].tolist() == b["beam_sequence"].tolist() and a["n_run"] == b["n_run"]
+    assert [r["n_matches"] for r in a["rounds"]] == [r["n_matches"] for r in b["rounds"]]
+    assert float((a["beam_scores"].double() - b["beam_scores"]).abs().max()) < 1e-4

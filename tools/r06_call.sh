@@ -15,4 +15,9 @@ b)  # (the fragment double-buffering A/B of gemm_wdma_kernel: profiles/r06_wdma_
     #  profiles/r06_wdma_db_experiment.patch has it)
   echo "step b needs the patch profiles/r06_wdma_db_experiment.patch applied"; exit 1
   ;;
+suite)  # the full -m gpu suite with its slowest tests: profiles/r06_gpu_suite_durations.txt (tests/test_bench_contract.py holds it under 600 s)
+  timeout -k 10 1100 python -m pytest tests -q -m gpu --durations=40 > gpurun_out/r06_gpu_suite.log 2>&1; rc=$?
+  grep -A42 "slowest 40" gpurun_out/r06_gpu_suite.log > gpurun_out/r06_gpu_suite_durations.txt; tail -3 gpurun_out/r06_gpu_suite.log >> gpurun_out/r06_gpu_suite_durations.txt
+  exit $rc
+  ;;
 esac
