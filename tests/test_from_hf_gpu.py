@@ -179,6 +179,6 @@ def test_unsupported_checkpoints_and_dtypes_raise():
     with pytest.raises(TypeError):
         HipLlama.from_synthetic(synth.llama_68m(V), 1, dtype=torch.float64)
     with pytest.raises(atspeed_amd._lib.AtSpeedError):
-        HipLlama.from_synthetic(synth.llama_68m(V), 1, dtype=torch.float16, max_slots=256, max_tokens=256, max_logit_rows=128).enable_fp8()   # fp8 copies are made of bf16 weights
+        HipLlama.from_synthetic(synth.llama_68m(V), 1, dtype=torch.float32, max_slots=256, max_tokens=256, max_logit_rows=128).enable_fp8()   # fp8 copies are made of 16-bit weights (bf16 or, since round 6, fp16)
     with pytest.raises(NotImplementedError):
         HipLlama.from_hf(_hf(torch.float16, 8, layers=1, kv_heads=4))     # grouped-query attention

@@ -115,18 +115,11 @@ def _fulldims_against_oracle(models, K, DK, strict, n_users=12):
         if same and not strict and u == 0:
             # the arbiter is exercised on every box (a near tie may occur on none of the twelve users): user 0's list, which equals the fp32 oracle's,
             # against the fp64 search -- the engine held to the truth directly
-            rt64, rd64 = _arbiter(rt, rd)
-            R.SCORE_DTYPE = torch.float64
-            try:
-                truth = R.BSSD(rt64, rd64, prompt, 4, 4, K, DK, fn)
-                t_sc = [float(x) for x in truth["beam_scores"]]
-                sc64 = _oracle_scores_of(rt64, prompt, out["beam_sequence"][:, P:].cpu().tolist(), dtype=torch.float64)
-            finally:
-                R.SCORE_DTYPE = torch.float32
-            gap = max(abs(a - b) for a, b in zip(sc64, t_sc))
+            t_items, t_sc = _fp64_truth(rt, rd, prompt, K, fn)
+            gap = _fp64_gap(rt, rd, prompt, out["beam_sequence"][:, P:].cpu().tolist(), t_items, t_sc)
             max_fp64_gap = max(max_fp64_gap, gap)
-            print(f"  user 0 against the fp64 search: same items {out['beam_sequence'][:, P:].cpu().tolist() == truth['beam_sequence'][:, P:].tolist()}, "
-                  f"largest fp64 score gap at a rank {gap:.2e}, engine's own scores off by {float(np.abs(out['beam_scores'].cpu().double().numpy() - np.asarray(t_sc)).max()):.2e}")
+            print(f"  user 0 against the fp64 search: same items {out['beam_sequence'][:, P:].cpu().tolist() == t_items}, largest fp64 score gap at a rank {gap:.2e}, "
+                  f"engine's own scores off by {float(np.abs(out['beam_scores'].cpu().double().numpy() - np.asarray(t_sc)).max()):.2e}")
             assert gap < 4 * FP32_NOISE
             np.testing.assert_allclose(out["beam_scores"].cpu().double().numpy(), np.asarray(t_sc), atol=SCORE_TOL, rtol=0)
             fp64_legs += 1
@@ -138,20 +131,13 @@ def _fulldims_against_oracle(models, K, DK, strict, n_users=12):
             if fp64_legs < FP64_LEG_USERS:
                 # the fp64 arbiter: the same beam search on the same weight values in double precision is the truth both fp32 evaluations approximate;
                 # each list's items are scored in fp64 (one packed forward) and held, rank by rank, to the fp64 search's own scores
-                rt64, rd64 = _arbiter(rt, rd)
-                R.SCORE_DTYPE = torch.float64
-                try:
-                    truth = R.BSSD(rt64, rd64, prompt, 4, 4, K, DK, fn)
-                    t_sc = [float(x) for x in truth["beam_scores"]]
-                    for who, items in (("engine", g_items), ("fp32 oracle", r_items)):
-                        sc64 = _oracle_scores_of(rt64, prompt, items, dtype=torch.float64)
-                        gap = max(abs(a - b) for a, b in zip(sc64, t_sc))
-                        max_fp64_gap = max(max_fp64_gap, gap)
-                        n_same = sum(a == b for a, b in zip(items, truth["beam_sequence"][:, P:].tolist()))
-                        print(f"  user {u}: {who}'s list against the fp64 search: {n_same} of {K} ranks hold the same item, largest fp64 score gap at a rank {gap:.2e}")
-                        assert gap < 4 * FP32_NOISE, (u, who, gap)
-                finally:
-                    R.SCORE_DTYPE = torch.float32
+                t_items, t_sc = _fp64_truth(rt, rd, prompt, K, fn)
+                for who, items in (("engine", g_items), ("fp32 oracle", r_items)):
+                    gap = _fp64_gap(rt, rd, prompt, items, t_items, t_sc)
+                    max_fp64_gap = max(max_fp64_gap, gap)
+                    print(f"  user {u}: {who}'s list against the fp64 search: {sum(a == b for a, b in zip(items, t_items))} of {K} ranks hold the same item, "
+                          f"largest fp64 score gap at a rank {gap:.2e}")
+                    assert gap < 4 * FP32_NOISE, (u, who, gap)
                 np.testing.assert_allclose(out["beam_scores"].cpu().double().numpy(), np.asarray(t_sc), atol=SCORE_TOL, rtol=0)
                 fp64_legs += 1
             else:
@@ -182,6 +168,29 @@ def _fulldims_against_oracle(models, K, DK, strict, n_users=12):
     print(f"K={K} DK={DK}: checked exactly {checked}, near ties {near_ties} of {len(PROMPTS)} users ({fp64_legs} judged by the fp64 arbiter, largest fp64 gap {max_fp64_gap:.2e})")
     assert checked + near_ties == len(PROMPTS)
     return checked, near_ties
+
+
+def _fp64_truth(rt, rd, prompt, K, fn):
+    """The arbiter's list: the plain constrained beam search of the target (beamSD.py:544-595) in double precision -- by the lossless property
+    (beam-SD == target_generate in exact arithmetic: every fixture of the real reference has it) the top-K any faithful evaluation approximates; a
+    third of the tokens of an fp64 beam-SD run and no draft forwards.  -> (items [K][L], scores [K] as floats)"""
+    rt64, _ = _arbiter(rt, rd)
+    R.SCORE_DTYPE = torch.float64
+    try:
+        truth = R.target_generate(rt64, prompt, 4, K, fn)
+    finally:
+        R.SCORE_DTYPE = torch.float32
+    P = len(prompt)
+    return truth["beam_sequence"][:, P:].tolist(), [float(x) for x in truth["beam_scores"]]
+
+
+def _fp64_gap(rt, rd, prompt, items, t_items, t_sc):
+    """Largest |fp64 score of the list's item at rank i - the fp64 search's score at rank i| (0 for a list that IS the fp64 list: no forward needed)."""
+    if items == t_items:
+        return 0.0
+    rt64, _ = _arbiter(rt, rd)
+    sc64 = _oracle_scores_of(rt64, prompt, items, dtype=torch.float64)
+    return max(abs(a - b) for a, b in zip(sc64, t_sc))
 
 
 def _oracle_scores_of(ref_model, prompt, seqs, dtype=torch.float32):

@@ -28,7 +28,13 @@ def _st():
 
 
 def _rand(shape, seed, std=1.0):
+    """Seeded N(0, std^2) fp32 values (CPU tensor).  Large operands come from the library's fill kernel, which test_fill_hash_normal_bit_exact pins
+    bit for bit to synth.hash_normal (numpy): the 90 M-element weights of the Llama-7B shapes cost ~1.5 s each in numpy -- a third of the suite."""
     n = int(np.prod(shape))
+    if n >= (1 << 20) and torch.cuda.is_available():
+        t = torch.empty(n, dtype=torch.float32, device="cuda")
+        _lib.check(_lib.load().atspeed_fill_hash_normal(t.data_ptr(), n, seed, float(synth.normal_scale(std)), 0.0, _lib.ATSPEED_F32, 0, _st()))
+        return t.cpu().reshape(shape)
     return torch.from_numpy(synth.hash_normal(n, seed, std).reshape(shape))
 
 
