@@ -182,7 +182,9 @@ int atspeed_llama_fp8_counters(atspeed_llama* m, int64_t* fp8_out, int64_t* othe
 /* how many qkv projections (one per layer per forward) ran with the rotary embedding and the KV-cache scatter in the GEMM's epilogue
  * (batched bf16 forwards, head_dim 128, hidden % 256 == 0: the reference's apply_rotary_pos_emb + cache update, modeling_llama.py as
  * called from beamSD.py:120, without re-reading the projection) rather than as the separate pass, since the last reset; -1 on a NULL
- * model.  ATSPEED_FUSE_QKV_ROPE=0 in the environment (read at each forward) selects the separate pass: results are bit-identical. */
+ * model.  The switch "fuse_qkv_rope" (atspeed_set_switch; initial value ATSPEED_FUSE_QKV_ROPE, default 1) = 0 selects the separate pass:
+ * results are bit-identical.  Since round 6 ONE user's W8A8 qkv projection (1-256 tokens, 150-256 unsplit tiles of 64 weight rows: Llama-7B's
+ * 192) carries the same epilogue in the weight-streaming kernel. */
 int64_t atspeed_llama_rope_fused_launches(atspeed_llama* m, int32_t reset);
 /* bytes of the split-K arena this model owns (0: none yet -- it is allocated in front of the model's first forward of >= 257 tokens, so a
  * draft or a one-user target never holds one; thin ring-kernel grids of a model without one take the device's shared arena or the plain grid) */
