@@ -1404,7 +1404,13 @@ static bool stream_is_capturing(hipStream_t st) {
 template <int EPI>
 int launch_big(const bf16_t* x, const bf16_t* w, void* c, int m, int n, int k, int ldx, int ldc, hipStream_t st, int pk, const RopeEpi& rope = RopeEpi{},
                float* lse_part = nullptr, const unsigned char* tile_store = nullptr, const SkArena* arena = nullptr) {
-  constexpr int gm = 4;
+  // height of the tile bands an XCD walks (its ~32 concurrent tiles are gm token-tile rows x 32 / gm weight panels).  4 is the measured minimum of
+  // the L2-miss traffic (2 / 4 / 8: 12.45 / 9.57 / 11.96 GB per gate_up launch, round 2; 6 -- the 5.7 x 5.7 optimum of the panel count -- in round 6,
+  // profiles/r06_ring_raster_ab.txt).  -DATS_RING_GM=n builds a probe library for that A/B (tools/r06_call.sh raster); not a run-time switch.
+#ifndef ATS_RING_GM
+#define ATS_RING_GM 4
+#endif
+  constexpr int gm = ATS_RING_GM;
   const int tiles_n = (n + 255) / 256;
   constexpr int LDS8 = EPI == EPI_F32_LSE ? 136 * 1024 : 128 * 1024, LDS4 = EPI == EPI_F32_LSE ? 100 * 1024 : 96 * 1024;
   static thread_local AtsPerDeviceFlag attr_flag;

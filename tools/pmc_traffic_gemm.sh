@@ -1,12 +1,12 @@
 #!/bin/bash
 # HBM-side traffic (L2 misses to the fabric) of ONE ring-GEMM shape per launch, for env-selected variants: separate rocprofv3 --pmc passes
-# (FETCH_SIZE and WRITE_SIZE do not fit one pass), kernel-trace off.  usage: tools/pmc_traffic_gemm.sh TAG M N K   (env passes through)
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass), kernel-trace off.  usage: tools/pmc_traffic_gemm.sh TAG M N K [EPI]   (env passes through; EPI 0 store / 2 residual / 3 SwiGLU)
 set -e
 TAG=$1; M=$2; N=$3; K=$4
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmct_$TAG
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE -d $OUT/f -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/one_gemm.py $M $N $K > $OUT.f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/w -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/one_gemm.py $M $N $K > $OUT.w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/f -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/one_gemm.py $M $N $K $5 > $OUT.f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/w -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/one_gemm.py $M $N $K $5 > $OUT.w.log 2>&1
 python3 - <<PY
 import csv, glob
 def avg(d):

@@ -20,4 +20,15 @@ suite)  # the full -m gpu suite with its slowest tests: profiles/r06_gpu_suite_d
   grep -A42 "slowest 40" gpurun_out/r06_gpu_suite.log > gpurun_out/r06_gpu_suite_durations.txt; tail -3 gpurun_out/r06_gpu_suite.log >> gpurun_out/r06_gpu_suite_durations.txt
   exit $rc
   ;;
+raster)  # one raster experiment on the headline GEMM (gate_up, 26 112 tokens, SwiGLU epilogue): band height of the XCD tile groups.
+  # probe libraries: hipcc -DATS_RING_GM=<n> of gemm.hip linked with the product objects (built in the container, tools/probe/libatspeed_gm<n>.so)
+  : > gpurun_out/r06_raster.log
+  for g in 4 6 2; do
+    L=$PWD/tools/probe/libatspeed_gm$g.so; [ $g = 4 ] && L=$PWD/atspeed_amd/lib/libatspeed_hip.so
+    echo "== GM=$g ($L)" >> gpurun_out/r06_raster.log
+    ATSPEED_LIB=$L GEMM_AB_EPI=3 timeout -k 10 300 python tools/gemm_ab.py 26112 2>&1 | grep gate_up >> gpurun_out/r06_raster.log || exit 1
+    ATSPEED_LIB=$L GEMM_AB_EPI=3 timeout -k 10 300 python tools/gemm_ab.py 26112 2>&1 | grep gate_up >> gpurun_out/r06_raster.log || exit 1
+    ATSPEED_LIB=$L bash tools/pmc_traffic_gemm.sh gm$g 26112 22016 4096 3 >> gpurun_out/r06_raster.log 2>&1 || exit 1
+  done
+  ;;
 esac
