@@ -38,4 +38,9 @@ for _ in range(reps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 acc = (sum(o["total_accept_steps"] for o in outs) / max(1, sum(o["n_run"] for o in outs))) if mode == "bssd" else 0.0
-print(f"MARK {mode} users {users} resid_scale {rs}{' fp8' if fp8 else ''}: {dt * 1e3:.2f} ms to last result, {1e3 * dt / users:.2f} ms/user, {users * 20 / dt:.1f} items/s, accept {acc:.3f}", flush=True)
+stage = ""
+if mode == "bssd" and users == 1:      # the engine's own stage clocks (hipEvents; the CSV columns of inference.py:183-187) and forward counts of the last call
+    o = outs[0]
+    stage = (f"; stages draft {1e3 * o['draft_time_cost']:.2f} target {1e3 * o['target_time_cost']:.2f} verify {1e3 * o['verify_time_cost']:.2f} ms, "
+             f"{o['n_target_forwards']} target / {o['n_draft_forwards']} draft forwards")
+print(f"MARK {mode} users {users} resid_scale {rs}{' fp8' if fp8 else ''}: {dt * 1e3:.2f} ms to last result, {1e3 * dt / users:.2f} ms/user, {users * 20 / dt:.1f} items/s, accept {acc:.3f}{stage}", flush=True)
