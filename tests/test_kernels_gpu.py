@@ -1163,6 +1163,8 @@ def test_wdma_m_split_form(lib, kind, m, n, k, epi):
         tol = (2e-5 * np.sqrt(k) if epi == _lib.EPI_F32 else 1e-2) * float(ref.abs().max())
     for o in outs[:2]:
         assert float((o[:m, : ref.shape[1]].float().cpu() - ref).abs().max()) <= tol
-    same_cut = kind == "fp8" or epi != _lib.EPI_RESID                  # the 16-bit split forms cut K in 8 (one tile) / 4 (two tiles) parts: other fp32 sums
-    if same_cut and sum(cnts[0][f] for f in fam) == 1:
+    # same kernel family both times, and no other K cut: the e4m3 split forms cut K in 4 parts either way; the 16-bit ones in 8 (one tile) / 4 (two tiles)
+    # parts, and the 16-bit qkv projection is split in the one-tile form only
+    same_cut = cnts[0] == cnts[1] and (kind == "fp8" or cnts[1][PATH_WDMA] == 1)
+    if same_cut:
         assert torch.equal(outs[0], outs[1]), f"max |diff| {float((outs[0].float() - outs[1].float()).abs().max()):.3e}"
