@@ -1650,14 +1650,14 @@ template <int BM, int BN, int NST, int EPI, bool SPLIT = false, int WM = 2, bool
 __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restrict__ X, const void* __restrict__ W, void* __restrict__ Cv,
                                                              int M, int N, int K, int ldx, int ldc, int pk, int n_split,
                                                              const float* __restrict__ sx = nullptr, const float* __restrict__ sw = nullptr,
-                                                             RopeEpi rope = RopeEpi{}, int m_tiles = 1) {
+                                                             RopeEpi rope = RopeEpi{}) {
   // EPI_QKV_ROPE (round 6; one user's W8A8 qkv projection at head_dim 128, 64-row weight tiles, no split): RoPE and the KV-cache scatter in
   // the epilogue, as in the ring kernels' EPI_QKV_ROPE.  A rotation pairs columns d and d + 64 of a head, and a 64-row tile cannot hold a whole
   // head; since the DMA's per-lane source address is free, tile t (0 / 1) of a head takes the weight rows {32 t + 16 wn + q, 64 + 32 t + 16 wn + q}
   // (wn = the wave's half of the tile, q < 16) laid out so that a lane's accumulators acc[0][j][r] and acc[1][j][r] ARE the pair (d, d + 64):
   // no exchange between lanes or waves.  Numerics = the plain store + rope_kv_segs_vec_kernel: the projection rounded to the 16-bit type,
   // the rotation in fp32 on those values (rope_first / rope_second), one more rounding -- bit-identical (tests/test_closures_gpu.py).
-  static_assert(EPI != EPI_QKV_ROPE || (F8 && !SPLIT && (BN == 64 || BN == 128)), "RoPE epilogue: the W8A8 no-split form with 64- or 128-row weight tiles");
+  static_assert(EPI != EPI_QKV_ROPE || (F8 && !SPLIT && BN == 64), "RoPE epilogue: the W8A8 no-split form with 64-row weight tiles");
   constexpr int RB = 128, STAGE = (BM + BN) * RB, NWAVE = 2 * WM;
   constexpr int ESZ = F8 ? 1 : 2, BK = RB / ESZ;                       // k per stage: 64 (16-bit) or 128 (e4m3)
   constexpr int NPIECE = (BM + BN) / 8, NP = NPIECE / NWAVE;           // 1 KB pieces per stage; per wave
@@ -1666,17 +1666,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restr
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WM, wm = wave % WM, lq = lane & 15, g = lane >> 4;
-  // M-split (round 6; 129-256 tokens): the token rows are cut into m_tiles = 2 tiles of BM = 128 rows -- a workgroup's stage then holds 128 X rows
-  // instead of 256 (the X tile was two thirds of every stage: each workgroup re-streams all of X through its LDS-DMA, the "X-tile tax"), and the two
-  // workgroups of a weight tile sit on the SAME XCD (ids 16 g + 8 z + b -> weight tile 8 g + b, token tile z: b is the XCD under round-robin
-  // dispatch) and walk W at the same pace, so the second reader's lines are L2 hits.
-  int ntile = blockIdx.x, m0 = 0;
-  if (m_tiles == 2) {
-    ntile = (int)(blockIdx.x >> 4) * 8 + (int)(blockIdx.x & 7);
-    m0 = (int)((blockIdx.x >> 3) & 1) * BM;
-    if (ntile * BN >= N || m0 >= M) return;                            // (uniform over the workgroup: before any barrier)
-  }
-  const int n0 = ntile * BN;
+  const int n0 = blockIdx.x * BN;
   int kt0 = 0, n_kt = K / BK;                                          // launcher: K % BK == 0; this part's tiles are kt0 .. kt0 + n_kt - 1
   if constexpr (SPLIT) {
     const int all = n_kt, z = blockIdx.y;
@@ -1695,13 +1685,10 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restr
     const bool w = row >= BM;                                          // uniform per piece (BM % 8 == 0)
     int wr = n0 + row - BM;                                            // weight row of this LDS row
     if constexpr (EPI == EPI_QKV_ROPE) {
-      // LDS row rw = (wn, i, q): wave half wn = rw / (BN/2), 16-row tile i, row q.  Tiles i < NI/2 hold columns d, tiles i >= NI/2 their partners d + 64:
-      // column = i_half * 64 + t * BN/2 + wn * BN/4 + i_lo * 16 + q of the head, t = the head's tile (BN = 64: two per head; BN = 128: one)
-      const int rw = row - BM, rwn = rw / (BN / 2), ri = (rw % (BN / 2)) >> 4, rq = rw & 15;
-      constexpr int TPH = 128 / BN;                                    // tiles per head
-      wr = (ntile / TPH) * 128 + (ri / (NI / 2)) * 64 + (ntile % TPH) * (BN / 2) + rwn * (BN / 4) + (ri % (NI / 2)) * 16 + rq;
+      const int rw = row - BM;                                         // LDS row (wn, i, q) = (rw >> 5, (rw >> 4) & 1, rw & 15) -> column i * 64 + 32 t + 16 wn + q of the head
+      wr = (int)(blockIdx.x >> 1) * 128 + ((rw >> 4) & 1) * 64 + (int)(blockIdx.x & 1) * 32 + (rw >> 5) * 16 + (rw & 15);
     }
-    const int gr = w ? min(wr, N - 1) : min(m0 + row, M - 1);
+    const int gr = w ? min(wr, N - 1) : min(row, M - 1);
     const unsigned ldb = (w ? (unsigned)K : (unsigned)ldx) * ESZ;      // row bytes
     voff[j] = pk ? (unsigned)(gr >> 1) * (ldb * 2u) + (gr & 1) * 64 + (unsigned)(c >> 2) * 128 + (c & 3) * 16 : (unsigned)gr * ldb + c * 16;
     m0p[j] = __builtin_amdgcn_readfirstlane((int)lbase + piece * 1024);
@@ -1769,13 +1756,13 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restr
   const int nw = n0 + wn * (BN / 2);
   // weight row (= output column) of acc[i][.][r]
   auto wcol = [&](int i, int r) {
-    if constexpr (EPI == EPI_QKV_ROPE) return (ntile / (128 / BN)) * 128 + (i / (NI / 2)) * 64 + (ntile % (128 / BN)) * (BN / 2) + wn * (BN / 4) + (i % (NI / 2)) * 16 + g * 4 + r;
+    if constexpr (EPI == EPI_QKV_ROPE) return (int)(blockIdx.x >> 1) * 128 + i * 64 + (int)(blockIdx.x & 1) * 32 + wn * 16 + g * 4 + r;
     else return nw + i * 16 + g * 4 + r;
   };
   if constexpr (F8) {                                                  // W8A8: per-token x per-output-row scales on the accumulators
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-      const float fx = sx[min(m0 + wm * (BM / WM) + j * 16 + lq, M - 1)];
+      const float fx = sx[min(wm * (BM / WM) + j * 16 + lq, M - 1)];
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -1783,22 +1770,19 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restr
     }
   }
   if constexpr (EPI == EPI_QKV_ROPE) {
-    static_assert(NI % 2 == 0, "a lane holds the pairs (d, d + 64) in its weight tiles i and i + NI/2");
+    static_assert(NI == 2, "a lane holds the pair (d, d + 64) in its two weight tiles");
     bf16_t* qkv = reinterpret_cast<bf16_t*>(Cv);
     const int H = rope.hidden;
-    constexpr int TPH = 128 / BN;
-    const int hb = (ntile / TPH) * 128;                                // the head's first column in [q | k | v]
+    const int hb = (int)(blockIdx.x >> 1) * 128;                       // the head's first column in [q | k | v]
     const int sec = hb / H, fsec = hb - sec * H;                       // 0 q, 1 k, 2 v (uniform over the workgroup); the head's first column inside it
-#pragma unroll
-    for (int il = 0; il < NI / 2; ++il) {
-    const int d0 = (ntile % TPH) * (BN / 2) + wn * (BN / 4) + il * 16 + g * 4;   // pair index of r = 0: this lane owns d0 .. d0 + 3 and their partners 64 further
+    const int d0 = (int)(blockIdx.x & 1) * 32 + wn * 16 + g * 4;       // pair index of r = 0: this lane owns d0 .. d0 + 3 and their partners 64 further
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-      const int gm = m0 + wm * (BM / WM) + j * 16 + lq;
+      const int gm = wm * (BM / WM) + j * 16 + lq;
       if (gm >= M) continue;
       const RowInfo ri = rope.rows[gm];
-      const uint32_t a01 = f2bf_pk(acc[il][j][0], acc[il][j][1]), a23 = f2bf_pk(acc[il][j][2], acc[il][j][3]);     // x[d]: the projection's 16-bit outputs
-      const uint32_t b01 = f2bf_pk(acc[il + NI / 2][j][0], acc[il + NI / 2][j][1]), b23 = f2bf_pk(acc[il + NI / 2][j][2], acc[il + NI / 2][j][3]);     // x[d + 64]
+      const uint32_t a01 = f2bf_pk(acc[0][j][0], acc[0][j][1]), a23 = f2bf_pk(acc[0][j][2], acc[0][j][3]);     // x[d]: the projection's 16-bit outputs
+      const uint32_t b01 = f2bf_pk(acc[1][j][0], acc[1][j][1]), b23 = f2bf_pk(acc[1][j][2], acc[1][j][3]);     // x[d + 64]
       if (sec == 2) {
         bf16_t* dst = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ri.vc) + rope.layer_off) + (size_t)ri.slot * H + fsec + d0;
         *reinterpret_cast<uint2*>(dst) = make_uint2(a01, a23);
@@ -1817,14 +1801,13 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restr
         *reinterpret_cast<uint2*>(dst + 64) = o1;
       }
     }
-    }
     return;
   }
   if constexpr (SPLIT) {
     float* P = reinterpret_cast<float*>(Cv) + (size_t)blockIdx.y * M * N;
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-      const int gm = m0 + wm * (BM / WM) + j * 16 + lq;
+      const int gm = wm * (BM / WM) + j * 16 + lq;
       if (gm >= M) continue;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -1841,7 +1824,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_wdma_kernel(const void* __restr
   }
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
-    const int gm = m0 + wm * (BM / WM) + j * 16 + lq;
+    const int gm = wm * (BM / WM) + j * 16 + lq;
     if (gm >= M) continue;
     if constexpr (EPI == EPI_SWIGLU) {                                 // gate rows 32b .. 32b+15, up rows 32b+16 .. 32b+31: tiles (2q, 2q+1)
       bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
@@ -2067,25 +2050,18 @@ int launch_cfg(const T* a, const T* w, void* c, int m, int n, int k, int lda, in
 // 75.9 / 85.5 / 89.6 -> 64.1 / 70.4 / 73.1 (4.2 TB/s at 60 tokens).  NOT the qkv projection (12288 rows: 96 tiles of 128 leave 160 CUs idle,
 // 35-42 us; 192 tiles of 64 give 27.7 / 32.6 against 30.9 / 35.4, but the split-K form hands its slabs to the RoPE kernel, which the
 // bf16 store + separate RoPE pass of this form gives back: 22.71 vs 22.65 ms per user) and not N = 4096 (split-K + fused reduce / norm).
-// M-split of the weight-streaming kernels at 129-256 tokens (gemm_wdma_kernel's m_tiles = 2; switch "wdma_msplit", ATSPEED_WDMA_MSPLIT): two 128-row
-// token tiles per weight tile instead of one 256-row tile -- a third less LDS-DMA per workgroup and k-tile, all 256 CUs instead of 172-192.
-static bool wdma_msplit(int m) { return m > 128 && m <= 256 && ats_switch(ATS_SW_WDMA_MSPLIT) != 0; }
 static bool wdma_applies(int m, int n, int k, int lda, int epilogue) {
   static const int on = env_int("ATSPEED_GEMM_WDMA", 1);
   constexpr int min_m = 33;
   constexpr int max_m = 256;
   if (!on || m < min_m || m > max_m || k % 64 != 0 || k < 512 || (lda % 8) != 0 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return false;
   const int t192 = (n + 191) / 192, t128 = (n + 127) / 128;
-  if (wdma_msplit(m)) {                                                // 2 x tiles of 128 (qkv: 192 workgroups) or of 192 weight rows (gate_up: 230)
-    const bool okm = (2 * t128 >= 150 && 2 * t128 <= 256) || (2 * t192 >= 150 && 2 * t192 <= 256);
-    if (okm) return epilogue == EPI_STORE || epilogue == EPI_F32 || (epilogue == EPI_SWIGLU && n % 32 == 0);
-  }
   const bool ok128 = t128 >= 150 && t128 <= 256, ok192 = t192 >= 150 && t192 <= 256;
   if (!(ok128 || (ok192 && m <= 128))) return false;                  // 129-256 rows: 128-row tiles only
   return epilogue == EPI_STORE || epilogue == EPI_F32 || (epilogue == EPI_SWIGLU && n % 32 == 0);
 }
 template <int BM, int BN, int NST, int EPI, int WM = 2>
-int launch_wdma_cfg(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, int lda, int ldc, hipStream_t st, int pk, int m_tiles = 1) {
+int launch_wdma_cfg(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, int lda, int ldc, hipStream_t st, int pk) {
   auto kern = gemm_wdma_kernel<BM, BN, NST, EPI, false, WM>;
   constexpr int lds = NST * (BM + BN) * 128;
   static thread_local AtsPerDeviceFlag attr_flag;
@@ -2094,8 +2070,7 @@ int launch_wdma_cfg(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int
     ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  const int nt = (n + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3(m_tiles == 2 ? 16 * ((nt + 7) / 8) : nt), dim3(128 * WM), lds, st, (const void*)a, (const void*)w, c, m, n, k, lda, ldc, pk, 1, (const float*)nullptr, (const float*)nullptr, RopeEpi{}, m_tiles);
+  hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN), dim3(128 * WM), lds, st, (const void*)a, (const void*)w, c, m, n, k, lda, ldc, pk, 1, (const float*)nullptr, (const float*)nullptr, RopeEpi{});
   ATS_LAUNCH_CHECK();
   ats_count_path(ATS_PATH_WDMA);
   return ATSPEED_OK;
@@ -2105,7 +2080,7 @@ static int wdma_split_count(int m, int n, int k, int lda) {
   static const int on_all = env_int("ATSPEED_GEMM_WDMA", 1);
   constexpr int min_m = 33;
   if (!on_all || m < min_m || m > 256 || k % 64 != 0 || (lda % 8) != 0 || n < 2048 || !dma_offsets_fit(n, k, 2) || !dma_offsets_fit(m, lda, 2)) return 0;
-  const int t128 = ((n + 127) / 128) * (wdma_msplit(m) ? 2 : 1), n_kt = k / 64;      // M-split: two 128-row token tiles per weight tile
+  const int t128 = (n + 127) / 128, n_kt = k / 64;
   if (t128 >= 150) return 0;                                           // wide enough for the no-split form (or too wide for one round)
   // k-tiles per part at least: 8 up to 128 tokens (o_proj, K = 4096: 8 parts of 8 tiles, 15.8 / 18.8 -> 13.5 / 16.0 us at 60 / 100 tokens), 16 above
   // (at 225 tokens the 8 x 8 form lost: 24.4 vs 23.7 us)
@@ -2114,7 +2089,7 @@ static int wdma_split_count(int m, int n, int k, int lda) {
   return (s >= 2 && t128 * s >= 150) ? s : 0;
 }
 template <int BM, int NST, int WM = 2>
-int launch_wdma_split_cfg(const bf16_t* a, const bf16_t* w, float* partial, int m, int n, int k, int lda, int splits, hipStream_t st, int pk, int m_tiles = 1) {
+int launch_wdma_split_cfg(const bf16_t* a, const bf16_t* w, float* partial, int m, int n, int k, int lda, int splits, hipStream_t st, int pk) {
   auto kern = gemm_wdma_kernel<BM, 128, NST, EPI_F32, true, WM>;
   constexpr int lds = NST * (BM + 128) * 128;
   static thread_local AtsPerDeviceFlag attr_flag;
@@ -2123,8 +2098,7 @@ int launch_wdma_split_cfg(const bf16_t* a, const bf16_t* w, float* partial, int 
     ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  const int nt = (n + 127) / 128;
-  hipLaunchKernelGGL(kern, dim3(m_tiles == 2 ? 16 * ((nt + 7) / 8) : nt, splits), dim3(128 * WM), lds, st, (const void*)a, (const void*)w, (void*)partial, m, n, k, lda, n, pk, splits, (const float*)nullptr, (const float*)nullptr, RopeEpi{}, m_tiles);
+  hipLaunchKernelGGL(kern, dim3((n + 127) / 128, splits), dim3(128 * WM), lds, st, (const void*)a, (const void*)w, (void*)partial, m, n, k, lda, n, pk, splits, (const float*)nullptr, (const float*)nullptr, RopeEpi{});
   ATS_LAUNCH_CHECK();
   ats_count_path(ATS_PATH_WDMA_SPLIT);
   return ATSPEED_OK;
@@ -2132,7 +2106,6 @@ int launch_wdma_split_cfg(const bf16_t* a, const bf16_t* w, float* partial, int 
 static int launch_wdma_split(const bf16_t* a, const bf16_t* w, float* partial, int m, int n, int k, int lda, int splits, hipStream_t st, int pk) {
   if (m <= 64)  return launch_wdma_split_cfg<64, 6>(a, w, partial, m, n, k, lda, splits, st, pk);
   if (m <= 128) return launch_wdma_split_cfg<128, 4>(a, w, partial, m, n, k, lda, splits, st, pk);
-  if (wdma_msplit(m)) return launch_wdma_split_cfg<128, 4>(a, w, partial, m, n, k, lda, splits, st, pk, 2);
   return launch_wdma_split_cfg<256, 3, 4>(a, w, partial, m, n, k, lda, splits, st, pk);      // 2 x 4 waves (the 2 x 2 form: +12-15 % at 150-256 tokens, round 3)
 }
 template <int EPI>
@@ -2148,10 +2121,7 @@ int launch_wdma(const bf16_t* a, const bf16_t* w, void* c, int m, int n, int k, 
     if (ok128) return launch_wdma_cfg<128, 128, 4, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);          // 32 KB x 4 (x 5 = all 160 KB: no faster)
     return launch_wdma_cfg<128, 192, 3, EPI>(a, w, c, m, n, k, lda, ldc, st, pk);                     // 40 KB x 3
   }
-  if (wdma_msplit(m)) {                                                                                 // 129-256 tokens as two 128-row token tiles per weight tile
-    if (2 * t128 >= 150 && 2 * t128 <= 256) return launch_wdma_cfg<128, 128, 4, EPI>(a, w, c, m, n, k, lda, ldc, st, pk, 2);     // qkv: 96 x 2
-    if (2 * t192 >= 150 && 2 * t192 <= 256) return launch_wdma_cfg<128, 192, 4, EPI>(a, w, c, m, n, k, lda, ldc, st, pk, 2);     // gate_up: 115 x 2, 40 KB x 4
-  }
+  (void)t192;
   return launch_wdma_cfg<256, 128, 3, EPI, 4>(a, w, c, m, n, k, lda, ldc, st, pk);                    // 129-256 tokens: 48 KB x 3 (the X rows are two thirds of a stage), 8 waves
 }
 
@@ -2485,16 +2455,14 @@ static bool wdma8_bn64(int n) {
   static const int on = env_int("ATSPEED_FP8_SMALL_BN64", 2);
   return on && n <= (on >= 2 ? 16384 : 4096) && n % 64 == 0;
 }
-// M-split (129-256 tokens, switch "wdma_msplit"): weight tiles of 128 rows (192 above N = 16384: gate_up's 115) x two 128-row token tiles
-static int wdma8_msplit_bn(int n) { return n > 16384 ? 192 : 128; }
-static int wdma8_split_count(int m, int n, int k) {                    // 1: no split
-  const int t128 = wdma_msplit(m) ? 2 * ((n + wdma8_msplit_bn(n) - 1) / wdma8_msplit_bn(n)) : wdma8_bn64(n) ? (n + 63) / 64 : (n + 127) / 128, n_kt = k / 128;
+static int wdma8_split_count(int n, int k) {                           // 1: no split
+  const int t128 = wdma8_bn64(n) ? (n + 63) / 64 : (n + 127) / 128, n_kt = k / 128;
   if (t128 >= 150) return 1;
   return std::max(1, std::min(256 / t128, n_kt / 4));                  // at least 4 tiles (512 k) per part (8: the same within 2 %, 16: +3 % per user)
 }
 template <int BM, int NST, int EPI, bool SPLIT, int WM = 2, int BN = 128>
 int launch_wdma8_cfg(const unsigned char* xq, const float* sx, const unsigned char* wq, const float* sw, void* c, int m, int n, int k, int ldc,
-                     int splits, hipStream_t st, int pk, const RopeEpi& rope = RopeEpi{}, int m_tiles = 1) {
+                     int splits, hipStream_t st, int pk, const RopeEpi& rope = RopeEpi{}) {
   auto kern = gemm_wdma_kernel<BM, BN, NST, EPI, SPLIT, WM, true>;
   constexpr int lds = NST * (BM + BN) * 128;
   static thread_local AtsPerDeviceFlag attr_flag;
@@ -2503,8 +2471,7 @@ int launch_wdma8_cfg(const unsigned char* xq, const float* sx, const unsigned ch
     ATS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  const int nt = (n + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3(m_tiles == 2 ? 16 * ((nt + 7) / 8) : nt, SPLIT ? splits : 1), dim3(128 * WM), lds, st, (const void*)xq, (const void*)wq, c, m, n, k, k, ldc, pk, splits, sx, sw, rope, m_tiles);
+  hipLaunchKernelGGL(kern, dim3((n + BN - 1) / BN, SPLIT ? splits : 1), dim3(128 * WM), lds, st, (const void*)xq, (const void*)wq, c, m, n, k, k, ldc, pk, splits, sx, sw, rope);
   ATS_LAUNCH_CHECK();
   ats_count_path(SPLIT ? ATS_PATH_FP8_WDMA_SPLIT : ATS_PATH_FP8_WDMA);
   return ATSPEED_OK;
@@ -2512,14 +2479,8 @@ int launch_wdma8_cfg(const unsigned char* xq, const float* sx, const unsigned ch
 template <int EPI, bool SPLIT>
 int launch_wdma8(const unsigned char* xq, const float* sx, const unsigned char* wq, const float* sw, void* c, int m, int n, int k, int ldc,
                  int splits, hipStream_t st, int pk, const RopeEpi& rope = RopeEpi{}) {
-  if (wdma_msplit(m)) {                                                // 129-256 tokens: two 128-row token tiles per weight tile of 128 (192) rows
-    if constexpr (EPI == EPI_SWIGLU || EPI == EPI_STORE || EPI == EPI_F32) {
-      if (!SPLIT && wdma8_msplit_bn(n) == 192) return launch_wdma8_cfg<128, 4, EPI, false, 2, 192>(xq, sx, wq, sw, c, m, n, k, ldc, 1, st, pk, rope, 2);       // 40 KB x 4
-    }
-    return launch_wdma8_cfg<128, 4, EPI, SPLIT>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk, rope, 2);                                                      // 32 KB x 4
-  }
   {
-    if (EPI == EPI_QKV_ROPE || wdma8_bn64(n)) {                        // (the RoPE epilogue: 64-row tiles here, 128-row ones in the M-split form; the caller asked ats_gemm_fp8_qkv_rope_applies)
+    if (EPI == EPI_QKV_ROPE || wdma8_bn64(n)) {                        // (the RoPE epilogue exists for 64-row tiles only: the caller asked ats_gemm_fp8_qkv_rope_applies)
       if (m <= 32)  return launch_wdma8_cfg<32, 8, EPI, SPLIT, 2, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk, rope);     // 12 KB x 8
       if (m <= 64)  return launch_wdma8_cfg<64, 8, EPI, SPLIT, 2, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk, rope);     // 16 KB x 8
       if (m <= 128) return launch_wdma8_cfg<128, 6, EPI, SPLIT, 2, 64>(xq, sx, wq, sw, c, m, n, k, ldc, splits, st, pk, rope);    // 24 KB x 6
@@ -2549,7 +2510,7 @@ bool ats_gemm_fp8_applies(int m, int n, int k, int ldc, int epilogue) {
   return big_fill_pct(tn * ((m + 255) / 256)) >= 60 || big_fill_pct(tn * ((m + 127) / 128)) >= 60;
 }
 size_t ats_gemm_fp8_workspace_bytes(int m, int n, int k) {
-  if (m <= 256) return wdma8_applies(m, n, k) ? (size_t)std::max(wdma8_split_count(m, n, k), wdma8_split_count(1, n, k)) * m * n * sizeof(float) : 0;
+  if (m <= 256) return wdma8_applies(m, n, k) ? (size_t)wdma8_split_count(n, k) * m * n * sizeof(float) : 0;
   return (size_t)mx_split_count(m, n, k) * m * n * sizeof(float);
 }
 
@@ -2560,7 +2521,7 @@ int ats_gemm_fp8(const void* xq, const float* sx, const void* wq, const float* s
   if (m >= 1 && m <= 256 && wdma8_applies(m, n, k)) {
     ATS_REQUIRE(epilogue != EPI_SWIGLU || ((ldc & 3) == 0 && n % 32 == 0), ATSPEED_ERR_INVALID, "gemm_fp8: SwiGLU needs N %% 32 == 0 and ldc %% 4 == 0");
     ATS_REQUIRE((((uintptr_t)xq | (uintptr_t)wq) & 15) == 0, ATSPEED_ERR_INVALID, "gemm_fp8: operands must be 16-byte aligned");
-    int s_ = wdma8_split_count(m, n, k);
+    int s_ = wdma8_split_count(n, k);
     if (s_ > 1 && !wdma8_ws_ok(m, n, s_, ws, ws_bytes)) s_ = 1;         // no room for the slabs: one part per tile
     if (s_ == 1 && epilogue != EPI_RESID) {
       switch (epilogue) {
@@ -2617,7 +2578,7 @@ int ats_gemm_fp8_partials(const void* xq, const float* sx, const void* wq, const
                           hipStream_t st, int* splits_out, int pk) {
   *splits_out = 0;
   if (m < 1 || m > 256 || !wdma8_applies(m, n, k) || (n % 4) != 0) return ATSPEED_OK;
-  const int s_ = wdma8_split_count(m, n, k);
+  const int s_ = wdma8_split_count(n, k);
   if (s_ < 2 || !wdma8_ws_ok(m, n, s_, ws, ws_bytes)) return ATSPEED_OK;
   ATS_REQUIRE(xq && sx && wq && sw && (((uintptr_t)xq | (uintptr_t)wq) & 15) == 0, ATSPEED_ERR_INVALID, "gemm_fp8_partials: null / unaligned operand");
   ATS_TRY((launch_wdma8<EPI_F32, true>((const unsigned char*)xq, sx, (const unsigned char*)wq, sw, ws, m, n, k, n, s_, st, pk)));
@@ -2633,7 +2594,7 @@ int ats_gemm_fp8_resid_norm(const void* xq, const float* sx, const void* wq, con
   if (m <= 0) return ATSPEED_OK;
   ATS_REQUIRE(xn || (q_out && s_out), ATSPEED_ERR_INVALID, "gemm_fp8_resid_norm: no output for the norm");
   if (m <= 256 && wdma8_applies(m, n, k) && n <= 8192 && (n % 4) == 0 && (ldh % 4) == 0) {
-    const int s_ = wdma8_split_count(m, n, k);
+    const int s_ = wdma8_split_count(n, k);
     if (wdma8_ws_ok(m, n, s_, ws, ws_bytes)) {
       ATS_REQUIRE(xq && sx && wq && sw && h && norm_w && (((uintptr_t)xq | (uintptr_t)wq) & 15) == 0, ATSPEED_ERR_INVALID, "gemm_fp8_resid_norm: null / unaligned operand");
       ATS_TRY((launch_wdma8<EPI_F32, true>((const unsigned char*)xq, sx, (const unsigned char*)wq, sw, ws, m, n, k, n, s_, st, pk)));
@@ -2663,10 +2624,7 @@ int ats_gemm_fp8_resid_norm(const void* xq, const float* sx, const void* wq, con
 bool ats_gemm_fp8_qkv_rope_applies(int m, int hidden, int head_dim) {
   if (!ats_switch(ATS_SW_FUSE_QKV_ROPE) || m < 1 || head_dim != 128 || hidden % 256 != 0) return false;
   // one user's tokens: the weight-streaming kernel's epilogue, where the projection runs as 150-256 unsplit tiles of 64 weight rows (Llama-7B: 192)
-  if (m <= 256) {
-    if (!wdma8_applies(m, 3 * hidden, hidden) || wdma8_split_count(m, 3 * hidden, hidden) != 1) return false;
-    return wdma_msplit(m) ? (3 * hidden <= 16384 && 2 * (3 * hidden / 128) <= 256) : (wdma8_bn64(3 * hidden) && (3 * hidden + 63) / 64 <= 256);
-  }
+  if (m <= 256) return wdma8_applies(m, 3 * hidden, hidden) && wdma8_bn64(3 * hidden) && wdma8_split_count(3 * hidden, hidden) == 1 && (3 * hidden + 63) / 64 <= 256;
   return ats_gemm_fp8_applies(m, 3 * hidden, hidden, 3 * hidden, EPI_STORE);   // the ring kernel's epilogue
 }
 

@@ -1103,68 +1103,3 @@ def test_gemm_ring_cut_in_k(lib, m, n, k, epi, dtype):
     got = outs[0][:, :n].float()
     tol = (2e-5 * np.sqrt(k) if epi == _lib.EPI_F32 else 1e-2) * float(ref.abs().max())
     assert float((got - ref).abs().max()) <= tol and float((c0[:, :n].float() - ref).abs().max()) <= tol
-
-
-MSPLIT_SHAPES = [("fp8", 228, 22016, 4096, 3), ("fp8", 228, 12288, 4096, 0), ("fp8", 228, 4096, 11008, 2), ("fp8", 228, 4096, 4096, 2), ("fp8", 256, 22016, 4096, 3),
-                 ("fp8", 129, 22016, 4096, 3), ("fp8", 200, 32859, 4096, 1), ("fp8", 190, 6144, 2048, 0),
-                 ("bf16", 228, 22016, 4096, 3), ("bf16", 228, 12288, 4096, 0), ("bf16", 228, 4096, 11008, 2), ("bf16", 228, 4096, 4096, 2), ("bf16", 129, 22016, 4096, 3),
-                 ("bf16", 256, 12288, 4096, 0), ("fp16", 228, 22016, 4096, 3), ("fp16", 200, 4096, 11008, 2)]
-
-
-@pytest.mark.parametrize("kind,m,n,k,epi", MSPLIT_SHAPES)
-def test_wdma_m_split_form(lib, kind, m, n, k, epi):
-    """Round 6: one user's 129-256 tokens as TWO 128-row token tiles per weight tile (gemm_wdma_kernel, m_tiles = 2; switch `wdma_msplit`): a
-    workgroup's stage holds 128 X rows instead of 256, the pair of a weight tile shares an XCD.  Against torch fp32 / the dequantised fp64 product,
-    and against the one-tile form: every output element is the same sum in the same order (bit-identical) wherever both forms cut K alike."""
-    dt = torch.float16 if kind == "fp16" else torch.bfloat16
-    a = _rand((m, k), 71, 1.0).to(dt).cuda()
-    w = _rand((n, k), 72, 0.03).to(dt).cuda()
-    ws = torch.empty(128 << 20, dtype=torch.uint8, device="cuda")
-    mp = (m + 1) // 2 * 2
-    if epi == _lib.EPI_SWIGLU:
-        from atspeed_amd.model import _interleave_gate_up
-        w = _interleave_gate_up(w[: n // 2].contiguous(), w[n // 2:].contiguous())
-    if epi == _lib.EPI_F32:
-        ldc = (n + 63) // 64 * 64; mk = lambda: torch.zeros(mp, ldc, dtype=torch.float32, device="cuda")
-    elif epi == _lib.EPI_SWIGLU:
-        ldc = n // 2; mk = lambda: torch.zeros(mp, ldc, dtype=dt, device="cuda")
-    else:
-        ldc = n; base = (_rand((mp, n), 73).to(dt).cuda() if epi == _lib.EPI_RESID else torch.zeros(mp, n, dtype=dt, device="cuda"))
-        mk = lambda: base.clone()
-    if kind == "fp8":
-        xq = torch.empty(m, k, dtype=torch.uint8, device="cuda"); sx = torch.empty(m, device="cuda")
-        wq = torch.empty(n, k, dtype=torch.uint8, device="cuda"); sw = torch.empty(n, device="cuda")
-        _lib.check(lib.atspeed_quant_rows_fp8(a.data_ptr(), m, k, xq.data_ptr(), sx.data_ptr(), _st()))
-        _lib.check(lib.atspeed_quant_rows_fp8(w.data_ptr(), n, k, wq.data_ptr(), sw.data_ptr(), _st()))
-        prod = ((_fp8_to_float(xq).double() @ _fp8_to_float(wq).double().T) * sx.cpu().double()[:, None] * sw.cpu().double()[None, :]).float()
-        run = lambda c: _lib.check(lib.atspeed_gemm_fp8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), c.data_ptr(), m, n, k, ldc, epi, ws.data_ptr(), ws.numel(), _st()))
-    else:
-        code = _lib.ATSPEED_F16 if kind == "fp16" else _lib.ATSPEED_BF16
-        prod = a.float().cpu() @ w.float().cpu().T
-        run = lambda c: _lib.check(lib.atspeed_gemm(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, k, ldc, code, epi, ws.data_ptr(), ws.numel(), _st()))
-    outs, cnts = [], []
-    for on in (0, 1, 1):
-        with _lib.switches(wdma_msplit=on):
-            _path_counters(lib, reset=True)
-            c = mk()
-            run(c)
-            torch.cuda.synchronize()
-            outs.append(c); cnts.append(_path_counters(lib))
-    fam = (PATH_FP8_WDMA, PATH_FP8_WDMA_SPLIT) if kind == "fp8" else (PATH_WDMA, PATH_WDMA_SPLIT)
-    assert sum(cnts[1][f] for f in fam) == 1, cnts[1]                 # the M-split launch is a weight-streaming launch
-    assert torch.equal(outs[1], outs[2])
-    if epi == _lib.EPI_SWIGLU:
-        v = prod.view(m, n // 32, 2, 16)
-        rnd = lambda t: t.to(dt).float()
-        ref = torch.nn.functional.silu(rnd(v[:, :, 0].reshape(m, n // 2))) * rnd(v[:, :, 1].reshape(m, n // 2))
-        tol = 3e-2 * float(ref.abs().max())
-    else:
-        ref = prod + (base[:m].float().cpu() if epi == _lib.EPI_RESID else 0.0)
-        tol = (2e-5 * np.sqrt(k) if epi == _lib.EPI_F32 else 1e-2) * float(ref.abs().max())
-    for o in outs[:2]:
-        assert float((o[:m, : ref.shape[1]].float().cpu() - ref).abs().max()) <= tol
-    # same kernel family both times, and no other K cut: the e4m3 split forms cut K in 4 parts either way; the 16-bit ones in 8 (one tile) / 4 (two tiles)
-    # parts, and the 16-bit qkv projection is split in the one-tile form only
-    same_cut = cnts[0] == cnts[1] and (kind == "fp8" or cnts[1][PATH_WDMA] == 1)
-    if same_cut:
-        assert torch.equal(outs[0], outs[1]), f"max |diff| {float((outs[0].float() - outs[1].float()).abs().max()):.3e}"

@@ -31,9 +31,8 @@ raster)  # one raster experiment on the headline GEMM (gate_u
     ATSPEED_LIB=$L bash tools/pmc_traffic_gemm.sh gm$g 26112 22016 4096 3 >> gpurun_out/r06_raster.log 2>&1 || exit 1
   done
   ;;
-msplit)  # M-split of the weight-streaming kernels at 129-256 tokens: tests, then A/B on one user per call
-  timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py tests/test_closures_gpu.py -x -q -m gpu -k "m_split or one_user_fp8_rope" > gpurun_out/r06c_t1.log 2>&1 && \
-  : > gpurun_out/r06c_ab.log && \
-  for f in fp8 ""; do for rs in 3e-6 none; do for v in 0 1; do ATSPEED_WDMA_MSPLIT=$v timeout -k 10 300 python tools/batch_run.py 1 bssd 12 $rs $f 2>&1 | grep MARK | sed "s/^/msplit=$v /" >> gpurun_out/r06c_ab.log || exit 1; done; done; done
+msplit)  # (A/B of the M-split form of gemm_wdma_kernel at 129-256 tokens: profiles/r06_wdma_msplit_ab.txt; no gain, not in the tree,
+         #  profiles/r06_wdma_msplit_experiment.patch has it)
+  echo "step msplit needs profiles/r06_wdma_msplit_experiment.patch applied"; exit 1
   ;;
 esac
