@@ -35,7 +35,7 @@ struct SwDef { const char* name; const char* env; int dflt; };
 const SwDef kSwitches[ATS_N_SW] = {{"gemm_sk", "ATSPEED_GEMM_SK", 1},           {"gemm_sk_g", nullptr, 0},
                                    {"gemm_panel", "ATSPEED_GEMM_PANEL", 1},     {"gemm_force_mt", "ATSPEED_GEMM_FORCE_MT", 0},
                                    {"graphs", "ATSPEED_GRAPHS", 0},             {"fuse_qkv_rope", "ATSPEED_FUSE_QKV_ROPE", 1},
-                                   {"gemm_kcut", "ATSPEED_GEMM_KCUT", 2}};
+                                   {"gemm_kcut", "ATSPEED_GEMM_KCUT", 2},       {"fuse_qkv_reduce", "ATSPEED_FUSE_QKV_REDUCE", 1}};
 std::atomic<int> g_switch[ATS_N_SW];
 std::once_flag g_switch_once;
 void switches_init() {

@@ -2033,6 +2033,7 @@ int launch_cfg(const T* a, const T* w, void* c, int m, int n, int k, int lda, in
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a, w, c, m, n, k, lda, ldc, p.k_per_split, partial, pk);
     ATS_LAUNCH_CHECK();
     ats_count_path(ATS_PATH_TILED);
+    if (c == nullptr) return ATSPEED_OK;        // partials only: the caller's next kernel sums the slabs itself (ats_gemm_partials)
     return reduce_splits<T, EPI>(partial, c, m, n, ldc, p.splits, st, fn, pk);
   } else {
     auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI, false>;
@@ -2289,11 +2290,31 @@ int ats_gemm_partials(const void* a, const void* w, int m, int n, int k, int lda
     }
   }
   const int rs = ring_split_count(m, n, k);
-  if (rs < 1 || (lda % 8) != 0 || (n % 4) != 0 || ((uintptr_t)workspace & 15) != 0 || (size_t)rs * m * n * sizeof(float) > workspace_bytes) return ATSPEED_OK;
-  ATS_REQUIRE(a && w && workspace, ATSPEED_ERR_INVALID, "gemm: null operand");
-  ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "gemm: operands must be 16-byte aligned");
-  ATS_TRY(launch_ring_split<EPI_STORE>((const bf16_t*)a, (const bf16_t*)w, nullptr, m, n, k, lda, n, rs, (float*)workspace, st, nullptr, pk));
-  *splits_out = rs;
+  if (rs >= 1 && (lda % 8) == 0 && (n % 4) == 0 && ((uintptr_t)workspace & 15) == 0 && (size_t)rs * m * n * sizeof(float) <= workspace_bytes) {
+    ATS_REQUIRE(a && w && workspace, ATSPEED_ERR_INVALID, "gemm: null operand");
+    ATS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, ATSPEED_ERR_INVALID, "gemm: operands must be 16-byte aligned");
+    ATS_TRY(launch_ring_split<EPI_STORE>((const bf16_t*)a, (const bf16_t*)w, nullptr, m, n, k, lda, n, rs, (float*)workspace, st, nullptr, pk));
+    *splits_out = rs;
+    return ATSPEED_OK;
+  }
+  // Round 6: the LDS-tiled split-K kernel's slabs too (up to 32 tokens: the K-beam final step of one user, beamSD.py:505-509; the draft's forwards).
+  // Its reduce pass was one more launch per layer; the RoPE kernel sums the same slabs in the same order and rounds as the reduce pass stored.
+  if (k % 8 == 0 && lda % 8 == 0 && (n % 4) == 0 && workspace && ((uintptr_t)workspace & 15) == 0 && a && w && (((uintptr_t)a | (uintptr_t)w) & 15) == 0) {
+    Plan p = make_plan<bf16_t>(m, n, k);
+    if (p.bn == 64 && p.bm != 128) p.bn = 128;
+    if (p.splits > 1 && p.bn == 128 && (size_t)p.splits * m * n * sizeof(float) <= workspace_bytes) {
+      const bf16_t* A = (const bf16_t*)a; const bf16_t* Wt = (const bf16_t*)w; float* P = (float*)workspace;
+      int rc;
+      switch (p.bm) {
+        case 16:  rc = launch_cfg<bf16_t, 16, 128, 1, 4, EPI_STORE>(A, Wt, nullptr, m, n, k, lda, n, p, P, st, nullptr, pk); break;
+        case 32:  rc = launch_cfg<bf16_t, 32, 128, 1, 4, EPI_STORE>(A, Wt, nullptr, m, n, k, lda, n, p, P, st, nullptr, pk); break;
+        case 64:  rc = launch_cfg<bf16_t, 64, 128, 1, 4, EPI_STORE>(A, Wt, nullptr, m, n, k, lda, n, p, P, st, nullptr, pk); break;
+        default:  rc = launch_cfg<bf16_t, 128, 128, 2, 2, EPI_STORE>(A, Wt, nullptr, m, n, k, lda, n, p, P, st, nullptr, pk); break;
+      }
+      ATS_TRY(rc);
+      *splits_out = p.splits;
+    }
+  }
   return ATSPEED_OK;
 }
 

@@ -56,6 +56,7 @@ enum { ATS_SW_GEMM_SK = 0,        // "gemm_sk"       ATSPEED_GEMM_SK (1): ring k
        ATS_SW_GRAPHS,             // "graphs"        ATSPEED_GRAPHS (0): replay recurring forwards as hipGraphs
        ATS_SW_FUSE_QKV_ROPE,      // "fuse_qkv_rope" ATSPEED_FUSE_QKV_ROPE (1): RoPE + KV scatter in the qkv projection's epilogue
        ATS_SW_GEMM_KCUT,          // "gemm_kcut"     ATSPEED_GEMM_KCUT (1): bf16 N <= 4096 projections at 257-1100 tokens cut in K over the whole chip
+       ATS_SW_FUSE_QKV_REDUCE,    // "fuse_qkv_reduce" ATSPEED_FUSE_QKV_REDUCE (1): one user's qkv split-K slabs are summed by the RoPE kernel instead of a reduce launch
        ATS_N_SW };
 int ats_switch(int id);
 

@@ -337,7 +337,7 @@ int atspeed_gemm_path_counters(int64_t* out, int32_t n, int32_t reset);
  * variable is the way to set it for a whole run) and changeable afterwards only through this call (tests and sweeps that compare two
  * settings in one process) -- the dispatch path never calls getenv.  Names: "gemm_sk" (ATSPEED_GEMM_SK, 1), "gemm_sk_g" (no variable; test
  * hook, 0), "gemm_panel" (ATSPEED_GEMM_PANEL, 1), "gemm_force_mt" (ATSPEED_GEMM_FORCE_MT, 0), "graphs" (ATSPEED_GRAPHS, 0),
- * "fuse_qkv_rope" (ATSPEED_FUSE_QKV_ROPE, 1), "gemm_kcut" (ATSPEED_GEMM_KCUT, 1); meanings in INTEGRATION.md.  Unknown name: ATSPEED_ERR_INVALID. */
+ * "fuse_qkv_rope" (ATSPEED_FUSE_QKV_ROPE, 1), "fuse_qkv_reduce" (ATSPEED_FUSE_QKV_REDUCE, 1), "gemm_kcut" (ATSPEED_GEMM_KCUT, 2); meanings in INTEGRATION.md.  Unknown name: ATSPEED_ERR_INVALID. */
 int atspeed_set_switch(const char* name, int32_t value);
 int atspeed_get_switch(const char* name, int32_t* value_out);
 /* atspeed_gemm / atspeed_gemm_fp8 on operands in the packed layout (a / xq and w / wq through atspeed_pack_rows; K % 32 == 0, for fp8 K % 64 == 0):

@@ -2,6 +2,7 @@
 sentence, generation_trie.py:92-98), the post-top-k id filter of one_step_beam_search (beamSD.py:80-86) on the device path,
 config 3 at its stated batch (Games, strict trie, 256 users in lock step), the RCCL collective, and the decoder cache's
 lifetime across a beam-size sweep (inference.py:151)."""
+import ctypes as C
 import gc
 import os
 
@@ -311,6 +312,41 @@ def test_one_user_fp8_rope_in_the_weight_streaming_qkv_epilogue_equals_the_separ
     for k in (0, 1):
         x, y = res["1"][k], res["0"][k]
         assert bool(torch.isfinite(x).all()) and torch.equal(x, y), f"forward {k}: max |diff| {float((x - y).abs().max()):.3e} of max |logit| {float(y.abs().max()):.3f}"
+
+
+@pytest.mark.parametrize("dims,T,dtype", [(synth.LlamaDims(32256, 4096, 2, 32, 1024), 20, torch.bfloat16), (synth.LlamaDims(32256, 4096, 2, 32, 1024), 100, torch.bfloat16),
+                                          (synth.LlamaDims(32256, 4096, 2, 32, 1024), 228, torch.float16), (synth.LlamaDims(32256, 768, 2, 12, 3072), 40, torch.bfloat16),
+                                          (synth.LlamaDims(32256, 768, 2, 12, 3072), 7, torch.float16)], ids=["7b_20", "7b_100", "7b_228_fp16", "68m_40", "68m_7_fp16"])
+def test_qkv_slabs_summed_by_the_rope_kernel_equal_the_reduce_launch(dims, T, dtype):
+    """One user's 16-bit qkv projection leaves fp32 split-K slabs that RoPE + the KV scatter sum themselves (one launch less per layer).  Round 6 extends
+    that to the LDS-tiled kernel's slabs (<= 32 tokens: the K-beam final step, beamSD.py:505-509; the draft's 40-token steps).  Same sums in the same
+    order, same rounding: logits bit-identical to the `fuse_qkv_reduce` switch off, first forward and a second one over the cached K / V."""
+    V = dims.vocab_size
+    m = HipLlama.from_synthetic(dims, 95, std=0.02, head_std=0.05, dtype=dtype, max_slots=512, max_tokens=512, max_logit_rows=448)
+    g = torch.Generator().manual_seed(13)
+    ids = torch.randint(3, V, (T,), generator=g).to(torch.int32)
+    vis = torch.tril(torch.ones(T, T, dtype=torch.bool))
+    if T > 12:
+        vis[8:, 3] = False
+    ar = torch.arange(T, dtype=torch.int32)
+    B = 20
+    ids2 = torch.randint(3, V, (B,), generator=g).to(torch.int32)
+    vis2 = torch.zeros(B, T + B, dtype=torch.bool)
+    vis2[:, :T] = True
+    vis2[:, T:] = torch.eye(B, dtype=torch.bool)
+    ar2 = torch.full((B,), T, dtype=torch.int32)
+    sl2 = torch.arange(T, T + B, dtype=torch.int32)
+    res = {}
+    cnt = (C.c_int64 * 16)()
+    for mode in (1, 0):
+        with _lib.switches(fuse_qkv_reduce=mode):
+            _lib.load().atspeed_gemm_path_counters(cnt, 16, 1)
+            a = m.forward_raw(ids.cuda(), ar.cuda(), ar.clone().cuda(), vis_bits_from_bool(vis, 512).cuda(), T, min(T, 6)).clone()
+            b = m.forward_raw(ids2.cuda(), ar2.cuda(), sl2.cuda(), vis_bits_from_bool(vis2, 512).cuda(), T + B, B).clone()
+            torch.cuda.synchronize()
+            res[mode] = (a, b)
+    for k in (0, 1):
+        assert bool(torch.isfinite(res[1][k]).all()) and torch.equal(res[1][k], res[0][k]), f"forward {k}: max |diff| {float((res[1][k] - res[0][k]).abs().max()):.3e}"
 
 
 def test_rccl_two_ranks(tmp_path):

@@ -35,4 +35,9 @@ msplit)  # (A/B of the M-split form of gemm_wdma_kernel at 129-256 tokens: profi
          #  profiles/r06_wdma_msplit_experiment.patch has it)
   echo "step msplit needs profiles/r06_wdma_msplit_experiment.patch applied"; exit 1
   ;;
+d)  # the tiled kernel's qkv slabs summed by RoPE (<= 32 tokens, draft): equality tests, A/B on one user per call
+  timeout -k 10 600 python -m pytest tests/test_closures_gpu.py tests/test_bssd_gpu.py tests/test_from_hf_gpu.py -x -q -m gpu -k "qkv_slabs or lossless or from_hf" > gpurun_out/r06d_t1.log 2>&1 && \
+  : > gpurun_out/r06d_ab.log && \
+  for rs in none 3e-6; do for v in 1 0 1 0; do ATSPEED_FUSE_QKV_REDUCE=$v timeout -k 10 300 python tools/batch_run.py 1 bssd 12 $rs 2>&1 | grep MARK | sed "s/^/fuse_qkv_reduce=$v /" >> gpurun_out/r06d_ab.log || exit 1; done; done
+  ;;
 esac
