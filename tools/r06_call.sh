@@ -40,4 +40,21 @@ d)  # the tiled kernel's qkv slabs summed by RoPE (<= 32 tokens, draft): equalit
   : > gpurun_out/r06d_ab.log && \
   for rs in none 3e-6; do for v in 1 0 1 0; do ATSPEED_FUSE_QKV_REDUCE=$v timeout -k 10 300 python tools/batch_run.py 1 bssd 12 $rs 2>&1 | grep MARK | sed "s/^/fuse_qkv_reduce=$v /" >> gpurun_out/r06d_ab.log || exit 1; done; done
   ;;
+profile)  # the round's profiles/ artefacts: default bench line + kernel stats + PMC traffic (tools/profile_round.sh), then the one-user W8A8 trace
+  ATSPEED_COMMIT=${ATSPEED_COMMIT:-unknown} bash tools/profile_round.sh > gpurun_out/r06_profile_round.log 2>&1 || { tail -20 gpurun_out/r06_profile_round.log; exit 1; }
+  cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+  for cfg in "fp8:none fp8" "bf16:none"; do
+    tag=${cfg%%:*}; args=${cfg#*:}
+    rm -rf gpurun_out/bt
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/bt -o bt --output-format csv -- python3 tools/batch_run.py 1 bssd 6 $args > gpurun_out/r06_band_bssd_u1_${tag}.log 2>&1 || { tail -5 gpurun_out/r06_band_bssd_u1_${tag}.log; exit 1; }
+    python tools/trace_gaps.py $(find gpurun_out/bt -name "*kernel_trace.csv") 0.6 > gpurun_out/r06_band_bssd_u1_${tag}_gaps.txt
+    cp $(find gpurun_out/bt -name "*kernel_stats.csv") gpurun_out/r06_band_bssd_u1_${tag}_kernel_stats.csv
+    grep MARK gpurun_out/r06_band_bssd_u1_${tag}.log
+  done
+  rm -rf gpurun_out/bt
+  ;;
+fulldims)  # the K = 20 full-dims test with its prints (fp64 arbiter numbers)
+  timeout -k 10 600 python -m pytest tests/test_fulldims_gpu.py -x -q -s -m gpu -k "equals_oracle" > gpurun_out/r06_fulldims_k20.log 2>&1; rc=$?
+  grep -n "fp64\|near ties\|checked exactly\|user " gpurun_out/r06_fulldims_k20.log | tail -30; exit $rc
+  ;;
 esac
