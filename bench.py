@@ -92,7 +92,7 @@ def parse():
 
 
 # ------------------------------------------------------------------------------------------------ roofline.traffic provenance
-TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r06_pmc_traffic.json")
 KERNEL_SOURCES = ("gemm.hip", "common.h")          # the GEMM kernels and the device helpers they use (internal.h holds only host-side declarations for them)
 
 
