@@ -58,14 +58,8 @@ def fulldims_fp32():
     release_decoders(tgt, drf)
 
 
-FP64_LEG_USERS = 2      # near-tied users judged by the fp64 arbiter (~40 s of CPU each at these dims); further ones keep the fp32 criterion
-
-
-def _arbiter(rt, rd):
-    """The SAME two models in double precision (RefLlama(dtype=float64): the fp32 weight values widened per use -- no second copy)."""
-    if not hasattr(rt, "_arbiter"):
-        rt._arbiter = (RefLlama(rt.d, rt.w, max_slots=512, dtype=torch.float64), RefLlama(rd.d, rd.w, max_slots=512, dtype=torch.float64))
-    return rt._arbiter
+FP64_LEG_USERS = 2      # near-tied users judged by the fp64 arbiter (~20-40 s of CPU each at these dims); further ones keep the fp32 criterion
+from tests.arbiter import fp64_gap as _fp64_gap_of, fp64_truth as _fp64_truth_of, oracle_scores_of as _oracle_scores_of      # noqa: E402
 
 
 @pytest.mark.parametrize("K,DK", [(1, 2), (2, 4)])
@@ -171,43 +165,11 @@ def _fulldims_against_oracle(models, K, DK, strict, n_users=12):
 
 
 def _fp64_truth(rt, rd, prompt, K, fn):
-    """The arbiter's list: the plain constrained beam search of the target (beamSD.py:544-595) in double precision -- by the lossless property
-    (beam-SD == target_generate in exact arithmetic: every fixture of the real reference has it) the top-K any faithful evaluation approximates; a
-    third of the tokens of an fp64 beam-SD run and no draft forwards.  -> (items [K][L], scores [K] as floats)"""
-    rt64, _ = _arbiter(rt, rd)
-    R.SCORE_DTYPE = torch.float64
-    try:
-        truth = R.target_generate(rt64, prompt, 4, K, fn)
-    finally:
-        R.SCORE_DTYPE = torch.float32
-    P = len(prompt)
-    return truth["beam_sequence"][:, P:].tolist(), [float(x) for x in truth["beam_scores"]]
+    return _fp64_truth_of(rt, prompt, K, fn)
 
 
 def _fp64_gap(rt, rd, prompt, items, t_items, t_sc):
-    """Largest |fp64 score of the list's item at rank i - the fp64 search's score at rank i| (0 for a list that IS the fp64 list: no forward needed)."""
-    if items == t_items:
-        return 0.0
-    rt64, _ = _arbiter(rt, rd)
-    sc64 = _oracle_scores_of(rt64, prompt, items, dtype=torch.float64)
-    return max(abs(a - b) for a, b in zip(sc64, t_sc))
-
-
-def _oracle_scores_of(ref_model, prompt, seqs, dtype=torch.float32):
-    """oracle beam scores (fp32; fp64 with the arbiter model and dtype=torch.float64) of arbitrary generated sequences (sum of full-vocabulary log-probabilities, beamSD.py:58,69-70) from one
-    packed forward: the prompt once, every sequence a branch under a tree mask."""
-    P, L, n = len(prompt), len(seqs[0]), len(seqs)
-    ids = [int(t) for t in prompt] + [int(t) for sq in seqs for t in sq[:-1]]
-    T = len(ids)
-    pos = list(range(P)) + [P + j for _ in seqs for j in range(L - 1)]
-    vis = torch.zeros(T, T, dtype=torch.bool)
-    vis[:P, :P] = torch.tril(torch.ones(P, P, dtype=torch.bool))
-    for i in range(n):
-        lo = P + i * (L - 1)
-        vis[lo: lo + L - 1, :P] = True
-        vis[lo: lo + L - 1, lo: lo + L - 1] = torch.tril(torch.ones(L - 1, L - 1, dtype=torch.bool))
-    logp = torch.log_softmax(ref_model.forward(torch.tensor(ids), torch.tensor(pos), torch.arange(T), vis, n_logit_rows=T - P + 1).to(dtype), dim=-1)
-    return [float(sum(logp[r, int(t)] for r, t in zip([0] + [1 + i * (L - 1) + j for j in range(L - 1)], sq))) for i, sq in enumerate(seqs)]
+    return _fp64_gap_of(rt, prompt, items, t_items, t_sc)
 
 
 def _tree_inputs(P, B, V, g, hide=5):

@@ -1,6 +1,9 @@
 """The oracle (oracle/*.py) is only trustworthy because these tests pin it to outputs of
 the REAL reference (tests/golden/*.json, produced by tests/golden/gen_golden.py importing
 /root/reference/code) and to the installed HF Llama.  CPU only."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -202,3 +205,26 @@ def test_fp64_arbiter_mode_of_the_oracle_agrees_with_the_fp32_oracle():
     assert a["beam_sequence"].tolist() == b["beam_sequence"].tolist() and a["n_run"] == b["n_run"]
     assert [r["n_matches"] for r in a["rounds"]] == [r["n_matches"] for r in b["rounds"]]
     assert float((a["beam_scores"].double() - b["beam_scores"]).abs().max()) < 1e-4
+
+
+def test_fp64_arbiter_helpers_judge_a_list_against_the_fp64_search():
+    """tests/arbiter.py (what the K = 20 full-dims GPU test calls when the engine and the fp32 oracle disagree): the fp64 plain beam search gives the
+    golden items; a list that equals it has gap 0 without a forward; a list with two ranks swapped has exactly the fp64 score difference of the two
+    items as its gap; fp32 scoring of the same sequences agrees with the fp64 scoring to re-association noise."""
+    import torch
+    from oracle.llama_ref import RefLlama
+    from tests.arbiter import fp64_gap, fp64_truth, oracle_scores_of
+    from tests.golden.cases import CASES, build_case_inputs
+    case = next(c for c in CASES if c["name"] == "k20_dk40_sigma01_s7")
+    ci = build_case_inputs(case)
+    rt = RefLlama(ci["target_dims"], ci["target_sd"])
+    t_items, t_sc = fp64_truth(rt, ci["prompt"], case["K"], ci["fn"])
+    gold = next(g for g in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bssd_golden.json"))) if g["name"] == case["name"])
+    assert t_items == gold["tg_tokens"]                                   # the real reference's plain beam search
+    assert fp64_gap(rt, ci["prompt"], t_items, t_items, t_sc) == 0.0
+    swapped = [list(x) for x in t_items]
+    swapped[3], swapped[4] = swapped[4], swapped[3]
+    gap = fp64_gap(rt, ci["prompt"], swapped, t_items, t_sc)
+    assert abs(gap - abs(t_sc[3] - t_sc[4])) < 1e-9 and gap > 0
+    s32 = oracle_scores_of(rt, ci["prompt"], t_items)
+    assert max(abs(a - b) for a, b in zip(s32, t_sc)) < 1e-4
