@@ -5,7 +5,8 @@ set -e
 TAG=$1; M=$2; N=$3; K=$4; EPI=${5:-0}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 cd /tmp && export TMPDIR=/tmp
-for pass in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+# (round 6: + the wait / matrix-pipe pass VERDICT r5 asked for -- SQ_VALU_MFMA_BUSY_CYCLES, SQ_WAIT_INST_LDS, SQ_WAIT_INST_ANY)
+for pass in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $pass | cut -d" " -f1)
   rocprofv3 --pmc $pass -d $OUT/$tag -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/one_gemm_fp8.py $M $N $K $EPI > $OUT.$tag.log 2>&1
 done
@@ -29,6 +30,13 @@ for kern, cs in agg.items():
     if "FETCH_SIZE" in c: d["hbm_read_bytes_per_launch"] = 2 * c["FETCH_SIZE"] * 1024
     if "WRITE_SIZE" in c: d["hbm_write_bytes_per_launch"] = c["WRITE_SIZE"] * 1024
     if "SQ_LDS_BANK_CONFLICT" in c: d["lds_bank_conflict_cycles"] = c["SQ_LDS_BANK_CONFLICT"]; d["lds_active_cycles"] = c.get("SQ_LDS_IDX_ACTIVE")
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("SQ_BUSY_CYCLES"):
+        # SQ_BUSY_CYCLES sums the busy cycles of the shader engines' sequencers; the matrix pipes' busy cycles against the wave-SIMD time the launch occupied
+        # (SQ_WAVE_CYCLES counts 4-cycle quanta per wave; waves_per_simd of them share one SIMD's pipe)
+        wps = 2 if "4, true>" in kern or ", 4, false>" in kern else 1
+        d["mfma_pipe_busy_fraction"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["SQ_WAVE_CYCLES"] * 4 / wps) if c.get("SQ_WAVE_CYCLES") else None
+        d["wave_time_waiting_fraction"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None
+        d["wave_time_waiting_on_lds_fraction"] = c.get("SQ_WAIT_INST_LDS", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None
     out[kern] = d
 json.dump(out, open(root + ".json", "w"), indent=1)
 print(json.dumps(out, indent=1))

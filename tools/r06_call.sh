@@ -57,4 +57,21 @@ fulldims)  # the K = 20 full-dims test with its prints (fp64 arbiter numbers)
   timeout -k 10 600 python -m pytest tests/test_fulldims_gpu.py -x -q -s -m gpu -k "equals_oracle" > gpurun_out/r06_fulldims_k20.log 2>&1; rc=$?
   grep -n "fp64\|near ties\|checked exactly\|user " gpurun_out/r06_fulldims_k20.log | tail -30; exit $rc
   ;;
+pmc8)  # counters of the W8A8 weight-streaming kernel at 228 tokens (gate_up, down): matrix pipe busy, waits, LDS, HBM-side bytes -> profiles/r06_pmc_wdma8.json
+  bash tools/pmc_wdma8.sh gate_up_228 228 22016 4096 3 > gpurun_out/r06_pmc8_gate_up.log 2>&1 || { tail -5 gpurun_out/r06_pmc8_gate_up.log; exit 1; }
+  bash tools/pmc_wdma8.sh down_228 228 4096 11008 2 > gpurun_out/r06_pmc8_down.log 2>&1 || { tail -5 gpurun_out/r06_pmc8_down.log; exit 1; }
+  bash tools/pmc_wdma8.sh gate_up_32 20 22016 4096 3 > gpurun_out/r06_pmc8_gate_up20.log 2>&1 || { tail -5 gpurun_out/r06_pmc8_gate_up20.log; exit 1; }
+  python3 - <<'PY'
+import json
+out = {"_what": "rocprofv3 --pmc passes (tools/pmc_wdma8.sh, round 6: + SQ_VALU_MFMA_BUSY_CYCLES / SQ_WAIT_INST_LDS / SQ_WAIT_INST_ANY) of the W8A8 weight-streaming kernel on engine-like launches (packed e4m3 operands, own epilogue, six weight copies in rotation); per-launch averages, FETCH doubled per the gfx950 note"}
+for tag in ("gate_up_228", "down_228", "gate_up_32"):
+    out[tag] = json.load(open(f"gpurun_out/pmc_{tag}.json"))
+json.dump(out, open("gpurun_out/r06_pmc_wdma8.json", "w"), indent=1)
+for tag, d in out.items():
+    if tag.startswith("_"): continue
+    for k, v in d.items():
+        if isinstance(v, dict) and "counters" in v:
+            print(tag, k, {x: (round(y, 4) if isinstance(y, float) else y) for x, y in v.items() if x != "counters"})
+PY
+  ;;
 esac
