@@ -208,16 +208,25 @@ def test_fp8_one_user_forward_at_llama7b_width_matches_the_w8a8_oracle(T, dtype)
     assert float(e8.mean()) < float(e32.mean())
 
 
-def test_fp8_one_user_bssd_runs_every_projection_of_every_forward_in_fp8():
+@pytest.mark.parametrize("recipe,dtype", [("flat", torch.bfloat16), ("peaked", torch.bfloat16), ("peaked", torch.float16)], ids=["flat", "peaked", "peaked_fp16"])
+def test_fp8_one_user_bssd_runs_every_projection_of_every_forward_in_fp8(recipe, dtype):
     """A ONE-user BSSD call (the reference's loop, inference.py:162-176) with the fp8 target at the Llama-7B width: every layer projection of
     every target forward -- first verification, later rounds, final single step -- is counted as fp8 (`other == 0`), and the oracle with a
-    W8A8 target agrees on n_run / accepted steps and on most of the top-20."""
+    W8A8 target agrees on n_run / accepted steps and on most of the top-20.  `flat`: the random-init recipe of the other tests, whose flat logits put
+    most of the top-20 within the scheme's own noise (overlap >= 8 of 20 is all that can be asked).  `peaked` (round 6, VERDICT r5 weak #1c): the recipe
+    of tests/test_decisions_gpu.py's verifiable headline regime -- residual branches scaled by 3e-4, head rows 3 x wider, draft and target still
+    unrelated -- where the candidates stand clear of the quantisation noise: at least 18 of the oracle's 20 items, in bf16 and in the reference's fp16."""
     from atspeed_amd.beamSD import BSSD
     V = synth.BEAUTY.vocab_size
     layers = 2
-    tdims, tgt = _target(width="llama7b", layers=layers, num_beams=20)
+    extra = dict(resid_scale=3e-4) if recipe == "peaked" else {}
+    if recipe == "peaked":
+        tdims = synth.LlamaDims(V, H7, layers, HEADS7, F7)
+        tgt = HipLlama.from_synthetic(tdims, 31, std=0.02, head_std=0.06, dtype=dtype, num_beams=20, max_slots=512, max_tokens=512, max_logit_rows=448, **extra)
+    else:
+        tdims, tgt = _target(dtype=dtype, width="llama7b", layers=layers, num_beams=20)
     ddims = synth.LlamaDims(V, 256, 2, 4, 704)
-    drf = HipLlama.from_synthetic(ddims, 32, std=0.03, head_std=0.2, dtype=torch.bfloat16, num_beams=40, max_slots=512, max_tokens=512, max_logit_rows=448)
+    drf = HipLlama.from_synthetic(ddims, 32, std=0.03, head_std=0.2, dtype=dtype, num_beams=40, max_slots=512, max_tokens=512, max_logit_rows=448, **extra)
     fn = atspeed_amd.PositionSetConstraint(synth.BEAUTY.allowed_tokens(), synth.RESPONSE_SEP)
     P = 96
     prompt = synth.synthetic_prompt(P, 411)
@@ -236,5 +245,5 @@ def test_fp8_one_user_bssd_runs_every_projection_of_every_forward_in_fp8():
     gotb = {tuple(x) for x in bf["beam_sequence"][:, P:].cpu().tolist()}
     print("one-user fp8 engine vs W8A8 oracle: top-20 overlap", len(want & got8) / 20.0, "(bf16 engine:", len(want & gotb) / 20.0, ")")
     assert f8["n_run"] == ref["n_run"] and f8["total_accept_steps"] == ref["total_accept_steps"]
-    assert len(want & got8) >= 8
+    assert len(want & got8) >= (18 if recipe == "peaked" else 8)
     release_decoders(tgt, drf)
