@@ -548,7 +548,7 @@ int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const Seg
     ATS_REQUIRE(t.qtile_rows == 64 || t.qtile_rows == 128 || t.qtile_rows == 256, ATSPEED_ERR_INVALID, "attention: query tile of %d rows", t.qtile_rows);
     static const int rows32 = getenv("ATSPEED_ATTN32") ? atoi(getenv("ATSPEED_ATTN32")) : 1;
     // small grids (one user: 32-64 workgroups) are latency-bound per workgroup and keep the 16-rows-per-wave kernel (twice the waves per tile)
-    static const int rows32_min_wgs = getenv("ATSPEED_ATTN32_MIN_WGS") ? atoi(getenv("ATSPEED_ATTN32_MIN_WGS")) : 512;
+    constexpr int rows32_min_wgs = 512;       // (round 6: a constant -- no test or tool set ATSPEED_ATTN32_MIN_WGS; measured in round 2)
     if (rows_per_wave == 32 || (rows_per_wave == 0 && rows32 && t.n_qtiles * n_heads >= rows32_min_wgs)) {
 #define ATS_ATTN32(DHV, NWV)                                                                                                   \
   {                                                                                                                            \
@@ -570,7 +570,7 @@ int ats_tree_attention_segs(const void* q, int ldq, const SegTable& t, const Seg
     }
     // one user's forwards (at most one workgroup per CU): the DMA-ring form, the whole K/V of a user in flight before the first product
     static const int ring_on = getenv("ATSPEED_ATTN_RING") ? atoi(getenv("ATSPEED_ATTN_RING")) : 1;
-    static const int ring_max_wgs = getenv("ATSPEED_ATTN_RING_MAX_WGS") ? atoi(getenv("ATSPEED_ATTN_RING_MAX_WGS")) : 256;
+    constexpr int ring_max_wgs = 256;         // (round 6: a constant -- one user's forwards; ATSPEED_ATTN_RING_MAX_WGS was set by nothing)
     {
       const int nw = t.qtile_rows / 16;
       const size_t tile = (size_t)64 * head_dim * 2 + (size_t)64 * (head_dim * 2 + 32);

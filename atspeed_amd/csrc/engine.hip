@@ -599,7 +599,7 @@ static int llama_forward_segs(atspeed_llama* m, const SegTable& t, float* logits
   // items/s in the one-user-at-a-time loop) -- the ~10 us between dependent kernels is the GPU's own barrier / cache-flush latency,
   // not host launch cost, and a graph keeps every node boundary
   const int use_graphs = ats_switch(ATS_SW_GRAPHS);                // (atspeed_set_switch("graphs", 1): the tests compare both modes in one process)
-  static const int graph_max_tok = getenv("ATSPEED_GRAPH_MAX_TOKENS") ? atoi(getenv("ATSPEED_GRAPH_MAX_TOKENS")) : 512;
+  constexpr int graph_max_tok = 512;
   if (use_graphs && !m->prof_on && logits_out == nullptr && T <= graph_max_tok) {
     const ActCtx::GraphKey key(T, t.total_logit, t.n, t.n_qtiles, t.qtile_rows, m->fp8.empty() ? 0 : 1);
     auto it = cx->graphs.find(key);
@@ -924,8 +924,6 @@ static int seg_finish(SegTable& t) {
   // lock-step batches (thousands of workgroups) run the 32-rows-per-wave kernel: its 4-wave 128-row tile also wins on short segments
   // (the idle waves still carry a quarter of the tile's DMA): 249 vs 286 us at 256 users
   if (t.n >= 16) t.qtile_rows = 128;
-  static const int force_rows = getenv("ATSPEED_ATTN_QTILE") ? atoi(getenv("ATSPEED_ATTN_QTILE")) : 0;      // tuning: 64 / 128 / 256
-  if (force_rows == 64 || force_rows == 128 || force_rows == 256) t.qtile_rows = force_rows;
   for (int i = 0; i < t.n; ++i) {
     t.seg[i].row0 = t.total_tok; t.total_tok += t.seg[i].n_tok;
     t.seg[i].logit_row0 = t.total_logit; t.total_logit += t.seg[i].n_logit;

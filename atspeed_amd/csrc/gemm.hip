@@ -1877,14 +1877,12 @@ static int env_int(const char* name, int dflt) {
 template <typename T>
 Plan make_plan(int m, int n, int k) {
   constexpr int BK = GemmTraits<T>::BK;
-  static const int target_env = env_int("ATSPEED_GEMM_TARGET_WGS", 0);
-  static const int force_bn = env_int("ATSPEED_GEMM_BN", 0);
   Plan p;
   p.bm = m <= 16 ? 16 : (m <= 32 ? 32 : (m <= 64 ? 64 : 128));
   // measured on MI355X (tools/sweep_gemm.sh): ~3 workgroups per CU for the pure streaming shapes (M <= 64),
   // ~2 per CU above; the widest GEMM (gate_up) prefers 64-column tiles over split-K slabs at M > 128
-  const int target_wgs = target_env ? target_env : (m <= 64 ? 768 : 512);
-  p.bn = force_bn ? force_bn : ((sizeof(T) == 2 && p.bm == 128 && m > 128 && n >= 16384 && n < 32000) ? 64 : 128);
+  const int target_wgs = m <= 64 ? 768 : 512;       // (constants since round 6: ATSPEED_GEMM_TARGET_WGS / ATSPEED_GEMM_BN were tools/sweep_gemm.sh's, round 1)
+  p.bn = (sizeof(T) == 2 && p.bm == 128 && m > 128 && n >= 16384 && n < 32000) ? 64 : 128;
   int tiles = ((m + p.bm - 1) / p.bm) * ((n + p.bn - 1) / p.bn);
   int ktiles = (k + BK - 1) / BK;
   int splits = 1;

@@ -872,11 +872,9 @@ int ats_lse_rows(const float* logits, int n_rows, int vocab, int ld, float* lse,
   ATS_REQUIRE((ld & 3) == 0 && ((uintptr_t)logits & 15) == 0, ATSPEED_ERR_INVALID, "lse: rows must be 16-byte aligned (ld %d)", ld);
   // measured (tools/lse_bench.py, 30976 rows of 32859): 1024 threads 6.2 TB/s, 512: 6.5, 256 (four double-buffered chunks per row, eight
   // workgroups per CU): 6.9 TB/s = 98 % of the measured read peak; a single user's 121 rows are launch-bound (6.0 us with 512 threads, 6.6 with 256)
-  static const int force_nt = getenv("ATSPEED_LSE_THREADS") ? atoi(getenv("ATSPEED_LSE_THREADS")) : 0;
-  const int nt = force_nt ? force_nt : (n_rows >= 1024 ? 256 : 512);
-  if (nt == 256)       lse_rows_kernel<256><<<n_rows, 256, 0, st>>>(logits, vocab, ld, lse);
-  else if (nt == 1024) lse_rows_kernel<1024><<<n_rows, 1024, 0, st>>>(logits, vocab, ld, lse);
-  else                 lse_rows_kernel<512><<<n_rows, 512, 0, st>>>(logits, vocab, ld, lse);
+  const int nt = n_rows >= 1024 ? 256 : 512;
+  if (nt == 256) lse_rows_kernel<256><<<n_rows, 256, 0, st>>>(logits, vocab, ld, lse);
+  else           lse_rows_kernel<512><<<n_rows, 512, 0, st>>>(logits, vocab, ld, lse);
   ATS_LAUNCH_CHECK();
   return ATSPEED_OK;
 }
