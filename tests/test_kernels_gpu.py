@@ -2,7 +2,6 @@
 oracle / plain fp32 torch on the same seeded inputs.  Run with -m gpu on the MI355X box."""
 import ctypes as C
 
-import os
 
 import numpy as np
 import pytest
