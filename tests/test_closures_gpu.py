@@ -314,6 +314,42 @@ def test_one_user_fp8_rope_in_the_weight_streaming_qkv_epilogue_equals_the_separ
         assert bool(torch.isfinite(x).all()) and torch.equal(x, y), f"forward {k}: max |diff| {float((x - y).abs().max()):.3e} of max |logit| {float(y.abs().max()):.3f}"
 
 
+def test_fp8_rope_epilogue_of_the_weight_streaming_kernel_with_several_users_in_one_small_forward():
+    """Three users' tokens in ONE forward of 177 rows (<= 256: the weight-streaming W8A8 kernels, not the ring): the fused RoPE epilogue finds every row's
+    cache, slot and position through RowInfo, as the batched ring epilogue does.  Bit-identical to the separate pass, first forwards and second
+    forwards over each user's own cached K / V."""
+    V = 32000 + 256
+    dims = synth.LlamaDims(V, 4096, 2, 32, 1024)
+    m = HipLlama.from_synthetic(dims, 97, std=0.02, head_std=0.05, dtype=torch.bfloat16, max_slots=256, max_tokens=256, max_logit_rows=256)
+    m.enable_fp8()
+    g = torch.Generator().manual_seed(14)
+    first, second = [], []
+    for i, T in enumerate((70, 41, 66)):
+        ids = torch.randint(3, V, (T,), generator=g).to(torch.int32)
+        vis = torch.tril(torch.ones(T, T, dtype=torch.bool))
+        vis[8:, 3 + i] = False
+        ar = torch.arange(T, dtype=torch.int32)
+        first.append((ids, ar, ar.clone(), vis_bits_from_bool(vis, 256), T, 3))
+        B = 20 + i
+        ids2 = torch.randint(3, V, (B,), generator=g).to(torch.int32)
+        vis2 = torch.zeros(B, T + B, dtype=torch.bool)
+        vis2[:, :T] = True
+        vis2[:, T:] = torch.eye(B, dtype=torch.bool)
+        second.append((ids2, torch.full((B,), T, dtype=torch.int32), torch.arange(T, T + B, dtype=torch.int32), vis_bits_from_bool(vis2, 256), T + B, B))
+    res = {}
+    for mode in (1, 0):
+        with _lib.switches(fuse_qkv_rope=mode):
+            m.rope_fused_launches(reset=True)
+            a = [o.clone() for o in m.forward_raw_batch(first)]
+            b = [o.clone() for o in m.forward_raw_batch(second)]
+            torch.cuda.synchronize()
+            res[mode] = (a, b, m.rope_fused_launches())
+    assert res[1][2] == 2 * dims.n_layers and res[0][2] == 0
+    for k in (0, 1):
+        for x, y in zip(res[1][k], res[0][k]):
+            assert bool(torch.isfinite(x).all()) and torch.equal(x, y), f"forward {k}: max |diff| {float((x - y).abs().max()):.3e}"
+
+
 @pytest.mark.parametrize("dims,T,dtype", [(synth.LlamaDims(32256, 4096, 2, 32, 1024), 20, torch.bfloat16), (synth.LlamaDims(32256, 4096, 2, 32, 1024), 100, torch.bfloat16),
                                           (synth.LlamaDims(32256, 4096, 2, 32, 1024), 228, torch.float16), (synth.LlamaDims(32256, 768, 2, 12, 3072), 40, torch.bfloat16),
                                           (synth.LlamaDims(32256, 768, 2, 12, 3072), 7, torch.float16)], ids=["7b_20", "7b_100", "7b_228_fp16", "68m_40", "68m_7_fp16"])
