@@ -1060,7 +1060,7 @@ def test_split_k_tail_with_an_unaligned_deal(lib, m, n, k, epi, G):
 
 # ------------------------------------------------------------------ round 6: K-cut ring form
 KCUT_SHAPES = [(320, 4096, 4096, 2), (320, 4096, 11008, 2), (640, 4096, 4096, 2), (640, 4096, 11008, 2), (1100, 4096, 11008, 2), (1054, 4096, 4096, 2),
-               (257, 4096, 4096, 0), (900, 4096, 4096, 1), (700, 2048, 8192, 0)]
+               (257, 4096, 4096, 0), (900, 4096, 4096, 1), (700, 2048, 8192, 0), (600, 3000, 2048, 2), (1099, 1028, 2304, 0)]
 
 
 @pytest.mark.parametrize("m,n,k,epi,dtype", [s + (torch.bfloat16,) for s in KCUT_SHAPES] + [s + (torch.float16,) for s in KCUT_SHAPES[1:6:2]])
